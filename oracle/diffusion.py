@@ -1,0 +1,81 @@
+"""DDPM reverse step, guidance inner loop and the planning loop (oracle; test infrastructure).
+
+Follows mpd/models/diffusion_models/sample_functions.py:5-83 and diffusion_model_base.py:121-182,285-316.
+Noise is INJECTED (``noise[0]`` = the initial x ~ N(0,I), ``noise[1+k]`` = the randn_like of the k-th loop
+iteration) so that a CPU oracle run and a GPU run see the same stream (SURVEY.md section 7 "RNG").
+"""
+import torch
+
+from . import schedules as _sched
+from .unet import unet_forward
+
+
+def apply_hard_conditioning(x: torch.Tensor, hard_conds: dict) -> torch.Tensor:
+    # sample_functions.py:5-8 (in place)
+    for k, v in hard_conds.items():
+        x[:, k, :] = v.clone()
+    return x
+
+
+def predict_start_from_noise(buf: dict, x: torch.Tensor, t: int, eps: torch.Tensor, predict_epsilon: bool = True):
+    # diffusion_model_base.py:121-132
+    if predict_epsilon:
+        return buf["sqrt_recip_alphas_cumprod"][t] * x - buf["sqrt_recipm1_alphas_cumprod"][t] * eps
+    return eps
+
+
+def p_mean(buf: dict, sd: dict, x: torch.Tensor, t: int, predict_epsilon: bool = True, eps_fn=None) -> torch.Tensor:
+    # diffusion_model_base.py:143-155 + q_posterior :134-141
+    B = x.shape[0]
+    tt = torch.full((B,), t, dtype=torch.long)
+    eps = eps_fn(x, tt) if eps_fn is not None else unet_forward(sd, x, tt)
+    x0 = predict_start_from_noise(buf, x, t, eps, predict_epsilon)
+    x0 = x0.clamp(-1.0, 1.0)
+    return buf["posterior_mean_coef1"][t] * x0 + buf["posterior_mean_coef2"][t] * x
+
+
+def guide_gradient_steps(x: torch.Tensor, hard_conds: dict, guide, n_guide_steps: int) -> torch.Tensor:
+    # sample_functions.py:65-83 (scale_grad_by_std=False as inference.py:240-244 leaves the default)
+    for _ in range(n_guide_steps):
+        x = x + guide(x)
+        x = apply_hard_conditioning(x, hard_conds)
+    return x
+
+
+def ddpm_step(buf: dict, sd: dict, x: torch.Tensor, hard_conds: dict, i: int, noise: torch.Tensor,
+              guide=None, n_guide_steps: int = 1, t_start_guide: float = float("inf"),
+              noise_std: float = 1.0, predict_epsilon: bool = True, eps_fn=None) -> torch.Tensor:
+    """One ddpm_sample_fn call at loop index i (may be negative). sample_functions.py:17-62."""
+    t = max(i, 0)  # :28-30
+    x = p_mean(buf, sd, x, t, predict_epsilon, eps_fn)
+    std = torch.exp(0.5 * buf["posterior_log_variance_clipped"][t])  # :35-36
+    if guide is not None and i < t_start_guide:  # :39 compares t_single (the un-clamped index)
+        x = guide_gradient_steps(x, hard_conds, guide, n_guide_steps)
+    n = noise.clone()
+    if t == 0:  # :52
+        n.zero_()
+    return x + std * n * noise_std  # :62
+
+
+def p_sample_loop(buf: dict, sd: dict, hard_conds: dict, noise: torch.Tensor, T: int,
+                  n_diffusion_steps_without_noise: int = 0, **kw) -> torch.Tensor:
+    """diffusion_model_base.py:157-182 with return_chain=True.  Returns chain [T+n0+1, B, H, D]
+    (already in run_inference's 'diffsteps b h d' order, :310)."""
+    x = apply_hard_conditioning(noise[0].clone(), hard_conds)
+    chain = [x.clone()]
+    k = 1
+    for i in reversed(range(-n_diffusion_steps_without_noise, T)):
+        x = ddpm_step(buf, sd, x, hard_conds, i, noise[k], **kw)
+        x = apply_hard_conditioning(x, hard_conds)
+        chain.append(x.clone())
+        k += 1
+    return torch.stack(chain, dim=0)
+
+
+def run_inference(sd: dict, hard_conds: dict, noise: torch.Tensor, T: int, variance_schedule: str = "exponential",
+                  n_diffusion_steps_without_noise: int = 0, **kw) -> torch.Tensor:
+    """diffusion_model_base.py:285-316: hard conds 'd -> b d', full chain [steps+1, B, H, D]."""
+    buf = _sched.make_buffers(T, variance_schedule)
+    B = noise.shape[1]
+    hc = {k: (v[None, :].expand(B, -1).clone() if v.dim() == 1 else v.clone()) for k, v in hard_conds.items()}
+    return p_sample_loop(buf, sd, hc, noise, T, n_diffusion_steps_without_noise, **kw)
