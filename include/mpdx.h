@@ -1,0 +1,133 @@
+/*
+ * mpdx.h - C ABI of libmpdx.so: the MI355X (gfx950) guided reverse-diffusion trajectory sampler.
+ *
+ * The reference (jacarvalho/mpd-public) has NO native / FFI interface for this path: it is three Python callable
+ * protocols.  Each entry point below states the reference Python interface it replaces
+ * (file:line under /root/reference) - this is what a maintainer's ctypes stub binds.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, >0 = hipError_t, <0 = MPDX_E_* ; never throws across the ABI;
+ *     mpdx_last_error() returns a thread-local human-readable message for the last non-zero return.
+ *   - the CALLER owns every device buffer (PyTorch caching allocator in practice) and passes raw device pointers;
+ *     the library never allocates caller-visible device memory and never synchronises: it only enqueues work on
+ *     the hipStream_t it is given (void* here so that the header needs no HIP include).
+ *   - tensors are contiguous fp32 row-major.  Trajectories are [B, H, D] exactly as the reference's x.
+ *   - one handle per model; a handle is host-side metadata only (layer table, offsets); not thread-safe per handle.
+ */
+#ifndef MPDX_H
+#define MPDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPDX_E_INVALID   (-1) /* bad argument / unsupported configuration */
+#define MPDX_E_NOTFOUND  (-2) /* unknown parameter name */
+#define MPDX_E_STATE     (-3) /* call order violated (e.g. forward before all parameters were packed) */
+
+#define MPDX_MAX_LEVELS 8
+
+typedef struct mpdx_unet mpdx_unet; /* opaque */
+
+/* TemporalUnet.__init__ arguments that shape the network (mpd/models/diffusion_models/temporal_unet.py:22-35),
+ * for the only configuration the reference builds: conditioning_type=None, self_attention=False. */
+typedef struct mpdx_unet_cfg {
+    int32_t state_dim;                  /* D */
+    int32_t n_support_points;           /* H (64) */
+    int32_t unet_input_dim;             /* 32 */
+    int32_t n_levels;                   /* len(dim_mults) */
+    int32_t dim_mults[MPDX_MAX_LEVELS]; /* (1,2,4,8) or (1,2,4): UNET_DIM_MULTS, temporal_unet.py:14-17 */
+    int32_t time_emb_dim;               /* 32 */
+} mpdx_unet_cfg;
+
+const char* mpdx_last_error(void);
+int mpdx_version(void);
+
+/* ---- model construction: replaces TemporalUnet(**unet_configs) + load_state_dict (inference.py:132-148) ---- */
+int    mpdx_unet_create(const mpdx_unet_cfg* cfg, mpdx_unet** out);
+void   mpdx_unet_destroy(mpdx_unet* u);
+/* number of state-dict tensors the model expects; their names/shapes (identical to the reference's keys) */
+int    mpdx_unet_num_params(const mpdx_unet* u);
+int    mpdx_unet_param_info(const mpdx_unet* u, int idx, const char** name, int32_t shape[3], int32_t* ndim);
+/* sizes (in floats) of the caller-allocated device buffers */
+size_t mpdx_unet_packed_floats(const mpdx_unet* u);             /* repacked weights (MFMA fragment order)       */
+size_t mpdx_unet_timetab_floats(const mpdx_unet* u, int T);     /* per-timestep conditioning table [T, sum C_out] */
+size_t mpdx_unet_workspace_floats(const mpdx_unet* u, int B);   /* activations for a batch of B trajectories    */
+/* repack one state-dict tensor (device pointer, reference layout) into `packed` */
+int    mpdx_unet_pack_param(mpdx_unet* u, const char* name, const float* src_dev, size_t n_floats,
+                            float* packed_dev, void* stream);
+/* TimeEncoder + every block's cond_mlp depend only on the integer t (layers.py:229-255,336-340): tabulate them.
+ * freqs16 = the 16 sinusoid frequencies exp(-k*ln(1e4)/15) computed by the host exactly as layers.py:249-251. */
+int    mpdx_unet_build_timetab(mpdx_unet* u, const float* packed_dev, const float* freqs16_dev, int T,
+                               float* timetab_dev, void* stream);
+
+/* ---- eps-model call: replaces model(x, t, context=None) (diffusion_model_base.py:147; temporal_unet.py:118) ----
+ * x, eps: [B,H,D]; t: the (batch-constant) integer timestep, 0 <= t < T. */
+int mpdx_unet_forward(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, int T,
+                      const float* x, int t, float* eps, int B, float* ws, void* stream);
+
+/* ---- one reverse step: replaces ddpm_sample_fn's arithmetic (sample_functions.py:17-62) together with
+ * p_mean_variance / predict_start_from_noise / q_posterior (diffusion_model_base.py:121-155) and
+ * apply_hard_conditioning (sample_functions.py:5-8).  Scalars are the t-th entries of the registered buffers. */
+typedef struct mpdx_step_coefs {
+    float sqrt_recip_alphas_cumprod;    /* diffusion_model_base.py:90  */
+    float sqrt_recipm1_alphas_cumprod;  /* :91 */
+    float posterior_mean_coef1;         /* :100 */
+    float posterior_mean_coef2;         /* :102 */
+    float noise_scale;                  /* exp(0.5*posterior_log_variance_clipped[t]) ; 0 when t == 0 */
+    float noise_std_extra;              /* noise_std_extra_schedule_fn(t) (0.5 at inference.py:243), 1 if None */
+    int32_t predict_epsilon;            /* :121-132 */
+    int32_t clip_denoised;              /* :149-150 */
+} mpdx_step_coefs;
+
+/* x_io[B,H,D] is updated in place to  hard_cond( mean + noise_scale*noise*noise_std_extra ).
+ * noise may be NULL (treated as 0).  hard_start/hard_goal: [B,D] values written at horizon index 0 / H-1
+ * (NULL = no hard conditioning).  If mean_only != 0 the posterior mean (before noise, before hard conditioning)
+ * is written instead - the point where the reference inserts the guide (sample_functions.py:39-48).
+ * chain_out (optional): a second [B,H,D] destination that receives the same values (chain.append, :175-176).
+ * absmax_out (optional, uint32 per context): atomicMax of the bit pattern of max|x| over each context's
+ * n_per_ctx trajectories - the whole-tensor range test of LimitsNormalizer.unnormalize (normalization.py:160). */
+int mpdx_ddpm_step(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, int T,
+                   float* x_io, const float* noise, const float* hard_start, const float* hard_goal,
+                   const mpdx_step_coefs* coefs, int t, int mean_only, float* chain_out,
+                   uint32_t* absmax_out, int n_per_ctx, int B, float* ws, void* stream);
+
+/* finish a guided step: x = hard_cond(x + noise_scale*noise*noise_std_extra), optional chain copy */
+int mpdx_add_noise(float* x_io, const float* noise, const float* hard_start, const float* hard_goal,
+                   float noise_scale, float noise_std_extra, float* chain_out, int B, int H, int D, void* stream);
+
+/* standard-normal generator for the production path (Philox4x32-10 + Box-Muller); replaces torch.randn /
+ * torch.randn_like (diffusion_model_base.py:165, sample_functions.py:51).  Parity runs inject noise instead. */
+int mpdx_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
+
+/* ---- the whole planning loop: replaces GaussianDiffusionModel.p_sample_loop driven by run_inference
+ * (diffusion_model_base.py:157-182,285-316) with sample_fn=ddpm_sample_fn.  Everything is enqueued on `stream`
+ * without a single host synchronisation: the t-dependent branches of the reference (`t_single < 0`,
+ * `t_single < t_start_guide`, sample_functions.py:28-29,39) depend only on the integer loop index.
+ *   coefs  : host array [T], entry t = the scalars of timestep t (see mpdx_step_coefs)
+ *   x      : [B,H,D]; in: x_T ~ N(0,I) (hard conditioning is applied here, :165-166); out: the final trajectories
+ *   noise  : [T + n_without_noise, B,H,D] the randn_like draw of each loop iteration, in loop order
+ *   chain  : NULL or [T + n_without_noise + 1, B,H,D] <- x after every iteration, index 0 = conditioned x_T
+ *            (the 'diffsteps b h d' layout run_inference returns, :310)                                        */
+int mpdx_plan(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, int T, const mpdx_step_coefs* coefs,
+              int n_without_noise, float* x, const float* noise, const float* hard_start, const float* hard_goal,
+              float* chain, int B, float* ws, void* stream);
+
+/* ---- measurement helpers (bench.py's roofline leg; not used by the planning path) ----
+ * One U-Net pass with a hipEvent pair around every kernel launch, on `stream`.  This call DOES synchronise the
+ * stream (it reads the events).  ms_out[i] = duration of launch i; flops_out[i] = its algorithmic FLOPs
+ * (2*C_out*B*L_out*C_in*taps, 0 for the final 1x1+step kernel); names_out[i] -> static layer name.
+ * Returns the number of launches written (<= cap) in *n_out. */
+int mpdx_unet_profile(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, int T, const float* x, int t,
+                      int B, float* ws, void* stream, int cap, float* ms_out, double* flops_out,
+                      const char** names_out, int* n_out);
+/* tile the dispatcher picks for launch i at batch B: writes "MTxNT/WNxWK" into buf */
+int mpdx_unet_layer_tile(const mpdx_unet* u, int i, int B, char* buf, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPDX_H */

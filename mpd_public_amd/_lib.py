@@ -1,0 +1,94 @@
+"""ctypes binding of libmpdx.so (C ABI declared in include/mpdx.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "libmpdx.so"
+_lib = None
+
+MAX_LEVELS = 8
+
+
+class UnetCfg(C.Structure):
+    _fields_ = [("state_dim", C.c_int32), ("n_support_points", C.c_int32), ("unet_input_dim", C.c_int32),
+                ("n_levels", C.c_int32), ("dim_mults", C.c_int32 * MAX_LEVELS), ("time_emb_dim", C.c_int32)]
+
+
+class StepCoefs(C.Structure):
+    _fields_ = [("sqrt_recip_alphas_cumprod", C.c_float), ("sqrt_recipm1_alphas_cumprod", C.c_float),
+                ("posterior_mean_coef1", C.c_float), ("posterior_mean_coef2", C.c_float),
+                ("noise_scale", C.c_float), ("noise_std_extra", C.c_float),
+                ("predict_epsilon", C.c_int32), ("clip_denoised", C.c_int32)]
+
+
+# every symbol include/mpdx.h declares: name -> (restype, argtypes)
+_vp, _sz, _i, _f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+SIGNATURES = {
+    "mpdx_last_error": (C.c_char_p, []),
+    "mpdx_version": (_i, []),
+    "mpdx_unet_create": (_i, [C.POINTER(UnetCfg), C.POINTER(_vp)]),
+    "mpdx_unet_destroy": (None, [_vp]),
+    "mpdx_unet_num_params": (_i, [_vp]),
+    "mpdx_unet_param_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_int32 * 3), C.POINTER(C.c_int32)]),
+    "mpdx_unet_packed_floats": (_sz, [_vp]),
+    "mpdx_unet_timetab_floats": (_sz, [_vp, _i]),
+    "mpdx_unet_workspace_floats": (_sz, [_vp, _i]),
+    "mpdx_unet_pack_param": (_i, [_vp, C.c_char_p, _vp, _sz, _vp, _vp]),
+    "mpdx_unet_build_timetab": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "mpdx_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "mpdx_ddpm_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, C.POINTER(StepCoefs), _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "mpdx_add_noise": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _i, _i, _i, _vp]),
+    "mpdx_plan": (_i, [_vp, _vp, _vp, _i, C.POINTER(StepCoefs), _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "mpdx_unet_profile": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                C.POINTER(C.c_char_p), C.POINTER(C.c_int)]),
+    "mpdx_unet_layer_tile": (_i, [_vp, _i, _i, C.c_char_p, _sz]),
+    "mpdx_randn": (_i, [_vp, _sz, C.c_uint64, C.c_uint64, _vp]),
+}
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load():
+    """Load libmpdx.so and bind every declared symbol; raises RuntimeError (never falls back) when unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise RuntimeError(f"{_LIB_PATH} is missing - build it with `python -m mpd_public_amd.build` (hipcc, gfx950). "
+                           "mpd_public_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(str(_LIB_PATH))
+    except OSError as e:  # pragma: no cover
+        raise RuntimeError(f"cannot load {_LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{_LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().mpdx_last_error()
+        raise RuntimeError(f"libmpdx {what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> int:
+    """Raw device pointer of a contiguous fp32 CUDA(HIP) tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,309 @@
+// conv_block.hpp - the temporal-conv building block of TemporalUnet as an implicit GEMM on the gfx950 matrix cores.
+//
+// Replaces (one launch each) the ATen chains behind
+//   Conv1dBlock            Conv1d(k=5,pad=2) -> GroupNorm(8) -> Mish      mpd/models/layers/layers.py:276-293
+//   ResidualTemporalBlock  "+ cond_mlp(t)" and "+ residual"               mpd/models/layers/layers.py:343-355
+//   Downsample1d           Conv1d(k=3,stride=2,pad=1)                     mpd/models/layers/layers.py:258-264
+//   Upsample1d             ConvTranspose1d(k=4,stride=2,pad=1)            mpd/models/layers/layers.py:267-273
+//   residual_conv          Conv1d(k=1)                                    mpd/models/layers/layers.py:340-341
+//
+// Formulation.  out[co, (b,l)] = sum_{ci,tap} W[co,ci,tap] * X[b, ci, l*stride + tap - pad]
+//   GEMM M = C_out, N = batch*positions, K = C_in*taps, exact fp32 on v_mfma_f32_16x16x4_f32
+//   (bitwise an fmaf chain; 157 TFLOP/s peak = the fp32 vector peak, but reachable from one wave per SIMD).
+//
+// Data layout.  Activations live in HBM channel-last [B][L][C] (the model's own [B,H,D] is already that), so a
+//   trajectory's horizon window is staged into LDS with straight 16-B copies and an MFMA B-fragment
+//   (4 consecutive input channels at one horizon position) is ONE ds_read_b128.  The horizon halo (conv padding)
+//   is materialised as zero rows in LDS, so taps are just row offsets into the staged window.
+//   Weights are pre-packed ONCE (pack_conv_weights) in MFMA A-fragment order
+//   Wp[m16][c16][slot][lane][4]: a wave's A operand for (16 out-channels, 16 in-channels, tap) is one coalesced 1-KiB load.
+//
+// Work split.  A workgroup owns MT output channels x NT positions (whole trajectories, so GroupNorm statistics are
+//   tile-local: MT is a multiple of the group size, NT a multiple of L).  Its waves split N (WN) and K (WK);
+//   K-partials are reduced through LDS in a fixed order (deterministic).  Then one wave per GroupNorm region
+//   (group x trajectory) does bias -> mean/var (wave shuffles) -> affine -> Mish -> (+time bias | +residual) -> store.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mpdx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+enum : int { CONV_S1 = 0, CONV_DOWN = 1, CONV_UPT = 2 };
+enum : int { EPI_BIAS = 0, EPI_GN_MISH = 1 };
+
+struct ConvArgs {
+    const float* src1;   // [B][L_in][c1]
+    const float* src2;   // [B][L_in][c2] second half of a channel concat (torch.cat((x, h.pop()), dim=1)), or null
+    const float* wp;     // packed weights
+    const float* bias;   // [C_out]
+    const float* gamma;  // GroupNorm weight [C_out]
+    const float* beta;   // GroupNorm bias   [C_out]
+    const float* tbias;  // per-timestep cond_mlp row [C_out] added after Mish, or null
+    const float* res;    // residual [B][L_out][C_out] added after Mish, or null
+    float* dst;          // [B][L_out][C_out]
+    int c1, c2;
+    int B, L_in, L_out, C_out;
+    int cin_pad;         // C_in rounded up to 16
+    int rs;              // LDS row stride in floats (cin_pad + bank pad)
+    int gs;              // GroupNorm channels per group
+    int n_tiles_n;       // ceil(B*L_out / NT)
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// Mish(x) = x*tanh(softplus(x)) (torch: softplus threshold 20).  tanh(log1p(e^x)) == n/(n+2), n = e^x(e^x+2).
+__device__ __forceinline__ float mish(float x) {
+    if (x > 20.0f) return x;
+    const float e = expf(x);
+    const float n = e * (e + 2.0f);
+    return x * (n / (n + 2.0f));
+}
+
+template <int MODE, int KS>
+struct ConvGeom {
+    static constexpr int PAD = (MODE == CONV_S1) ? KS / 2 : 1;
+    static constexpr int NTAP = (MODE == CONV_UPT) ? 2 : KS;   // k-groups per 16-channel chunk (per parity class)
+    static constexpr int NSLOT = (MODE == CONV_UPT) ? 4 : KS;  // packed weight slots per chunk
+};
+
+// weight slot -> tap index k of the reference weight tensor.
+//   CONV_S1/CONV_DOWN: slot == k.
+//   CONV_UPT (ConvTranspose1d k=4,s=2,p=1: out[o] += x[i]*w[k] with o = 2i - 1 + k):
+//     even o=2m : k=1 (i=m),   k=3 (i=m-1)   -> slots 0,1
+//     odd  o=2m+1: k=2 (i=m),  k=0 (i=m+1)   -> slots 2,3
+__host__ __device__ inline int upt_slot_to_k(int slot) { return slot == 0 ? 1 : slot == 1 ? 3 : slot == 2 ? 2 : 0; }
+
+template <int MODE, int KS, int EPI, int MT, int NT, int WN, int WK>
+__global__ __launch_bounds__(64 * WN * WK) void conv_block_kernel(const ConvArgs a) {
+    using G = ConvGeom<MODE, KS>;
+    constexpr int NWAVE = WN * WK, NTHR = 64 * NWAVE;
+    constexpr int MS = MT / 16, NSUB = NT / 16, NSW = NSUB / WN;
+    constexpr int PAD = G::PAD, NTAP = G::NTAP, NSLOT = G::NSLOT;
+    constexpr int MTP = MT + 4;  // padded row of the reduction buffer (conflict-free ds_write_b128)
+    static_assert(NSUB % WN == 0, "N split");
+    static_assert(MODE != CONV_UPT || (NSW % 2 == 0), "transposed conv pairs even/odd sub-tiles");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WN, wk = wave / WN;
+    const int n_mt = a.C_out / MT;
+    const int mt = blockIdx.x % n_mt, nt = blockIdx.x / n_mt;
+    const int L_in = a.L_in, L_out = a.L_out;
+    const int spt = NT / L_out;  // trajectories per tile
+    const int s0 = nt * spt;
+    const int LP = L_in + 2 * PAD;
+    const int RS = a.rs;
+    const int cin = a.c1 + a.c2;
+    const int c4n = a.cin_pad >> 2;
+
+    // ------------------------------------------------------------------ stage the horizon windows (+halo) into LDS
+    {
+        const int rows = spt * LP;
+        const int total = rows * c4n;
+        const bool vec_ok = ((a.c1 & 3) == 0) && ((a.c2 & 3) == 0);
+        for (int idx = tid; idx < total; idx += NTHR) {
+            const int row = idx / c4n, c = (idx - row * c4n) << 2;
+            const int s = row / LP, lp = row - s * LP;
+            const int li = lp - PAD, b = s0 + s;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (li >= 0 && li < L_in && b < a.B && c < cin) {
+                const size_t pos = (size_t)b * L_in + li;
+                if (vec_ok) {
+                    v = (c < a.c1) ? *(const f32x4*)(a.src1 + pos * a.c1 + c)
+                                   : *(const f32x4*)(a.src2 + pos * a.c2 + (c - a.c1));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ce = c + e;
+                        if (ce < a.c1) v[e] = a.src1[pos * a.c1 + ce];
+                        else if (ce < cin) v[e] = a.src2[pos * a.c2 + (ce - a.c1)];
+                    }
+                }
+            }
+            *(f32x4*)(smem + row * RS + c) = v;
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ MFMA main loop (K split over wk)
+    const int j = lane & 15, q = lane >> 4;
+    int boff[NSW];   // lane's base offset (floats) into the staged window for each of its N sub-tiles
+    int npos[NSW];   // tile-local output position of the lane's MFMA column
+#pragma unroll
+    for (int i = 0; i < NSW; ++i) {
+        const int ns = wn * NSW + i;
+        if (MODE == CONV_UPT) {
+            const int gm = (ns >> 1) * 16 + j;          // global input index within the tile
+            const int s = gm / L_in, m = gm - s * L_in;
+            boff[i] = (s * LP + m + PAD) * RS + q * 4;  // row of input m (tap row offsets added below)
+            npos[i] = s * L_out + 2 * m + (ns & 1);
+        } else {
+            const int n = ns * 16 + j;
+            const int s = n / L_out, l = n - s * L_out;
+            const int r0 = (MODE == CONV_DOWN) ? 2 * l : l;
+            boff[i] = (s * LP + r0) * RS + q * 4;
+            npos[i] = n;
+        }
+    }
+
+    f32x4 acc[MS][NSW];
+#pragma unroll
+    for (int m = 0; m < MS; ++m)
+#pragma unroll
+        for (int i = 0; i < NSW; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nc16 = a.cin_pad >> 4;
+    const int ngroups = nc16 * NTAP;
+    const float* wbase = a.wp + (size_t)(mt * MS) * nc16 * NSLOT * 256 + lane * 4;
+    constexpr int NCLS = (MODE == CONV_UPT) ? 2 : 1;
+
+    for (int g = wk; g < ngroups; g += WK) {
+        const int c16 = g / NTAP, ts = g - c16 * NTAP;
+        f32x4 af[MS][NCLS];
+#pragma unroll
+        for (int m = 0; m < MS; ++m)
+#pragma unroll
+            for (int p = 0; p < NCLS; ++p) {
+                const int slot = (MODE == CONV_UPT) ? (p * 2 + ts) : ts;
+                af[m][p] = *(const f32x4*)(wbase + ((size_t)(m * nc16 + c16) * NSLOT + slot) * 256);
+            }
+#pragma unroll
+        for (int i = 0; i < NSW; ++i) {
+            const int p = (MODE == CONV_UPT) ? (i & 1) : 0;
+            // row offset of this tap in the staged (zero-haloed) window:
+            //   conv/down: staged row (l*stride + tap) holds true index l*stride + tap - PAD;
+            //   convT:     boff already points at input m; even outputs use (m, m-1), odd outputs (m, m+1).
+            const int roff = (MODE == CONV_UPT) ? ((ts == 0) ? 0 : (p == 0 ? -1 : 1)) : ts;
+            const f32x4 bf = *(const f32x4*)(smem + boff[i] + roff * RS + c16 * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int m = 0; m < MS; ++m)
+                    acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][p][e], bf[e], acc[m][i], 0, 0, 0);
+        }
+    }
+
+    // ------------------------------------------------------------------ K-partials -> LDS (fixed-order reduction)
+    __syncthreads();  // every wave is done reading the staged window; reuse the memory
+    float* red = smem;
+#pragma unroll
+    for (int m = 0; m < MS; ++m)
+#pragma unroll
+        for (int i = 0; i < NSW; ++i)
+            *(f32x4*)(red + ((size_t)(wk * NT + npos[i]) * MTP + m * 16 + q * 4)) = acc[m][i];
+    __syncthreads();
+
+    // ------------------------------------------------------------------ epilogue
+    if (EPI == EPI_GN_MISH) {
+        const int gs = a.gs;
+        const int gpt = MT / gs;           // groups per tile
+        const int nreg = spt * gpt;        // GroupNorm regions in the tile
+        const int re = gs * L_out;         // elements per region: 256 (down/mid/final) or 128 (up path)
+        const float inv_re = 1.0f / (float)re;
+        for (int r = wave; r < nreg; r += NWAVE) {
+            const int s = r / gpt, gl = r - s * gpt;
+            const int b = s0 + s;
+            if (re == 256) {
+                const int e0 = lane * 4;
+                const int l = e0 / gs, c = gl * gs + (e0 - l * gs);
+                const int n = s * L_out + l, co = mt * MT + c;
+                f32x4 v = *(const f32x4*)(red + (size_t)n * MTP + c);
+#pragma unroll
+                for (int k = 1; k < WK; ++k) v += *(const f32x4*)(red + ((size_t)(k * NT + n)) * MTP + c);
+                v += *(const f32x4*)(a.bias + co);
+                const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * inv_re;
+                const f32x4 d = v - mean;
+                const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * inv_re;
+                const float rstd = 1.0f / sqrtf(var + 1e-5f);
+                const f32x4 ga = *(const f32x4*)(a.gamma + co), be = *(const f32x4*)(a.beta + co);
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = mish(d[e] * rstd * ga[e] + be[e]);
+                if (a.tbias) y += *(const f32x4*)(a.tbias + co);
+                if (b < a.B) {
+                    const size_t o = ((size_t)b * L_out + l) * a.C_out + co;
+                    if (a.res) y += *(const f32x4*)(a.res + o);
+                    *(f32x4*)(a.dst + o) = y;
+                }
+            } else {  // re == 128
+                const int e0 = lane * 2;
+                const int l = e0 / gs, c = gl * gs + (e0 - l * gs);
+                const int n = s * L_out + l, co = mt * MT + c;
+                f32x2 v = *(const f32x2*)(red + (size_t)n * MTP + c);
+#pragma unroll
+                for (int k = 1; k < WK; ++k) v += *(const f32x2*)(red + ((size_t)(k * NT + n)) * MTP + c);
+                v += *(const f32x2*)(a.bias + co);
+                const float mean = wave_sum(v[0] + v[1]) * inv_re;
+                const f32x2 d = v - mean;
+                const float var = wave_sum(d[0] * d[0] + d[1] * d[1]) * inv_re;
+                const float rstd = 1.0f / sqrtf(var + 1e-5f);
+                const f32x2 ga = *(const f32x2*)(a.gamma + co), be = *(const f32x2*)(a.beta + co);
+                f32x2 y;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) y[e] = mish(d[e] * rstd * ga[e] + be[e]);
+                if (a.tbias) y += *(const f32x2*)(a.tbias + co);
+                if (b < a.B) {
+                    const size_t o = ((size_t)b * L_out + l) * a.C_out + co;
+                    if (a.res) y += *(const f32x2*)(a.res + o);
+                    *(f32x2*)(a.dst + o) = y;
+                }
+            }
+        }
+    } else {
+        constexpr int M4 = MT / 4;
+        for (int idx = tid; idx < NT * M4; idx += NTHR) {
+            const int n = idx / M4, c = (idx - n * M4) * 4;
+            const int s = n / L_out, l = n - s * L_out, b = s0 + s;
+            const int co = mt * MT + c;
+            f32x4 v = *(const f32x4*)(red + (size_t)n * MTP + c);
+#pragma unroll
+            for (int k = 1; k < WK; ++k) v += *(const f32x4*)(red + ((size_t)(k * NT + n)) * MTP + c);
+            v += *(const f32x4*)(a.bias + co);
+            if (b < a.B) *(f32x4*)(a.dst + ((size_t)b * L_out + l) * a.C_out + co) = v;
+        }
+    }
+}
+
+// LDS bytes a launch needs: max(staged windows, K-partial buffer)
+template <int MODE, int KS, int MT, int NT, int WK>
+inline size_t conv_block_lds_bytes(int L_in, int L_out, int rs) {
+    using G = ConvGeom<MODE, KS>;
+    const size_t stage = (size_t)(NT / L_out) * (L_in + 2 * G::PAD) * rs * sizeof(float);
+    const size_t red = (size_t)WK * NT * (MT + 4) * sizeof(float);
+    return stage > red ? stage : red;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight repacking: reference layout -> MFMA A-fragment order  Wp[m16][c16][slot][lane][4]
+//   conv:   src [C_out][C_in][k]        (nn.Conv1d)
+//   convT:  src [C_in][C_out][k]        (nn.ConvTranspose1d)
+__global__ void pack_conv_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int C_out, int C_in,
+                                         int ksz, int cin_pad, int nslot, int transposed) {
+    const int nc16 = cin_pad >> 4;
+    const size_t total = (size_t)(C_out >> 4) * nc16 * nslot * 256;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = i & 3, lane = (i >> 2) & 63;
+        size_t r = i >> 8;
+        const int slot = r % nslot; r /= nslot;
+        const int c16 = r % nc16; const int m16 = r / nc16;
+        const int co = m16 * 16 + (lane & 15);
+        const int ci = c16 * 16 + (lane >> 4) * 4 + e;
+        float v = 0.f;
+        if (ci < C_in) {
+            if (transposed) v = src[((size_t)ci * C_out + co) * ksz + upt_slot_to_k(slot)];
+            else v = src[((size_t)co * C_in + ci) * ksz + slot];
+        }
+        dst[i] = v;
+    }
+}
+
+}  // namespace mpdx

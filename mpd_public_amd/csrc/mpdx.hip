@@ -1,0 +1,779 @@
+// mpdx.hip - libmpdx.so: host-side layer plan + C ABI (include/mpdx.h) + the small streaming kernels.
+//
+// gfx950 only.  No CUDA shims, no dual paths.  All device memory is caller-owned; nothing here synchronises.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mpdx.h"
+#include "conv_block.hpp"
+
+namespace mpdx {
+
+// ------------------------------------------------------------------------------------------------ error plumbing
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                                 \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail((int)e_, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ small kernels
+
+// TimeEncoder (layers.py:229-255) and every ResidualTemporalBlock.cond_mlp (layers.py:336-340) depend only on the
+// integer timestep: tabulate row t = [ cond_mlp_0(temb_t) | cond_mlp_1(temb_t) | ... ] once per model.
+struct TimeTabArgs {
+    const float* packed;
+    const float* freqs;  // [16]
+    float* tab;          // [T][row]
+    int w1, b1, w2, b2;  // offsets of time_mlp.encoder.{1,3}.{weight,bias}
+    int row;             // sum of C_out over blocks
+    int nblk;
+    int woff[40], boff[40], cout[40], toff[40];
+};
+
+__global__ __launch_bounds__(128) void timetab_kernel(const TimeTabArgs a) {
+    __shared__ float emb[32], h1[128], te[32];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    if (tid < 16) {
+        const float arg = (float)t * a.freqs[tid];  // x[:, None] * emb[None, :]  layers.py:252
+        emb[tid] = sinf(arg);
+        emb[tid + 16] = cosf(arg);
+    }
+    __syncthreads();
+    {   // Linear(32,128) + Mish
+        const float* w = a.packed + a.w1 + tid * 32;
+        float s = a.packed[a.b1 + tid];
+        for (int k = 0; k < 32; ++k) s = fmaf(w[k], emb[k], s);
+        h1[tid] = mish(s);
+    }
+    __syncthreads();
+    if (tid < 32) {  // Linear(128,32), then the Mish that opens every cond_mlp
+        const float* w = a.packed + a.w2 + tid * 128;
+        float s = a.packed[a.b2 + tid];
+        for (int k = 0; k < 128; ++k) s = fmaf(w[k], h1[k], s);
+        te[tid] = mish(s);
+    }
+    __syncthreads();
+    for (int blk = 0; blk < a.nblk; ++blk) {
+        for (int c = tid; c < a.cout[blk]; c += 128) {
+            const float* w = a.packed + a.woff[blk] + c * 32;
+            float s = a.packed[a.boff[blk] + c];
+            for (int k = 0; k < 32; ++k) s = fmaf(w[k], te[k], s);
+            a.tab[(size_t)t * a.row + a.toff[blk] + c] = s;
+        }
+    }
+}
+
+// final_conv[1] (Conv1d(32 -> D, k=1), temporal_unet.py:113-116) fused with the DDPM posterior step
+// (diffusion_model_base.py:121-155, sample_functions.py:31-62) and hard conditioning (sample_functions.py:5-8).
+// One thread per (trajectory, horizon index); the arithmetic is rounded op by op exactly as the reference's
+// separate elementwise ATen kernels are (no fma contraction), so given the same eps the update is bit-identical.
+struct FinalArgs {
+    const float* h;      // [B][H][C] output of final_conv[0]
+    const float* w;      // [D][C]
+    const float* bias;   // [D]
+    const float* x_in;   // [B][H][D]
+    const float* noise;  // [B][H][D] or null
+    const float* hs;     // hard start [B][D] or null
+    const float* hg;     // hard goal  [B][D] or null
+    float* out;          // eps (mode 0) or x_next (mode 1/2)
+    float* chain;        // optional second destination
+    uint32_t* absmax;    // optional per-context max|out| (bit pattern)
+    int B, H, D, C;
+    int mode;            // 0: eps only; 1: full step; 2: posterior mean only (guide insertion point)
+    int n_per_ctx;
+    mpdx_step_coefs k;
+};
+
+__global__ __launch_bounds__(256) void final_step_kernel(const FinalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* w = sm;                 // [D][C]
+    float* bs = sm + a.D * a.C;    // [D]
+    for (int i = threadIdx.x; i < a.D * a.C; i += blockDim.x) w[i] = a.w[i];
+    for (int i = threadIdx.x; i < a.D; i += blockDim.x) bs[i] = a.bias[i];
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;  // b*H + l
+    const bool live = p < a.B * a.H;
+    const int b = live ? p / a.H : 0, l = live ? p - b * a.H : 0;
+    float vmax = 0.f;
+    if (live) {
+        const float* hp = a.h + (size_t)p * a.C;
+        for (int d = 0; d < a.D; ++d) {
+            float s = bs[d];
+            for (int c = 0; c < a.C; c += 4) {
+                const f32x4 hv = *(const f32x4*)(hp + c);
+                const f32x4 wv = *(const f32x4*)(w + d * a.C + c);
+                s = fmaf(hv[0], wv[0], s); s = fmaf(hv[1], wv[1], s);
+                s = fmaf(hv[2], wv[2], s); s = fmaf(hv[3], wv[3], s);
+            }
+            const size_t o = (size_t)p * a.D + d;
+            float r;
+            if (a.mode == 0) {
+                r = s;
+            } else {
+                const float xv = a.x_in[o];
+                float x0;
+                if (a.k.predict_epsilon)
+                    x0 = __fsub_rn(__fmul_rn(a.k.sqrt_recip_alphas_cumprod, xv), __fmul_rn(a.k.sqrt_recipm1_alphas_cumprod, s));
+                else
+                    x0 = s;
+                if (a.k.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+                r = __fadd_rn(__fmul_rn(a.k.posterior_mean_coef1, x0), __fmul_rn(a.k.posterior_mean_coef2, xv));
+                if (a.mode == 1) {
+                    if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, a.noise[o]), a.k.noise_std_extra));
+                    if (a.hs && l == 0) r = a.hs[(size_t)b * a.D + d];
+                    if (a.hg && l == a.H - 1) r = a.hg[(size_t)b * a.D + d];
+                }
+            }
+            a.out[o] = r;
+            if (a.chain) a.chain[o] = r;
+            vmax = fmaxf(vmax, fabsf(r));
+        }
+    }
+    if (a.absmax) {
+        // one wave == one trajectory when H == 64: reduce in-wave, one atomic per wave
+        const int ctx = b / a.n_per_ctx;
+        const int ctx0 = __builtin_amdgcn_readfirstlane(ctx);
+        if (__all(ctx == ctx0)) {
+            float m = vmax;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+            if ((threadIdx.x & 63) == 0) atomicMax(a.absmax + ctx0, __float_as_uint(m));
+        } else if (live) {
+            atomicMax(a.absmax + ctx, __float_as_uint(vmax));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void add_noise_kernel(float* x, const float* noise, const float* hs, const float* hg,
+                                                         float scale, float extra, float* chain, int B, int H, int D) {
+    const size_t n = (size_t)B * H * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = i % D;
+        const size_t p = i / D;
+        const int l = p % H;
+        const size_t b = p / H;
+        float r = x[i];
+        if (noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(scale, noise[i]), extra));
+        if (hs && l == 0) r = hs[b * D + d];
+        if (hg && l == H - 1) r = hg[b * D + d];
+        x[i] = r;
+        if (chain) chain[i] = r;
+    }
+}
+
+// Philox4x32-10 counter-based generator + Box-Muller: 4 normals per counter.
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__global__ __launch_bounds__(256) void randn_kernel(float* out, size_t n, uint64_t seed, uint64_t offset) {
+    const size_t nquad = (n + 3) / 4;
+    for (size_t qd = (size_t)blockIdx.x * blockDim.x + threadIdx.x; qd < nquad; qd += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t ctr = qd + offset;
+        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c0, c1, c2, c3, k0, k1);
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = ((float)(c3 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+        float s0, cs0, s1, cs1;
+        sincosf(6.28318530717958647692f * u1, &s0, &cs0);
+        sincosf(6.28318530717958647692f * u3, &s1, &cs1);
+        const float z[4] = {r0 * cs0, r0 * s0, r1 * cs1, r1 * s1};
+        const size_t base = qd * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (base + e < n) out[base + e] = z[e];
+    }
+}
+
+__global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------ host-side model
+enum ParamKind { PK_VEC = 0, PK_CONV = 1, PK_CONVT = 2 };
+
+struct Param {
+    std::string name;
+    int32_t shape[3] = {0, 0, 0};
+    int32_t ndim = 0;
+    size_t n = 0;       // floats in the reference tensor
+    size_t off = 0;     // offset (floats) in the packed buffer
+    size_t pn = 0;      // floats in the packed buffer
+    int kind = PK_VEC;
+    int cout = 0, cin = 0, ksz = 0, cin_pad = 0, nslot = 0;
+    bool done = false;
+};
+
+enum { SRC_X = -1, SRC_NONE = -2 };
+
+struct Layer {
+    int mode = CONV_S1, ks = 5, epi = EPI_GN_MISH;
+    int c1 = 0, c2 = 0, cout = 0, L_in = 0, L_out = 0, gs = 0;
+    int src1 = SRC_NONE, src2 = SRC_NONE, dst = 0, res = SRC_NONE;  // workspace slots
+    int w = -1, b = -1, gamma = -1, beta = -1;                       // param indices
+    int tb_off = -1;                                                 // offset in a time-table row
+    int cin_pad = 0, rs = 0;
+    std::string name;
+};
+
+}  // namespace mpdx
+
+struct mpdx_unet {
+    mpdx_unet_cfg cfg;
+    std::vector<mpdx::Param> params;
+    std::unordered_map<std::string, int> pidx;
+    std::vector<mpdx::Layer> layers;
+    size_t packed_floats = 0;
+    size_t slot_floats = 0;   // per-trajectory floats of one activation slot
+    int n_slots = 0;
+    int tt_row = 0;           // floats per time-table row
+    std::vector<int> tt_w, tt_b, tt_cout, tt_off;  // cond_mlp param indices per block
+    int final_slot = 0;       // slot holding final_conv[0]'s output
+    int n_done = 0;
+};
+
+namespace mpdx {
+
+static int gn_groups(int c) {  // layers.py:389-395
+    if (c < 8) return 1;
+    for (int g = 8; g < 18; ++g)
+        if (c % g == 0) return g;
+    return 1;
+}
+
+static int add_param(mpdx_unet* u, const std::string& name, std::initializer_list<int> shape, int kind = PK_VEC) {
+    Param p;
+    p.name = name;
+    p.ndim = (int)shape.size();
+    p.n = 1;
+    int i = 0;
+    for (int s : shape) { p.shape[i++] = s; p.n *= (size_t)s; }
+    p.kind = kind;
+    if (kind == PK_CONV) {
+        p.cout = p.shape[0]; p.cin = p.shape[1]; p.ksz = p.shape[2];
+        p.nslot = p.ksz;
+    } else if (kind == PK_CONVT) {
+        p.cin = p.shape[0]; p.cout = p.shape[1]; p.ksz = p.shape[2];
+        p.nslot = 4;
+    }
+    if (kind != PK_VEC) {
+        p.cin_pad = (p.cin + 15) / 16 * 16;
+        p.pn = (size_t)(p.cout / 16) * (p.cin_pad / 16) * p.nslot * 256;
+    } else {
+        p.pn = (p.n + 3) / 4 * 4;
+    }
+    p.off = u->packed_floats;
+    u->packed_floats += p.pn;
+    u->pidx[name] = (int)u->params.size();
+    u->params.push_back(p);
+    return (int)u->params.size() - 1;
+}
+
+// LDS row stride (floats) for the staged window: smallest pad that minimises ds_read_b128 bank conflicts of the
+// B-fragment gather (lane (j,q) reads 16 B at row(j)*rs + 4q; ds_read_b128 is served in the four 16-lane groups
+// listed in MI355X_MICROARCH.md section LDS; bank = dword address mod 64).
+static int pick_row_stride(int cin_pad, int mode, int L_in, int L_out, int LP) {
+    static const int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                      {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                      {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                      {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    int best_rs = cin_pad, best = 1 << 30;
+    for (int pad = 0; pad <= 64; pad += 4) {
+        const int rs = cin_pad + pad;
+        int score = 0;
+        for (int g = 0; g < 4; ++g) {
+            int cnt[16] = {0};
+            int worst = 0;
+            for (int i = 0; i < 16; ++i) {
+                const int lane = groups[g][i], j = lane & 15, q = lane >> 4;
+                int row;
+                if (mode == CONV_UPT) { const int s = j / L_in, m = j % L_in; row = s * LP + m; }
+                else { const int s = j / L_out, l = j % L_out; row = s * LP + (mode == CONV_DOWN ? 2 * l : l); }
+                const int slot16 = ((row * rs + q * 4) & 63) >> 2;
+                worst = std::max(worst, ++cnt[slot16]);
+            }
+            score += worst;
+        }
+        if (score < best) { best = score; best_rs = rs; }
+        if (best == 4) break;
+    }
+    return best_rs;
+}
+
+static void build_model(mpdx_unet* u) {
+    const mpdx_unet_cfg& c = u->cfg;
+    const int nl = c.n_levels, D = c.state_dim, H = c.n_support_points, te = c.time_emb_dim;
+    std::vector<int> dims(nl + 1);
+    dims[0] = D;
+    for (int i = 0; i < nl; ++i) dims[i + 1] = c.unet_input_dim * c.dim_mults[i];
+
+    add_param(u, "time_mlp.encoder.1.weight", {128, 32});
+    add_param(u, "time_mlp.encoder.1.bias", {128});
+    add_param(u, "time_mlp.encoder.3.weight", {te, 128});
+    add_param(u, "time_mlp.encoder.3.bias", {te});
+
+    const int P0 = 0, P1 = 1, HB = 2, RB = 3, S0 = 4;
+    u->n_slots = S0 + nl;
+    auto other = [&](int s) { return s == P0 ? P1 : P0; };
+    size_t slot = 0;
+
+    auto conv_layer = [&](const std::string& wname, const std::string& bname, int mode, int ks, int epi, int src1, int c1,
+                          int src2, int c2, int cout, int L_in, int L_out, int dst) -> Layer& {
+        Layer l;
+        l.name = wname; l.mode = mode; l.ks = ks; l.epi = epi;
+        l.src1 = src1; l.c1 = c1; l.src2 = src2; l.c2 = c2; l.cout = cout; l.L_in = L_in; l.L_out = L_out; l.dst = dst;
+        if (mode == CONV_UPT) l.w = add_param(u, wname, {c1 + c2, cout, ks}, PK_CONVT);
+        else l.w = add_param(u, wname, {cout, c1 + c2, ks}, PK_CONV);
+        l.b = add_param(u, bname, {cout});
+        l.cin_pad = (c1 + c2 + 15) / 16 * 16;
+        const int pad = (mode == CONV_S1) ? ks / 2 : 1;
+        l.rs = pick_row_stride(l.cin_pad, mode, L_in, L_out, L_in + 2 * pad);
+        slot = std::max(slot, (size_t)cout * L_out);
+        u->layers.push_back(l);
+        return u->layers.back();
+    };
+    auto cblock = [&](const std::string& p, int src1, int c1, int src2, int c2, int cout, int L, int dst) -> Layer& {
+        Layer& l = conv_layer(p + ".block.0.weight", p + ".block.0.bias", CONV_S1, 5, EPI_GN_MISH, src1, c1, src2, c2, cout, L, L, dst);
+        const int idx = (int)u->layers.size() - 1;
+        const int ga = add_param(u, p + ".block.2.weight", {cout});
+        const int be = add_param(u, p + ".block.2.bias", {cout});
+        Layer& ll = u->layers[idx];
+        ll.gamma = ga; ll.beta = be;
+        ll.gs = cout / gn_groups(cout);
+        (void)l;
+        return ll;
+    };
+    auto rtb = [&](const std::string& p, int src1, int c1, int src2, int c2, int cout, int L, int dst) {
+        {
+            Layer& b0 = cblock(p + ".blocks.0", src1, c1, src2, c2, cout, L, HB);
+            b0.tb_off = u->tt_row;
+        }
+        const int i1 = (int)u->layers.size();
+        cblock(p + ".blocks.1", HB, cout, SRC_NONE, 0, cout, L, dst);
+        const int tw = add_param(u, p + ".cond_mlp.1.weight", {cout, te});
+        const int tbp = add_param(u, p + ".cond_mlp.1.bias", {cout});
+        u->tt_w.push_back(tw); u->tt_b.push_back(tbp); u->tt_cout.push_back(cout); u->tt_off.push_back(u->tt_row);
+        u->tt_row += cout;
+        int res = src1;
+        if (c1 + c2 != cout) {
+            // residual 1x1 conv runs BEFORE blocks.1 in launch order: insert it ahead of that layer
+            Layer keep = u->layers[i1];
+            u->layers.pop_back();
+            conv_layer(p + ".residual_conv.weight", p + ".residual_conv.bias", CONV_S1, 1, EPI_BIAS, src1, c1, src2, c2, cout, L, L, RB);
+            u->layers.push_back(keep);
+            res = RB;
+        }
+        u->layers.back().res = res;
+    };
+
+    int L = H, cur = SRC_X, curC = D;
+    for (int i = 0; i < nl; ++i) {
+        const int co = dims[i + 1];
+        const std::string p = "downs." + std::to_string(i);
+        const int a = other(cur);
+        rtb(p + ".0", cur, curC, SRC_NONE, 0, co, L, a);
+        rtb(p + ".1", a, co, SRC_NONE, 0, co, L, S0 + i);
+        cur = S0 + i; curC = co;
+        if (i < nl - 1) {
+            conv_layer(p + ".4.conv.weight", p + ".4.conv.bias", CONV_DOWN, 3, EPI_BIAS, cur, co, SRC_NONE, 0, co, L, L / 2, P0);
+            cur = P0; L /= 2;
+        }
+    }
+    rtb("mid_block1", cur, curC, SRC_NONE, 0, curC, L, P0);
+    rtb("mid_block2", P0, curC, SRC_NONE, 0, curC, L, P1);
+    cur = P1;
+    for (int j = 0; j < nl - 1; ++j) {
+        const int lv = nl - 1 - j;            // level whose skip is popped
+        const int dout = dims[lv + 1], din = dims[lv];
+        const std::string p = "ups." + std::to_string(j);
+        const int a = other(cur);
+        rtb(p + ".0", cur, dout, S0 + lv, dout, din, L, a);
+        const int b = other(a);
+        rtb(p + ".1", a, din, SRC_NONE, 0, din, L, b);
+        const int d = other(b);
+        conv_layer(p + ".4.conv.weight", p + ".4.conv.bias", CONV_UPT, 4, EPI_BIAS, b, din, SRC_NONE, 0, din, L, 2 * L, d);
+        cur = d; L *= 2; curC = din;
+    }
+    cblock("final_conv.0", cur, curC, SRC_NONE, 0, c.unet_input_dim, L, HB);
+    u->final_slot = HB;
+    add_param(u, "final_conv.1.weight", {D, c.unet_input_dim, 1});
+    add_param(u, "final_conv.1.bias", {D});
+    u->slot_floats = std::max(slot, (size_t)c.unet_input_dim * H);
+}
+
+// ------------------------------------------------------------------------------------------------ conv dispatch
+template <int MODE, int KS, int EPI, int MT, int NT, int WN, int WK>
+static int launch_conv(const ConvArgs& a, hipStream_t st) {
+    const size_t lds = conv_block_lds_bytes<MODE, KS, MT, NT, WK>(a.L_in, a.L_out, a.rs);
+    if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "conv tile needs %zu B of LDS", lds);
+    auto kern = conv_block_kernel<MODE, KS, EPI, MT, NT, WN, WK>;
+    if (lds > 64 * 1024) {
+        static thread_local bool raised = false;  // per instantiation
+        if (!raised) {
+            HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+    }
+    const int grid = (a.C_out / MT) * a.n_tiles_n;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WN * WK), lds, st, a);
+    return 0;
+}
+
+// tile choice: keep >= ~256 workgroups in flight when the batch is small, grow the tile (weight reuse) when it is large
+static void choose_tile(const Layer& l, int B, int& MT, int& NT) {
+    const int min_mt = (l.epi == EPI_GN_MISH && l.gs > 16) ? 32 : 16;
+    const int min_nt = std::max(32, l.L_out);
+    const long npos = (long)B * l.L_out;
+    MT = 32; NT = 64;
+    auto wgs = [&](int mt, int nt) { return (long)(l.cout / mt) * ((npos + nt - 1) / nt); };
+    if (wgs(MT, NT) >= 512) return;
+    if (min_nt <= 32) NT = 32;
+    if (wgs(MT, NT) >= 256) return;
+    if (min_mt <= 16) MT = 16;
+}
+
+static int layer_ntap(const Layer& l) { return l.mode == CONV_UPT ? 2 : l.ks; }
+static bool layer_ksplit(const Layer& l) {
+    if (!(l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH)) return true;
+    return (l.cin_pad / 16) * layer_ntap(l) >= 16;  // enough K to feed 8 K-split waves
+}
+static double layer_flops(const Layer& l, int B) {
+    return 2.0 * l.cout * (double)B * l.L_out * (l.c1 + l.c2) * layer_ntap(l);
+}
+
+template <int MODE, int KS, int EPI>
+static int dispatch_tile(const Layer& l, ConvArgs& a, int B, hipStream_t st) {
+    int MT, NT;
+    choose_tile(l, B, MT, NT);
+    if (l.cout % MT) MT = 16;
+    if (l.cout % MT || NT % l.L_out) return fail(MPDX_E_INVALID, "layer %s: no tile for C_out=%d L=%d", l.name.c_str(), l.cout, l.L_out);
+    a.n_tiles_n = (int)(((long)B * l.L_out + NT - 1) / NT);
+    const bool ksplit = layer_ksplit(l);
+#define MPDX_TILE(mt, nt)                                                                        \
+    if (MT == mt && NT == nt) {                                                                  \
+        if (ksplit) return launch_conv<MODE, KS, EPI, mt, nt, 1, 8>(a, st);                      \
+        return launch_conv<MODE, KS, EPI, mt, nt, nt / 16, 8 / (nt / 16)>(a, st);               \
+    }
+    MPDX_TILE(32, 64) MPDX_TILE(32, 32) MPDX_TILE(16, 64) MPDX_TILE(16, 32)
+#undef MPDX_TILE
+    return fail(MPDX_E_INVALID, "no instantiation for tile %dx%d", MT, NT);
+}
+
+template <int MODE, int KS, int EPI>
+static int dispatch_tile_ksplit_only(const Layer& l, ConvArgs& a, int B, hipStream_t st) {
+    int MT, NT;
+    choose_tile(l, B, MT, NT);
+    if (l.cout % MT) MT = 16;
+    if (l.cout % MT || NT % l.L_out) return fail(MPDX_E_INVALID, "layer %s: no tile for C_out=%d L=%d", l.name.c_str(), l.cout, l.L_out);
+    a.n_tiles_n = (int)(((long)B * l.L_out + NT - 1) / NT);
+#define MPDX_TILE(mt, nt) \
+    if (MT == mt && NT == nt) return launch_conv<MODE, KS, EPI, mt, nt, 1, 8>(a, st);
+    MPDX_TILE(32, 64) MPDX_TILE(32, 32) MPDX_TILE(16, 64) MPDX_TILE(16, 32)
+#undef MPDX_TILE
+    return fail(MPDX_E_INVALID, "no instantiation for tile %dx%d", MT, NT);
+}
+
+static int run_layer(const mpdx_unet* u, const Layer& l, const float* packed, const float* tt_row, const float* x,
+                     float* ws, int B, hipStream_t st) {
+    const size_t slot = u->slot_floats * (size_t)B;
+    auto src = [&](int s) -> const float* { return s == SRC_X ? x : (s == SRC_NONE ? nullptr : ws + slot * s); };
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src1 = src(l.src1); a.src2 = src(l.src2);
+    a.c1 = l.c1; a.c2 = l.c2;
+    a.wp = packed + u->params[l.w].off;
+    a.bias = packed + u->params[l.b].off;
+    a.gamma = l.gamma >= 0 ? packed + u->params[l.gamma].off : nullptr;
+    a.beta = l.beta >= 0 ? packed + u->params[l.beta].off : nullptr;
+    a.tbias = (l.tb_off >= 0 && tt_row) ? tt_row + l.tb_off : nullptr;
+    a.res = src(l.res);
+    a.dst = ws + slot * l.dst;
+    a.B = B; a.L_in = l.L_in; a.L_out = l.L_out; a.C_out = l.cout;
+    a.cin_pad = l.cin_pad; a.rs = l.rs; a.gs = l.gs;
+    if (l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH) return dispatch_tile<CONV_S1, 5, EPI_GN_MISH>(l, a, B, st);
+    if (l.mode == CONV_S1 && l.ks == 1 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 1, EPI_BIAS>(l, a, B, st);
+    if (l.mode == CONV_DOWN && l.ks == 3) return dispatch_tile_ksplit_only<CONV_DOWN, 3, EPI_BIAS>(l, a, B, st);
+    if (l.mode == CONV_UPT && l.ks == 4) return dispatch_tile_ksplit_only<CONV_UPT, 4, EPI_BIAS>(l, a, B, st);
+    return fail(MPDX_E_INVALID, "layer %s: unsupported conv (mode %d k %d epi %d)", l.name.c_str(), l.mode, l.ks, l.epi);
+}
+
+static int check_ready(const mpdx_unet* u) {
+    if (u->n_done != (int)u->params.size())
+        return fail(MPDX_E_STATE, "%d of %zu parameters packed; call mpdx_unet_pack_param for every state-dict tensor first",
+                    u->n_done, u->params.size());
+    return 0;
+}
+
+static int run_unet_body(mpdx_unet* u, const float* packed, const float* timetab, int T, const float* x, int t, int B,
+                         float* ws, hipStream_t st) {
+    if (int rc = check_ready(u)) return rc;
+    if (t < 0 || t >= T) return fail(MPDX_E_INVALID, "timestep %d outside [0,%d)", t, T);
+    if (B <= 0) return fail(MPDX_E_INVALID, "B must be positive");
+    const float* row = timetab + (size_t)t * u->tt_row;
+    for (const Layer& l : u->layers)
+        if (int rc = run_layer(u, l, packed, row, x, ws, B, st)) return rc;
+    return 0;
+}
+
+static int run_final(mpdx_unet* u, const float* packed, FinalArgs& fa, int B, float* ws, hipStream_t st) {
+    const mpdx_unet_cfg& c = u->cfg;
+    fa.h = ws + u->slot_floats * (size_t)B * u->final_slot;
+    fa.w = packed + u->params[u->pidx.at("final_conv.1.weight")].off;
+    fa.bias = packed + u->params[u->pidx.at("final_conv.1.bias")].off;
+    fa.B = B; fa.H = c.n_support_points; fa.D = c.state_dim; fa.C = c.unet_input_dim;
+    const int n = B * c.n_support_points;
+    const size_t lds = (size_t)(fa.D * fa.C + fa.D) * sizeof(float);
+    hipLaunchKernelGGL(final_step_kernel, dim3((n + 255) / 256), dim3(256), lds, st, fa);
+    return 0;
+}
+
+}  // namespace mpdx
+
+using namespace mpdx;
+
+extern "C" {
+
+const char* mpdx_last_error(void) { return g_err; }
+int mpdx_version(void) { return 1; }
+
+int mpdx_unet_create(const mpdx_unet_cfg* cfg, mpdx_unet** out) {
+    if (!cfg || !out) return fail(MPDX_E_INVALID, "null argument");
+    if (cfg->n_levels < 2 || cfg->n_levels > MPDX_MAX_LEVELS) return fail(MPDX_E_INVALID, "n_levels %d unsupported", cfg->n_levels);
+    if (cfg->state_dim < 1 || cfg->state_dim > 64) return fail(MPDX_E_INVALID, "state_dim %d unsupported", cfg->state_dim);
+    if (cfg->time_emb_dim != 32) return fail(MPDX_E_INVALID, "time_emb_dim must be 32 (TimeEncoder(32, .), temporal_unet.py:66)");
+    if (cfg->unet_input_dim % 16) return fail(MPDX_E_INVALID, "unet_input_dim must be a multiple of 16");
+    const int H = cfg->n_support_points;
+    if (H < 16 || (H & (H - 1)) || (H >> (cfg->n_levels - 1)) < 8)
+        return fail(MPDX_E_INVALID, "n_support_points %d must be a power of two with >= 8 points at the coarsest level", H);
+    mpdx_unet* u = new mpdx_unet();
+    u->cfg = *cfg;
+    build_model(u);
+    // GroupNorm regions must be 128 or 256 elements (one wave, 2 or 4 channels per lane)
+    for (const Layer& l : u->layers)
+        if (l.epi == EPI_GN_MISH) {
+            const int re = l.gs * l.L_out;
+            if ((re != 128 && re != 256) || l.gs < 4 || 32 % l.gs) {
+                std::string nm = l.name;
+                delete u;
+                return fail(MPDX_E_INVALID, "layer %s: GroupNorm region of %d elements (group of %d) unsupported", nm.c_str(), re, l.gs);
+            }
+        }
+    if ((int)u->tt_w.size() > 40) { delete u; return fail(MPDX_E_INVALID, "too many residual blocks"); }
+    *out = u;
+    return 0;
+}
+
+void mpdx_unet_destroy(mpdx_unet* u) { delete u; }
+
+int mpdx_unet_num_params(const mpdx_unet* u) { return u ? (int)u->params.size() : 0; }
+
+int mpdx_unet_param_info(const mpdx_unet* u, int idx, const char** name, int32_t shape[3], int32_t* ndim) {
+    if (!u || idx < 0 || idx >= (int)u->params.size()) return fail(MPDX_E_INVALID, "bad parameter index %d", idx);
+    const Param& p = u->params[idx];
+    if (name) *name = p.name.c_str();
+    if (shape) { shape[0] = p.shape[0]; shape[1] = p.shape[1]; shape[2] = p.shape[2]; }
+    if (ndim) *ndim = p.ndim;
+    return 0;
+}
+
+size_t mpdx_unet_packed_floats(const mpdx_unet* u) { return u ? u->packed_floats : 0; }
+size_t mpdx_unet_timetab_floats(const mpdx_unet* u, int T) { return u ? (size_t)T * u->tt_row : 0; }
+size_t mpdx_unet_workspace_floats(const mpdx_unet* u, int B) { return u ? u->slot_floats * (size_t)B * u->n_slots : 0; }
+
+int mpdx_unet_pack_param(mpdx_unet* u, const char* name, const float* src, size_t n, float* packed, void* stream) {
+    if (!u || !name || !src || !packed) return fail(MPDX_E_INVALID, "null argument");
+    auto it = u->pidx.find(name);
+    if (it == u->pidx.end()) return fail(MPDX_E_NOTFOUND, "unexpected state-dict key '%s'", name);
+    Param& p = u->params[it->second];
+    if (n != p.n) return fail(MPDX_E_INVALID, "'%s': got %zu floats, expected %zu", name, n, p.n);
+    hipStream_t st = (hipStream_t)stream;
+    if (p.kind == PK_VEC) {
+        hipLaunchKernelGGL(copy_kernel, dim3((unsigned)std::min<size_t>((p.n + 255) / 256, 1024)), dim3(256), 0, st, src, packed + p.off, p.n);
+    } else {
+        hipLaunchKernelGGL(pack_conv_weights_kernel, dim3((unsigned)std::min<size_t>((p.pn + 255) / 256, 2048)), dim3(256), 0, st, src,
+                           packed + p.off, p.cout, p.cin, p.ksz, p.cin_pad, p.nslot, p.kind == PK_CONVT ? 1 : 0);
+    }
+    HIP_TRY(hipGetLastError());
+    if (!p.done) { p.done = true; u->n_done++; }
+    return 0;
+}
+
+int mpdx_unet_build_timetab(mpdx_unet* u, const float* packed, const float* freqs16, int T, float* timetab, void* stream) {
+    if (!u || !packed || !freqs16 || !timetab || T <= 0) return fail(MPDX_E_INVALID, "bad argument");
+    if (int rc = check_ready(u)) return rc;
+    TimeTabArgs a;
+    memset(&a, 0, sizeof(a));
+    a.packed = packed; a.freqs = freqs16; a.tab = timetab;
+    a.w1 = (int)u->params[u->pidx.at("time_mlp.encoder.1.weight")].off;
+    a.b1 = (int)u->params[u->pidx.at("time_mlp.encoder.1.bias")].off;
+    a.w2 = (int)u->params[u->pidx.at("time_mlp.encoder.3.weight")].off;
+    a.b2 = (int)u->params[u->pidx.at("time_mlp.encoder.3.bias")].off;
+    a.row = u->tt_row;
+    a.nblk = (int)u->tt_w.size();
+    for (int i = 0; i < a.nblk; ++i) {
+        a.woff[i] = (int)u->params[u->tt_w[i]].off;
+        a.boff[i] = (int)u->params[u->tt_b[i]].off;
+        a.cout[i] = u->tt_cout[i];
+        a.toff[i] = u->tt_off[i];
+    }
+    hipLaunchKernelGGL(timetab_kernel, dim3(T), dim3(128), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mpdx_unet_forward(mpdx_unet* u, const float* packed, const float* timetab, int T, const float* x, int t, float* eps,
+                      int B, float* ws, void* stream) {
+    if (!u || !packed || !timetab || !x || !eps || !ws) return fail(MPDX_E_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = run_unet_body(u, packed, timetab, T, x, t, B, ws, st)) return rc;
+    FinalArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.out = eps; fa.mode = 0; fa.n_per_ctx = 1;
+    if (int rc = run_final(u, packed, fa, B, ws, st)) return rc;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mpdx_ddpm_step(mpdx_unet* u, const float* packed, const float* timetab, int T, float* x_io, const float* noise,
+                   const float* hard_start, const float* hard_goal, const mpdx_step_coefs* coefs, int t, int mean_only,
+                   float* chain_out, uint32_t* absmax_out, int n_per_ctx, int B, float* ws, void* stream) {
+    if (!u || !packed || !timetab || !x_io || !coefs || !ws) return fail(MPDX_E_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = run_unet_body(u, packed, timetab, T, x_io, t, B, ws, st)) return rc;
+    FinalArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.x_in = x_io; fa.out = x_io; fa.noise = noise; fa.hs = hard_start; fa.hg = hard_goal;
+    fa.chain = chain_out; fa.absmax = absmax_out; fa.n_per_ctx = n_per_ctx > 0 ? n_per_ctx : B;
+    fa.mode = mean_only ? 2 : 1;
+    fa.k = *coefs;
+    if (int rc = run_final(u, packed, fa, B, ws, st)) return rc;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mpdx_add_noise(float* x_io, const float* noise, const float* hard_start, const float* hard_goal, float noise_scale,
+                   float noise_std_extra, float* chain_out, int B, int H, int D, void* stream) {
+    if (!x_io || B <= 0) return fail(MPDX_E_INVALID, "bad argument");
+    const size_t n = (size_t)B * H * D;
+    hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+                       x_io, noise, hard_start, hard_goal, noise_scale, noise_std_extra, chain_out, B, H, D);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mpdx_plan(mpdx_unet* u, const float* packed, const float* timetab, int T, const mpdx_step_coefs* coefs, int n_without_noise,
+              float* x, const float* noise, const float* hard_start, const float* hard_goal, float* chain, int B, float* ws,
+              void* stream) {
+    if (!u || !packed || !timetab || !coefs || !x || !noise || !ws || T <= 0 || n_without_noise < 0 || B <= 0)
+        return fail(MPDX_E_INVALID, "bad argument");
+    if (int rc = check_ready(u)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int H = u->cfg.n_support_points, D = u->cfg.state_dim;
+    const size_t n = (size_t)B * H * D;
+    // x_T with hard conditioning; chain[0]
+    hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, x, (const float*)nullptr,
+                       hard_start, hard_goal, 0.f, 0.f, chain, B, H, D);
+    int k = 0;
+    for (int i = T - 1; i >= -n_without_noise; --i, ++k) {
+        const int t = i < 0 ? 0 : i;
+        if (int rc = run_unet_body(u, packed, timetab, T, x, t, B, ws, st)) return rc;
+        FinalArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.x_in = x; fa.out = x;
+        fa.noise = (t == 0) ? nullptr : noise + (size_t)k * n;   // noise[t == 0] = 0  (sample_functions.py:52)
+        fa.hs = hard_start; fa.hg = hard_goal;
+        fa.chain = chain ? chain + (size_t)(k + 1) * n : nullptr;
+        fa.n_per_ctx = B;
+        fa.mode = 1;
+        fa.k = coefs[t];
+        if (int rc = run_final(u, packed, fa, B, ws, st)) return rc;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mpdx_unet_profile(mpdx_unet* u, const float* packed, const float* timetab, int T, const float* x, int t, int B, float* ws,
+                      void* stream, int cap, float* ms_out, double* flops_out, const char** names_out, int* n_out) {
+    if (!u || !packed || !timetab || !x || !ws || !ms_out || !n_out) return fail(MPDX_E_INVALID, "null argument");
+    if (int rc = check_ready(u)) return rc;
+    if (t < 0 || t >= T) return fail(MPDX_E_INVALID, "timestep %d outside [0,%d)", t, T);
+    hipStream_t st = (hipStream_t)stream;
+    const int nl = (int)u->layers.size() + 1;
+    if (cap < nl) return fail(MPDX_E_INVALID, "need room for %d launches", nl);
+    std::vector<hipEvent_t> ev(2 * nl);
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    const float* row = timetab + (size_t)t * u->tt_row;
+    int rc = 0;
+    for (int i = 0; i < nl - 1 && !rc; ++i) {
+        HIP_TRY(hipEventRecord(ev[2 * i], st));
+        rc = run_layer(u, u->layers[i], packed, row, x, ws, B, st);
+        HIP_TRY(hipEventRecord(ev[2 * i + 1], st));
+        if (flops_out) flops_out[i] = layer_flops(u->layers[i], B);
+        if (names_out) names_out[i] = u->layers[i].name.c_str();
+    }
+    if (!rc) {
+        static float* scratch = nullptr;  // eps sink owned by the library (measurement helper only)
+        static size_t scratch_n = 0;
+        const size_t need = (size_t)B * u->cfg.n_support_points * u->cfg.state_dim;
+        if (scratch_n < need) { if (scratch) (void)hipFree(scratch); HIP_TRY(hipMalloc(&scratch, need * sizeof(float))); scratch_n = need; }
+        FinalArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.out = scratch; fa.mode = 0; fa.n_per_ctx = 1;
+        HIP_TRY(hipEventRecord(ev[2 * (nl - 1)], st));
+        rc = run_final(u, packed, fa, B, ws, st);
+        HIP_TRY(hipEventRecord(ev[2 * (nl - 1) + 1], st));
+        if (flops_out) flops_out[nl - 1] = 0.0;
+        if (names_out) names_out[nl - 1] = "final_conv.1+ddpm_step";
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < nl && !rc; ++i) HIP_TRY(hipEventElapsedTime(&ms_out[i], ev[2 * i], ev[2 * i + 1]));
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    *n_out = nl;
+    return rc;
+}
+
+int mpdx_unet_layer_tile(const mpdx_unet* u, int i, int B, char* buf, size_t buflen) {
+    if (!u || !buf || i < 0 || i >= (int)u->layers.size()) return fail(MPDX_E_INVALID, "bad layer index");
+    const Layer& l = u->layers[i];
+    int MT, NT;
+    choose_tile(l, B, MT, NT);
+    if (l.cout % MT) MT = 16;
+    const bool ks = layer_ksplit(l);
+    snprintf(buf, buflen, "%dx%d/%dx%d", MT, NT, ks ? 1 : NT / 16, ks ? 8 : 8 / (NT / 16));
+    return 0;
+}
+
+int mpdx_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
+    if (!out) return fail(MPDX_E_INVALID, "null argument");
+    if (n == 0) return 0;
+    const size_t nquad = (n + 3) / 4;
+    hipLaunchKernelGGL(randn_kernel, dim3((unsigned)std::min<size_t>((nquad + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, out, n,
+                       seed, offset);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,211 @@
+"""GaussianDiffusionModel - drop-in for mpd.models.diffusion_models.diffusion_model_base.GaussianDiffusionModel
+(diffusion_model_base.py:46-316): same constructor, same registered buffers (state-dict compatible), same
+``run_inference / conditional_sample / p_sample_loop / p_mean_variance / warmup`` protocol.
+
+The sampling half runs on libmpdx.so.  The training half (q_sample / p_losses / loss, :320-357) and ddim_sample
+(:184-259) are outside the hot path this package accelerates: signatures are kept and
+raise NotImplementedError.
+"""
+from __future__ import annotations
+
+from copy import copy
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .sample_functions import apply_hard_conditioning, ddpm_sample_fn, extract, step_coefs
+from .schedules import diffusion_buffers
+
+
+def make_timesteps(batch_size, i, device):
+    return torch.full((batch_size,), i, device=device, dtype=torch.long)
+
+
+class GaussianDiffusionModel(nn.Module):
+    def __init__(self, model=None, variance_schedule="exponential", n_diffusion_steps=100, clip_denoised=True,
+                 predict_epsilon=False, loss_type="l2", context_model=None, **kwargs):
+        super().__init__()
+        self.model = model
+        self.context_model = context_model
+        self.n_diffusion_steps = n_diffusion_steps
+        self.state_dim = self.model.state_dim
+        self.clip_denoised = clip_denoised
+        self.predict_epsilon = predict_epsilon
+        self.loss_type = loss_type
+        for name, value in diffusion_buffers(variance_schedule, n_diffusion_steps).items():
+            self.register_buffer(name, value)
+        self._host = None
+        self._host_stamp = None
+        self._coef_cache = {}
+        self._rng_seed = 0
+        self._rng_offset = 0
+
+    # ---------------------------------------------------------------------------------------------- helpers
+    def host_buffers(self):
+        """CPU copies of the schedule buffers (scalars are passed to the kernels by value)."""
+        stamp = tuple((b.data_ptr(), b._version) for b in self.buffers())
+        if self._host is None or self._host_stamp != stamp:
+            host = {k: v.detach().to("cpu", torch.float32) for k, v in self.named_buffers() if "." not in k}
+            # model_std = exp(0.5 * posterior_log_variance_clipped[t])  (sample_functions.py:35-36), fp32 like the reference
+            host["noise_scale"] = torch.exp(0.5 * host["posterior_log_variance_clipped"])
+            self._host = {k: v.numpy() for k, v in host.items()}
+            self._host_stamp = stamp
+            self._coef_cache = {}
+        return self._host
+
+    def manual_seed(self, seed: int):
+        """Seed of the device noise generator (Philox counter stream of mpdx_randn)."""
+        self._rng_seed, self._rng_offset = int(seed), 0
+        return self
+
+    def fill_randn(self, out: torch.Tensor):
+        n = out.numel()
+        _lib.check(_lib.load().mpdx_randn(out.data_ptr(), n, self._rng_seed, self._rng_offset, _lib.current_stream()), "mpdx_randn")
+        self._rng_offset += (n + 3) // 4
+        return out
+
+    # ---------------------------------------------------------------------------------------------- fused loop
+    def _coef_table(self, noise_std_extra_schedule_fn):
+        """ctypes array [T] of mpdx_step_coefs, cached per (schedule buffers, extra-noise schedule values)."""
+        T = self.n_diffusion_steps
+        self.host_buffers()
+        extras = tuple(1.0 if noise_std_extra_schedule_fn is None else float(noise_std_extra_schedule_fn(t)) for t in range(T))
+        arr = self._coef_cache.get(extras)
+        if arr is None:
+            arr = (_lib.StepCoefs * T)()
+            for t in range(T):
+                arr[t] = step_coefs(self, t, extras[t])
+            self._coef_cache[extras] = arr
+        return arr
+
+    @torch.no_grad()
+    def plan(self, hard_conds, n_samples, horizon=None, n_diffusion_steps_without_noise=0, noise=None,
+             noise_std_extra_schedule_fn=None, return_chain=True):
+        """The whole reverse loop of p_sample_loop (diffusion_model_base.py:157-182) enqueued by ONE mpdx_plan call,
+        without host synchronisation.  hard_conds: {0: start[B,D] or [D], H-1: goal}.  Returns (x_final, chain or None)
+        with chain laid out [steps+1, B, H, D] (run_inference's order)."""
+        H = horizon or self.model.n_support_points
+        D, T, n0, B = self.state_dim, self.n_diffusion_steps, int(n_diffusion_steps_without_noise), int(n_samples)
+        dev = self.betas.device
+        if set(hard_conds.keys()) - {0, H - 1}:
+            raise NotImplementedError("fused plan supports hard conditions at horizon indices 0 and H-1 only")
+
+        def cond(v):
+            if v is None:
+                return None
+            v = v.to(device=dev, dtype=torch.float32)
+            return (v.reshape(1, -1).expand(B, -1) if v.dim() == 1 else v).contiguous()
+
+        hs, hg = cond(hard_conds.get(0)), cond(hard_conds.get(H - 1))
+        hdl, packed, tab, ws = self.model.engine(T, B)
+        steps = T + n0
+        if noise is None:
+            noise = self.fill_randn(torch.empty((steps + 1, B, H, D), device=dev, dtype=torch.float32))
+        else:
+            noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+            assert tuple(noise.shape) == (steps + 1, B, H, D), noise.shape
+        coefs = self._coef_table(noise_std_extra_schedule_fn)
+        x = noise[0].clone()
+        chain = torch.empty((steps + 1, B, H, D), device=dev, dtype=torch.float32) if return_chain else None
+        _lib.check(_lib.load().mpdx_plan(hdl, packed.data_ptr(), tab.data_ptr(), self.model._timetab_T, coefs, n0,
+                                         x.data_ptr(), noise[1:].data_ptr(), _lib.ptr(hs), _lib.ptr(hg), _lib.ptr(chain), B,
+                                         ws.data_ptr(), _lib.current_stream()), "mpdx_plan")
+        return x, chain
+
+    # ---------------------------------------------------------------------------------------------- sampling
+    def p_mean_variance(self, x, hard_conds, context, t):
+        """(model_mean, posterior_variance, posterior_log_variance) as diffusion_model_base.py:143-155."""
+        if context is not None:
+            raise NotImplementedError("context is always None on this path")
+        if not self.clip_denoised:
+            raise RuntimeError("clip_denoised=False is an error in the reference too (:152)")
+        tt = int(t.reshape(-1)[0])
+        B = x.shape[0]
+        hdl, packed, tab, ws = self.model.engine(self.n_diffusion_steps, B)
+        mean = x.to(torch.float32).contiguous().clone()
+        _lib.check(_lib.load().mpdx_ddpm_step(hdl, packed.data_ptr(), tab.data_ptr(), self.model._timetab_T, mean.data_ptr(), None,
+                                              None, None, step_coefs(self, tt), tt, 1, None, None, B, B, ws.data_ptr(),
+                                              _lib.current_stream()), "mpdx_ddpm_step")
+        return mean, extract(self.posterior_variance, t, x.shape), extract(self.posterior_log_variance_clipped, t, x.shape)
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, hard_conds, context=None, return_chain=False, sample_fn=ddpm_sample_fn,
+                      n_diffusion_steps_without_noise=0, noise=None, **sample_kwargs):
+        """diffusion_model_base.py:157-182.  ``noise`` ([steps+1, B, H, D], optional) injects the random stream."""
+        device = self.betas.device
+        batch_size = shape[0]
+        if noise is not None:
+            x = noise[0].to(device=device, dtype=torch.float32).clone()
+        else:
+            x = self.fill_randn(torch.empty(shape, device=device, dtype=torch.float32))
+        x = apply_hard_conditioning(x, hard_conds)
+        chain = [x] if return_chain else None
+        k = 1
+        for i in reversed(range(-n_diffusion_steps_without_noise, self.n_diffusion_steps)):
+            t = make_timesteps(batch_size, i, device)
+            if noise is not None:
+                sample_kwargs["noise"] = noise[k]
+            x, values = sample_fn(self, x, hard_conds, context, t, **sample_kwargs)
+            x = apply_hard_conditioning(x, hard_conds)
+            if return_chain:
+                chain.append(x)
+            k += 1
+        if return_chain:
+            return x, torch.stack(chain, dim=1)
+        return x
+
+    @torch.no_grad()
+    def ddim_sample(self, shape, hard_conds, **kwargs):
+        raise NotImplementedError("ddim_sample (diffusion_model_base.py:184-259) is outside the accelerated hot path (SURVEY.md 8f-1)")
+
+    @torch.no_grad()
+    def conditional_sample(self, hard_conds, horizon=None, batch_size=1, ddim=False, **sample_kwargs):
+        horizon = horizon or self.horizon
+        shape = (batch_size, horizon, self.state_dim)
+        if ddim:
+            return self.ddim_sample(shape, hard_conds, **sample_kwargs)
+        return self.p_sample_loop(shape, hard_conds, **sample_kwargs)
+
+    def forward(self, cond, *args, **kwargs):
+        raise NotImplementedError  # as diffusion_model_base.py:274-276
+
+    @torch.no_grad()
+    def warmup(self, horizon=64, device="cuda"):
+        x = torch.randn((2, horizon, self.state_dim), device=device)
+        self.model(x, make_timesteps(2, 1, device), context=None)
+
+    @torch.no_grad()
+    def run_inference(self, context=None, hard_conds=None, n_samples=1, return_chain=False, **diffusion_kwargs):
+        """diffusion_model_base.py:285-316: returns the chain [steps+1, n_samples, H, D] (or its last element)."""
+        hard_conds = copy(hard_conds)
+        if context is not None:
+            raise NotImplementedError("context is always None on this path (inference.py:182)")
+        kw = dict(diffusion_kwargs)
+        horizon = kw.pop("horizon", None)
+        fused = diffusion_kwargs.pop("fused", True)  # extension: fused=False forces the step-by-step protocol loop
+        kw.pop("fused", None)
+        if fused and kw.pop("sample_fn", ddpm_sample_fn) is ddpm_sample_fn and kw.get("guide") is None and not kw.get("ddim", False) \
+                and not kw.get("scale_grad_by_std", False) and set(hard_conds.keys()) <= {0, (horizon or self.model.n_support_points) - 1}:
+            # fused path: one mpdx_plan call for the whole loop
+            x, chain = self.plan(hard_conds, n_samples, horizon, kw.get("n_diffusion_steps_without_noise", 0), kw.get("noise"),
+                                 kw.get("noise_std_extra_schedule_fn"), return_chain=True)
+            return chain if return_chain else chain[-1]
+        for k, v in hard_conds.items():
+            hard_conds[k] = v.reshape(1, -1).expand(n_samples, -1).contiguous()  # 'd -> b d'
+        samples, chain = self.conditional_sample(hard_conds, context=None, batch_size=n_samples, return_chain=True,
+                                                 **diffusion_kwargs)
+        chain = chain.permute(1, 0, 2, 3)  # 'b diffsteps h d -> diffsteps b h d'
+        if return_chain:
+            return chain
+        return chain[-1]
+
+    # ---------------------------------------------------------------------------------------------- training (out of scope)
+    def q_sample(self, x_start, t, noise=None):
+        raise NotImplementedError("training path (diffusion_model_base.py:320-357) is out of scope of mpd_public_amd")
+
+    def p_losses(self, x_start, context, t, hard_conds):
+        raise NotImplementedError("training path (diffusion_model_base.py:320-357) is out of scope of mpd_public_amd")
+
+    def loss(self, x, context, *args):
+        raise NotImplementedError("training path (diffusion_model_base.py:320-357) is out of scope of mpd_public_amd")

@@ -1,0 +1,93 @@
+"""Drop-ins for mpd.models.diffusion_models.sample_functions (sample_functions.py:5-83).
+
+Same names, arguments and return values; the arithmetic runs in libmpdx.so:
+``ddpm_sample_fn`` = U-Net forward + posterior step (one mpdx_ddpm_step call), optional guide steps, noise.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+
+
+def apply_hard_conditioning(x, conditions):
+    """x[:, t, :] = val for every (t, val) (in place, as sample_functions.py:5-8)."""
+    H = x.shape[1]
+    keys = set(conditions.keys())
+    if x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and keys <= {0, H - 1} and \
+            all(v.is_cuda and v.shape == (x.shape[0], x.shape[2]) for v in conditions.values()):
+        hs = conditions.get(0)
+        hg = conditions.get(H - 1)
+        hs = hs.contiguous().float() if hs is not None else None
+        hg = hg.contiguous().float() if hg is not None else None
+        _lib.check(_lib.load().mpdx_add_noise(x.data_ptr(), None, _lib.ptr(hs), _lib.ptr(hg), 0.0, 0.0, None,
+                                              x.shape[0], H, x.shape[2], _lib.current_stream()), "mpdx_add_noise")
+        return x
+    for t, val in conditions.items():  # exotic conditioning indices: plain indexed writes
+        x[:, t, :] = val.clone()
+    return x
+
+
+def extract(a, t, x_shape):
+    b, *_ = t.shape
+    out = a.gather(-1, t)
+    return out.reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+def step_coefs(model, t: int, noise_std_extra: float = 1.0) -> "_lib.StepCoefs":
+    """The t-th entries of the model's registered buffers as the scalar block mpdx_ddpm_step takes."""
+    c = model.host_buffers()
+    scale = 0.0 if t == 0 else float(c["noise_scale"][t])  # noise[t == 0] = 0  (sample_functions.py:52)
+    return _lib.StepCoefs(float(c["sqrt_recip_alphas_cumprod"][t]), float(c["sqrt_recipm1_alphas_cumprod"][t]),
+                          float(c["posterior_mean_coef1"][t]), float(c["posterior_mean_coef2"][t]), scale,
+                          float(noise_std_extra), int(bool(model.predict_epsilon)), int(bool(model.clip_denoised)))
+
+
+@torch.no_grad()
+def ddpm_sample_fn(model, x, hard_conds, context, t, guide=None, n_guide_steps=1, scale_grad_by_std=False,
+                   t_start_guide=torch.inf, noise_std_extra_schedule_fn=None, debug=False, noise=None, **kwargs):
+    """One reverse step (sample_functions.py:17-62).  Returns (x_next, None); hard conditioning is applied by the
+    caller afterwards, as p_sample_loop does (diffusion_model_base.py:173).  ``noise`` (optional) injects the
+    randn_like draw for parity runs."""
+    if context is not None:
+        raise NotImplementedError("context is always None on this path (inference.py:182)")
+    t_single = int(t.reshape(-1)[0])  # host sync, as the reference's `if t_single < 0`
+    tt = max(t_single, 0)
+    B, H, D = x.shape
+    x = x.to(torch.float32).contiguous()
+    lib = _lib.load()
+    hdl, packed, tab, ws = model.model.engine(model.n_diffusion_steps, B)
+    extra = 1.0 if noise_std_extra_schedule_fn is None else float(noise_std_extra_schedule_fn(t_single))
+    coefs = step_coefs(model, tt, extra)
+    if noise is None and tt != 0:
+        noise = torch.empty_like(x)
+        model.fill_randn(noise)
+    st = _lib.current_stream()
+    use_guide = guide is not None and t_single < t_start_guide
+    nz = _lib.ptr(noise) if tt != 0 else None
+    out = x.clone()
+    _lib.check(lib.mpdx_ddpm_step(hdl, packed.data_ptr(), tab.data_ptr(), model.model._timetab_T, out.data_ptr(),
+                                  None if use_guide else nz, None, None, coefs, tt, 1 if use_guide else 0, None, None, B, B,
+                                  ws.data_ptr(), st), "mpdx_ddpm_step")
+    if use_guide:
+        model_var = None
+        if scale_grad_by_std:
+            model_var = torch.exp(extract(model.posterior_log_variance_clipped, torch.full((B,), tt, device=x.device, dtype=torch.long), x.shape))
+        out = guide_gradient_steps(out, hard_conds=hard_conds, guide=guide, n_guide_steps=n_guide_steps,
+                                   scale_grad_by_std=scale_grad_by_std, model_var=model_var)
+        _lib.check(lib.mpdx_add_noise(out.data_ptr(), nz, None, None, coefs.noise_scale, extra, None, B, H, D, st), "mpdx_add_noise")
+    return out, None
+
+
+def guide_gradient_steps(x, hard_conds=None, guide=None, n_guide_steps=1, scale_grad_by_std=False, model_var=None,
+                         debug=False, **kwargs):
+    """sample_functions.py:65-83."""
+    for _ in range(n_guide_steps):
+        grad_scaled = guide(x)
+        if scale_grad_by_std:
+            grad_scaled = model_var * grad_scaled
+        x = x + grad_scaled
+        x = apply_hard_conditioning(x, hard_conds)
+    return x

@@ -73,9 +73,10 @@ def p_sample_loop(buf: dict, sd: dict, hard_conds: dict, noise: torch.Tensor, T:
 
 
 def run_inference(sd: dict, hard_conds: dict, noise: torch.Tensor, T: int, variance_schedule: str = "exponential",
-                  n_diffusion_steps_without_noise: int = 0, **kw) -> torch.Tensor:
-    """diffusion_model_base.py:285-316: hard conds 'd -> b d', full chain [steps+1, B, H, D]."""
-    buf = _sched.make_buffers(T, variance_schedule)
+                  n_diffusion_steps_without_noise: int = 0, dtype=torch.float32, **kw) -> torch.Tensor:
+    """diffusion_model_base.py:285-316: hard conds 'd -> b d', full chain [steps+1, B, H, D].
+    dtype=float64 evaluates the same algorithm (same fp32 schedule buffers) in double: the rounding-free yardstick."""
+    buf = {k: v.to(dtype) for k, v in _sched.make_buffers(T, variance_schedule).items()}
     B = noise.shape[1]
     hc = {k: (v[None, :].expand(B, -1).clone() if v.dim() == 1 else v.clone()) for k, v in hard_conds.items()}
     return p_sample_loop(buf, sd, hc, noise, T, n_diffusion_steps_without_noise, **kw)

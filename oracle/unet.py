@@ -30,9 +30,13 @@ def sinusoidal_pos_emb(t: torch.Tensor, dim: int = 32) -> torch.Tensor:
     return torch.cat((e.sin(), e.cos()), dim=-1)
 
 
+def _cast(sd: dict, e: torch.Tensor) -> torch.Tensor:
+    return e.to(next(iter(sd.values())).dtype)
+
+
 def time_embedding(sd: dict, t: torch.Tensor) -> torch.Tensor:
     # layers.py:229-240: SinusoidalPosEmb(32) -> Linear(32,128) -> Mish -> Linear(128,32)
-    e = sinusoidal_pos_emb(t, 32)
+    e = _cast(sd, sinusoidal_pos_emb(t, 32))
     e = F.linear(e, sd["time_mlp.encoder.1.weight"], sd["time_mlp.encoder.1.bias"])
     e = F.mish(e)
     return F.linear(e, sd["time_mlp.encoder.3.weight"], sd["time_mlp.encoder.3.bias"])
