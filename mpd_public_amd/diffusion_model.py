@@ -108,7 +108,8 @@ class GaussianDiffusionModel(nn.Module):
         coefs = self._coef_table(noise_std_extra_schedule_fn)
         x = noise[0].clone()
         chain = torch.empty((steps + 1, B, H, D), device=dev, dtype=torch.float32) if return_chain else None
-        _lib.check(_lib.load().mpdx_plan(hdl, packed.data_ptr(), tab.data_ptr(), self.model._timetab_T, coefs, n0,
+        # T here is the LOOP length / coefficient-table length (not the time-table capacity)
+        _lib.check(_lib.load().mpdx_plan(hdl, packed.data_ptr(), tab.data_ptr(), T, coefs, n0,
                                          x.data_ptr(), noise[1:].data_ptr(), _lib.ptr(hs), _lib.ptr(hg), _lib.ptr(chain), B,
                                          ws.data_ptr(), _lib.current_stream()), "mpdx_plan")
         return x, chain
