@@ -124,6 +124,10 @@ int mpdx_plan(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, i
 int mpdx_unet_profile(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, int T, const float* x, int t,
                       int B, float* ws, void* stream, int cap, float* ms_out, double* flops_out,
                       const char** names_out, int* n_out);
+/* `reps` back-to-back launches of layer `layer` between two events; dbg = ablation mask (1 skip staging, 2 skip
+ * MFMA loop, 4 skip epilogue, 8 skip weight loads); synchronises. */
+int mpdx_bench_layer(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, const float* x, int layer, int B,
+                     float* ws, void* stream, int reps, int dbg, float* ms_per_launch);
 /* tile the dispatcher picks for launch i at batch B: writes "MTxNT/WNxWK" into buf */
 int mpdx_unet_layer_tile(const mpdx_unet* u, int i, int B, char* buf, size_t buflen);
 

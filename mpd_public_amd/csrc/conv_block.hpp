@@ -50,6 +50,7 @@ struct ConvArgs {
     int rs;              // LDS row stride in floats (cin_pad + bank pad)
     int gs;              // GroupNorm channels per group
     int n_tiles_n;       // ceil(B*L_out / NT)
+    int dbg;             // ablation mask for mpdx_bench_layer: 1 skip staging, 2 skip MFMA loop, 4 skip epilogue
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_block_kernel(const ConvArgs
     constexpr int MS = MT / 16, NSUB = NT / 16, NSW = NSUB / WN;
     constexpr int PAD = G::PAD, NTAP = G::NTAP, NSLOT = G::NSLOT;
     constexpr int MTP = MT + 4;  // padded row of the reduction buffer (conflict-free ds_write_b128)
+    constexpr int MTP4 = MTP / 4;
     static_assert(NSUB % WN == 0, "N split");
     static_assert(MODE != CONV_UPT || (NSW % 2 == 0), "transposed conv pairs even/odd sub-tiles");
 
@@ -101,35 +103,75 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_block_kernel(const ConvArgs
     const int spt = NT / L_out;  // trajectories per tile
     const int s0 = nt * spt;
     const int LP = L_in + 2 * PAD;
-    const int RS = a.rs;
+    const int RS4 = a.rs >> 2;  // LDS row stride in float4 units (all LDS indexing is in 16-B units: provably aligned)
+    f32x4* const smem4 = (f32x4*)smem;
     const int cin = a.c1 + a.c2;
     const int c4n = a.cin_pad >> 2;
 
+    // ------------------------------------------------------------------ weight prefetch (independent of LDS)
+    // Each wave owns k-groups wk, wk+WK, ...; their A fragments are streamed from L2/HBM through a PF-deep register
+    // ring so that the ~1-2 us load latency is paid once per kernel, under the staging phase, not once per iteration.
+    constexpr int NCLS = (MODE == CONV_UPT) ? 2 : 1;
+    constexpr int PF = 4;
+    const int nc16 = a.cin_pad >> 4;
+    const int ngroups = nc16 * NTAP;
+    const float* wbase = a.wp + (size_t)(mt * MS) * nc16 * NSLOT * 256 + lane * 4;
+    f32x4 af[PF][MS][NCLS];
+    auto load_a = [&](int g, f32x4 (&dst)[MS][NCLS]) {
+        const int c16 = g / NTAP, ts = g - c16 * NTAP;
+#pragma unroll
+        for (int m = 0; m < MS; ++m)
+#pragma unroll
+            for (int p = 0; p < NCLS; ++p) {
+                const int slot = (MODE == CONV_UPT) ? (p * 2 + ts) : ts;
+                dst[m][p] = *(const f32x4*)(wbase + ((size_t)(m * nc16 + c16) * NSLOT + slot) * 256);
+            }
+    };
+    const int niter = (ngroups + WK - 1) / WK;  // uniform over the workgroup's waves
+    // ring loads are UNCONDITIONAL (index clamped to a valid k-group) so that the compiler can count them:
+    // the wait in front of ring slot u is then a counted vmcnt((PF-1)*MS*NCLS), never vmcnt(0).
+    auto ring_g = [&](int it) { const int g = wk + it * WK; return g < ngroups ? g : ngroups - 1; };
+#pragma unroll
+    for (int u = 0; u < PF; ++u) load_a(ring_g(u), af[u]);
+
     // ------------------------------------------------------------------ stage the horizon windows (+halo) into LDS
-    {
+    if (!(a.dbg & 1)) {
         const int rows = spt * LP;
         const int total = rows * c4n;
         const bool vec_ok = ((a.c1 & 3) == 0) && ((a.c2 & 3) == 0);
-        for (int idx = tid; idx < total; idx += NTHR) {
-            const int row = idx / c4n, c = (idx - row * c4n) << 2;
-            const int s = row / LP, lp = row - s * LP;
-            const int li = lp - PAD, b = s0 + s;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (li >= 0 && li < L_in && b < a.B && c < cin) {
-                const size_t pos = (size_t)b * L_in + li;
-                if (vec_ok) {
-                    v = (c < a.c1) ? *(const f32x4*)(a.src1 + pos * a.c1 + c)
-                                   : *(const f32x4*)(a.src2 + pos * a.c2 + (c - a.c1));
-                } else {
+        constexpr int SB = 4;  // loads in flight per thread
+        for (int base = tid; base < total; base += NTHR * SB) {
+            f32x4 v[SB];
+            int dsto[SB];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int ce = c + e;
-                        if (ce < a.c1) v[e] = a.src1[pos * a.c1 + ce];
-                        else if (ce < cin) v[e] = a.src2[pos * a.c2 + (ce - a.c1)];
+            for (int u = 0; u < SB; ++u) {
+                const int idx = base + u * NTHR;
+                v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dsto[u] = -1;
+                if (idx < total) {
+                    const int row = idx / c4n, c = (idx - row * c4n) << 2;
+                    const int s = row / LP, lp = row - s * LP;
+                    const int li = lp - PAD, b = s0 + s;
+                    dsto[u] = row * RS4 + (c >> 2);
+                    if (li >= 0 && li < L_in && b < a.B && c < cin) {
+                        const size_t pos = (size_t)b * L_in + li;
+                        if (vec_ok) {
+                            v[u] = (c < a.c1) ? *(const f32x4*)(a.src1 + pos * a.c1 + c)
+                                              : *(const f32x4*)(a.src2 + pos * a.c2 + (c - a.c1));
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int ce = c + e;
+                                if (ce < a.c1) v[u][e] = a.src1[pos * a.c1 + ce];
+                                else if (ce < cin) v[u][e] = a.src2[pos * a.c2 + (ce - a.c1)];
+                            }
+                        }
                     }
                 }
             }
-            *(f32x4*)(smem + row * RS + c) = v;
+#pragma unroll
+            for (int u = 0; u < SB; ++u)
+                if (dsto[u] >= 0) smem4[dsto[u]] = v[u];
         }
     }
     __syncthreads();
@@ -144,13 +186,13 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_block_kernel(const ConvArgs
         if (MODE == CONV_UPT) {
             const int gm = (ns >> 1) * 16 + j;          // global input index within the tile
             const int s = gm / L_in, m = gm - s * L_in;
-            boff[i] = (s * LP + m + PAD) * RS + q * 4;  // row of input m (tap row offsets added below)
+            boff[i] = (s * LP + m + PAD) * RS4 + q;  // row of input m (tap row offsets added below), float4 units
             npos[i] = s * L_out + 2 * m + (ns & 1);
         } else {
             const int n = ns * 16 + j;
             const int s = n / L_out, l = n - s * L_out;
             const int r0 = (MODE == CONV_DOWN) ? 2 * l : l;
-            boff[i] = (s * LP + r0) * RS + q * 4;
+            boff[i] = (s * LP + r0) * RS4 + q;
             npos[i] = n;
         }
     }
@@ -161,34 +203,28 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_block_kernel(const ConvArgs
 #pragma unroll
         for (int i = 0; i < NSW; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nc16 = a.cin_pad >> 4;
-    const int ngroups = nc16 * NTAP;
-    const float* wbase = a.wp + (size_t)(mt * MS) * nc16 * NSLOT * 256 + lane * 4;
-    constexpr int NCLS = (MODE == CONV_UPT) ? 2 : 1;
-
-    for (int g = wk; g < ngroups; g += WK) {
-        const int c16 = g / NTAP, ts = g - c16 * NTAP;
-        f32x4 af[MS][NCLS];
+    for (int it0 = 0; it0 < niter && !(a.dbg & 2); it0 += PF) {
 #pragma unroll
-        for (int m = 0; m < MS; ++m)
+        for (int u = 0; u < PF; ++u) {
+            const int g = wk + (it0 + u) * WK;
+            if (g < ngroups) {  // wave-uniform; only LDS reads + MFMAs are conditional
+                const int c16 = g / NTAP, ts = g - c16 * NTAP;
 #pragma unroll
-            for (int p = 0; p < NCLS; ++p) {
-                const int slot = (MODE == CONV_UPT) ? (p * 2 + ts) : ts;
-                af[m][p] = *(const f32x4*)(wbase + ((size_t)(m * nc16 + c16) * NSLOT + slot) * 256);
+                for (int i = 0; i < NSW; ++i) {
+                    const int p = (MODE == CONV_UPT) ? (i & 1) : 0;
+                    // row offset of this tap in the staged (zero-haloed) window:
+                    //   conv/down: staged row (l*stride + tap) holds true index l*stride + tap - PAD;
+                    //   convT:     boff already points at input m; even outputs use (m, m-1), odd outputs (m, m+1).
+                    const int roff = (MODE == CONV_UPT) ? ((ts == 0) ? 0 : (p == 0 ? -1 : 1)) : ts;
+                    const f32x4 bf = smem4[boff[i] + roff * RS4 + c16 * 4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int m = 0; m < MS; ++m)
+                            acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][m][p][e], bf[e], acc[m][i], 0, 0, 0);
+                }
             }
-#pragma unroll
-        for (int i = 0; i < NSW; ++i) {
-            const int p = (MODE == CONV_UPT) ? (i & 1) : 0;
-            // row offset of this tap in the staged (zero-haloed) window:
-            //   conv/down: staged row (l*stride + tap) holds true index l*stride + tap - PAD;
-            //   convT:     boff already points at input m; even outputs use (m, m-1), odd outputs (m, m+1).
-            const int roff = (MODE == CONV_UPT) ? ((ts == 0) ? 0 : (p == 0 ? -1 : 1)) : ts;
-            const f32x4 bf = *(const f32x4*)(smem + boff[i] + roff * RS + c16 * 16);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int m = 0; m < MS; ++m)
-                    acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][p][e], bf[e], acc[m][i], 0, 0, 0);
+            load_a(ring_g(it0 + u + PF), af[u]);  // refill this ring slot (unconditional, clamped)
         }
     }
 
@@ -199,10 +235,14 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_block_kernel(const ConvArgs
     for (int m = 0; m < MS; ++m)
 #pragma unroll
         for (int i = 0; i < NSW; ++i)
-            *(f32x4*)(red + ((size_t)(wk * NT + npos[i]) * MTP + m * 16 + q * 4)) = acc[m][i];
+            smem4[(wk * NT + npos[i]) * MTP4 + m * 4 + q] = acc[m][i];
     __syncthreads();
 
     // ------------------------------------------------------------------ epilogue
+    if (a.dbg & 4) {
+        if (tid == 0 && red[0] == 123.456f) a.dst[0] = red[1];
+        return;
+    }
     if (EPI == EPI_GN_MISH) {
         const int gs = a.gs;
         const int gpt = MT / gs;           // groups per tile
@@ -216,46 +256,52 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_block_kernel(const ConvArgs
                 const int e0 = lane * 4;
                 const int l = e0 / gs, c = gl * gs + (e0 - l * gs);
                 const int n = s * L_out + l, co = mt * MT + c;
-                f32x4 v = *(const f32x4*)(red + (size_t)n * MTP + c);
+                // issue the epilogue's global operands first: their latency hides under the LDS reduction + statistics
+                const size_t o = ((size_t)(b < a.B ? b : 0) * L_out + l) * a.C_out + co;
+                const f32x4 bi = *(const f32x4*)(a.bias + co);
+                const f32x4 ga = *(const f32x4*)(a.gamma + co), be = *(const f32x4*)(a.beta + co);
+                f32x4 tb = {0.f, 0.f, 0.f, 0.f}, rs4 = {0.f, 0.f, 0.f, 0.f};
+                if (a.tbias) tb = *(const f32x4*)(a.tbias + co);
+                if (a.res) rs4 = *(const f32x4*)(a.res + o);
+                const int ri = n * MTP4 + (c >> 2);  // gs % 4 == 0 -> c % 4 == 0
+                f32x4 v = smem4[ri];
 #pragma unroll
-                for (int k = 1; k < WK; ++k) v += *(const f32x4*)(red + ((size_t)(k * NT + n)) * MTP + c);
-                v += *(const f32x4*)(a.bias + co);
+                for (int k = 1; k < WK; ++k) v += smem4[ri + k * NT * MTP4];
+                v += bi;
                 const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * inv_re;
                 const f32x4 d = v - mean;
                 const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * inv_re;
                 const float rstd = 1.0f / sqrtf(var + 1e-5f);
-                const f32x4 ga = *(const f32x4*)(a.gamma + co), be = *(const f32x4*)(a.beta + co);
                 f32x4 y;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = mish(d[e] * rstd * ga[e] + be[e]);
-                if (a.tbias) y += *(const f32x4*)(a.tbias + co);
-                if (b < a.B) {
-                    const size_t o = ((size_t)b * L_out + l) * a.C_out + co;
-                    if (a.res) y += *(const f32x4*)(a.res + o);
-                    *(f32x4*)(a.dst + o) = y;
-                }
+                y += tb;
+                y += rs4;
+                if (b < a.B) *(f32x4*)(a.dst + o) = y;
             } else {  // re == 128
                 const int e0 = lane * 2;
                 const int l = e0 / gs, c = gl * gs + (e0 - l * gs);
                 const int n = s * L_out + l, co = mt * MT + c;
+                const size_t o = ((size_t)(b < a.B ? b : 0) * L_out + l) * a.C_out + co;
+                const f32x2 bi = *(const f32x2*)(a.bias + co);
+                const f32x2 ga = *(const f32x2*)(a.gamma + co), be = *(const f32x2*)(a.beta + co);
+                f32x2 tb = {0.f, 0.f}, rs2 = {0.f, 0.f};
+                if (a.tbias) tb = *(const f32x2*)(a.tbias + co);
+                if (a.res) rs2 = *(const f32x2*)(a.res + o);
                 f32x2 v = *(const f32x2*)(red + (size_t)n * MTP + c);
 #pragma unroll
                 for (int k = 1; k < WK; ++k) v += *(const f32x2*)(red + ((size_t)(k * NT + n)) * MTP + c);
-                v += *(const f32x2*)(a.bias + co);
+                v += bi;
                 const float mean = wave_sum(v[0] + v[1]) * inv_re;
                 const f32x2 d = v - mean;
                 const float var = wave_sum(d[0] * d[0] + d[1] * d[1]) * inv_re;
                 const float rstd = 1.0f / sqrtf(var + 1e-5f);
-                const f32x2 ga = *(const f32x2*)(a.gamma + co), be = *(const f32x2*)(a.beta + co);
                 f32x2 y;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) y[e] = mish(d[e] * rstd * ga[e] + be[e]);
-                if (a.tbias) y += *(const f32x2*)(a.tbias + co);
-                if (b < a.B) {
-                    const size_t o = ((size_t)b * L_out + l) * a.C_out + co;
-                    if (a.res) y += *(const f32x2*)(a.res + o);
-                    *(f32x2*)(a.dst + o) = y;
-                }
+                y += tb;
+                y += rs2;
+                if (b < a.B) *(f32x2*)(a.dst + o) = y;
             }
         }
     } else {
@@ -264,9 +310,10 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_block_kernel(const ConvArgs
             const int n = idx / M4, c = (idx - n * M4) * 4;
             const int s = n / L_out, l = n - s * L_out, b = s0 + s;
             const int co = mt * MT + c;
-            f32x4 v = *(const f32x4*)(red + (size_t)n * MTP + c);
+            const int ri = n * MTP4 + (c >> 2);
+            f32x4 v = smem4[ri];
 #pragma unroll
-            for (int k = 1; k < WK; ++k) v += *(const f32x4*)(red + ((size_t)(k * NT + n)) * MTP + c);
+            for (int k = 1; k < WK; ++k) v += smem4[ri + k * NT * MTP4];
             v += *(const f32x4*)(a.bias + co);
             if (b < a.B) *(f32x4*)(a.dst + ((size_t)b * L_out + l) * a.C_out + co) = v;
         }

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -442,17 +443,31 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
-// tile choice: keep >= ~256 workgroups in flight when the batch is small, grow the tile (weight reuse) when it is large
+// tile choice.  Measured on MI355X at B=100 (tools/ablate_layers.py): per-launch time is dominated by fixed costs
+// (launch boundary ~3 us, epilogue ~1.9 us), halving the tile to co-schedule two workgroups per CU does NOT pay
+// (the MFMA phase gets slower: every output column re-streams the weights), so: the largest tile that still
+// gives >= `target` workgroups (default 160 of the 256 CUs), growing with the batch for weight reuse.
+// MPDX_TILE=MTxNT / MPDX_TARGET_WGS override (development).
 static void choose_tile(const Layer& l, int B, int& MT, int& NT) {
     const int min_mt = (l.epi == EPI_GN_MISH && l.gs > 16) ? 32 : 16;
-    const int min_nt = std::max(32, l.L_out);
+    const int min_nt = std::max(l.mode == CONV_UPT ? 32 : 16, l.L_out);
     const long npos = (long)B * l.L_out;
-    MT = 32; NT = 64;
+    static const char* ov = getenv("MPDX_TILE");
+    if (ov) {
+        int mt = 0, nt = 0;
+        if (sscanf(ov, "%dx%d", &mt, &nt) == 2 && mt >= min_mt && nt >= min_nt && l.cout % mt == 0 && nt % l.L_out == 0) { MT = mt; NT = nt; return; }
+    }
+    static const int target = getenv("MPDX_TARGET_WGS") ? atoi(getenv("MPDX_TARGET_WGS")) : 160;
     auto wgs = [&](int mt, int nt) { return (long)(l.cout / mt) * ((npos + nt - 1) / nt); };
-    if (wgs(MT, NT) >= 512) return;
-    if (min_nt <= 32) NT = 32;
-    if (wgs(MT, NT) >= 256) return;
-    if (min_mt <= 16) MT = 16;
+    const int mts[2] = {32, 16}, nts[3] = {64, 32, 16};
+    // largest tile that still yields >= target workgroups; else the smallest legal tile
+    for (int nt : nts)
+        for (int mt : mts) {
+            if (mt < min_mt || nt < min_nt || l.cout % mt) continue;
+            if (wgs(mt, nt) >= target) { MT = mt; NT = nt; return; }
+        }
+    MT = (min_mt <= 16 && l.cout % 16 == 0) ? 16 : 32;
+    NT = min_nt;
 }
 
 static int layer_ntap(const Layer& l) { return l.mode == CONV_UPT ? 2 : l.ks; }
@@ -477,7 +492,7 @@ static int dispatch_tile(const Layer& l, ConvArgs& a, int B, hipStream_t st) {
         if (ksplit) return launch_conv<MODE, KS, EPI, mt, nt, 1, 8>(a, st);                      \
         return launch_conv<MODE, KS, EPI, mt, nt, nt / 16, 8 / (nt / 16)>(a, st);               \
     }
-    MPDX_TILE(32, 64) MPDX_TILE(32, 32) MPDX_TILE(16, 64) MPDX_TILE(16, 32)
+    MPDX_TILE(32, 64) MPDX_TILE(32, 32) MPDX_TILE(16, 64) MPDX_TILE(16, 32) MPDX_TILE(32, 16) MPDX_TILE(16, 16)
 #undef MPDX_TILE
     return fail(MPDX_E_INVALID, "no instantiation for tile %dx%d", MT, NT);
 }
@@ -492,12 +507,13 @@ static int dispatch_tile_ksplit_only(const Layer& l, ConvArgs& a, int B, hipStre
 #define MPDX_TILE(mt, nt) \
     if (MT == mt && NT == nt) return launch_conv<MODE, KS, EPI, mt, nt, 1, 8>(a, st);
     MPDX_TILE(32, 64) MPDX_TILE(32, 32) MPDX_TILE(16, 64) MPDX_TILE(16, 32)
+    if constexpr (MODE != CONV_UPT) { MPDX_TILE(32, 16) MPDX_TILE(16, 16) }
 #undef MPDX_TILE
     return fail(MPDX_E_INVALID, "no instantiation for tile %dx%d", MT, NT);
 }
 
 static int run_layer(const mpdx_unet* u, const Layer& l, const float* packed, const float* tt_row, const float* x,
-                     float* ws, int B, hipStream_t st) {
+                     float* ws, int B, hipStream_t st, int dbg = 0) {
     const size_t slot = u->slot_floats * (size_t)B;
     auto src = [&](int s) -> const float* { return s == SRC_X ? x : (s == SRC_NONE ? nullptr : ws + slot * s); };
     ConvArgs a;
@@ -512,7 +528,7 @@ static int run_layer(const mpdx_unet* u, const Layer& l, const float* packed, co
     a.res = src(l.res);
     a.dst = ws + slot * l.dst;
     a.B = B; a.L_in = l.L_in; a.L_out = l.L_out; a.C_out = l.cout;
-    a.cin_pad = l.cin_pad; a.rs = l.rs; a.gs = l.gs;
+    a.cin_pad = l.cin_pad; a.rs = l.rs; a.gs = l.gs; a.dbg = dbg;
     if (l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH) return dispatch_tile<CONV_S1, 5, EPI_GN_MISH>(l, a, B, st);
     if (l.mode == CONV_S1 && l.ks == 1 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 1, EPI_BIAS>(l, a, B, st);
     if (l.mode == CONV_DOWN && l.ks == 3) return dispatch_tile_ksplit_only<CONV_DOWN, 3, EPI_BIAS>(l, a, B, st);
@@ -753,6 +769,50 @@ int mpdx_unet_profile(mpdx_unet* u, const float* packed, const float* timetab, i
     for (auto& e : ev) (void)hipEventDestroy(e);
     *n_out = nl;
     return rc;
+}
+
+int mpdx_bench_layer(mpdx_unet* u, const float* packed, const float* timetab, const float* x, int layer, int B, float* ws,
+                     void* stream, int reps, int dbg, float* ms_per_launch) {
+    if (!u || !packed || !timetab || !x || !ws || !ms_per_launch) return fail(MPDX_E_INVALID, "null argument");
+    if (int rc = check_ready(u)) return rc;
+    if (layer < 0 || layer >= (int)u->layers.size()) return fail(MPDX_E_INVALID, "bad layer index");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i)
+        if (int rc = run_layer(u, u->layers[layer], packed, timetab, x, ws, B, st, dbg & 15)) return rc;
+    if (dbg & 16) {  // replay the same launches from a hipGraph (device-side launch cadence, no host in the loop)
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < reps; ++i)
+            if (int rc = run_layer(u, u->layers[layer], packed, timetab, x, ws, B, st, dbg & 15)) return rc;
+        HIP_TRY(hipStreamEndCapture(st, &graph));
+        HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        HIP_TRY(hipGraphLaunch(exec, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipEventRecord(e0, st));
+        HIP_TRY(hipGraphLaunch(exec, st));
+        HIP_TRY(hipEventRecord(e1, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        float msg = 0.f;
+        HIP_TRY(hipEventElapsedTime(&msg, e0, e1));
+        *ms_per_launch = msg / reps;
+        (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        return 0;
+    }
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i)
+        if (int rc = run_layer(u, u->layers[layer], packed, timetab, x, ws, B, st, dbg)) return rc;
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch = ms / reps;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
 }
 
 int mpdx_unet_layer_tile(const mpdx_unet* u, int i, int B, char* buf, size_t buflen) {
