@@ -103,6 +103,55 @@ int mpdx_add_noise(float* x_io, const float* noise, const float* hard_start, con
  * torch.randn_like (diffusion_model_base.py:165, sample_functions.py:51).  Parity runs inject noise instead. */
 int mpdx_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
 
+/* ---- cost guidance: replaces guide(x) = GuideManagerTrajectoriesWithVelocity.forward (guides.py:173-211) and one
+ * iteration of guide_gradient_steps (sample_functions.py:74-81).  The cost terms are the ones inference.py:188-225
+ * builds: one CostCollision per collision field of the task + CostGPTrajectory, weights as at :204,213.
+ * Their arithmetic is un-vendored in the reference (empty submodules): restated, see oracle/costs.py. */
+#define MPDX_MAX_FIELDS 4
+#define MPDX_FIELD_OBJECTS   0 /* sdf to sphere/box primitives (task.df_collision_objects / extra objects) */
+#define MPDX_FIELD_WORKSPACE 1 /* workspace-boundary planes */
+#define MPDX_FIELD_SELF      2 /* robot self collision (Panda) */
+#define MPDX_ROBOT_POINTMASS 0
+#define MPDX_ROBOT_PANDA     1
+
+typedef struct mpdx_field {
+    int32_t kind;                       /* MPDX_FIELD_* */
+    float   weight;                     /* weight_grad_cost_collision (inference.py:55) */
+    int32_t sphere_off, n_spheres;      /* float offset into prims, 4 floats each: cx,cy,cz,r (cz unused in 2-D) */
+    int32_t box_off, n_boxes;           /* 6 floats each: cx,cy,cz,hx,hy,hz */
+    float   ws_min[3], ws_max[3];       /* MPDX_FIELD_WORKSPACE */
+} mpdx_field;
+
+typedef struct mpdx_guide_params {
+    int32_t robot;                      /* MPDX_ROBOT_* */
+    int32_t q_dim;                      /* 2, 3 (point mass) or 7 (Panda); state dim D = 2*q_dim (pos + vel) */
+    int32_t ws_dim;                     /* workspace dimension 2 or 3 */
+    int32_t interpolate;                /* interpolate_trajectories_for_collision (guides.py:152) */
+    int32_t n_interp;                   /* num_interpolated_points_for_collision; effective reference value 128 */
+    int32_t clip_grad;                  /* clip_grad (guides.py:151), rule 'norm' */
+    float   max_grad_norm;              /* 1.0 */
+    float   mins[16], maxs[16];         /* LimitsNormalizer limits of the trajectory field (normalization.py:92-93) */
+    float   cutoff_margin;              /* obstacle_cutoff_margin (inference.py:110) */
+    float   link_margin;                /* point-mass collision radius */
+    int32_t n_fields;
+    mpdx_field fields[MPDX_MAX_FIELDS];
+    int32_t use_gp;                     /* CostGPTrajectory present */
+    float   gp_weight;                  /* weight_grad_cost_smoothness (inference.py:56) */
+    float   dt;                         /* trajectory_duration / n_support_points (inference.py:120) */
+    float   sigma_gp;                   /* 1.0 */
+    const float* prims;                 /* device pointer: primitive table */
+    int32_t n_prim_floats;
+} mpdx_guide_params;
+
+/* one guide iteration on x[B,H,D] (normalised).  grad_out == NULL: x <- hard_cond(x + guide(x)) in place and
+ * absmax_out[ctx] <- atomicMax(max|x_new|) ; grad_out != NULL: grad_out <- guide(x), x untouched.
+ * absmax_in[ctx] holds the bit pattern of max|x| over the context's n_per_ctx trajectories (the whole-tensor range
+ * test of LimitsNormalizer.unnormalize, normalization.py:160). */
+int mpdx_guide_step(const mpdx_guide_params* gp, float* x, float* grad_out, const float* hard_start, const float* hard_goal,
+                    const uint32_t* absmax_in, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, void* stream);
+/* absmax_out[ctx] <- atomicMax over the context's trajectories (caller zeroes absmax_out first) */
+int mpdx_absmax(const float* x, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, void* stream);
+
 /* ---- the whole planning loop: replaces GaussianDiffusionModel.p_sample_loop driven by run_inference
  * (diffusion_model_base.py:157-182,285-316) with sample_fn=ddpm_sample_fn.  Everything is enqueued on `stream`
  * without a single host synchronisation: the t-dependent branches of the reference (`t_single < 0`,
@@ -111,10 +160,15 @@ int mpdx_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* strea
  *   x      : [B,H,D]; in: x_T ~ N(0,I) (hard conditioning is applied here, :165-166); out: the final trajectories
  *   noise  : [T + n_without_noise, B,H,D] the randn_like draw of each loop iteration, in loop order
  *   chain  : NULL or [T + n_without_noise + 1, B,H,D] <- x after every iteration, index 0 = conditioned x_T
- *            (the 'diffsteps b h d' layout run_inference returns, :310)                                        */
+ *            (the 'diffsteps b h d' layout run_inference returns, :310)
+ *   guide  : NULL (planner_alg 'diffusion_prior') or the cost guide; applied n_guide_steps times on the posterior
+ *            mean of every iteration whose loop index i < t_start_guide (sample_functions.py:39-48)
+ *   guide_flags : device scratch, (T + n_without_noise) * (n_guide_steps + 1) * ceil(B / n_per_ctx) uint32
+ *   n_per_ctx   : trajectories per start/goal context (n_samples); contexts are consecutive blocks of the batch   */
 int mpdx_plan(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, int T, const mpdx_step_coefs* coefs,
               int n_without_noise, float* x, const float* noise, const float* hard_start, const float* hard_goal,
-              float* chain, int B, float* ws, void* stream);
+              float* chain, int B, float* ws, const mpdx_guide_params* guide, int n_guide_steps, int t_start_guide,
+              uint32_t* guide_flags, int n_per_ctx, void* stream);
 
 /* ---- measurement helpers (bench.py's roofline leg; not used by the planning path) ----
  * One U-Net pass with a hipEvent pair around every kernel launch, on `stream`.  This call DOES synchronise the

@@ -7,5 +7,10 @@ from .temporal_unet import TemporalUnet, UNET_DIM_MULTS  # noqa: F401
 from .diffusion_model import GaussianDiffusionModel  # noqa: F401
 from .sample_functions import ddpm_sample_fn, guide_gradient_steps, apply_hard_conditioning, extract  # noqa: F401
 
+from .guides import GuideManagerTrajectoriesWithVelocity  # noqa: F401
+from .planning import CostCollision, CostGPTrajectory, CostComposite, PlanningTask, make_env, make_robot  # noqa: F401
+from .datasets import TrajectoryDataset, LimitsNormalizer  # noqa: F401
+
 __all__ = ["TemporalUnet", "UNET_DIM_MULTS", "GaussianDiffusionModel", "ddpm_sample_fn", "guide_gradient_steps",
-           "apply_hard_conditioning", "extract"]
+           "apply_hard_conditioning", "extract", "GuideManagerTrajectoriesWithVelocity", "CostCollision", "CostGPTrajectory",
+           "CostComposite", "PlanningTask", "TrajectoryDataset", "LimitsNormalizer", "make_env", "make_robot"]

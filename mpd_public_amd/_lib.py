@@ -25,6 +25,24 @@ class StepCoefs(C.Structure):
                 ("predict_epsilon", C.c_int32), ("clip_denoised", C.c_int32)]
 
 
+MAX_FIELDS = 4
+FIELD_OBJECTS, FIELD_WORKSPACE, FIELD_SELF = 0, 1, 2
+ROBOT_POINTMASS, ROBOT_PANDA = 0, 1
+
+
+class Field(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("weight", C.c_float), ("sphere_off", C.c_int32), ("n_spheres", C.c_int32),
+                ("box_off", C.c_int32), ("n_boxes", C.c_int32), ("ws_min", C.c_float * 3), ("ws_max", C.c_float * 3)]
+
+
+class GuideParams(C.Structure):
+    _fields_ = [("robot", C.c_int32), ("q_dim", C.c_int32), ("ws_dim", C.c_int32), ("interpolate", C.c_int32),
+                ("n_interp", C.c_int32), ("clip_grad", C.c_int32), ("max_grad_norm", C.c_float),
+                ("mins", C.c_float * 16), ("maxs", C.c_float * 16), ("cutoff_margin", C.c_float), ("link_margin", C.c_float),
+                ("n_fields", C.c_int32), ("fields", Field * MAX_FIELDS), ("use_gp", C.c_int32), ("gp_weight", C.c_float),
+                ("dt", C.c_float), ("sigma_gp", C.c_float), ("prims", C.c_void_p), ("n_prim_floats", C.c_int32)]
+
+
 # every symbol include/mpdx.h declares: name -> (restype, argtypes)
 _vp, _sz, _i, _f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
 SIGNATURES = {
@@ -42,7 +60,10 @@ SIGNATURES = {
     "mpdx_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "mpdx_ddpm_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, C.POINTER(StepCoefs), _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "mpdx_add_noise": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _i, _i, _i, _vp]),
-    "mpdx_plan": (_i, [_vp, _vp, _vp, _i, C.POINTER(StepCoefs), _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "mpdx_plan": (_i, [_vp, _vp, _vp, _i, C.POINTER(StepCoefs), _i, _vp, _vp, _vp, _vp, _vp, _i, _vp,
+                        C.POINTER(GuideParams), _i, _i, _vp, _i, _vp]),
+    "mpdx_guide_step": (_i, [C.POINTER(GuideParams), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mpdx_absmax": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "mpdx_unet_profile": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(C.c_double),
                                 C.POINTER(C.c_char_p), C.POINTER(C.c_int)]),
     "mpdx_bench_layer": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, C.POINTER(C.c_float)]),

@@ -1,0 +1,397 @@
+// guide.hpp - one cost-guidance update of the trajectory batch, hand-derived gradients (no autograd on device).
+//
+// Replaces one iteration of guide_gradient_steps (mpd/models/diffusion_models/sample_functions.py:74-81):
+//     x = x + guide(x);  apply_hard_conditioning(x)
+// with guide = GuideManagerTrajectoriesWithVelocity.forward (mpd/models/diffusion_models/guides.py:173-211):
+//     unnormalise (LimitsNormalizer.unnormalize incl. its whole-tensor range test, mpd/datasets/normalization.py:156-167)
+//     -> interpolate 64 -> 128 points (interpolate_points_v1, guides.py:184) -> per cost term: d cost / d x_unnormalised
+//     -> per-waypoint norm clip over all D dims of (g + 1e-6) (guides.py:224-230) -> zero first/last waypoint (:202-203)
+//     -> weight (:206) -> negate (:210).  The gradient is w.r.t. the UNNORMALISED x and is added to the NORMALISED x
+//     (reproduced, not fixed - SURVEY.md 3.3).
+// The cost arithmetic itself (CostCollision / CostGPTrajectory / robot FK / SDF fields) lives in un-vendored
+// submodules of the reference; it is restated from the published formulas (oracle/costs.py header) - PARITY UNPINNED.
+//
+// Mapping.  One 64-lane wave per trajectory, lane h = support point h (H <= 64).  The [H, D] state is read with
+// coalesced loads; the horizon window needed by the interpolation and by the GP prior's 3-point finite-difference
+// stencil is staged in LDS; interpolated points are processed lane-strided (i = lane, lane+64, ...); the transpose
+// of the interpolation (scatter of point gradients to support points) is a deterministic LDS gather (no atomics);
+// max|x| for the next iteration's range test is a wave reduction + one atomicMax per trajectory.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mpdx.h"
+
+namespace mpdx {
+
+// Franka Panda, modified DH (Craig): T_i = Rot_x(alpha_{i-1}) Trans_x(a_{i-1}) Rot_z(theta_i) Trans_z(d_i)
+__device__ static const float kPandaA[7] = {0.0f, 0.0f, 0.0f, 0.0825f, -0.0825f, 0.0f, 0.088f};
+__device__ static const float kPandaD[7] = {0.333f, 0.0f, 0.316f, 0.0f, 0.384f, 0.0f, 0.0f};
+__device__ static const float kPandaCA[7] = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};       // cos(alpha)
+__device__ static const float kPandaSA[7] = {0.0f, -1.0f, 1.0f, 1.0f, -1.0f, 1.0f, 1.0f};     // sin(alpha)
+// collision spheres: frame (1..7), offset along the frame's z axis, radius (synthetic geometry)
+constexpr int kPandaNS = 11;
+__device__ static const int kPandaSF[kPandaNS] = {1, 1, 3, 3, 4, 5, 5, 5, 7, 7, 7};
+__device__ static const float kPandaSO[kPandaNS] = {-0.15f, 0.0f, -0.15f, 0.0f, 0.0f, -0.25f, -0.12f, 0.0f, 0.0f, 0.107f, 0.17f};
+__device__ static const float kPandaSR[kPandaNS] = {0.10f, 0.10f, 0.09f, 0.09f, 0.09f, 0.08f, 0.08f, 0.08f, 0.07f, 0.06f, 0.06f};
+constexpr int kPandaNP = 12;  // self-collision pairs
+__device__ static const int kPandaPA[kPandaNP] = {8, 8, 8, 9, 9, 9, 9, 10, 10, 10, 10, 10};
+__device__ static const int kPandaPB[kPandaNP] = {0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
+
+struct GuideArgs {
+    mpdx_guide_params gp;
+    float* x;               // [B][H][D] normalised trajectories (updated in place unless grad_out)
+    float* grad_out;        // optional: write the guide increment instead of applying it (API path guide(x))
+    const float* hs;        // hard start [B][D] or null
+    const float* hg;        // hard goal  [B][D] or null
+    const uint32_t* amax_in;   // per-context max|x| bit pattern of the INPUT (range test)
+    uint32_t* amax_out;        // per-context max|x| of the OUTPUT (next iteration), or null
+    int B, H, D, n_per_ctx;
+};
+
+template <int DIM>
+__device__ __forceinline__ void objects_force(const float* __restrict__ prims, const mpdx_field& f, const float (&p)[DIM], float margin,
+                                              float (&force)[DIM]) {
+    // d cost / d p  for  cost = relu(margin - min_prims sdf(p))
+    float best = 3.0e38f;
+    float g[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) g[j] = 0.f;
+    const float* sp = prims + f.sphere_off;
+    for (int s = 0; s < f.n_spheres; ++s) {
+        float d[DIM], n2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) { d[j] = p[j] - sp[s * 4 + j]; n2 += d[j] * d[j]; }
+        const float n = sqrtf(n2);
+        const float sd = n - sp[s * 4 + 3];
+        if (sd < best) {
+            best = sd;
+            const float inv = n > 0.f ? 1.0f / n : 0.f;
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) g[j] = d[j] * inv;
+        }
+    }
+    const float* bp = prims + f.box_off;
+    for (int s = 0; s < f.n_boxes; ++s) {
+        float d[DIM], sg[DIM], mx = -3.0e38f, n2 = 0.f;
+        int jm = 0;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+            const float c = p[j] - bp[s * 6 + j];
+            sg[j] = c > 0.f ? 1.f : (c < 0.f ? -1.f : 0.f);
+            d[j] = fabsf(c) - bp[s * 6 + 3 + j];
+            if (d[j] > mx) { mx = d[j]; jm = j; }
+            const float r = fmaxf(d[j], 0.f);
+            n2 += r * r;
+        }
+        const float n = sqrtf(n2);
+        const float sd = fminf(mx, 0.f) + n;
+        if (sd < best) {
+            best = sd;
+            if (mx > 0.f) {  // outside: gradient of |relu(d)|
+                const float inv = 1.0f / n;
+#pragma unroll
+                for (int j = 0; j < DIM; ++j) g[j] = sg[j] * fmaxf(d[j], 0.f) * inv;
+            } else {  // inside (or on the surface): gradient of max_j d_j
+#pragma unroll
+                for (int j = 0; j < DIM; ++j) g[j] = (j == jm) ? sg[j] : 0.f;
+            }
+        }
+    }
+    const bool active = (margin - best) > 0.f;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) force[j] = active ? -g[j] : 0.f;
+}
+
+template <int DIM>
+__device__ __forceinline__ void workspace_force(const mpdx_field& f, const float (&p)[DIM], float margin, float (&force)[DIM]) {
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        const float lo = p[j] - f.ws_min[j], hi = f.ws_max[j] - p[j];
+        force[j] = ((margin - lo) > 0.f ? -1.f : 0.f) + ((margin - hi) > 0.f ? 1.f : 0.f);
+    }
+}
+
+// QD = configuration-space dim (2, 3 point mass; 7 Panda), DIM = workspace dim, ROBOT as in mpdx.h
+template <int QD, int DIM, int ROBOT>
+__global__ __launch_bounds__(64) void guide_step_kernel(const GuideArgs a) {
+    constexpr int D = 2 * QD;
+    constexpr int MAXF = MPDX_MAX_FIELDS;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const mpdx_guide_params& gp = a.gp;
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const int H = a.H;
+    const int N = gp.interpolate ? gp.n_interp : H;
+    const bool live = lane < H;
+    // LDS carve: unnormalised state [H][D] | point forces A,B [MAXF][N][QD] each | primitive table
+    float* sx = sm;
+    float* sA = sx + H * D;
+    float* sB = sA + MAXF * N * QD;
+    float* sprim = sB + MAXF * N * QD;
+    for (int i = lane; i < gp.n_prim_floats; i += 64) sprim[i] = gp.prims[i];
+
+    // ---- load + unnormalise (normalization.py:156-167)
+    const int ctx = b / a.n_per_ctx;
+    const bool clipall = __uint_as_float(a.amax_in[ctx]) > 1.0001f;  // x.max() > 1+eps or x.min() < -1-eps (eps = 1e-4)
+    float xn[D], xu[D];
+    const size_t base = ((size_t)b * H + (live ? lane : 0)) * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        xn[d] = live ? a.x[base + d] : 0.f;
+        const float c = clipall ? fminf(fmaxf(xn[d], -1.f), 1.f) : xn[d];
+        const float u01 = __fadd_rn(c, 1.0f) * 0.5f;
+        xu[d] = __fadd_rn(__fmul_rn(u01, __fsub_rn(gp.maxs[d], gp.mins[d])), gp.mins[d]);
+        if (live) sx[lane * D + d] = xu[d];
+    }
+    __syncthreads();
+
+    // ---- collision terms on the interpolated positions
+    const float scale = (N > 1) ? (float)(H - 1) / (float)(N - 1) : 0.f;  // align_corners=True
+    for (int i = lane; i < N; i += 64) {
+        int i0 = i, i1 = i;
+        float l0 = 1.f, l1 = 0.f;
+        if (gp.interpolate) {
+            const float u = scale * (float)i;
+            i0 = (int)u;
+            if (i0 > H - 1) i0 = H - 1;
+            i1 = i0 + 1 < H ? i0 + 1 : H - 1;
+            l1 = u - (float)i0;
+            l0 = 1.0f - l1;
+        }
+        float q[QD];
+#pragma unroll
+        for (int j = 0; j < QD; ++j) q[j] = l0 * sx[i0 * D + j] + l1 * sx[i1 * D + j];
+
+        if (ROBOT == MPDX_ROBOT_POINTMASS) {
+            float p[DIM];
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) p[j] = q[j];
+            const float margin = gp.link_margin + gp.cutoff_margin;
+            for (int f = 0; f < gp.n_fields; ++f) {
+                float force[DIM];
+                if (gp.fields[f].kind == MPDX_FIELD_OBJECTS) objects_force<DIM>(sprim, gp.fields[f], p, margin, force);
+                else if (gp.fields[f].kind == MPDX_FIELD_WORKSPACE) workspace_force<DIM>(gp.fields[f], p, margin, force);
+                else {
+#pragma unroll
+                    for (int j = 0; j < DIM; ++j) force[j] = 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < QD; ++j) {
+                    sA[(f * N + i) * QD + j] = l0 * force[j];
+                    sB[(f * N + i) * QD + j] = l1 * force[j];
+                }
+            }
+        } else {
+            // ---- Panda forward kinematics: frame origins O_k, z axes Z_k (world)
+            float O[7][3], Z[7][3];
+            float R[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}, T[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                float st, ct;
+                sincosf(q[k < QD ? k : 0], &st, &ct);
+                const float ca = kPandaCA[k], sa = kPandaSA[k], aa = kPandaA[k], dd = kPandaD[k];
+                // local transform columns (modified DH)
+                const float L[3][3] = {{ct, -st, 0.f}, {st * ca, ct * ca, -sa}, {st * sa, ct * sa, ca}};
+                const float Lt[3] = {aa, -sa * dd, ca * dd};
+                float Rn[3][3], Tn[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Rn[r][c] = R[r][0] * L[0][c] + R[r][1] * L[1][c] + R[r][2] * L[2][c];
+                    Tn[r] = R[r][0] * Lt[0] + R[r][1] * Lt[1] + R[r][2] * Lt[2] + T[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) R[r][c] = Rn[r][c];
+                    T[r] = Tn[r];
+                    O[k][r] = Tn[r];
+                    Z[k][r] = Rn[r][2];
+                }
+            }
+            float P[kPandaNS][3];
+#pragma unroll
+            for (int s = 0; s < kPandaNS; ++s) {
+                const int fr = kPandaSF[s] - 1;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) P[s][r] = O[fr][r] + kPandaSO[s] * Z[fr][r];
+            }
+            for (int f = 0; f < gp.n_fields; ++f) {
+                float F[kPandaNS][3];
+#pragma unroll
+                for (int s = 0; s < kPandaNS; ++s) { F[s][0] = 0.f; F[s][1] = 0.f; F[s][2] = 0.f; }
+                const int kind = gp.fields[f].kind;
+                if (kind == MPDX_FIELD_OBJECTS || kind == MPDX_FIELD_WORKSPACE) {
+#pragma unroll
+                    for (int s = 0; s < kPandaNS; ++s) {
+                        const float margin = kPandaSR[s] + gp.cutoff_margin;
+                        float p3[3] = {P[s][0], P[s][1], P[s][2]}, fo[3];
+                        if (kind == MPDX_FIELD_OBJECTS) objects_force<3>(sprim, gp.fields[f], p3, margin, fo);
+                        else workspace_force<3>(gp.fields[f], p3, margin, fo);
+                        F[s][0] = fo[0]; F[s][1] = fo[1]; F[s][2] = fo[2];
+                    }
+                } else if (kind == MPDX_FIELD_SELF) {
+#pragma unroll
+                    for (int pr = 0; pr < kPandaNP; ++pr) {
+                        const int sa_ = kPandaPA[pr], sb_ = kPandaPB[pr];
+                        const float dx = P[sa_][0] - P[sb_][0], dy = P[sa_][1] - P[sb_][1], dz = P[sa_][2] - P[sb_][2];
+                        const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                        if (kPandaSR[sa_] + kPandaSR[sb_] - dist > 0.f && dist > 0.f) {
+                            const float inv = 1.0f / dist;
+                            F[sa_][0] -= dx * inv; F[sa_][1] -= dy * inv; F[sa_][2] -= dz * inv;
+                            F[sb_][0] += dx * inv; F[sb_][1] += dy * inv; F[sb_][2] += dz * inv;
+                        }
+                    }
+                }
+                // Jacobian transpose: d P_s / d theta_j = z_j x (P_s - O_j) for j <= frame(s)
+#pragma unroll
+                for (int jn = 0; jn < 7; ++jn) {
+                    float g = 0.f;
+#pragma unroll
+                    for (int s = 0; s < kPandaNS; ++s) {
+                        if (jn <= kPandaSF[s] - 1) {
+                            const float rx = P[s][0] - O[jn][0], ry = P[s][1] - O[jn][1], rz = P[s][2] - O[jn][2];
+                            const float cx = Z[jn][1] * rz - Z[jn][2] * ry, cy = Z[jn][2] * rx - Z[jn][0] * rz,
+                                        cz = Z[jn][0] * ry - Z[jn][1] * rx;
+                            g += F[s][0] * cx + F[s][1] * cy + F[s][2] * cz;
+                        }
+                    }
+                    if (jn < QD) {
+                        sA[(f * N + i) * QD + jn] = l0 * g;
+                        sB[(f * N + i) * QD + jn] = l1 * g;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- gather to support points (transpose of the interpolation), clip, zero ends, weight
+    float total[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) total[d] = 0.f;
+    const bool interior = live && lane > 0 && lane < H - 1;
+    if (live) {
+        int ilo = lane, ihi = lane;
+        if (gp.interpolate && scale > 0.f) {
+            ilo = (int)((float)lane / scale) - 2;
+            ihi = (int)((float)(lane + 1) / scale) + 2;
+            if (ilo < 0) ilo = 0;
+            if (ihi > N - 1) ihi = N - 1;
+        }
+        for (int f = 0; f < gp.n_fields; ++f) {
+            float g[QD];
+#pragma unroll
+            for (int j = 0; j < QD; ++j) g[j] = 0.f;
+            for (int i = ilo; i <= ihi; ++i) {
+                int i0 = i, i1 = i;
+                if (gp.interpolate) {
+                    const float u = scale * (float)i;
+                    i0 = (int)u;
+                    if (i0 > H - 1) i0 = H - 1;
+                    i1 = i0 + 1 < H ? i0 + 1 : H - 1;
+                }
+                if (i0 == lane) {
+#pragma unroll
+                    for (int j = 0; j < QD; ++j) g[j] += sA[(f * N + i) * QD + j];
+                }
+                if (i1 == lane && gp.interpolate) {
+#pragma unroll
+                    for (int j = 0; j < QD; ++j) g[j] += sB[(f * N + i) * QD + j];
+                }
+            }
+            // clip_grad_by_norm over ALL D dims of (g + 1e-6): the velocity dims of a collision gradient are 0
+            float n2 = (float)QD * (1e-6f * 1e-6f);
+#pragma unroll
+            for (int j = 0; j < QD; ++j) n2 += (g[j] + 1e-6f) * (g[j] + 1e-6f);
+            float ratio = 1.f;
+            if (gp.clip_grad) {
+                const float n = sqrtf(n2);
+                ratio = fminf(fmaxf(n, 0.f), gp.max_grad_norm) / n;
+            }
+            if (interior) {
+#pragma unroll
+                for (int j = 0; j < QD; ++j) total[j] += gp.fields[f].weight * (ratio * g[j]);
+            }
+        }
+    }
+
+    // ---- GP prior (constant-velocity, GPMP2): 3-point stencil over the horizon
+    if (gp.use_gp) {
+        const float dt = gp.dt, s2 = 1.0f / (gp.sigma_gp * gp.sigma_gp);
+        const float c_qq = 24.0f / (dt * dt * dt), c_qv = 12.0f / (dt * dt), c_vv = 8.0f / dt;
+        float av[QD], bv[QD];  // a_h = d c_h / d e_q,  b_h = d c_h / d e_v  for the segment (h, h+1)
+#pragma unroll
+        for (int j = 0; j < QD; ++j) {
+            float eq = 0.f, ev = 0.f;
+            if (live && lane < H - 1) {
+                eq = sx[(lane + 1) * D + j] - xu[j] - dt * xu[QD + j];
+                ev = sx[(lane + 1) * D + QD + j] - xu[QD + j];
+            }
+            av[j] = (c_qq * eq - c_qv * ev) * s2;
+            bv[j] = (-c_qv * eq + c_vv * ev) * s2;
+        }
+        float g[D];
+#pragma unroll
+        for (int j = 0; j < QD; ++j) {
+            float ap = __shfl_up(av[j], 1, 64), bp = __shfl_up(bv[j], 1, 64);
+            if (lane == 0) { ap = 0.f; bp = 0.f; }
+            g[j] = ap - av[j];
+            g[QD + j] = bp - bv[j] - dt * av[j];
+        }
+        float n2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) n2 += (g[d] + 1e-6f) * (g[d] + 1e-6f);
+        float ratio = 1.f;
+        if (gp.clip_grad) {
+            const float n = sqrtf(n2);
+            ratio = fminf(fmaxf(n, 0.f), gp.max_grad_norm) / n;
+        }
+        if (interior) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) total[d] += gp.gp_weight * (ratio * g[d]);
+        }
+    }
+
+    // ---- apply:  x = x + (-grad);  hard conditioning;  max|x| for the next range test
+    float vmax = 0.f;
+    if (live) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float inc = -1.0f * total[d];
+            if (a.grad_out) {
+                a.grad_out[base + d] = inc;
+            } else {
+                float r = __fadd_rn(xn[d], inc);
+                if (a.hs && lane == 0) r = a.hs[(size_t)b * D + d];
+                if (a.hg && lane == H - 1) r = a.hg[(size_t)b * D + d];
+                a.x[base + d] = r;
+                vmax = fmaxf(vmax, fabsf(r));
+            }
+        }
+    }
+    if (a.amax_out && !a.grad_out) {
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, s, 64));
+        if (lane == 0) atomicMax(a.amax_out + ctx, __float_as_uint(vmax));
+    }
+}
+
+// per-context max|x| (the range test of LimitsNormalizer.unnormalize) for the API path
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, uint32_t* out, size_t per_ctx, int n_ctx) {
+    const int ctx = blockIdx.y;
+    const float* p = x + (size_t)ctx * per_ctx;
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_ctx; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(p[i]));
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out + ctx, __float_as_uint(m));
+}
+
+inline size_t guide_lds_bytes(const mpdx_guide_params& gp, int H, int D) {
+    const int N = gp.interpolate ? gp.n_interp : H;
+    return (size_t)(H * D + 2 * MPDX_MAX_FIELDS * N * (D / 2) + gp.n_prim_floats) * sizeof(float);
+}
+
+}  // namespace mpdx

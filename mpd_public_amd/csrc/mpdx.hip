@@ -14,6 +14,7 @@
 
 #include "../../include/mpdx.h"
 #include "conv_block.hpp"
+#include "guide.hpp"
 
 namespace mpdx {
 
@@ -566,6 +567,30 @@ static int run_final(mpdx_unet* u, const float* packed, FinalArgs& fa, int B, fl
     return 0;
 }
 
+static int launch_guide(const mpdx_guide_params* gp, float* x, float* grad_out, const float* hs, const float* hg,
+                        const uint32_t* amax_in, uint32_t* amax_out, int n_per_ctx, int B, int H, int D, hipStream_t st) {
+    if (!gp || !x || !amax_in) return fail(MPDX_E_INVALID, "null argument");
+    if (H > 64 || H < 2) return fail(MPDX_E_INVALID, "guide kernel maps one support point per lane: H=%d unsupported (max 64)", H);
+    if (D != 2 * gp->q_dim || D > 16) return fail(MPDX_E_INVALID, "state dim %d != 2*q_dim (%d)", D, gp->q_dim);
+    if (gp->n_fields < 0 || gp->n_fields > MPDX_MAX_FIELDS) return fail(MPDX_E_INVALID, "n_fields %d", gp->n_fields);
+    if (gp->interpolate && (gp->n_interp < H || gp->n_interp > 8 * H)) return fail(MPDX_E_INVALID, "n_interp %d unsupported", gp->n_interp);
+    if (gp->n_prim_floats > 0 && !gp->prims) return fail(MPDX_E_INVALID, "primitive table missing");
+    GuideArgs a;
+    a.gp = *gp; a.x = x; a.grad_out = grad_out; a.hs = hs; a.hg = hg; a.amax_in = amax_in; a.amax_out = amax_out;
+    a.B = B; a.H = H; a.D = D; a.n_per_ctx = n_per_ctx > 0 ? n_per_ctx : B;
+    const size_t lds = guide_lds_bytes(*gp, H, D);
+    if (lds > 64 * 1024) return fail(MPDX_E_INVALID, "guide needs %zu B of LDS", lds);
+    if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 2 && gp->ws_dim == 2)
+        hipLaunchKernelGGL((guide_step_kernel<2, 2, MPDX_ROBOT_POINTMASS>), dim3(B), dim3(64), lds, st, a);
+    else if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 3 && gp->ws_dim == 3)
+        hipLaunchKernelGGL((guide_step_kernel<3, 3, MPDX_ROBOT_POINTMASS>), dim3(B), dim3(64), lds, st, a);
+    else if (gp->robot == MPDX_ROBOT_PANDA && gp->q_dim == 7 && gp->ws_dim == 3)
+        hipLaunchKernelGGL((guide_step_kernel<7, 3, MPDX_ROBOT_PANDA>), dim3(B), dim3(64), lds, st, a);
+    else
+        return fail(MPDX_E_INVALID, "unsupported robot %d / q_dim %d / ws_dim %d", gp->robot, gp->q_dim, gp->ws_dim);
+    return 0;
+}
+
 }  // namespace mpdx
 
 using namespace mpdx;
@@ -700,8 +725,27 @@ int mpdx_add_noise(float* x_io, const float* noise, const float* hard_start, con
     return 0;
 }
 
+int mpdx_guide_step(const mpdx_guide_params* gp, float* x, float* grad_out, const float* hard_start, const float* hard_goal,
+                    const uint32_t* absmax_in, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, void* stream) {
+    if (int rc = launch_guide(gp, x, grad_out, hard_start, hard_goal, absmax_in, absmax_out, n_per_ctx, B, H, D, (hipStream_t)stream)) return rc;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mpdx_absmax(const float* x, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, void* stream) {
+    if (!x || !absmax_out || B <= 0) return fail(MPDX_E_INVALID, "bad argument");
+    const int npc = n_per_ctx > 0 ? n_per_ctx : B;
+    if (B % npc) return fail(MPDX_E_INVALID, "B=%d is not a multiple of n_per_ctx=%d", B, npc);
+    const size_t per = (size_t)npc * H * D;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<size_t>((per + 255) / 256, 64), B / npc), dim3(256), 0, (hipStream_t)stream, x,
+                       absmax_out, per, B / npc);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int mpdx_plan(mpdx_unet* u, const float* packed, const float* timetab, int T, const mpdx_step_coefs* coefs, int n_without_noise,
               float* x, const float* noise, const float* hard_start, const float* hard_goal, float* chain, int B, float* ws,
+              const mpdx_guide_params* guide, int n_guide_steps, int t_start_guide, uint32_t* guide_flags, int n_per_ctx,
               void* stream) {
     if (!u || !packed || !timetab || !coefs || !x || !noise || !ws || T <= 0 || n_without_noise < 0 || B <= 0)
         return fail(MPDX_E_INVALID, "bad argument");
@@ -709,23 +753,43 @@ int mpdx_plan(mpdx_unet* u, const float* packed, const float* timetab, int T, co
     hipStream_t st = (hipStream_t)stream;
     const int H = u->cfg.n_support_points, D = u->cfg.state_dim;
     const size_t n = (size_t)B * H * D;
+    const int npc = n_per_ctx > 0 ? n_per_ctx : B;
+    const int n_ctx = (B + npc - 1) / npc;
+    const int steps = T + n_without_noise;
+    if (guide) {
+        if (!guide_flags || n_guide_steps < 1) return fail(MPDX_E_INVALID, "guide needs guide_flags and n_guide_steps >= 1");
+        if (B % npc) return fail(MPDX_E_INVALID, "B=%d is not a multiple of n_per_ctx=%d", B, npc);
+        HIP_TRY(hipMemsetAsync(guide_flags, 0, (size_t)steps * (n_guide_steps + 1) * n_ctx * sizeof(uint32_t), st));
+    }
     // x_T with hard conditioning; chain[0]
     hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, x, (const float*)nullptr,
                        hard_start, hard_goal, 0.f, 0.f, chain, B, H, D);
     int k = 0;
     for (int i = T - 1; i >= -n_without_noise; --i, ++k) {
         const int t = i < 0 ? 0 : i;
+        const bool guided = guide && i < t_start_guide;  // sample_functions.py:39 compares the un-clamped index
         if (int rc = run_unet_body(u, packed, timetab, T, x, t, B, ws, st)) return rc;
+        const float* nz = (t == 0) ? nullptr : noise + (size_t)k * n;  // noise[t == 0] = 0  (sample_functions.py:52)
+        float* ch = chain ? chain + (size_t)(k + 1) * n : nullptr;
         FinalArgs fa;
         memset(&fa, 0, sizeof(fa));
         fa.x_in = x; fa.out = x;
-        fa.noise = (t == 0) ? nullptr : noise + (size_t)k * n;   // noise[t == 0] = 0  (sample_functions.py:52)
-        fa.hs = hard_start; fa.hg = hard_goal;
-        fa.chain = chain ? chain + (size_t)(k + 1) * n : nullptr;
-        fa.n_per_ctx = B;
-        fa.mode = 1;
         fa.k = coefs[t];
-        if (int rc = run_final(u, packed, fa, B, ws, st)) return rc;
+        fa.n_per_ctx = npc;
+        if (!guided) {
+            fa.noise = nz; fa.hs = hard_start; fa.hg = hard_goal; fa.chain = ch; fa.mode = 1;
+            if (int rc = run_final(u, packed, fa, B, ws, st)) return rc;
+        } else {
+            uint32_t* fl = guide_flags + (size_t)k * (n_guide_steps + 1) * n_ctx;
+            fa.mode = 2; fa.absmax = fl;  // posterior mean + its max|.| per context
+            if (int rc = run_final(u, packed, fa, B, ws, st)) return rc;
+            for (int j = 0; j < n_guide_steps; ++j)
+                if (int rc = launch_guide(guide, x, nullptr, hard_start, hard_goal, fl + (size_t)j * n_ctx, fl + (size_t)(j + 1) * n_ctx, npc, B, H,
+                                          D, st))
+                    return rc;
+            hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, x, nz, hard_start,
+                               hard_goal, coefs[t].noise_scale, coefs[t].noise_std_extra, ch, B, H, D);
+        }
     }
     HIP_TRY(hipGetLastError());
     return 0;

@@ -81,10 +81,15 @@ class GaussianDiffusionModel(nn.Module):
 
     @torch.no_grad()
     def plan(self, hard_conds, n_samples, horizon=None, n_diffusion_steps_without_noise=0, noise=None,
-             noise_std_extra_schedule_fn=None, return_chain=True):
+             noise_std_extra_schedule_fn=None, return_chain=True, guide=None, n_guide_steps=1, t_start_guide=float("inf"),
+             n_per_context=None):
         """The whole reverse loop of p_sample_loop (diffusion_model_base.py:157-182) enqueued by ONE mpdx_plan call,
         without host synchronisation.  hard_conds: {0: start[B,D] or [D], H-1: goal}.  Returns (x_final, chain or None)
-        with chain laid out [steps+1, B, H, D] (run_inference's order)."""
+        with chain laid out [steps+1, B, H, D] (run_inference's order).
+        guide: a mpd_public_amd.GuideManagerTrajectoriesWithVelocity (device guide) or None.
+        n_per_context: trajectories per start/goal context when hard_conds are per-trajectory [B,D] tables of several
+        contexts (the whole-tensor range test of LimitsNormalizer is evaluated per context, as one reference call per
+        context would)."""
         H = horizon or self.model.n_support_points
         D, T, n0, B = self.state_dim, self.n_diffusion_steps, int(n_diffusion_steps_without_noise), int(n_samples)
         dev = self.betas.device
@@ -108,10 +113,18 @@ class GaussianDiffusionModel(nn.Module):
         coefs = self._coef_table(noise_std_extra_schedule_fn)
         x = noise[0].clone()
         chain = torch.empty((steps + 1, B, H, D), device=dev, dtype=torch.float32) if return_chain else None
+        npc = int(n_per_context or B)
+        gp_ref, flags, n_gs, t_sg = None, None, 0, 0
+        if guide is not None:
+            import ctypes as C
+            gp_ref = C.byref(guide.device_params(dev))
+            n_gs = int(n_guide_steps)
+            t_sg = int(min(t_start_guide, T + 1)) if t_start_guide != float("inf") else T + 1
+            flags = torch.empty(steps * (n_gs + 1) * ((B + npc - 1) // npc), dtype=torch.int32, device=dev)
         # T here is the LOOP length / coefficient-table length (not the time-table capacity)
         _lib.check(_lib.load().mpdx_plan(hdl, packed.data_ptr(), tab.data_ptr(), T, coefs, n0,
                                          x.data_ptr(), noise[1:].data_ptr(), _lib.ptr(hs), _lib.ptr(hg), _lib.ptr(chain), B,
-                                         ws.data_ptr(), _lib.current_stream()), "mpdx_plan")
+                                         ws.data_ptr(), gp_ref, n_gs, t_sg, _lib.ptr(flags), npc, _lib.current_stream()), "mpdx_plan")
         return x, chain
 
     # ---------------------------------------------------------------------------------------------- sampling
@@ -186,11 +199,14 @@ class GaussianDiffusionModel(nn.Module):
         horizon = kw.pop("horizon", None)
         fused = diffusion_kwargs.pop("fused", True)  # extension: fused=False forces the step-by-step protocol loop
         kw.pop("fused", None)
-        if fused and kw.pop("sample_fn", ddpm_sample_fn) is ddpm_sample_fn and kw.get("guide") is None and not kw.get("ddim", False) \
+        from .guides import GuideManagerTrajectoriesWithVelocity as _NativeGuide
+        if fused and kw.pop("sample_fn", ddpm_sample_fn) is ddpm_sample_fn \
+                and (kw.get("guide") is None or isinstance(kw.get("guide"), _NativeGuide)) and not kw.get("ddim", False) \
                 and not kw.get("scale_grad_by_std", False) and set(hard_conds.keys()) <= {0, (horizon or self.model.n_support_points) - 1}:
             # fused path: one mpdx_plan call for the whole loop
             x, chain = self.plan(hard_conds, n_samples, horizon, kw.get("n_diffusion_steps_without_noise", 0), kw.get("noise"),
-                                 kw.get("noise_std_extra_schedule_fn"), return_chain=True)
+                                 kw.get("noise_std_extra_schedule_fn"), return_chain=True, guide=kw.get("guide"),
+                                 n_guide_steps=kw.get("n_guide_steps", 1), t_start_guide=kw.get("t_start_guide", float("inf")))
             return chain if return_chain else chain[-1]
         for k, v in hard_conds.items():
             hard_conds[k] = v.reshape(1, -1).expand(n_samples, -1).contiguous()  # 'd -> b d'

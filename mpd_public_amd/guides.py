@@ -1,0 +1,101 @@
+"""GuideManagerTrajectoriesWithVelocity - drop-in for mpd/models/diffusion_models/guides.py:149-236.
+
+Same constructor (incl. the `**kwargs` that swallows inference.py:234's misspelt `num_interpolated_points`, so the
+effective number of interpolated points stays the class default 128) and the same call protocol
+``guide(x_normalized[B,H,D]) -> increment[B,H,D]`` (already negated and weighted).  The cost composite is compiled
+once into `mpdx_guide_params`; every call is one launch of the HIP guide kernel (csrc/guide.hpp).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .planning import CostCollision, CostComposite, CostGPTrajectory
+
+
+class GuideManagerTrajectoriesWithVelocity(nn.Module):
+    def __init__(self, dataset, cost, clip_grad=False, clip_grad_rule="norm", max_grad_norm=1.0, max_grad_value=0.1,
+                 interpolate_trajectories_for_collision=False, num_interpolated_points_for_collision=128,
+                 start_state_pos=None, goal_state_pos=None, num_steps=100, robot=None, n_samples=1, tensor_args=None, **kwargs):
+        super().__init__()
+        if not isinstance(cost, CostComposite):
+            raise TypeError("cost must be a mpd_public_amd.planning.CostComposite (arbitrary Python costs need autograd; "
+                            "the device guide has hand-derived gradients for the reference's cost terms only)")
+        if clip_grad and clip_grad_rule != "norm":
+            raise NotImplementedError("clip_grad_rule='value' is never used by the reference entry (inference.py:229-236)")
+        self.cost, self.dataset = cost, dataset
+        self.interpolate_trajectories_for_collision = interpolate_trajectories_for_collision
+        self.num_interpolated_points_for_collision = num_interpolated_points_for_collision
+        self.clip_grad, self.clip_grad_rule = clip_grad, clip_grad_rule
+        self.max_grad_norm, self.max_grad_value = max_grad_norm, max_grad_value
+        self._params = None
+        self._prims = None
+        self._flag = None
+
+    # ------------------------------------------------------------------------------------------- compile to device params
+    def device_params(self, device) -> "_lib.GuideParams":
+        if self._params is not None and self._prims.device == torch.device(device):
+            return self._params
+        ds, robot = self.dataset, self.dataset.robot
+        gp = _lib.GuideParams()
+        gp.robot, gp.q_dim, gp.ws_dim = robot.robot_id, robot.q_dim, ds.env.dim
+        gp.interpolate = int(bool(self.interpolate_trajectories_for_collision))
+        gp.n_interp = int(self.num_interpolated_points_for_collision)
+        gp.clip_grad, gp.max_grad_norm = int(bool(self.clip_grad)), float(self.max_grad_norm)
+        D = 2 * robot.q_dim
+        if ds.state_dim != D:
+            raise NotImplementedError("the velocity guide needs include_velocity=True (state = pos + vel)")
+        mins, maxs = ds.normalizer.mins.cpu().numpy(), ds.normalizer.maxs.cpu().numpy()
+        for d in range(D):
+            gp.mins[d], gp.maxs[d] = float(mins[d]), float(maxs[d])
+        gp.cutoff_margin, gp.link_margin = float(ds.task.obstacle_cutoff_margin), float(robot.link_margin)
+        prims, nf = [], 0
+        off = 0
+        gp.use_gp = 0
+        for c, w in zip(self.cost.cost_l, self.cost.weight_cost_l):
+            if isinstance(c, CostCollision):
+                if nf >= _lib.MAX_FIELDS:
+                    raise NotImplementedError(f"at most {_lib.MAX_FIELDS} collision fields")
+                f, fld = gp.fields[nf], c.field
+                f.kind, f.weight = fld.kind, float(w)
+                if fld.kind == _lib.FIELD_OBJECTS:
+                    sp, bx = fld.objects.prim_floats()
+                    f.sphere_off, f.n_spheres = off, sp.size // 4
+                    off += sp.size
+                    f.box_off, f.n_boxes = off, bx.size // 6
+                    off += bx.size
+                    prims += [sp, bx]
+                elif fld.kind == _lib.FIELD_WORKSPACE:
+                    for j in range(ds.env.dim):
+                        f.ws_min[j], f.ws_max[j] = float(fld.ws_min[j]), float(fld.ws_max[j])
+                nf += 1
+            elif isinstance(c, CostGPTrajectory):
+                if gp.use_gp:
+                    raise NotImplementedError("one CostGPTrajectory term")
+                gp.use_gp, gp.gp_weight, gp.dt, gp.sigma_gp = 1, float(w), float(c.dt), float(c.sigma_gp)
+            else:
+                raise NotImplementedError(type(c))
+        gp.n_fields = nf
+        table = np.concatenate(prims).astype(np.float32) if prims and sum(p.size for p in prims) else np.zeros(4, np.float32)
+        self._prims = torch.from_numpy(table).to(device)
+        gp.prims, gp.n_prim_floats = self._prims.data_ptr(), int(sum(p.size for p in prims)) if prims else 0
+        self._params = gp
+        return gp
+
+    # ------------------------------------------------------------------------------------------- guide protocol
+    @torch.no_grad()
+    def forward(self, x_normalized):
+        x = x_normalized.to(torch.float32).contiguous()
+        B, H, D = x.shape
+        gp = self.device_params(x.device)
+        lib, st = _lib.load(), _lib.current_stream()
+        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        _lib.check(lib.mpdx_absmax(x.data_ptr(), flag.data_ptr(), B, B, H, D, st), "mpdx_absmax")
+        out = torch.empty_like(x)
+        _lib.check(lib.mpdx_guide_step(C.byref(gp), x.data_ptr(), out.data_ptr(), None, None, flag.data_ptr(), None, B, B, H, D, st),
+                   "mpdx_guide_step")
+        return out
