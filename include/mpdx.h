@@ -152,6 +152,13 @@ int mpdx_guide_step(const mpdx_guide_params* gp, float* x, float* grad_out, cons
 /* absmax_out[ctx] <- atomicMax over the context's trajectories (caller zeroes absmax_out first) */
 int mpdx_absmax(const float* x, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, void* stream);
 
+/* ---- post-loop metrics: the arithmetic behind task.get_trajs_collision_and_free / compute_fraction_free_trajs /
+ * compute_collision_intensity_trajs and compute_smoothness / compute_path_length (inference.py:288-297,311-316;
+ * un-vendored, restated).  x_unnormalised [B,H,D]; out4 [B,4] = {#colliding interpolated waypoints, path length,
+ * smoothness, #waypoints checked}; n_check = interpolated waypoints per trajectory used for collision checking. */
+int mpdx_traj_metrics(const mpdx_guide_params* gp, const float* x_unnormalised, float* out4, int n_check, int B, int H, int D,
+                      void* stream);
+
 /* ---- the whole planning loop: replaces GaussianDiffusionModel.p_sample_loop driven by run_inference
  * (diffusion_model_base.py:157-182,285-316) with sample_fn=ddpm_sample_fn.  Everything is enqueued on `stream`
  * without a single host synchronisation: the t-dependent branches of the reference (`t_single < 0`,

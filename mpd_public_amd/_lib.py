@@ -63,6 +63,7 @@ SIGNATURES = {
     "mpdx_plan": (_i, [_vp, _vp, _vp, _i, C.POINTER(StepCoefs), _i, _vp, _vp, _vp, _vp, _vp, _i, _vp,
                         C.POINTER(GuideParams), _i, _i, _vp, _i, _vp]),
     "mpdx_guide_step": (_i, [C.POINTER(GuideParams), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mpdx_traj_metrics": (_i, [C.POINTER(GuideParams), _vp, _vp, _i, _i, _i, _i, _vp]),
     "mpdx_absmax": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "mpdx_unet_profile": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(C.c_double),
                                 C.POINTER(C.c_char_p), C.POINTER(C.c_int)]),

@@ -112,6 +112,163 @@ __device__ __forceinline__ void workspace_force(const mpdx_field& f, const float
     }
 }
 
+// Panda forward kinematics (modified DH): frame origins O_k and z axes Z_k in the world frame
+template <int QD>
+__device__ __forceinline__ void panda_fk(const float (&q)[QD], float (&O)[7][3], float (&Z)[7][3]) {
+    float R[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}, T[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        float st, ct;
+        sincosf(q[k < QD ? k : 0], &st, &ct);
+        const float ca = kPandaCA[k], sa = kPandaSA[k], aa = kPandaA[k], dd = kPandaD[k];
+        const float L[3][3] = {{ct, -st, 0.f}, {st * ca, ct * ca, -sa}, {st * sa, ct * sa, ca}};
+        const float Lt[3] = {aa, -sa * dd, ca * dd};
+        float Rn[3][3], Tn[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Rn[r][c] = R[r][0] * L[0][c] + R[r][1] * L[1][c] + R[r][2] * L[2][c];
+            Tn[r] = R[r][0] * Lt[0] + R[r][1] * Lt[1] + R[r][2] * Lt[2] + T[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) R[r][c] = Rn[r][c];
+            T[r] = Tn[r];
+            O[k][r] = Tn[r];
+            Z[k][r] = Rn[r][2];
+        }
+    }
+}
+
+// minimum signed distance of p to the field's primitives (collision checking)
+template <int DIM>
+__device__ __forceinline__ float objects_sdf(const float* __restrict__ prims, const mpdx_field& f, const float (&p)[DIM]) {
+    float best = 3.0e38f;
+    const float* sp = prims + f.sphere_off;
+    for (int s = 0; s < f.n_spheres; ++s) {
+        float n2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) { const float d = p[j] - sp[s * 4 + j]; n2 += d * d; }
+        best = fminf(best, sqrtf(n2) - sp[s * 4 + 3]);
+    }
+    const float* bp = prims + f.box_off;
+    for (int s = 0; s < f.n_boxes; ++s) {
+        float mx = -3.0e38f, n2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+            const float d = fabsf(p[j] - bp[s * 6 + j]) - bp[s * 6 + 3 + j];
+            mx = fmaxf(mx, d);
+            const float r = fmaxf(d, 0.f);
+            n2 += r * r;
+        }
+        best = fminf(best, fminf(mx, 0.f) + sqrtf(n2));
+    }
+    return best;
+}
+
+// Post-loop trajectory metrics (the arithmetic of task.get_trajs_collision_and_free / compute_collision_intensity_trajs
+// and torch_robotics.trajectory.metrics.compute_smoothness / compute_path_length, called at inference.py:288-297,
+// 311-316 - un-vendored, restated): per trajectory
+//   out[b][0] = number of interpolated waypoints in collision (a link sphere penetrates an object, leaves the
+//               workspace, or self-collides; margin = link radius, no cutoff margin)
+//   out[b][1] = path length  sum_h |q_{h+1} - q_h|      out[b][2] = smoothness  sum_h |v_{h+1} - v_h|
+//   out[b][3] = number of interpolated waypoints checked
+// x is UNNORMALISED [B,H,D] (inference.py:285 un-normalises before computing metrics).
+template <int QD, int DIM, int ROBOT>
+__global__ __launch_bounds__(64) void traj_metrics_kernel(const mpdx_guide_params gp, const float* __restrict__ x, float* __restrict__ out,
+                                                          int B, int H, int n_check) {
+    constexpr int D = 2 * QD;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x, b = blockIdx.x;
+    float* sx = sm;
+    float* sprim = sx + H * D;
+    for (int i = lane; i < gp.n_prim_floats; i += 64) sprim[i] = gp.prims[i];
+    const bool live = lane < H;
+    float xu[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        xu[d] = live ? x[((size_t)b * H + lane) * D + d] : 0.f;
+        if (live) sx[lane * D + d] = xu[d];
+    }
+    __syncthreads();
+    float plen = 0.f, smooth = 0.f;
+    if (live && lane < H - 1) {
+        float a2 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < QD; ++j) {
+            const float dq = sx[(lane + 1) * D + j] - xu[j], dv = sx[(lane + 1) * D + QD + j] - xu[QD + j];
+            a2 += dq * dq; v2 += dv * dv;
+        }
+        plen = sqrtf(a2); smooth = sqrtf(v2);
+    }
+    const int N = n_check;
+    const float scale = (N > 1) ? (float)(H - 1) / (float)(N - 1) : 0.f;
+    float ncoll = 0.f;
+    for (int i = lane; i < N; i += 64) {
+        const float u = scale * (float)i;
+        int i0 = (int)u;
+        if (i0 > H - 1) i0 = H - 1;
+        const int i1 = i0 + 1 < H ? i0 + 1 : H - 1;
+        const float l1 = u - (float)i0, l0 = 1.0f - l1;
+        float q[QD];
+#pragma unroll
+        for (int j = 0; j < QD; ++j) q[j] = l0 * sx[i0 * D + j] + l1 * sx[i1 * D + j];
+        bool hit = false;
+        if (ROBOT == MPDX_ROBOT_POINTMASS) {
+            float p[DIM];
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) p[j] = q[j];
+            for (int f = 0; f < gp.n_fields; ++f) {
+                if (gp.fields[f].kind == MPDX_FIELD_OBJECTS) hit |= objects_sdf<DIM>(sprim, gp.fields[f], p) < gp.link_margin;
+                else if (gp.fields[f].kind == MPDX_FIELD_WORKSPACE) {
+#pragma unroll
+                    for (int j = 0; j < DIM; ++j) hit |= (p[j] - gp.fields[f].ws_min[j] < gp.link_margin) || (gp.fields[f].ws_max[j] - p[j] < gp.link_margin);
+                }
+            }
+        } else {
+            float O[7][3], Z[7][3];
+            panda_fk(q, O, Z);
+            float P[kPandaNS][3];
+#pragma unroll
+            for (int s = 0; s < kPandaNS; ++s)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) P[s][r] = O[kPandaSF[s] - 1][r] + kPandaSO[s] * Z[kPandaSF[s] - 1][r];
+            for (int f = 0; f < gp.n_fields; ++f) {
+                const int kind = gp.fields[f].kind;
+                if (kind == MPDX_FIELD_SELF) {
+#pragma unroll
+                    for (int pr = 0; pr < kPandaNP; ++pr) {
+                        const float dx = P[kPandaPA[pr]][0] - P[kPandaPB[pr]][0], dy = P[kPandaPA[pr]][1] - P[kPandaPB[pr]][1],
+                                    dz = P[kPandaPA[pr]][2] - P[kPandaPB[pr]][2];
+                        hit |= sqrtf(dx * dx + dy * dy + dz * dz) < kPandaSR[kPandaPA[pr]] + kPandaSR[kPandaPB[pr]];
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < kPandaNS; ++s) {
+                        const float p3[3] = {P[s][0], P[s][1], P[s][2]};
+                        if (kind == MPDX_FIELD_OBJECTS) hit |= objects_sdf<3>(sprim, gp.fields[f], p3) < kPandaSR[s];
+                        else {
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) hit |= (p3[j] - gp.fields[f].ws_min[j] < kPandaSR[s]) || (gp.fields[f].ws_max[j] - p3[j] < kPandaSR[s]);
+                        }
+                    }
+                }
+            }
+        }
+        ncoll += hit ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        ncoll += __shfl_xor(ncoll, s, 64);
+        plen += __shfl_xor(plen, s, 64);
+        smooth += __shfl_xor(smooth, s, 64);
+    }
+    if (lane == 0) {
+        out[(size_t)b * 4 + 0] = ncoll; out[(size_t)b * 4 + 1] = plen; out[(size_t)b * 4 + 2] = smooth; out[(size_t)b * 4 + 3] = (float)N;
+    }
+}
+
 // QD = configuration-space dim (2, 3 point mass; 7 Panda), DIM = workspace dim, ROBOT as in mpdx.h
 template <int QD, int DIM, int ROBOT>
 __global__ __launch_bounds__(64) void guide_step_kernel(const GuideArgs a) {
@@ -183,33 +340,8 @@ __global__ __launch_bounds__(64) void guide_step_kernel(const GuideArgs a) {
                 }
             }
         } else {
-            // ---- Panda forward kinematics: frame origins O_k, z axes Z_k (world)
             float O[7][3], Z[7][3];
-            float R[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}, T[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                float st, ct;
-                sincosf(q[k < QD ? k : 0], &st, &ct);
-                const float ca = kPandaCA[k], sa = kPandaSA[k], aa = kPandaA[k], dd = kPandaD[k];
-                // local transform columns (modified DH)
-                const float L[3][3] = {{ct, -st, 0.f}, {st * ca, ct * ca, -sa}, {st * sa, ct * sa, ca}};
-                const float Lt[3] = {aa, -sa * dd, ca * dd};
-                float Rn[3][3], Tn[3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) Rn[r][c] = R[r][0] * L[0][c] + R[r][1] * L[1][c] + R[r][2] * L[2][c];
-                    Tn[r] = R[r][0] * Lt[0] + R[r][1] * Lt[1] + R[r][2] * Lt[2] + T[r];
-                }
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) R[r][c] = Rn[r][c];
-                    T[r] = Tn[r];
-                    O[k][r] = Tn[r];
-                    Z[k][r] = Rn[r][2];
-                }
-            }
+            panda_fk(q, O, Z);
             float P[kPandaNS][3];
 #pragma unroll
             for (int s = 0; s < kPandaNS; ++s) {

