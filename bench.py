@@ -29,10 +29,12 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch  # noqa: E402
 
 CONFIGS = {
-    # name: (robot, D, dim_mults, T, B, n_without_noise)
-    "cfg1": ("RobotPointMass", 4, (1, 2, 4, 8), 25, 8, 5),
-    "cfg2": ("RobotPointMass", 4, (1, 2, 4, 8), 100, 100, 5),
-    "cfg4u": ("RobotPanda", 14, (1, 2, 4, 8), 100, 100, 5),
+    # name: (env, robot, D, dim_mults, T, B, n_without_noise, guided, n_contexts)
+    "cfg1": ("EnvSimple2D", "RobotPointMass", 4, (1, 2, 4, 8), 25, 8, 5, False, 1),
+    "cfg2": ("EnvDense2D", "RobotPointMass", 4, (1, 2, 4, 8), 100, 100, 5, False, 1),          # BASELINE configs[1]: the metric's config
+    "cfg3": ("EnvNarrowPassageDense2D", "RobotPointMass", 4, (1, 2, 4, 8), 100, 100, 5, True, 1),
+    "cfg4": ("EnvSpheres3D", "RobotPanda", 14, (1, 2, 4, 8), 100, 100, 5, True, 1),
+    "cfg5": ("EnvSpheres3D", "RobotPanda", 14, (1, 2, 4, 8), 100, 6400, 5, True, 128),        # per-GPU shard of 1024 ctx x 50
 }
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_16x16x4_f32) = fp32 vector peak
 HBM_PEAK_GBS = 8000.0
@@ -101,7 +103,24 @@ def cpu_baseline_leg(sd, D, T, B, n0, min_seconds=10.0, max_plans=3):
     cores on the SAME workload: whole plans until >= min_seconds of CPU work (bounded sample)."""
     from oracle import diffusion as odiff
     from mpd_public_amd import synthetic as syn
-    cores = torch.get_num_threads()
+    # thread count: torch's default (all logical cores) oversubscribes these small per-layer ops badly on big hosts
+    # (measured: 128 threads -> 5.9 steps/s, slower than 8 threads); probe a few settings on 2 steps and keep the best.
+    import os as _os
+    probe_noise = torch.randn((4, B, 64, D))
+    hc0 = {0: torch.zeros(D), 63: torch.zeros(D)}
+    best = (1e30, torch.get_num_threads())
+    for nthr in sorted({8, 16, 32, 64, min(_os.cpu_count() or 8, 128)}):
+        if nthr > (_os.cpu_count() or 8):
+            continue
+        torch.set_num_threads(nthr)
+        odiff.run_inference(sd, hc0, probe_noise, 2, n_diffusion_steps_without_noise=1, noise_std=0.5)
+        t0 = time.perf_counter()
+        odiff.run_inference(sd, hc0, probe_noise, 2, n_diffusion_steps_without_noise=1, noise_std=0.5)
+        dt_ = time.perf_counter() - t0
+        if dt_ < best[0]:
+            best = (dt_, nthr)
+    torch.set_num_threads(best[1])
+    cores = best[1]
     hc = {0: torch.from_numpy(syn.synth_tensor("bench_hc0", (D,), "uniform")), 63: torch.from_numpy(syn.synth_tensor("bench_hc1", (D,), "uniform"))}
     gen = torch.Generator().manual_seed(30)
     noise = torch.randn((T + n0 + 1, B, 64, D), generator=gen)
@@ -137,17 +156,39 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
 
-    robot, D, mults, T, B, n0 = CONFIGS[args.config]
+    env_id, robot, D, mults, T, B, n0, guided, n_ctx = CONFIGS[args.config]
     dm, sd = build_model(D, mults, T, f"cuda:{local_rank}")
     dm.manual_seed(30 + rank)
     from mpd_public_amd import synthetic as syn
-    hc = {0: torch.from_numpy(syn.synth_tensor("bench_hc0", (D,), "uniform")).cuda(),
-          63: torch.from_numpy(syn.synth_tensor("bench_hc1", (D,), "uniform")).cuda()}
+    import mpd_public_amd as m
+    from math import ceil
     extra = lambda t: 0.5  # noqa: E731  inference.py:243
+    guide_kw = {}
+    if guided:  # guide built exactly as inference.py:188-236 builds it (weights 1e-2 / 1e-7, 5 guide steps, last quarter)
+        ds = m.TrajectoryDataset(env_id, robot, tensor_args={"device": torch.device("cuda", local_rank), "dtype": torch.float32})
+        H_, dt_ = 64, 5.0 / 64
+        cl = [m.CostCollision(ds.robot, H_, field=f, sigma_coll=1.0) for f in ds.task.get_collision_fields()]
+        wl = [1e-2] * len(cl)
+        cl.append(m.CostGPTrajectory(ds.robot, H_, dt_, sigma_gp=1.0)); wl.append(1e-7)
+        guide = m.GuideManagerTrajectoriesWithVelocity(ds, m.CostComposite(ds.robot, H_, cl, weights_cost_l=wl), clip_grad=True,
+                                                       interpolate_trajectories_for_collision=True).cuda()
+        guide_kw = dict(guide=guide, n_guide_steps=5, t_start_guide=ceil(0.25 * T))
+    if n_ctx == 1:
+        hc = {0: torch.from_numpy(syn.synth_tensor("bench_hc0", (D,), "uniform", 0.6)).cuda(),
+              63: torch.from_numpy(syn.synth_tensor("bench_hc1", (D,), "uniform", 0.6)).cuda()}
 
-    def one_plan():
-        return dm.run_inference(None, hc, n_samples=B, horizon=64, return_chain=True, n_diffusion_steps_without_noise=n0,
-                                noise_std_extra_schedule_fn=extra)
+        def one_plan():
+            return dm.run_inference(None, hc, n_samples=B, horizon=64, return_chain=True, n_diffusion_steps_without_noise=n0,
+                                    noise_std_extra_schedule_fn=extra, **guide_kw)
+    else:  # per-rank shard of independent contexts; per-trajectory hard conditions
+        from mpd_public_amd.parallel import expand_contexts
+        st = torch.from_numpy(syn.synth_tensor(f"bench_ctx_s{rank}", (n_ctx, D), "uniform", 0.6)).cuda()
+        gl = torch.from_numpy(syn.synth_tensor(f"bench_ctx_g{rank}", (n_ctx, D), "uniform", 0.6)).cuda()
+        hs, hg = expand_contexts(st, gl, B // n_ctx)
+
+        def one_plan():
+            x, chain = dm.plan({0: hs, 63: hg}, B, 64, n0, None, extra, return_chain=True, n_per_context=B // n_ctx, **guide_kw)
+            return chain
 
     def fence():
         torch.cuda.synchronize()
@@ -175,8 +216,9 @@ def main():
         "metric": "denoising-steps/s", "value": round(value, 2), "unit": "denoising-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.config}: EnvDense2D-{robot} shape, {B} trajectories x H=64 x D={D}, T={T} (+{n0}) reverse steps, "
-                               f"unguided, U-Net dim_mults {mults}, one plan = one bench step",
+        "config": {"workload": f"{args.config}: {env_id}-{robot} shape, {B} trajectories ({n_ctx} context(s)) x H=64 x D={D}, T={T} (+{n0}) "
+                               f"reverse steps, {'guided (collision + GP prior, 5 guide steps on the last T/4+5 iterations)' if guided else 'unguided'}, "
+                               f"U-Net dim_mults {mults}, one plan = one bench step",
                    "parallelism": "replicas" if world > 1 else "single", "denoising_steps_per_plan": steps_per_plan,
                    "trajectory_steps_per_s": round(value * B, 1)},
         "plan_wall_clock_ms": round(dt / args.steps * 1e3, 3),

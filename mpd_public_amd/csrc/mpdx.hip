@@ -460,11 +460,18 @@ static void choose_tile(const Layer& l, int B, int& MT, int& NT) {
     }
     static const int target = getenv("MPDX_TARGET_WGS") ? atoi(getenv("MPDX_TARGET_WGS")) : 160;
     auto wgs = [&](int mt, int nt) { return (long)(l.cout / mt) * ((npos + nt - 1) / nt); };
+    const int pad = (l.mode == CONV_S1) ? l.ks / 2 : 1;
+    auto lds = [&](int mt, int nt) {  // max(staged windows, K-partial buffer), as conv_block_lds_bytes
+        const size_t stage = (size_t)(nt / l.L_out) * (l.L_in + 2 * pad) * l.rs * sizeof(float);
+        const size_t red = (size_t)8 * nt * (mt + 4) * sizeof(float);
+        return std::max(stage, red);
+    };
     const int mts[2] = {32, 16}, nts[3] = {64, 32, 16};
-    // largest tile that still yields >= target workgroups; else the smallest legal tile
+    // largest tile that fits LDS (<= 96 KiB so that a second workgroup can co-reside) and still yields >= target
+    // workgroups; else the smallest legal tile
     for (int nt : nts)
         for (int mt : mts) {
-            if (mt < min_mt || nt < min_nt || l.cout % mt) continue;
+            if (mt < min_mt || nt < min_nt || l.cout % mt || lds(mt, nt) > 96 * 1024) continue;
             if (wgs(mt, nt) >= target) { MT = mt; NT = nt; return; }
         }
     MT = (min_mt <= 16 && l.cout % 16 == 0) ? 16 : 32;

@@ -133,3 +133,25 @@ def test_guided_plan_fused_equals_stepwise():
     a = dm.run_inference(None, hc, fused=True, **kw)
     b = dm.run_inference(None, hc, fused=False, **kw)   # p_sample_loop -> ddpm_sample_fn -> guide_gradient_steps -> guide(x)
     assert torch.equal(a, b)
+
+
+def test_multi_context_batch_equals_separate_plans():
+    """BASELINE configs[4] shape in miniature: several start/goal contexts in one batch (per-trajectory hard conditions,
+    per-context normaliser range test) == one plan per context, bit for bit."""
+    import mpd_public_amd as m
+    from mpd_public_amd.parallel import plan_contexts
+    T, n, C = 25, 4, 3
+    ds, dm, _, _, n0 = _guided_setup("EnvDense2D", "RobotPointMass", T, n, 0)
+    D = ds.state_dim
+    pg = product_guide(ds, 1e-2, 1e-7).cuda()
+    noise = t("mc_noise", (T + n0 + 1, C * n, 64, D)).cuda()
+    noise[0, n:2 * n] *= 1.5   # make context 1's early iterates exceed the +-1 range while the others need not
+    starts = torch.stack([ds.normalizer.normalize(torch.cat([t(f"mc_s{c}", (2,), "uniform", 0.7).cuda(), torch.zeros(2, device="cuda")])) for c in range(C)])
+    goals = torch.stack([ds.normalizer.normalize(torch.cat([t(f"mc_g{c}", (2,), "uniform", 0.7).cuda(), torch.zeros(2, device="cuda")])) for c in range(C)])
+    kw = dict(n_diffusion_steps_without_noise=n0, noise_std_extra_schedule_fn=lambda tt: 0.5, guide=pg, n_guide_steps=5,
+              t_start_guide=ceil(0.25 * T))
+    batched, (lo, hi) = plan_contexts(dm, starts, goals, n, horizon=64, noise=noise, **kw)
+    assert (lo, hi) == (0, C) and batched.shape == (C * n, 64, D)
+    for c in range(C):
+        x, _ = dm.plan({0: starts[c], 63: goals[c]}, n, 64, noise=noise[:, c * n:(c + 1) * n].contiguous(), return_chain=False, **kw)
+        assert torch.equal(batched[c * n:(c + 1) * n], x), c

@@ -1,0 +1,79 @@
+"""N>1 path on CPU: context sharding + the final gather on the gloo backend, world_size 2 (and 3, uneven blocks)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from mpd_public_amd.parallel import shard_range, expand_contexts, plan_contexts, gather_trajectories
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 128, 1024, 1025):
+        for w in (1, 2, 3, 8):
+            blocks = [shard_range(n, w, r) for r in range(w)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def test_expand_contexts_layout():
+    s = torch.arange(6.0).reshape(3, 2)
+    hs, hg = expand_contexts(s, s + 10, 4)
+    assert hs.shape == (12, 2)
+    assert torch.equal(hs[4:8], s[1].expand(4, 2)) and torch.equal(hg[8:], (s[2] + 10).expand(4, 2))
+
+
+def _stub_planner(hc, B, npc, **kw):
+    """Deterministic stand-in for model.plan: trajectory b = start*(1-s) + goal*s, tagged with its in-context index."""
+    hs, hg = hc[0], hc[63]
+    s = torch.linspace(0, 1, 64).reshape(1, 64, 1)
+    x = hs[:, None, :] * (1 - s) + hg[:, None, :] * s
+    return x + (torch.arange(B) % npc).reshape(B, 1, 1) * 1e-3
+
+
+def _reference(start, goal, n):
+    x, _ = plan_contexts(None, start, goal, n, planner=_stub_planner, horizon=64)
+    return x
+
+
+def _worker(rank, world, port, C, n, max_batch, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    start, goal = torch.rand((C, 4), generator=g), torch.rand((C, 4), generator=g)
+    local, (lo, hi) = plan_contexts(None, start, goal, n, rank=rank, world_size=world, max_batch=max_batch, planner=_stub_planner, horizon=64)
+    assert local.shape[0] == (hi - lo) * n
+    full = gather_trajectories(local, C, n)
+    ok = torch.equal(full, _reference(start, goal, n))
+    q.put((rank, bool(ok), tuple(full.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,C,n,max_batch", [(2, 8, 5, 8192), (2, 7, 3, 6), (3, 10, 4, 8)])
+def test_sharded_plan_and_gather_gloo(world, C, n, max_batch):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, C, n, max_batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(r[1] for r in res), res
+    assert all(r[2] == (C * n, 64, 4) for r in res)
