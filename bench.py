@@ -77,8 +77,9 @@ def roofline_leg(dm, B, T, reps=20):
     classes = defaultdict(lambda: [0.0, 0.0, 0])  # key -> [ms, flops, launches]
     for i in range(n.value):
         nm = names[i].decode()
-        if i < n.value - 1:
-            lib.mpdx_unet_layer_tile(hdl, i, B, buf, 64)
+        li = lib.mpdx_unet_unit_layer(hdl, i)
+        if li >= 0:
+            lib.mpdx_unet_layer_tile(hdl, li, B, buf, 64)
             kind = "conv_k5_gn_mish" if ".block.0." in nm else ("conv_k1" if "residual" in nm else ("down_k3s2" if "downs" in nm else "up_k4s2"))
             key = f"{kind}[{buf.value.decode()}] flops/launch={fl[i]:.3e}"
         else:

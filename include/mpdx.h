@@ -180,11 +180,14 @@ int mpdx_plan(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, i
 /* ---- measurement helpers (bench.py's roofline leg; not used by the planning path) ----
  * One U-Net pass with a hipEvent pair around every kernel launch, on `stream`.  This call DOES synchronise the
  * stream (it reads the events).  ms_out[i] = duration of launch i; flops_out[i] = its algorithmic FLOPs
- * (2*C_out*B*L_out*C_in*taps, 0 for the final 1x1+step kernel); names_out[i] -> static layer name.
+ * (2*C_out*B*L_out*C_in*taps summed over the layers of the launch, 0 for the final 1x1+step kernel); names_out[i] ->
+ * layer name, or "fused[...]" for a whole-trajectory fused segment (disable fusion with MPDX_FUSED=0).
  * Returns the number of launches written (<= cap) in *n_out. */
 int mpdx_unet_profile(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, int T, const float* x, int t,
                       int B, float* ws, void* stream, int cap, float* ms_out, double* flops_out,
                       const char** names_out, int* n_out);
+/* layer index behind launch unit i of mpdx_unet_profile (-1: fused whole-trajectory segment or the final kernel) */
+int mpdx_unet_unit_layer(const mpdx_unet* u, int i);
 /* `reps` back-to-back launches of layer `layer` between two events; dbg = ablation mask (1 skip staging, 2 skip
  * MFMA loop, 4 skip epilogue, 8 skip weight loads); synchronises. */
 int mpdx_bench_layer(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, const float* x, int layer, int B,

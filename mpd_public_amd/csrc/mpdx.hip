@@ -14,6 +14,7 @@
 
 #include "../../include/mpdx.h"
 #include "conv_block.hpp"
+#include "fused_level.hpp"
 #include "guide.hpp"
 
 namespace mpdx {
@@ -255,6 +256,18 @@ struct mpdx_unet {
     std::vector<int> tt_w, tt_b, tt_cout, tt_off;  // cond_mlp param indices per block
     int final_slot = 0;       // slot holding final_conv[0]'s output
     int n_done = 0;
+    // launch units: fused whole-trajectory segments (fused_level.hpp) or single layers
+    struct Fused {
+        int first = 0, count = 0;       // layer range [first, first+count)
+        bool has_final = false;         // final_conv[1] + DDPM step folded in
+        int in1 = 0, in2 = 0;           // input slots (SRC_X / SRC_NONE allowed)
+        int gout_slot[3] = {-1, -1, -1};
+        size_t lds_bytes = 0;
+        mpdx::FusedArgs tmpl;
+    };
+    std::vector<Fused> fused;
+    struct Unit { int fused; int layer; };   // fused >= 0: fused[fused]; else layers[layer]
+    std::vector<int> owner;                  // layer -> fused segment (-1: per-layer launch)
 };
 
 namespace mpdx {
@@ -426,6 +439,147 @@ static void build_model(mpdx_unet* u) {
     u->slot_floats = std::max(slot, (size_t)c.unet_input_dim * H);
 }
 
+// ------------------------------------------------------------------------------------------------ fused segments
+// Try to turn layers [i0, i1) (an outer U-Net level: 2 residual blocks + resample [+ final_conv[0]]) into one
+// fused_level_kernel program.  Returns false (and leaves the per-layer path) if any shape constraint fails.
+static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
+    mpdx_unet::Fused f;
+    f.first = i0; f.count = i1 - i0; f.has_final = with_final;
+    FusedArgs& a = f.tmpl;
+    memset(&a, 0, sizeof(a));
+    const Layer& l0 = u->layers[i0];
+    f.in1 = l0.src1; f.in2 = l0.src2;
+    a.gc1 = l0.c1; a.gc2 = l0.c2; a.L0 = l0.L_in;
+    if (f.count + (with_final ? 1 : 0) > kMaxFusedOps) return false;
+    int nbuf = 0;
+    size_t off4 = 0;
+    std::unordered_map<long, int> bufmap;  // (slot, L) -> LDS buffer
+    auto new_buf = [&](int cpad, int L) {
+        if (nbuf >= kMaxFusedBufs) return -1;
+        const int rs = pick_row_stride(cpad, CONV_S1, L, L, L + 4);
+        a.bufs[nbuf].off4 = (int)off4; a.bufs[nbuf].rs4 = rs / 4;
+        off4 += (size_t)(L + 4) * (rs / 4);
+        return nbuf++;
+    };
+    auto buf_for = [&](int slot, int L, int cpad) {
+        const long key = (long)(slot + 8) * 4096 + L;
+        auto it = bufmap.find(key);
+        if (it != bufmap.end()) return it->second;
+        const int id = new_buf(cpad, L);
+        bufmap[key] = id;
+        return id;
+    };
+    a.in_buf = new_buf(l0.cin_pad, l0.L_in);
+    if (a.in_buf < 0) return false;
+    bufmap[(long)(l0.src1 + 8) * 4096 + l0.L_in] = a.in_buf;
+    size_t red4 = 0;
+    int ng = 0;
+    for (int i = i0; i < i1; ++i) {
+        const Layer& l = u->layers[i];
+        FusedOp& op = a.ops[a.nops];
+        op.kind = (l.epi == EPI_GN_MISH) ? FOP_CONV_GN : FOP_CONV_BIAS;
+        op.mode = l.mode; op.ks = l.ks;
+        const int MSn = l.cout / 16, NSn = (l.mode == CONV_UPT) ? (l.L_in / 16) * 2 : l.L_out / 16;
+        const int T = MSn * NSn;
+        if (l.cout % 16 || l.L_out % 16 || (T != 4 && T != 8) || (l.mode == CONV_UPT && l.L_in % 16)) return false;
+        if (op.kind == FOP_CONV_GN && (l.cout / l.gs != 8 || (l.gs * l.L_out != 128 && l.gs * l.L_out != 256))) return false;
+        // source: the first layers read the staged input; later ones an LDS buffer produced in this segment
+        if (i == i0 || (l.src1 == l0.src1 && l.src2 == l0.src2 && l.L_in == l0.L_in)) op.src = a.in_buf;
+        else {
+            if (l.src2 != SRC_NONE) return false;
+            const long key = (long)(l.src1 + 8) * 4096 + l.L_in;
+            if (!bufmap.count(key)) return false;
+            op.src = bufmap[key];
+        }
+        op.res = -1;
+        if (l.res != SRC_NONE) {
+            const long key = (long)(l.res + 8) * 4096 + l.L_out;
+            if (!bufmap.count(key)) return false;
+            op.res = bufmap[key];
+        }
+        // destination: LDS if a later layer of the segment (or the final op) reads it; global if someone outside does
+        bool read_inside = with_final && i == i1 - 1;
+        for (int k = i + 1; k < i1; ++k) {
+            const Layer& n = u->layers[k];
+            if ((n.src1 == l.dst && n.L_in == l.L_out) || (n.res == l.dst && n.L_out == l.L_out)) read_inside = true;
+            if (n.dst == l.dst) break;  // overwritten
+        }
+        bool read_outside = false;
+        bool overwritten_inside = false;  // the slot is re-used by a later layer of this segment: this value never leaves
+        for (int k = i + 1; k < i1; ++k)
+            if (u->layers[k].dst == l.dst) { overwritten_inside = true; break; }
+        for (size_t k = i1; k < u->layers.size() && !overwritten_inside; ++k) {
+            const Layer& n = u->layers[k];
+            if (n.src1 == l.dst || n.src2 == l.dst || n.res == l.dst) { read_outside = true; break; }
+            if (n.dst == l.dst) break;
+        }
+        if (i == i1 - 1 && !with_final) read_outside = true;
+        op.dst = read_inside ? buf_for(l.dst, l.L_out, l.cout) : -1;
+        if (read_inside && op.dst < 0) return false;
+        if (op.dst >= 0 && (op.dst == op.src || op.dst == op.res)) return false;
+        op.gdst = -1;
+        if (read_outside) {
+            if (ng >= 3) return false;
+            f.gout_slot[ng] = l.dst;
+            op.gdst = ng++;
+        }
+        op.cin_pad = l.cin_pad; op.cout = l.cout; op.L_in = l.L_in; op.L_out = l.L_out; op.gs = l.gs;
+        op.w_off = (int)u->params[l.w].off; op.b_off = (int)u->params[l.b].off;
+        op.ga_off = l.gamma >= 0 ? (int)u->params[l.gamma].off : 0;
+        op.be_off = l.beta >= 0 ? (int)u->params[l.beta].off : 0;
+        op.tb_off = l.tb_off;
+        red4 = std::max(red4, (size_t)(8 / T) * l.L_out * ((l.cout + 4) / 4));
+        a.nops++;
+    }
+    if (with_final) {
+        const Layer& lf = u->layers[i1 - 1];
+        FusedOp& op = a.ops[a.nops++];
+        memset(&op, 0, sizeof(op));
+        op.kind = FOP_FINAL;
+        op.src = bufmap[(long)(lf.dst + 8) * 4096 + lf.L_out];
+        op.L_in = lf.L_out;
+        a.Cf = u->cfg.unet_input_dim; a.D = u->cfg.state_dim;
+        a.fw_off = (int)u->params[u->pidx.at("final_conv.1.weight")].off;
+        a.fb_off = (int)u->params[u->pidx.at("final_conv.1.bias")].off;
+    }
+    a.nbufs = nbuf;
+    a.red_off4 = (int)off4;
+    off4 += red4;
+    a.lds_float4 = (int)off4;
+    f.lds_bytes = off4 * 16;
+    if (f.lds_bytes > 160 * 1024) return false;
+    u->fused.push_back(f);
+    return true;
+}
+
+static void build_units(mpdx_unet* u) {
+    const int nl = u->cfg.n_levels;
+    const int n = (int)u->layers.size();
+    auto range_of = [&](const std::string& prefix, int& i0, int& i1) {
+        i0 = -1; i1 = -1;
+        for (int i = 0; i < n; ++i)
+            if (u->layers[i].name.compare(0, prefix.size(), prefix) == 0) { if (i0 < 0) i0 = i; i1 = i + 1; }
+        return i0 >= 0;
+    };
+    std::vector<int> owner(n, -1);
+    auto try_seg = [&](const std::string& prefix, bool with_final) {
+        int i0, i1;
+        if (!range_of(prefix, i0, i1)) return;
+        if (with_final) {
+            if (i1 != n - 1 || u->layers[n - 1].name.compare(0, 12, "final_conv.0") != 0) return;
+            i1 = n;
+        }
+        for (int i = i0; i < i1; ++i) if (owner[i] >= 0) return;
+        if (build_fused_segment(u, i0, i1, with_final))
+            for (int i = i0; i < i1; ++i) owner[i] = (int)u->fused.size() - 1;
+    };
+    try_seg("downs.0.", false);
+    if (nl >= 3) try_seg("downs.1.", false);
+    if (nl >= 3) try_seg("ups." + std::to_string(nl - 3) + ".", false);
+    try_seg("ups." + std::to_string(nl - 2) + ".", true);
+    u->owner = owner;
+}
+
 // ------------------------------------------------------------------------------------------------ conv dispatch
 template <int MODE, int KS, int EPI, int MT, int NT, int WN, int WK>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
@@ -551,15 +705,26 @@ static int check_ready(const mpdx_unet* u) {
     return 0;
 }
 
-static int run_unet_body(mpdx_unet* u, const float* packed, const float* timetab, int T, const float* x, int t, int B,
-                         float* ws, hipStream_t st) {
-    if (int rc = check_ready(u)) return rc;
-    if (t < 0 || t >= T) return fail(MPDX_E_INVALID, "timestep %d outside [0,%d)", t, T);
-    if (B <= 0) return fail(MPDX_E_INVALID, "B must be positive");
-    const float* row = timetab + (size_t)t * u->tt_row;
-    for (const Layer& l : u->layers)
-        if (int rc = run_layer(u, l, packed, row, x, ws, B, st)) return rc;
-    return 0;
+// bit k enables fused segment k (MPDX_FUSED=0 disables all, MPDX_FUSED_MASK=<bits> selects; default all)
+static unsigned fused_mask() {
+    static const unsigned m = (getenv("MPDX_FUSED") && atoi(getenv("MPDX_FUSED")) == 0) ? 0u
+                              : (getenv("MPDX_FUSED_MASK") ? (unsigned)strtoul(getenv("MPDX_FUSED_MASK"), nullptr, 0) : ~0u);
+    return m;
+}
+static bool fused_enabled() { return fused_mask() != 0; }
+// launch units for the current mask
+static std::vector<mpdx_unet::Unit> current_units(const mpdx_unet* u, bool* final_in_fused) {
+    std::vector<mpdx_unet::Unit> out;
+    const unsigned m = fused_mask();
+    bool fin = false;
+    for (int i = 0; i < (int)u->layers.size(); ++i) {
+        const int o = u->owner[i];
+        if (o >= 0 && ((m >> o) & 1u)) {
+            if (i == u->fused[o].first) { out.push_back({o, i}); fin |= u->fused[o].has_final; }
+        } else out.push_back({-1, i});
+    }
+    if (final_in_fused) *final_in_fused = fin;
+    return out;
 }
 
 static int run_final(mpdx_unet* u, const float* packed, FinalArgs& fa, int B, float* ws, hipStream_t st) {
@@ -571,6 +736,50 @@ static int run_final(mpdx_unet* u, const float* packed, FinalArgs& fa, int B, fl
     const int n = B * c.n_support_points;
     const size_t lds = (size_t)(fa.D * fa.C + fa.D) * sizeof(float);
     hipLaunchKernelGGL(final_step_kernel, dim3((n + 255) / 256), dim3(256), lds, st, fa);
+    return 0;
+}
+
+static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packed, const float* tt_row, const float* x, float* ws,
+                     int B, const FinalArgs* fa, hipStream_t st) {
+    const size_t slot = u->slot_floats * (size_t)B;
+    auto src = [&](int s) -> const float* { return s == SRC_X ? x : (s == SRC_NONE ? nullptr : ws + slot * s); };
+    FusedArgs a = f.tmpl;
+    a.packed = packed; a.tt_row = tt_row;
+    a.gsrc1 = src(f.in1); a.gsrc2 = src(f.in2);
+    for (int k = 0; k < 3; ++k) a.gout[k] = f.gout_slot[k] >= 0 ? ws + slot * f.gout_slot[k] : nullptr;
+    a.B = B;
+    if (f.has_final) {
+        if (!fa) return fail(MPDX_E_STATE, "fused final segment needs the step arguments");
+        a.x_in = fa->x_in; a.noise = fa->noise; a.hs = fa->hs; a.hg = fa->hg; a.out = fa->out; a.chain = fa->chain;
+        a.absmax = fa->absmax; a.fmode = fa->mode; a.n_per_ctx = fa->n_per_ctx > 0 ? fa->n_per_ctx : B; a.k = fa->k;
+    }
+    static bool raised = false;
+    if (!raised) {
+        HIP_TRY(hipFuncSetAttribute((const void*)fused_level_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised = true;
+    }
+    hipLaunchKernelGGL(fused_level_kernel, dim3(B), dim3(512), f.lds_bytes, st, a);
+    return 0;
+}
+
+// one U-Net pass + the final 1x1 conv / DDPM step described by `fa` (fa.mode 0: eps only)
+static int run_unet_and_final(mpdx_unet* u, const float* packed, const float* timetab, int T, const float* x, int t, int B,
+                              float* ws, FinalArgs& fa, hipStream_t st) {
+    if (int rc = check_ready(u)) return rc;
+    if (t < 0 || t >= T) return fail(MPDX_E_INVALID, "timestep %d outside [0,%d)", t, T);
+    if (B <= 0) return fail(MPDX_E_INVALID, "B must be positive");
+    const float* row = timetab + (size_t)t * u->tt_row;
+    const auto units = current_units(u, nullptr);
+    bool final_done = false;
+    for (const auto& un : units) {
+        if (un.fused >= 0) {
+            const auto& f = u->fused[un.fused];
+            if (int rc = run_fused(u, f, packed, row, x, ws, B, &fa, st)) return rc;
+            final_done |= f.has_final;
+        } else if (int rc = run_layer(u, u->layers[un.layer], packed, row, x, ws, B, st)) return rc;
+    }
+    if (!final_done)
+        if (int rc = run_final(u, packed, fa, B, ws, st)) return rc;
     return 0;
 }
 
@@ -630,6 +839,7 @@ int mpdx_unet_create(const mpdx_unet_cfg* cfg, mpdx_unet** out) {
             }
         }
     if ((int)u->tt_w.size() > 40) { delete u; return fail(MPDX_E_INVALID, "too many residual blocks"); }
+    build_units(u);
     *out = u;
     return 0;
 }
@@ -696,11 +906,10 @@ int mpdx_unet_forward(mpdx_unet* u, const float* packed, const float* timetab, i
                       int B, float* ws, void* stream) {
     if (!u || !packed || !timetab || !x || !eps || !ws) return fail(MPDX_E_INVALID, "null argument");
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = run_unet_body(u, packed, timetab, T, x, t, B, ws, st)) return rc;
     FinalArgs fa;
     memset(&fa, 0, sizeof(fa));
     fa.out = eps; fa.mode = 0; fa.n_per_ctx = 1;
-    if (int rc = run_final(u, packed, fa, B, ws, st)) return rc;
+    if (int rc = run_unet_and_final(u, packed, timetab, T, x, t, B, ws, fa, st)) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -710,14 +919,13 @@ int mpdx_ddpm_step(mpdx_unet* u, const float* packed, const float* timetab, int 
                    float* chain_out, uint32_t* absmax_out, int n_per_ctx, int B, float* ws, void* stream) {
     if (!u || !packed || !timetab || !x_io || !coefs || !ws) return fail(MPDX_E_INVALID, "null argument");
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = run_unet_body(u, packed, timetab, T, x_io, t, B, ws, st)) return rc;
     FinalArgs fa;
     memset(&fa, 0, sizeof(fa));
     fa.x_in = x_io; fa.out = x_io; fa.noise = noise; fa.hs = hard_start; fa.hg = hard_goal;
     fa.chain = chain_out; fa.absmax = absmax_out; fa.n_per_ctx = n_per_ctx > 0 ? n_per_ctx : B;
     fa.mode = mean_only ? 2 : 1;
     fa.k = *coefs;
-    if (int rc = run_final(u, packed, fa, B, ws, st)) return rc;
+    if (int rc = run_unet_and_final(u, packed, timetab, T, x_io, t, B, ws, fa, st)) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -794,7 +1002,6 @@ int mpdx_plan(mpdx_unet* u, const float* packed, const float* timetab, int T, co
     for (int i = T - 1; i >= -n_without_noise; --i, ++k) {
         const int t = i < 0 ? 0 : i;
         const bool guided = guide && i < t_start_guide;  // sample_functions.py:39 compares the un-clamped index
-        if (int rc = run_unet_body(u, packed, timetab, T, x, t, B, ws, st)) return rc;
         const float* nz = (t == 0) ? nullptr : noise + (size_t)k * n;  // noise[t == 0] = 0  (sample_functions.py:52)
         float* ch = chain ? chain + (size_t)(k + 1) * n : nullptr;
         FinalArgs fa;
@@ -804,11 +1011,11 @@ int mpdx_plan(mpdx_unet* u, const float* packed, const float* timetab, int T, co
         fa.n_per_ctx = npc;
         if (!guided) {
             fa.noise = nz; fa.hs = hard_start; fa.hg = hard_goal; fa.chain = ch; fa.mode = 1;
-            if (int rc = run_final(u, packed, fa, B, ws, st)) return rc;
+            if (int rc = run_unet_and_final(u, packed, timetab, T, x, t, B, ws, fa, st)) return rc;
         } else {
             uint32_t* fl = guide_flags + (size_t)k * (n_guide_steps + 1) * n_ctx;
             fa.mode = 2; fa.absmax = fl;  // posterior mean + its max|.| per context
-            if (int rc = run_final(u, packed, fa, B, ws, st)) return rc;
+            if (int rc = run_unet_and_final(u, packed, timetab, T, x, t, B, ws, fa, st)) return rc;
             for (int j = 0; j < n_guide_steps; ++j)
                 if (int rc = launch_guide(guide, x, nullptr, hard_start, hard_goal, fl + (size_t)j * n_ctx, fl + (size_t)(j + 1) * n_ctx, npc, B, H,
                                           D, st))
@@ -827,27 +1034,43 @@ int mpdx_unet_profile(mpdx_unet* u, const float* packed, const float* timetab, i
     if (int rc = check_ready(u)) return rc;
     if (t < 0 || t >= T) return fail(MPDX_E_INVALID, "timestep %d outside [0,%d)", t, T);
     hipStream_t st = (hipStream_t)stream;
-    const int nl = (int)u->layers.size() + 1;
+    bool fin_fused = false;
+    const auto units = current_units(u, &fin_fused);
+    const bool need_final = !fin_fused;
+    const int nl = (int)units.size() + (need_final ? 1 : 0);
     if (cap < nl) return fail(MPDX_E_INVALID, "need room for %d launches", nl);
+    static float* scratch = nullptr;  // eps sink owned by the library (measurement helper only)
+    static size_t scratch_n = 0;
+    const size_t need = (size_t)B * u->cfg.n_support_points * u->cfg.state_dim;
+    if (scratch_n < need) { if (scratch) (void)hipFree(scratch); HIP_TRY(hipMalloc(&scratch, need * sizeof(float))); scratch_n = need; }
+    FinalArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.out = scratch; fa.mode = 0; fa.n_per_ctx = 1;
     std::vector<hipEvent_t> ev(2 * nl);
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
     const float* row = timetab + (size_t)t * u->tt_row;
+    static std::vector<std::string> fused_names;
+    fused_names.resize(u->fused.size());
     int rc = 0;
-    for (int i = 0; i < nl - 1 && !rc; ++i) {
+    for (int i = 0; i < (int)units.size() && !rc; ++i) {
         HIP_TRY(hipEventRecord(ev[2 * i], st));
-        rc = run_layer(u, u->layers[i], packed, row, x, ws, B, st);
+        double fl = 0.0;
+        if (units[i].fused >= 0) {
+            const auto& f = u->fused[units[i].fused];
+            rc = run_fused(u, f, packed, row, x, ws, B, &fa, st);
+            for (int k = f.first; k < f.first + f.count; ++k) fl += layer_flops(u->layers[k], B);
+            fused_names[units[i].fused] = "fused[" + u->layers[f.first].name.substr(0, u->layers[f.first].name.find(".blocks")) + "..+" +
+                                          std::to_string(f.count) + (f.has_final ? " layers+final_conv.1+ddpm_step]" : " layers]");
+            if (names_out) names_out[i] = fused_names[units[i].fused].c_str();
+        } else {
+            rc = run_layer(u, u->layers[units[i].layer], packed, row, x, ws, B, st);
+            fl = layer_flops(u->layers[units[i].layer], B);
+            if (names_out) names_out[i] = u->layers[units[i].layer].name.c_str();
+        }
         HIP_TRY(hipEventRecord(ev[2 * i + 1], st));
-        if (flops_out) flops_out[i] = layer_flops(u->layers[i], B);
-        if (names_out) names_out[i] = u->layers[i].name.c_str();
+        if (flops_out) flops_out[i] = fl;
     }
-    if (!rc) {
-        static float* scratch = nullptr;  // eps sink owned by the library (measurement helper only)
-        static size_t scratch_n = 0;
-        const size_t need = (size_t)B * u->cfg.n_support_points * u->cfg.state_dim;
-        if (scratch_n < need) { if (scratch) (void)hipFree(scratch); HIP_TRY(hipMalloc(&scratch, need * sizeof(float))); scratch_n = need; }
-        FinalArgs fa;
-        memset(&fa, 0, sizeof(fa));
-        fa.out = scratch; fa.mode = 0; fa.n_per_ctx = 1;
+    if (!rc && need_final) {
         HIP_TRY(hipEventRecord(ev[2 * (nl - 1)], st));
         rc = run_final(u, packed, fa, B, ws, st);
         HIP_TRY(hipEventRecord(ev[2 * (nl - 1) + 1], st));
@@ -859,6 +1082,14 @@ int mpdx_unet_profile(mpdx_unet* u, const float* packed, const float* timetab, i
     for (auto& e : ev) (void)hipEventDestroy(e);
     *n_out = nl;
     return rc;
+}
+
+/* layer index of launch unit i (-1 for a fused unit / the final kernel): lets bench.py query the tile of a unit */
+int mpdx_unet_unit_layer(const mpdx_unet* u, int i) {
+    if (!u) return -1;
+    const auto units = current_units(u, nullptr);
+    if (i < 0 || i >= (int)units.size()) return -1;
+    return units[i].fused >= 0 ? -1 : units[i].layer;
 }
 
 int mpdx_bench_layer(mpdx_unet* u, const float* packed, const float* timetab, const float* x, int layer, int B, float* ws,

@@ -1,0 +1,123 @@
+"""CPU-only checks of the C ABI and the host logic (no compute calls): libmpdx.so loads without a GPU, exports every
+symbol include/mpdx.h declares, the ctypes binding covers all of them, and host-side validation behaves."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from mpd_public_amd import build, _lib
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def declared_symbols():
+    text = (ROOT / "include" / "mpdx.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpdx_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    from mpd_public_amd import _lib
+    decl = declared_symbols()
+    assert len(decl) >= 20
+    out = subprocess.run(["nm", "-D", "--defined-only", str(_lib.lib_path())], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (mpdx_[a-z_0-9]+)", out))
+    assert set(decl) <= exported, sorted(set(decl) - exported)
+    assert set(decl) == set(_lib.SIGNATURES), (sorted(set(decl) ^ set(_lib.SIGNATURES)))
+    for name in decl:
+        assert getattr(lib, name) is not None
+    assert lib.mpdx_version() >= 1
+
+
+def _create(lib, **kw):
+    from mpd_public_amd import _lib
+    cfg = dict(state_dim=4, n_support_points=64, unet_input_dim=32, n_levels=4, dim_mults=(1, 2, 4, 8), time_emb_dim=32)
+    cfg.update(kw)
+    c = _lib.UnetCfg(cfg["state_dim"], cfg["n_support_points"], cfg["unet_input_dim"], cfg["n_levels"],
+                     (C.c_int32 * _lib.MAX_LEVELS)(*cfg["dim_mults"]), cfg["time_emb_dim"])
+    h = C.c_void_p()
+    rc = lib.mpdx_unet_create(C.byref(c), C.byref(h))
+    return rc, h
+
+
+@pytest.mark.parametrize("D,mults", [(4, (1, 2, 4, 8)), (14, (1, 2, 4)), (6, (1, 2, 4, 8))])
+def test_handle_parameter_table_matches_reference_tree(lib, D, mults):
+    from oracle.unet import unet_param_shapes
+    rc, h = _create(lib, state_dim=D, n_levels=len(mults), dim_mults=mults)
+    assert rc == 0
+    got = {}
+    for i in range(lib.mpdx_unet_num_params(h)):
+        n, s, nd = C.c_char_p(), (C.c_int32 * 3)(), C.c_int32()
+        assert lib.mpdx_unet_param_info(h, i, C.byref(n), C.byref(s), C.byref(nd)) == 0
+        got[n.value.decode()] = tuple(s[: nd.value])
+    assert got == unet_param_shapes(D, 32, mults)
+    assert lib.mpdx_unet_packed_floats(h) >= sum(int(np.prod(v)) for v in got.values())
+    assert lib.mpdx_unet_workspace_floats(h, 100) == 100 * 2048 * (4 + len(mults))
+    assert lib.mpdx_unet_timetab_floats(h, 100) == 100 * sum(v[0] for k, v in got.items() if k.endswith("cond_mlp.1.bias"))
+    lib.mpdx_unet_destroy(h)
+
+
+def test_invalid_configurations_are_rejected_with_messages(lib):
+    for kw in (dict(n_levels=1), dict(state_dim=0), dict(time_emb_dim=16), dict(unet_input_dim=24), dict(n_support_points=48),
+               dict(n_support_points=16)):
+        rc, _ = _create(lib, **kw)
+        assert rc < 0, kw
+        assert lib.mpdx_last_error()
+    rc, h = _create(lib)
+    assert rc == 0
+    # unknown key / wrong size / forward before packing: errors, not crashes (pointers are never dereferenced on these paths)
+    dummy = C.c_void_p(16)
+    assert lib.mpdx_unet_pack_param(h, b"not.a.key", dummy, 4, dummy, None) == -2
+    assert lib.mpdx_unet_pack_param(h, b"final_conv.1.bias", dummy, 5, dummy, None) == -1
+    assert lib.mpdx_unet_forward(h, dummy, dummy, 100, dummy, 0, dummy, 1, dummy, None) == -3
+    assert b"parameters packed" in lib.mpdx_last_error()
+    lib.mpdx_unet_destroy(h)
+
+
+def test_product_schedule_buffers_bitexact_vs_reference(golden_dir):
+    from helpers import load_npz
+    from mpd_public_amd.schedules import diffusion_buffers
+    g = load_npz(golden_dir / "schedules.npz")
+    for T in (25, 100):
+        for sched in ("exponential", "cosine"):
+            for k, v in diffusion_buffers(sched, T).items():
+                np.testing.assert_array_equal(v.numpy(), g[f"{sched}_{T}_{k}"], err_msg=f"{sched} {T} {k}")
+
+
+def test_model_state_dict_and_loud_cpu_failure():
+    import mpd_public_amd as m
+    from helpers import synth_sd
+    net = m.TemporalUnet(n_support_points=64, state_dim=4, dim_mults=(1, 2, 4, 8))
+    net.load_state_dict(synth_sd(4, 1), strict=True)
+    dm = m.GaussianDiffusionModel(model=net, n_diffusion_steps=25, predict_epsilon=True)
+    assert len(dm.state_dict()) == 196 + 12
+    with pytest.raises(RuntimeError, match="GPU"):
+        net(torch.zeros(2, 64, 4), torch.zeros(2, dtype=torch.long))
+    with pytest.raises(NotImplementedError):
+        m.TemporalUnet(n_support_points=64, state_dim=4, conditioning_type="attention")
+    with pytest.raises(NotImplementedError):
+        dm.loss(torch.zeros(1, 64, 4), None)
+    c = m.sample_functions.step_coefs(dm, 0, 0.5)
+    assert c.noise_scale == 0.0 and c.noise_std_extra == 0.5 and c.predict_epsilon == 1
+
+
+def test_guide_descriptor_compiles_to_params_on_cpu():
+    import mpd_public_amd as m
+    from helpers import product_guide
+    ds = m.TrajectoryDataset("EnvSpheres3D", "RobotPanda")
+    g = product_guide(ds)
+    gp = g.device_params("cpu")
+    assert g.num_interpolated_points_for_collision == 128       # the misspelt kwarg is swallowed, as in the reference
+    assert (gp.robot, gp.q_dim, gp.ws_dim, gp.n_fields, gp.use_gp, gp.n_interp) == (1, 7, 3, 4, 1, 128)
+    assert [gp.fields[i].kind for i in range(4)] == [2, 0, 1, 0]
+    assert gp.fields[1].n_spheres == 15 and gp.fields[3].n_spheres == 2 and gp.n_prim_floats == 17 * 4
+    assert abs(gp.dt - 5.0 / 64) < 1e-9 and abs(gp.gp_weight - 1e-7) < 1e-12
