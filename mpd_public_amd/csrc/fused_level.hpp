@@ -15,8 +15,13 @@
 // channel-last layout [L+4 rows][C + pad] (rows 0,1 and L+2,L+3 stay zero: conv padding), plus the K-partial buffer.
 // A tiny op list (kernel argument) is interpreted: each conv is M = C_out (all), N = L positions, K = C_in*taps;
 // the (C_out/16)*(L/16) = 8 (or 4) MFMA sub-tiles map one per wave (K split in two when there are 4), partials meet
-// in LDS, then wave g normalises GroupNorm group g of the trajectory.  The next op's first weight fragments are
-// prefetched before the current op's epilogue so that the L2 latency of the weight stream is paid once per launch.
+// in LDS, then wave g normalises GroupNorm group g of the trajectory.
+// Weights reach the MFMAs through LDS-DMA (global_load_lds, 16 B per lane): the packed A-fragment layout
+// Wp[m16][c16][slot][lane][4] is already a sequence of lane-linear 1-KiB blocks, which is exactly the DMA's destination
+// shape (wave-uniform base + lane*16).  The blocks of op i+1 are DMA'd right after op i's MFMA barrier, so their
+// HBM/L2 latency hides under op i's GroupNorm epilogue; the k-loop itself reads A and B fragments from LDS only
+// (no vmcnt waits inside it - the register-ring version of this loop was serialised by hipcc to ~2 loads in flight).
+// Ops whose weights exceed the LDS weight window (the 256->64 k5 block: 320 KiB) run in c16 chunks.
 #pragma once
 #include "conv_block.hpp"
 
@@ -27,6 +32,8 @@ enum : int { FOP_CONV_GN = 0, FOP_CONV_BIAS = 1, FOP_FINAL = 2 };
 struct FusedBuf {
     int off4;   // offset in LDS, float4 units
     int rs4;    // row stride, float4 units
+    int rows;   // L + 4 (two zero halo rows on each side)
+    int clear_all;  // 1: the whole buffer must start zeroed (channel padding of the staged input)
 };
 
 struct FusedOp {
@@ -36,6 +43,9 @@ struct FusedOp {
     int gdst;          // index into FusedArgs.gout (-1: none)
     int cin_pad, cout, L_in, L_out, gs;
     int w_off, b_off, ga_off, be_off, tb_off;  // float offsets into packed weights / the time-table row (-1: none)
+    int p_off;         // float offset of this op's staged [bias | gamma | beta | tbias] block (4*cout floats) in LDS
+    // host-precomputed so that the kernel needs no integer division (sub-tile counts and group sizes are powers of two)
+    int lg_T, lg_MSn, lg_gs, lg_M4, ntap, nslot, nc16, cchunk;
 };
 
 constexpr int kMaxFusedOps = 14;
@@ -50,6 +60,13 @@ struct FusedArgs {
     int gc1, gc2, L0, in_buf;
     int B, nops, nbufs;
     int red_off4;        // K-partial buffer (float4 units)
+    int par_off4;        // staged per-op parameter vectors (float4 units)
+    int par_floats;      // their total length (<= 8*512)
+    int w_off4;          // LDS weight window (float4 units)
+    int w_cap_blocks;    // its capacity in 1-KiB A-fragment blocks
+    int lg_c4n;          // log2(float4 per staged input row) or -1 (generic division path)
+    int lg_cout;         // log2(C_out) of the segment's ops (uniform per segment)
+    int n_runs;          // parameter runs = 4 * (#conv ops): run r = op (r>>2), vector (r&3)
     int lds_float4;      // total LDS in float4 units (zeroed at start)
     FusedOp ops[kMaxFusedOps];
     FusedBuf bufs[kMaxFusedBufs];
@@ -58,42 +75,65 @@ struct FusedArgs {
     float* out; float* chain; uint32_t* absmax;
     int D, Cf, fmode, n_per_ctx, fw_off, fb_off;
     mpdx_step_coefs k;
+    long long* trace;    // dev tool: s_memtime stamps of workgroup 0 / wave 0 (null in production)
 };
-
-constexpr int kFusedPF = 4;
 
 struct FusedWork {   // one wave's share of a conv op
-    int ms, ns, kpart, g_lo, g_hi, ntap, nslot, nc16, G;
-    const float* wbase;
+    int ms, ns, kpart, ksplit, MSn;
 };
 
-__device__ __forceinline__ FusedWork fused_work(const FusedArgs& a, const FusedOp& op, int wave, int lane) {
+__device__ __forceinline__ FusedWork fused_work(const FusedOp& op, int wave) {
     FusedWork w;
-    const int MSn = op.cout >> 4;
-    const int NSn = (op.mode == CONV_UPT) ? (op.L_in >> 4) * 2 : (op.L_out >> 4);
-    const int T = MSn * NSn;            // 4 or 8 sub-tiles (host-verified)
-    const int ksplit = 8 / T;
-    const int sub = wave % T;
-    w.kpart = wave / T;
-    w.ms = sub % MSn;
-    w.ns = sub / MSn;
-    w.ntap = (op.mode == CONV_UPT) ? 2 : op.ks;
-    w.nslot = (op.mode == CONV_UPT) ? 4 : op.ks;
-    w.nc16 = op.cin_pad >> 4;
-    const int G = w.nc16 * w.ntap;
-    w.G = G;
-    const int per = (G + ksplit - 1) / ksplit;
-    w.g_lo = w.kpart * per;
-    w.g_hi = min(G, w.g_lo + per);
-    w.wbase = a.packed + op.w_off + (size_t)w.ms * w.nc16 * w.nslot * 256 + lane * 4;
+    w.MSn = 1 << op.lg_MSn;
+    const int sub = wave & ((1 << op.lg_T) - 1);
+    w.kpart = wave >> op.lg_T;
+    w.ksplit = 8 >> op.lg_T;
+    w.ms = sub & (w.MSn - 1);
+    w.ns = sub >> op.lg_MSn;
     return w;
 }
 
-__device__ __forceinline__ f32x4 fused_load_a(const FusedOp& op, const FusedWork& w, int g) {
-    g = g < w.G ? g : w.G - 1;  // clamp to a valid k-group: ring loads are unconditional
-    const int c16 = g / w.ntap, ts = g - c16 * w.ntap;
-    const int slot = (op.mode == CONV_UPT) ? ((w.ns & 1) * 2 + ts) : ts;
-    return *(const f32x4*)(w.wbase + ((size_t)c16 * w.nslot + slot) * 256);
+// LDS-DMA the A-fragment blocks of input-channel chunk [c_lo, c_lo + cn) of `op` into the weight window.
+// Window layout [ms][c16_local][slot] x 1 KiB: for a fixed ms both the global source and the window are one contiguous
+// run of cn*nslot blocks, so the copy loop needs no index decoding.  Every wave issues its share; completion =
+// vmcnt(0) + barrier.
+__device__ __forceinline__ void fused_dma_weights(const FusedArgs& a, const FusedOp& op, int c_lo, int cn, int wave, int lane, float* smem) {
+    const int run = cn * op.nslot;
+    const int MSn = 1 << op.lg_MSn;
+    for (int ms = 0; ms < MSn; ++ms) {
+        const float* src = a.packed + op.w_off + ((size_t)(ms * op.nc16 + c_lo) * op.nslot) * 256 + lane * 4;
+        float* dst = smem + (size_t)a.w_off4 * 4 + (size_t)(ms * run) * 256;
+        for (int r = wave; r < run; r += 8)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)r * 256),
+                                             (__attribute__((address_space(3))) void*)(dst + (size_t)r * 256), 16, 0, 0);
+    }
+}
+
+// K-loop of one wave over 16-input-channel chunks [cl_lo, cl_hi) of the weight window: taps are unrolled at compile
+// time and there is no per-k-group control flow, so hipcc software-pipelines the ds_reads against the MFMAs.
+// wrow: this wave's A blocks in the window (+lane), brow: its B row in the activation buffer (float4 units).
+template <int MODE, int KS>
+__device__ __forceinline__ void fused_mfma(const f32x4* __restrict__ wrow, const f32x4* __restrict__ brow, int rs4, int c_base, int cl_lo,
+                                           int cl_hi, int par, f32x4& acc0, f32x4& acc1) {
+    constexpr int NTAP = (MODE == CONV_UPT) ? 2 : KS;
+    constexpr int NSLOT = (MODE == CONV_UPT) ? 4 : KS;
+    for (int cl = cl_lo; cl < cl_hi; ++cl) {
+        f32x4 af[NTAP], bf[NTAP];
+#pragma unroll
+        for (int ts = 0; ts < NTAP; ++ts) {
+            const int roff = (MODE == CONV_UPT) ? ((ts == 0) ? 0 : (par == 0 ? -1 : 1)) : ts;
+            const int slot = (MODE == CONV_UPT) ? (par * 2 + ts) : ts;
+            af[ts] = wrow[(cl * NSLOT + slot) * 64];
+            bf[ts] = brow[roff * rs4 + (c_base + cl) * 4];
+        }
+#pragma unroll
+        for (int ts = 0; ts < NTAP; ++ts)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if ((ts & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ts][e], bf[ts][e], acc0, 0, 0, 0);
+                else acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ts][e], bf[ts][e], acc1, 0, 0, 0);
+            }
+    }
 }
 
 __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
@@ -103,39 +143,110 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     const int j = lane & 15, q = lane >> 4;
+    int tr = 0;
+#define FUSED_STAMP() do { if (a.trace && b == 0 && tid == 0) a.trace[tr] = (long long)__builtin_readcyclecounter(); ++tr; } while (0)
+    FUSED_STAMP();
 
-    // weight ring for the first op (overlaps the LDS clear and the input staging)
-    FusedWork wk = fused_work(a, a.ops[0], wave, lane);
-    f32x4 ring[kFusedPF];
-#pragma unroll
-    for (int u = 0; u < kFusedPF; ++u) ring[u] = fused_load_a(a.ops[0], wk, wk.g_lo + u);
-
-    // ---- clear LDS (halo rows / channel padding must be zero), then stage the input trajectory window
-    for (int i = tid; i < a.lds_float4; i += 512) sm4[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
+    // ---- prologue: every global load is issued first (input window, parameter vectors, weight DMA of the first op), the
+    //      halo / padding zeros are written while they fly, and ONE barrier closes it.
+    const FusedBuf ib = a.bufs[a.in_buf];
+    const int cin = a.gc1 + a.gc2;
+    const int c4n = (cin + 3) >> 2;
+    const int n_in = a.L0 * c4n;
+    constexpr int IK = 4;   // input float4 per thread (<= 2048 float4 per trajectory window)
+    f32x4 iv[IK];
+    int idst[IK];
     {
-        const FusedBuf ib = a.bufs[a.in_buf];
-        const int cin = a.gc1 + a.gc2;
-        const int c4n = (cin + 3) >> 2;
         const bool vec_ok = ((a.gc1 & 3) == 0) && ((a.gc2 & 3) == 0);
-        for (int idx = tid; idx < a.L0 * c4n; idx += 512) {
-            const int l = idx / c4n, c = (idx - l * c4n) << 2;
-            const size_t pos = (size_t)b * a.L0 + l;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (vec_ok) {
-                v = (c < a.gc1) ? *(const f32x4*)(a.gsrc1 + pos * a.gc1 + c) : *(const f32x4*)(a.gsrc2 + pos * a.gc2 + (c - a.gc1));
-            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ce = c + e;
-                    if (ce < a.gc1) v[e] = a.gsrc1[pos * a.gc1 + ce];
-                    else if (ce < cin) v[e] = a.gsrc2[pos * a.gc2 + (ce - a.gc1)];
+        for (int k = 0; k < IK; ++k) {
+            const int idx = tid + k * 512;
+            iv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            idst[k] = -1;
+            if (idx < n_in) {
+                const int l = a.lg_c4n >= 0 ? (idx >> a.lg_c4n) : (idx / c4n);
+                const int c = (idx - l * c4n) << 2;
+                const size_t pos = (size_t)b * a.L0 + l;
+                idst[k] = ib.off4 + (l + 2) * ib.rs4 + (c >> 2);
+                if (vec_ok) {
+                    iv[k] = (c < a.gc1) ? *(const f32x4*)(a.gsrc1 + pos * a.gc1 + c) : *(const f32x4*)(a.gsrc2 + pos * a.gc2 + (c - a.gc1));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ce = c + e;
+                        if (ce < a.gc1) iv[k][e] = a.gsrc1[pos * a.gc1 + ce];
+                        else if (ce < cin) iv[k][e] = a.gsrc2[pos * a.gc2 + (ce - a.gc1)];
+                    }
                 }
             }
-            sm4[ib.off4 + (l + 2) * ib.rs4 + (c >> 2)] = v;
         }
     }
+    // parameter vectors [bias | gamma | beta | tbias] x C_out of every op: run r is handled by wave r % 8, lane = channel
+    float* par = smem + (size_t)a.par_off4 * 4;
+    constexpr int RK = 7;   // runs per wave (<= 14 ops * 4 / 8)
+    float pvv[RK];
+    const int cout_seg = 1 << a.lg_cout;
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        const int r = wave + k * 8;
+        pvv[k] = 0.f;
+        if (r < a.n_runs && lane < cout_seg) {
+            const FusedOp& op = a.ops[r >> 2];
+            const int which = r & 3;
+            const float* src = (which == 0) ? a.packed + op.b_off
+                               : (op.kind != FOP_CONV_GN) ? nullptr
+                               : (which == 1) ? a.packed + op.ga_off
+                               : (which == 2) ? a.packed + op.be_off
+                               : (op.tb_off >= 0 ? a.tt_row + op.tb_off : nullptr);
+            if (src) pvv[k] = src[lane];
+        }
+    }
+    // weights of the first op
+    FusedWork wk = fused_work(a.ops[0], wave);
+    fused_dma_weights(a, a.ops[0], 0, a.ops[0].cchunk, wave, lane, smem);
+    // zeros: the 2+2 halo rows of every buffer (interiors are fully overwritten before they are read) and the
+    // channel padding of the staged input rows (disjoint from what the staging writes below)
+    {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int bi = 0; bi < a.nbufs; ++bi) {
+            const FusedBuf bb = a.bufs[bi];
+            for (int i = tid; i < 2 * bb.rs4; i += 512) {
+                sm4[bb.off4 + i] = z;
+                sm4[bb.off4 + (bb.rows - 2) * bb.rs4 + i] = z;
+            }
+        }
+        if (ib.clear_all) {
+            const int padw = ib.rs4 - c4n;   // float4 columns beyond the staged channels
+            for (int i = tid; i < a.L0 * padw; i += 512) {
+                const int l = i / padw, cc = i - l * padw;
+                sm4[ib.off4 + (l + 2) * ib.rs4 + c4n + cc] = z;
+            }
+        }
+    }
+    FUSED_STAMP();
+#pragma unroll
+    for (int k = 0; k < IK; ++k)
+        if (idst[k] >= 0) sm4[idst[k]] = iv[k];
+    for (int idx = tid + IK * 512; idx < n_in; idx += 512) {   // (not reached for the supported shapes; kept for safety)
+        const int l = idx / c4n, c = (idx - l * c4n) << 2;
+        const size_t pos = (size_t)b * a.L0 + l;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ce = c + e;
+            if (ce < a.gc1) v[e] = a.gsrc1[pos * a.gc1 + ce];
+            else if (ce < cin) v[e] = a.gsrc2[pos * a.gc2 + (ce - a.gc1)];
+        }
+        sm4[ib.off4 + (l + 2) * ib.rs4 + (c >> 2)] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        const int r = wave + k * 8;
+        if (r < a.n_runs && lane < cout_seg) par[(r >> 2) * 4 * cout_seg + (r & 3) * cout_seg + lane] = pvv[k];
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // this wave's DMA blocks have landed
     __syncthreads();
+    FUSED_STAMP();
 
     for (int oi = 0; oi < a.nops; ++oi) {
         const FusedOp& op = a.ops[oi];
@@ -180,10 +291,12 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
                 for (int s = 32; s >= 1; s >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, s, 64));
                 if (lane == 0) atomicMax(a.absmax + b / a.n_per_ctx, __float_as_uint(vmax));
             }
+            FUSED_STAMP();
             continue;
         }
 
         // ------------------------------------------------------------------ conv: MFMA over this wave's k-groups
+        wk = fused_work(op, wave);
         const FusedBuf sb = a.bufs[op.src];
         int boff, npos;
         if (op.mode == CONV_UPT) {
@@ -196,51 +309,54 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
             boff = sb.off4 + ((op.mode == CONV_DOWN ? 2 * l : l) + 2 - pad) * sb.rs4 + q;
             npos = l;
         }
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         const int par = wk.ns & 1;
-        for (int g0 = wk.g_lo; g0 < wk.g_hi; g0 += kFusedPF) {
-#pragma unroll
-            for (int u = 0; u < kFusedPF; ++u) {
-                const int g = g0 + u;
-                if (g < wk.g_hi) {
-                    const int c16 = g / wk.ntap, ts = g - c16 * wk.ntap;
-                    const int roff = (op.mode == CONV_UPT) ? ((ts == 0) ? 0 : (par == 0 ? -1 : 1)) : ts;
-                    const f32x4 bf = sm4[boff + roff * sb.rs4 + c16 * 4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][e], bf[e], acc, 0, 0, 0);
-                }
-                ring[u] = fused_load_a(op, wk, g + kFusedPF);
+        const int cchunk = op.cchunk;
+        for (int c_lo = 0; c_lo < op.nc16; c_lo += cchunk) {
+            const int cn = min(cchunk, op.nc16 - c_lo);
+            if (c_lo > 0) {  // next chunk of a large op: the window is free once every wave finished the previous chunk
+                __syncthreads();
+                fused_dma_weights(a, op, c_lo, cn, wave, lane, smem);
+                __builtin_amdgcn_s_waitcnt(0);
+                __syncthreads();
             }
+            // K split over 16-channel chunks (host guarantees cn % ksplit == 0 or ksplit == 1)
+            const int per = (wk.ksplit == 1) ? cn : ((cn + 1) >> 1);   // ksplit is 1 or 2
+            const int cl_lo = wk.kpart * per, cl_hi = min(cn, cl_lo + per);
+            const f32x4* wrow = sm4 + a.w_off4 + (size_t)(wk.ms * cn) * op.nslot * 64 + lane;
+            const f32x4* brow = sm4 + boff;
+            if (op.mode == CONV_S1 && op.ks == 5) fused_mfma<CONV_S1, 5>(wrow, brow, sb.rs4, c_lo, cl_lo, cl_hi, par, acc0, acc1);
+            else if (op.mode == CONV_S1) fused_mfma<CONV_S1, 1>(wrow, brow, sb.rs4, c_lo, cl_lo, cl_hi, par, acc0, acc1);
+            else if (op.mode == CONV_DOWN) fused_mfma<CONV_DOWN, 3>(wrow, brow, sb.rs4, c_lo, cl_lo, cl_hi, par, acc0, acc1);
+            else fused_mfma<CONV_UPT, 4>(wrow, brow, sb.rs4, c_lo, cl_lo, cl_hi, par, acc0, acc1);
         }
+        const f32x4 acc = acc0 + acc1;
+        FUSED_STAMP();   // MFMA loop done
         const int MTP4 = (op.cout + 4) >> 2;
         const int N = op.L_out;
         sm4[a.red_off4 + (wk.kpart * N + npos) * MTP4 + wk.ms * 4 + q] = acc;
-
-        // prefetch the next conv's first weight fragments before the epilogue (their latency hides under it)
-        const int MSn_cur = op.cout >> 4;
-        const int NSn_cur = (op.mode == CONV_UPT) ? (op.L_in >> 4) * 2 : (op.L_out >> 4);
-        const int ksplit_cur = 8 / (MSn_cur * NSn_cur);
-        if (oi + 1 < a.nops && a.ops[oi + 1].kind != FOP_FINAL) {
-            wk = fused_work(a, a.ops[oi + 1], wave, lane);
-#pragma unroll
-            for (int u = 0; u < kFusedPF; ++u) ring[u] = fused_load_a(a.ops[oi + 1], wk, wk.g_lo + u);
-        }
+        const int ksplit_cur = wk.ksplit;
         __syncthreads();
+        FUSED_STAMP();   // partials visible; the weight window is free
+
+        // DMA the next conv's weights now: the transfer overlaps this op's epilogue
+        if (oi + 1 < a.nops && a.ops[oi + 1].kind != FOP_FINAL)
+            fused_dma_weights(a, a.ops[oi + 1], 0, a.ops[oi + 1].cchunk, wave, lane, smem);
 
         // ------------------------------------------------------------------ epilogue
-        const float* bias = a.packed + op.b_off;
+        const float* par_op = smem + (size_t)a.par_off4 * 4 + op.p_off;  // [bias | gamma | beta | tbias] x cout
+        const float* bias = par_op;
         if (op.kind == FOP_CONV_GN) {
             // wave g normalises GroupNorm group g (8 groups per trajectory)
             const int gs = op.gs, re = gs * N;
-            const float inv_re = 1.0f / (float)re;
+            const float inv_re = (re == 256) ? (1.0f / 256.0f) : (1.0f / 128.0f);
             const FusedBuf db = a.bufs[op.dst];
             if (re == 256) {
                 const int e0 = lane * 4;
-                const int l = e0 / gs, c = wave * gs + (e0 - l * gs);
+                const int l = e0 >> op.lg_gs, c = wave * gs + (e0 & (gs - 1));
                 const f32x4 bi = *(const f32x4*)(bias + c);
-                const f32x4 ga = *(const f32x4*)(a.packed + op.ga_off + c), be = *(const f32x4*)(a.packed + op.be_off + c);
-                f32x4 tb = {0.f, 0.f, 0.f, 0.f};
-                if (op.tb_off >= 0) tb = *(const f32x4*)(a.tt_row + op.tb_off + c);
+                const f32x4 ga = *(const f32x4*)(par_op + op.cout + c), be = *(const f32x4*)(par_op + 2 * op.cout + c);
+                const f32x4 tb = *(const f32x4*)(par_op + 3 * op.cout + c);
                 f32x4 v = sm4[a.red_off4 + l * MTP4 + (c >> 2)];
                 for (int k = 1; k < ksplit_cur; ++k) v += sm4[a.red_off4 + (k * N + l) * MTP4 + (c >> 2)];
                 v += bi;
@@ -257,11 +373,10 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
                 if (op.gdst >= 0) *(f32x4*)(a.gout[op.gdst] + ((size_t)b * N + l) * op.cout + c) = y;
             } else {  // re == 128
                 const int e0 = lane * 2;
-                const int l = e0 / gs, c = wave * gs + (e0 - l * gs);
+                const int l = e0 >> op.lg_gs, c = wave * gs + (e0 & (gs - 1));
                 const f32x2 bi = *(const f32x2*)(bias + c);
-                const f32x2 ga = *(const f32x2*)(a.packed + op.ga_off + c), be = *(const f32x2*)(a.packed + op.be_off + c);
-                f32x2 tb = {0.f, 0.f};
-                if (op.tb_off >= 0) tb = *(const f32x2*)(a.tt_row + op.tb_off + c);
+                const f32x2 ga = *(const f32x2*)(par_op + op.cout + c), be = *(const f32x2*)(par_op + 2 * op.cout + c);
+                const f32x2 tb = *(const f32x2*)(par_op + 3 * op.cout + c);
                 const float* redf = smem + (size_t)a.red_off4 * 4;
                 f32x2 v = *(const f32x2*)(redf + (size_t)l * (MTP4 * 4) + c);
                 for (int k = 1; k < ksplit_cur; ++k) v += *(const f32x2*)(redf + (size_t)(k * N + l) * (MTP4 * 4) + c);
@@ -281,7 +396,7 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
         } else {  // bias only: residual 1x1 conv / Downsample1d / Upsample1d
             const int M4 = op.cout >> 2;
             for (int idx = tid; idx < N * M4; idx += 512) {
-                const int l = idx / M4, c4 = idx - l * M4;
+                const int l = idx >> op.lg_M4, c4 = idx & (M4 - 1);
                 f32x4 v = sm4[a.red_off4 + l * MTP4 + c4];
                 for (int k = 1; k < ksplit_cur; ++k) v += sm4[a.red_off4 + (k * N + l) * MTP4 + c4];
                 v += *(const f32x4*)(bias + c4 * 4);
@@ -289,8 +404,12 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
                 if (op.gdst >= 0) *(f32x4*)(a.gout[op.gdst] + ((size_t)b * N + l) * op.cout + c4 * 4) = v;
             }
         }
+        FUSED_STAMP();   // epilogue done (this wave)
+        __builtin_amdgcn_s_waitcnt(0);  // the next op's weight blocks issued by this wave have landed
         __syncthreads();
+        FUSED_STAMP();
     }
 }
+#undef FUSED_STAMP
 
 }  // namespace mpdx

@@ -457,7 +457,7 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
     auto new_buf = [&](int cpad, int L) {
         if (nbuf >= kMaxFusedBufs) return -1;
         const int rs = pick_row_stride(cpad, CONV_S1, L, L, L + 4);
-        a.bufs[nbuf].off4 = (int)off4; a.bufs[nbuf].rs4 = rs / 4;
+        a.bufs[nbuf].off4 = (int)off4; a.bufs[nbuf].rs4 = rs / 4; a.bufs[nbuf].rows = L + 4; a.bufs[nbuf].clear_all = 0;
         off4 += (size_t)(L + 4) * (rs / 4);
         return nbuf++;
     };
@@ -471,6 +471,7 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
     };
     a.in_buf = new_buf(l0.cin_pad, l0.L_in);
     if (a.in_buf < 0) return false;
+    a.bufs[a.in_buf].clear_all = (l0.cin_pad != l0.c1 + l0.c2) ? 1 : 0;  // channel padding of the staged input
     bufmap[(long)(l0.src1 + 8) * 4096 + l0.L_in] = a.in_buf;
     size_t red4 = 0;
     int ng = 0;
@@ -528,6 +529,14 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         op.ga_off = l.gamma >= 0 ? (int)u->params[l.gamma].off : 0;
         op.be_off = l.beta >= 0 ? (int)u->params[l.beta].off : 0;
         op.tb_off = l.tb_off;
+        auto lg2 = [](int v) { int k = 0; while ((1 << k) < v) ++k; return k; };
+        if ((1 << lg2(MSn)) != MSn || (1 << lg2(l.cout / 4)) != l.cout / 4) return false;
+        op.lg_T = lg2(T); op.lg_MSn = lg2(MSn); op.lg_M4 = lg2(l.cout / 4);
+        op.lg_gs = op.kind == FOP_CONV_GN ? lg2(l.gs) : 0;
+        if (op.kind == FOP_CONV_GN && (1 << op.lg_gs) != l.gs) return false;
+        op.ntap = (l.mode == CONV_UPT) ? 2 : l.ks;
+        op.nslot = (l.mode == CONV_UPT) ? 4 : l.ks;
+        op.nc16 = l.cin_pad / 16;
         red4 = std::max(red4, (size_t)(8 / T) * l.L_out * ((l.cout + 4) / 4));
         a.nops++;
     }
@@ -545,7 +554,58 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
     a.nbufs = nbuf;
     a.red_off4 = (int)off4;
     off4 += red4;
-    a.lds_float4 = (int)off4;
+    a.lds_float4 = (int)off4;   // cleared at kernel start (activation buffers + partials); parameters follow
+    a.par_off4 = (int)off4;
+    int poff = 0;
+    for (int k = 0; k < a.nops; ++k)
+        if (a.ops[k].kind != FOP_FINAL) { a.ops[k].p_off = poff; poff += 4 * a.ops[k].cout; }
+    a.par_floats = poff;
+    {   // uniform C_out per segment (parameter runs are indexed by lane = channel), at most 64 channels
+        int co = 0, nconv = 0;
+        for (int k = 0; k < a.nops; ++k)
+            if (a.ops[k].kind != FOP_FINAL) {
+                if (co && a.ops[k].cout != co) return false;
+                co = a.ops[k].cout;
+                if (a.ops[k].p_off != nconv * 4 * co) return false;
+                ++nconv;
+            }
+        int lg = 0;
+        while ((1 << lg) < co) ++lg;
+        if ((1 << lg) != co || co > 64 || nconv * 4 > 56) return false;
+        a.lg_cout = lg; a.n_runs = nconv * 4;
+        const int c4n = (a.gc1 + a.gc2 + 3) / 4;
+        int l4 = 0;
+        while ((1 << l4) < c4n) ++l4;
+        a.lg_c4n = ((1 << l4) == c4n) ? l4 : -1;
+        if ((size_t)a.L0 * c4n > 4 * 512) return false;   // prologue holds the input window in 4 float4 per thread
+    }
+    off4 += (size_t)(poff + 3) / 4;
+    // LDS weight window: as large as the remaining LDS allows (<= the largest op), in 1-KiB blocks; an op that
+    // does not fit runs in input-channel chunks, which need at least one 16-channel slab of every (m16, slot)
+    size_t need_blocks = 0, min_blocks = 0;
+    for (int k = 0; k < a.nops; ++k) {
+        const FusedOp& op = a.ops[k];
+        if (op.kind == FOP_FINAL) continue;
+        const size_t per_c16 = (size_t)(op.cout / 16) * (op.mode == CONV_UPT ? 4 : op.ks);
+        need_blocks = std::max(need_blocks, per_c16 * (op.cin_pad / 16));
+        min_blocks = std::max(min_blocks, per_c16);
+    }
+    const size_t budget_bytes = 150 * 1024;
+    if (off4 * 16 + min_blocks * 1024 > budget_bytes) return false;
+    const size_t cap = std::min(need_blocks, (budget_bytes - off4 * 16) / 1024);
+    a.w_off4 = (int)off4;
+    a.w_cap_blocks = (int)cap;
+    off4 += cap * 64;
+    for (int k = 0; k < a.nops; ++k) {  // input-channel chunk (in 16-channel units) each op streams through the window
+        FusedOp& op = a.ops[k];
+        if (op.kind == FOP_FINAL) continue;
+        const int per_c16 = (op.cout / 16) * op.nslot;
+        int fit = (int)(cap / per_c16);
+        if (fit >= op.nc16) fit = op.nc16;
+        else if ((8 >> op.lg_T) == 2) fit &= ~1;  // K is split in two over 16-channel chunks: keep chunks even
+        if (fit < 1) return false;
+        op.cchunk = fit;
+    }
     f.lds_bytes = off4 * 16;
     if (f.lds_bytes > 160 * 1024) return false;
     u->fused.push_back(f);
@@ -691,6 +751,10 @@ static int run_layer(const mpdx_unet* u, const Layer& l, const float* packed, co
     a.dst = ws + slot * l.dst;
     a.B = B; a.L_in = l.L_in; a.L_out = l.L_out; a.C_out = l.cout;
     a.cin_pad = l.cin_pad; a.rs = l.rs; a.gs = l.gs; a.dbg = dbg;
+    auto lg2 = [](int v) { int k = 0; while ((1 << k) < v) ++k; return k; };
+    a.lg_c4n = lg2(l.cin_pad / 4); a.lg_Lin = lg2(l.L_in); a.lg_Lout = lg2(l.L_out); a.lg_gs = l.gs > 0 ? lg2(l.gs) : 0;
+    if ((1 << a.lg_c4n) != l.cin_pad / 4 || (1 << a.lg_Lin) != l.L_in || (1 << a.lg_Lout) != l.L_out || (l.gs > 0 && (1 << a.lg_gs) != l.gs))
+        return fail(MPDX_E_INVALID, "layer %s: channel/length/group sizes must be powers of two", l.name.c_str());
     if (l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH) return dispatch_tile<CONV_S1, 5, EPI_GN_MISH>(l, a, B, st);
     if (l.mode == CONV_S1 && l.ks == 1 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 1, EPI_BIAS>(l, a, B, st);
     if (l.mode == CONV_DOWN && l.ks == 3) return dispatch_tile_ksplit_only<CONV_DOWN, 3, EPI_BIAS>(l, a, B, st);
@@ -739,6 +803,8 @@ static int run_final(mpdx_unet* u, const float* packed, FinalArgs& fa, int B, fl
     return 0;
 }
 
+static long long* g_fused_trace = nullptr;  // dev tool (mpdx_fused_trace)
+
 static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packed, const float* tt_row, const float* x, float* ws,
                      int B, const FinalArgs* fa, hipStream_t st) {
     const size_t slot = u->slot_floats * (size_t)B;
@@ -748,6 +814,7 @@ static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packe
     a.gsrc1 = src(f.in1); a.gsrc2 = src(f.in2);
     for (int k = 0; k < 3; ++k) a.gout[k] = f.gout_slot[k] >= 0 ? ws + slot * f.gout_slot[k] : nullptr;
     a.B = B;
+    a.trace = g_fused_trace;
     if (f.has_final) {
         if (!fa) return fail(MPDX_E_STATE, "fused final segment needs the step arguments");
         a.x_in = fa->x_in; a.noise = fa->noise; a.hs = fa->hs; a.hg = fa->hg; a.out = fa->out; a.chain = fa->chain;
@@ -1081,6 +1148,32 @@ int mpdx_unet_profile(mpdx_unet* u, const float* packed, const float* timetab, i
     for (int i = 0; i < nl && !rc; ++i) HIP_TRY(hipEventElapsedTime(&ms_out[i], ev[2 * i], ev[2 * i + 1]));
     for (auto& e : ev) (void)hipEventDestroy(e);
     *n_out = nl;
+    return rc;
+}
+
+/* dev tool: run fused segment `seg` once with per-phase s_memtime stamps of workgroup 0 / wave 0; stamps_out[n] */
+int mpdx_fused_trace(mpdx_unet* u, const float* packed, const float* timetab, const float* x, int seg, int B, float* ws, void* stream,
+                     long long* stamps_out, int cap, int* n_out, int* nops_out) {
+    if (!u || seg < 0 || seg >= (int)u->fused.size()) return fail(MPDX_E_INVALID, "bad segment");
+    if (int rc = check_ready(u)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    long long* dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, 256 * sizeof(long long)));
+    HIP_TRY(hipMemsetAsync(dev, 0, 256 * sizeof(long long), st));
+    static float* scratch = nullptr;
+    if (!scratch) HIP_TRY(hipMalloc(&scratch, (size_t)1 << 24));
+    FinalArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.out = scratch; fa.mode = 0; fa.n_per_ctx = 1;
+    g_fused_trace = dev;
+    int rc = run_fused(u, u->fused[seg], packed, timetab, x, ws, B, &fa, st);
+    g_fused_trace = nullptr;
+    HIP_TRY(hipStreamSynchronize(st));
+    const int n = std::min(cap, 256);
+    HIP_TRY(hipMemcpy(stamps_out, dev, n * sizeof(long long), hipMemcpyDeviceToHost));
+    (void)hipFree(dev);
+    if (n_out) *n_out = n;
+    if (nops_out) *nops_out = u->fused[seg].tmpl.nops;
     return rc;
 }
 

@@ -2,6 +2,8 @@
 """Per-layer timing + phase ablation of the conv-block kernels (development tool; needs a GPU).
 usage: python tools/ablate_layers.py [B] [layer-name-substring ...]"""
 import ctypes as C
+import os
+os.environ["MPDX_FUSED"] = "0"  # per-layer launch units: layer index == unit index
 import sys
 from pathlib import Path
 
