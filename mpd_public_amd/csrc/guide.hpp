@@ -119,7 +119,7 @@ __device__ __forceinline__ void panda_fk(const float (&q)[QD], float (&O)[7][3],
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
         float st, ct;
-        sincosf(q[k < QD ? k : 0], &st, &ct);
+        __sincosf(q[k < QD ? k : 0], &st, &ct);  // |q| <= pi (joint limits): the hardware sin/cos is accurate to ~1e-6 here
         const float ca = kPandaCA[k], sa = kPandaSA[k], aa = kPandaA[k], dd = kPandaD[k];
         const float L[3][3] = {{ct, -st, 0.f}, {st * ca, ct * ca, -sa}, {st * sa, ct * sa, ca}};
         const float Lt[3] = {aa, -sa * dd, ca * dd};
@@ -269,14 +269,19 @@ __global__ __launch_bounds__(64) void traj_metrics_kernel(const mpdx_guide_param
     }
 }
 
-// QD = configuration-space dim (2, 3 point mass; 7 Panda), DIM = workspace dim, ROBOT as in mpdx.h
-template <int QD, int DIM, int ROBOT>
-__global__ __launch_bounds__(64) void guide_step_kernel(const GuideArgs a) {
+// QD = configuration-space dim (2, 3 point mass; 7 Panda), DIM = workspace dim, ROBOT as in mpdx.h.
+// WPT = waves per trajectory.  The collision part (FK + SDF + Jacobian transpose per interpolated point and per field) is
+// split over WPT waves as (point slice) x (field): PW = min(WPT,2) point slices, WPT/PW field slots; wave 0 then gathers,
+// clips, adds the GP term and applies the update.  Point mass: WPT = 1; Panda: WPT = 8 (2 point halves x 4 fields).
+template <int QD, int DIM, int ROBOT, int WPT>
+__global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a) {
     constexpr int D = 2 * QD;
     constexpr int MAXF = MPDX_MAX_FIELDS;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const mpdx_guide_params& gp = a.gp;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int PW = WPT >= 2 ? 2 : 1, FW = WPT / PW;
     const int b = blockIdx.x;
     const int H = a.H;
     const int N = gp.interpolate ? gp.n_interp : H;
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(64) void guide_step_kernel(const GuideArgs a) {
     float* sA = sx + H * D;
     float* sB = sA + MAXF * N * QD;
     float* sprim = sB + MAXF * N * QD;
-    for (int i = lane; i < gp.n_prim_floats; i += 64) sprim[i] = gp.prims[i];
+    for (int i = threadIdx.x; i < gp.n_prim_floats; i += 64 * WPT) sprim[i] = gp.prims[i];
 
     // ---- load + unnormalise (normalization.py:156-167)
     const int ctx = b / a.n_per_ctx;
@@ -299,13 +304,13 @@ __global__ __launch_bounds__(64) void guide_step_kernel(const GuideArgs a) {
         const float c = clipall ? fminf(fmaxf(xn[d], -1.f), 1.f) : xn[d];
         const float u01 = __fadd_rn(c, 1.0f) * 0.5f;
         xu[d] = __fadd_rn(__fmul_rn(u01, __fsub_rn(gp.maxs[d], gp.mins[d])), gp.mins[d]);
-        if (live) sx[lane * D + d] = xu[d];
+        if (live && wv == 0) sx[lane * D + d] = xu[d];
     }
     __syncthreads();
 
     // ---- collision terms on the interpolated positions
     const float scale = (N > 1) ? (float)(H - 1) / (float)(N - 1) : 0.f;  // align_corners=True
-    for (int i = lane; i < N; i += 64) {
+    for (int i = (wv % PW) * 64 + lane; i < N; i += 64 * PW) {
         int i0 = i, i1 = i;
         float l0 = 1.f, l1 = 0.f;
         if (gp.interpolate) {
@@ -326,6 +331,7 @@ __global__ __launch_bounds__(64) void guide_step_kernel(const GuideArgs a) {
             for (int j = 0; j < DIM; ++j) p[j] = q[j];
             const float margin = gp.link_margin + gp.cutoff_margin;
             for (int f = 0; f < gp.n_fields; ++f) {
+                if ((f % FW) != wv / PW) continue;
                 float force[DIM];
                 if (gp.fields[f].kind == MPDX_FIELD_OBJECTS) objects_force<DIM>(sprim, gp.fields[f], p, margin, force);
                 else if (gp.fields[f].kind == MPDX_FIELD_WORKSPACE) workspace_force<DIM>(gp.fields[f], p, margin, force);
@@ -350,6 +356,7 @@ __global__ __launch_bounds__(64) void guide_step_kernel(const GuideArgs a) {
                 for (int r = 0; r < 3; ++r) P[s][r] = O[fr][r] + kPandaSO[s] * Z[fr][r];
             }
             for (int f = 0; f < gp.n_fields; ++f) {
+                if ((f % FW) != wv / PW) continue;
                 float F[kPandaNS][3];
 #pragma unroll
                 for (int s = 0; s < kPandaNS; ++s) { F[s][0] = 0.f; F[s][1] = 0.f; F[s][2] = 0.f; }
@@ -398,6 +405,7 @@ __global__ __launch_bounds__(64) void guide_step_kernel(const GuideArgs a) {
         }
     }
     __syncthreads();
+    if (wv != 0) return;   // wave 0 finishes the trajectory (no further workgroup barriers below)
 
     // ---- gather to support points (transpose of the interpolation), clip, zero ends, weight
     float total[D];

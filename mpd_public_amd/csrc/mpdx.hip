@@ -864,11 +864,11 @@ static int launch_guide(const mpdx_guide_params* gp, float* x, float* grad_out, 
     const size_t lds = guide_lds_bytes(*gp, H, D);
     if (lds > 64 * 1024) return fail(MPDX_E_INVALID, "guide needs %zu B of LDS", lds);
     if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 2 && gp->ws_dim == 2)
-        hipLaunchKernelGGL((guide_step_kernel<2, 2, MPDX_ROBOT_POINTMASS>), dim3(B), dim3(64), lds, st, a);
+        hipLaunchKernelGGL((guide_step_kernel<2, 2, MPDX_ROBOT_POINTMASS, 1>), dim3(B), dim3(64), lds, st, a);
     else if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 3 && gp->ws_dim == 3)
-        hipLaunchKernelGGL((guide_step_kernel<3, 3, MPDX_ROBOT_POINTMASS>), dim3(B), dim3(64), lds, st, a);
+        hipLaunchKernelGGL((guide_step_kernel<3, 3, MPDX_ROBOT_POINTMASS, 1>), dim3(B), dim3(64), lds, st, a);
     else if (gp->robot == MPDX_ROBOT_PANDA && gp->q_dim == 7 && gp->ws_dim == 3)
-        hipLaunchKernelGGL((guide_step_kernel<7, 3, MPDX_ROBOT_PANDA>), dim3(B), dim3(64), lds, st, a);
+        hipLaunchKernelGGL((guide_step_kernel<7, 3, MPDX_ROBOT_PANDA, 8>), dim3(B), dim3(512), lds, st, a);
     else
         return fail(MPDX_E_INVALID, "unsupported robot %d / q_dim %d / ws_dim %d", gp->robot, gp->q_dim, gp->ws_dim);
     return 0;
