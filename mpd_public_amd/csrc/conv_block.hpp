@@ -94,7 +94,7 @@ struct ConvGeom {
 __host__ __device__ inline int upt_slot_to_k(int slot) { return slot == 0 ? 1 : slot == 1 ? 3 : slot == 2 ? 2 : 0; }
 
 template <int MODE, int KS, int EPI, int MT, int NT, int WN, int WK>
-__global__ __launch_bounds__(64 * WN * WK) void conv_block_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int block_id) {
     using G = ConvGeom<MODE, KS>;
     constexpr int NWAVE = WN * WK, NTHR = 64 * NWAVE;
     constexpr int MS = MT / 16, NSUB = NT / 16, NSW = NSUB / WN;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_block_kernel(const ConvArgs
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WN, wk = wave / WN;
     const int n_mt = a.C_out / MT;   // MT is a compile-time power of two; one uniform division per workgroup
-    const int mt = blockIdx.x % n_mt, nt = blockIdx.x / n_mt;
+    const int mt = block_id % n_mt, nt = block_id / n_mt;
     const int L_in = a.L_in, L_out = a.L_out;
     const int spt = NT >> a.lg_Lout;  // trajectories per tile
     const int s0 = nt * spt;
@@ -341,6 +341,19 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_block_kernel(const ConvArgs
             if (b < a.B) *(f32x4*)(a.dst + ((size_t)b * L_out + l) * a.C_out + co) = v;
         }
     }
+}
+
+template <int MODE, int KS, int EPI, int MT, int NT, int WN, int WK>
+__global__ __launch_bounds__(64 * WN * WK) void conv_block_kernel(const ConvArgs a) {
+    conv_block_body<MODE, KS, EPI, MT, NT, WN, WK>(a, blockIdx.x);
+}
+
+// blocks[0] of a ResidualTemporalBlock (k5 conv + GroupNorm + Mish + time bias) and the block's residual 1x1 conv read the
+// same input and are independent: ONE launch, the first n_first workgroups run the former, the rest the latter.
+template <int MT, int NT>
+__global__ __launch_bounds__(512) void conv_pair_kernel(const ConvArgs a1, const ConvArgs a2, const int n_first) {
+    if ((int)blockIdx.x < n_first) conv_block_body<CONV_S1, 5, EPI_GN_MISH, MT, NT, 1, 8>(a1, blockIdx.x);
+    else conv_block_body<CONV_S1, 1, EPI_BIAS, MT, NT, 1, 8>(a2, blockIdx.x - n_first);
 }
 
 // LDS bytes a launch needs: max(staged windows, K-partial buffer)

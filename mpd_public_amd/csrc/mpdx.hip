@@ -734,11 +734,10 @@ static int dispatch_tile_ksplit_only(const Layer& l, ConvArgs& a, int B, hipStre
     return fail(MPDX_E_INVALID, "no instantiation for tile %dx%d", MT, NT);
 }
 
-static int run_layer(const mpdx_unet* u, const Layer& l, const float* packed, const float* tt_row, const float* x,
-                     float* ws, int B, hipStream_t st, int dbg = 0) {
+static int make_conv_args(const mpdx_unet* u, const Layer& l, const float* packed, const float* tt_row, const float* x, float* ws, int B,
+                          int dbg, ConvArgs& a) {
     const size_t slot = u->slot_floats * (size_t)B;
     auto src = [&](int s) -> const float* { return s == SRC_X ? x : (s == SRC_NONE ? nullptr : ws + slot * s); };
-    ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.src1 = src(l.src1); a.src2 = src(l.src2);
     a.c1 = l.c1; a.c2 = l.c2;
@@ -755,11 +754,56 @@ static int run_layer(const mpdx_unet* u, const Layer& l, const float* packed, co
     a.lg_c4n = lg2(l.cin_pad / 4); a.lg_Lin = lg2(l.L_in); a.lg_Lout = lg2(l.L_out); a.lg_gs = l.gs > 0 ? lg2(l.gs) : 0;
     if ((1 << a.lg_c4n) != l.cin_pad / 4 || (1 << a.lg_Lin) != l.L_in || (1 << a.lg_Lout) != l.L_out || (l.gs > 0 && (1 << a.lg_gs) != l.gs))
         return fail(MPDX_E_INVALID, "layer %s: channel/length/group sizes must be powers of two", l.name.c_str());
+    return 0;
+}
+
+static int run_layer(const mpdx_unet* u, const Layer& l, const float* packed, const float* tt_row, const float* x,
+                     float* ws, int B, hipStream_t st, int dbg = 0) {
+    ConvArgs a;
+    if (int rc = make_conv_args(u, l, packed, tt_row, x, ws, B, dbg, a)) return rc;
     if (l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH) return dispatch_tile<CONV_S1, 5, EPI_GN_MISH>(l, a, B, st);
     if (l.mode == CONV_S1 && l.ks == 1 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 1, EPI_BIAS>(l, a, B, st);
     if (l.mode == CONV_DOWN && l.ks == 3) return dispatch_tile_ksplit_only<CONV_DOWN, 3, EPI_BIAS>(l, a, B, st);
     if (l.mode == CONV_UPT && l.ks == 4) return dispatch_tile_ksplit_only<CONV_UPT, 4, EPI_BIAS>(l, a, B, st);
     return fail(MPDX_E_INVALID, "layer %s: unsupported conv (mode %d k %d epi %d)", l.name.c_str(), l.mode, l.ks, l.epi);
+}
+
+// blocks[0] + residual 1x1 conv of the same ResidualTemporalBlock in one launch (both read the block's input).
+// Returns 1 if the pair was launched, 0 if the shapes do not qualify (caller launches them separately), <0 on error.
+template <int MT, int NT>
+static int launch_pair(const ConvArgs& a1, const ConvArgs& a2, const Layer& l1, const Layer& l2, hipStream_t st) {
+    const size_t lds = std::max(conv_block_lds_bytes<CONV_S1, 5, MT, NT, 8>(l1.L_in, l1.L_out, l1.rs),
+                                conv_block_lds_bytes<CONV_S1, 1, MT, NT, 8>(l2.L_in, l2.L_out, l2.rs));
+    if (lds > 160 * 1024) return 0;
+    auto kern = conv_pair_kernel<MT, NT>;
+    static thread_local bool raised = false;
+    if (lds > 64 * 1024 && !raised) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised = true;
+    }
+    const int n1 = (a1.C_out / MT) * a1.n_tiles_n, n2 = (a2.C_out / MT) * a2.n_tiles_n;
+    hipLaunchKernelGGL(kern, dim3(n1 + n2), dim3(512), lds, st, a1, a2, n1);
+    return 1;
+}
+
+static int run_pair(const mpdx_unet* u, const Layer& l1, const Layer& l2, const float* packed, const float* tt_row, const float* x, float* ws,
+                    int B, hipStream_t st) {
+    static const bool off = getenv("MPDX_PAIR") && atoi(getenv("MPDX_PAIR")) == 0;
+    if (off) return 0;
+    if (!(l1.mode == CONV_S1 && l1.ks == 5 && l1.epi == EPI_GN_MISH && l2.mode == CONV_S1 && l2.ks == 1 && l2.epi == EPI_BIAS)) return 0;
+    if (l1.src1 != l2.src1 || l1.src2 != l2.src2 || l1.cout != l2.cout || l1.L_out != l2.L_out || !layer_ksplit(l1)) return 0;
+    int MT, NT;
+    choose_tile(l1, B, MT, NT);   // the k5 block decides the tile; the 1x1 conv has no constraint beyond it
+    if (l1.cout % MT) MT = 16;
+    if (l1.cout % MT || NT % l1.L_out) return 0;
+    ConvArgs a1, a2;
+    if (int rc = make_conv_args(u, l1, packed, tt_row, x, ws, B, 0, a1)) return rc;
+    if (int rc = make_conv_args(u, l2, packed, tt_row, x, ws, B, 0, a2)) return rc;
+    a1.n_tiles_n = a2.n_tiles_n = (int)(((long)B * l1.L_out + NT - 1) / NT);
+#define MPDX_PAIR_TILE(mt, nt) if (MT == mt && NT == nt) return launch_pair<mt, nt>(a1, a2, l1, l2, st);
+    MPDX_PAIR_TILE(32, 64) MPDX_PAIR_TILE(32, 32) MPDX_PAIR_TILE(16, 64) MPDX_PAIR_TILE(16, 32) MPDX_PAIR_TILE(32, 16) MPDX_PAIR_TILE(16, 16)
+#undef MPDX_PAIR_TILE
+    return 0;
 }
 
 static int check_ready(const mpdx_unet* u) {
@@ -838,12 +882,21 @@ static int run_unet_and_final(mpdx_unet* u, const float* packed, const float* ti
     const float* row = timetab + (size_t)t * u->tt_row;
     const auto units = current_units(u, nullptr);
     bool final_done = false;
-    for (const auto& un : units) {
+    for (size_t k = 0; k < units.size(); ++k) {
+        const auto& un = units[k];
         if (un.fused >= 0) {
             const auto& f = u->fused[un.fused];
             if (int rc = run_fused(u, f, packed, row, x, ws, B, &fa, st)) return rc;
             final_done |= f.has_final;
-        } else if (int rc = run_layer(u, u->layers[un.layer], packed, row, x, ws, B, st)) return rc;
+            continue;
+        }
+        // blocks[0] followed by the same block's residual 1x1 conv: one launch
+        if (k + 1 < units.size() && units[k + 1].fused < 0 && units[k + 1].layer == un.layer + 1) {
+            const int pr = run_pair(u, u->layers[un.layer], u->layers[un.layer + 1], packed, row, x, ws, B, st);
+            if (pr < 0) return pr;
+            if (pr == 1) { ++k; continue; }
+        }
+        if (int rc = run_layer(u, u->layers[un.layer], packed, row, x, ws, B, st)) return rc;
     }
     if (!final_done)
         if (int rc = run_final(u, packed, fa, B, ws, st)) return rc;
