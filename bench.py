@@ -77,7 +77,7 @@ def roofline_leg(dm, B, T, reps=20):
     classes = defaultdict(lambda: [0.0, 0.0, 0])  # key -> [ms, flops, launches]
     for i in range(n.value):
         nm = names[i].decode()
-        li = lib.mpdx_unet_unit_layer(hdl, i)
+        li = lib.mpdx_unet_unit_layer(hdl, B, i)
         if li >= 0:
             lib.mpdx_unet_layer_tile(hdl, li, B, buf, 64)
             kind = "conv_k5_gn_mish" if ".block.0." in nm else ("conv_k1" if "residual" in nm else ("down_k3s2" if "downs" in nm else "up_k4s2"))
@@ -96,7 +96,7 @@ def roofline_leg(dm, B, T, reps=20):
     out = C.c_float()
     durs = []
     for i in range(n.value):
-        li = lib.mpdx_unet_unit_layer(hdl, i)
+        li = lib.mpdx_unet_unit_layer(hdl, B, i)
         if li < 0:
             continue
         lib.mpdx_unet_layer_tile(hdl, li, B, buf, 64)

@@ -189,8 +189,8 @@ int mpdx_unet_profile(mpdx_unet* u, const float* packed_dev, const float* timeta
 /* dev tool: per-phase s_memtime stamps (workgroup 0, wave 0) of one launch of fused segment `seg` */
 int mpdx_fused_trace(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, const float* x, int seg, int B,
                      float* ws, void* stream, long long* stamps_out, int cap, int* n_out, int* nops_out);
-/* layer index behind launch unit i of mpdx_unet_profile (-1: fused whole-trajectory segment or the final kernel) */
-int mpdx_unet_unit_layer(const mpdx_unet* u, int i);
+/* layer index behind launch unit i of mpdx_unet_profile at batch B (-1: fused whole-trajectory segment or the final kernel) */
+int mpdx_unet_unit_layer(const mpdx_unet* u, int B, int i);
 /* `reps` back-to-back launches of layer `layer` between two events; dbg = ablation mask (1 skip staging, 2 skip
  * MFMA loop, 4 skip epilogue, 8 skip weight loads); synchronises. */
 int mpdx_bench_layer(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, const float* x, int layer, int B,

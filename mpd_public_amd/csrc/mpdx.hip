@@ -813,17 +813,22 @@ static int check_ready(const mpdx_unet* u) {
     return 0;
 }
 
-// bit k enables fused segment k (MPDX_FUSED=0 disables all, MPDX_FUSED_MASK=<bits> selects; default all)
-static unsigned fused_mask() {
-    static const unsigned m = (getenv("MPDX_FUSED") && atoi(getenv("MPDX_FUSED")) == 0) ? 0u
-                              : (getenv("MPDX_FUSED_MASK") ? (unsigned)strtoul(getenv("MPDX_FUSED_MASK"), nullptr, 0) : ~0u);
-    return m;
+// bit k enables fused segment k.  Default: all segments for small batches, none for large ones - a fused kernel streams
+// the segment's weights once per TRAJECTORY, the per-layer kernels once per 32-64 positions x all trajectories of a tile,
+// so beyond a few hundred trajectories weight reuse wins (measured crossover on MI355X between B=400 and B=800,
+// tools/sweep_fused_vs_layer.py).  MPDX_FUSED=0/1 forces none/all, MPDX_FUSED_MASK=<bits> selects segments.
+static unsigned fused_mask(int B) {
+    static const int forced = getenv("MPDX_FUSED") ? atoi(getenv("MPDX_FUSED")) : -1;
+    static const long mask_env = getenv("MPDX_FUSED_MASK") ? (long)strtoul(getenv("MPDX_FUSED_MASK"), nullptr, 0) : -1;
+    if (forced == 0) return 0u;
+    if (mask_env >= 0) return (unsigned)mask_env;
+    if (forced > 0) return ~0u;
+    return B <= 512 ? ~0u : 0u;
 }
-static bool fused_enabled() { return fused_mask() != 0; }
-// launch units for the current mask
-static std::vector<mpdx_unet::Unit> current_units(const mpdx_unet* u, bool* final_in_fused) {
+// launch units for batch B
+static std::vector<mpdx_unet::Unit> current_units(const mpdx_unet* u, int B, bool* final_in_fused) {
     std::vector<mpdx_unet::Unit> out;
-    const unsigned m = fused_mask();
+    const unsigned m = fused_mask(B);
     bool fin = false;
     for (int i = 0; i < (int)u->layers.size(); ++i) {
         const int o = u->owner[i];
@@ -880,7 +885,7 @@ static int run_unet_and_final(mpdx_unet* u, const float* packed, const float* ti
     if (t < 0 || t >= T) return fail(MPDX_E_INVALID, "timestep %d outside [0,%d)", t, T);
     if (B <= 0) return fail(MPDX_E_INVALID, "B must be positive");
     const float* row = timetab + (size_t)t * u->tt_row;
-    const auto units = current_units(u, nullptr);
+    const auto units = current_units(u, B, nullptr);
     bool final_done = false;
     for (size_t k = 0; k < units.size(); ++k) {
         const auto& un = units[k];
@@ -1155,7 +1160,7 @@ int mpdx_unet_profile(mpdx_unet* u, const float* packed, const float* timetab, i
     if (t < 0 || t >= T) return fail(MPDX_E_INVALID, "timestep %d outside [0,%d)", t, T);
     hipStream_t st = (hipStream_t)stream;
     bool fin_fused = false;
-    const auto units = current_units(u, &fin_fused);
+    const auto units = current_units(u, B, &fin_fused);
     const bool need_final = !fin_fused;
     const int nl = (int)units.size() + (need_final ? 1 : 0);
     if (cap < nl) return fail(MPDX_E_INVALID, "need room for %d launches", nl);
@@ -1231,9 +1236,9 @@ int mpdx_fused_trace(mpdx_unet* u, const float* packed, const float* timetab, co
 }
 
 /* layer index of launch unit i (-1 for a fused unit / the final kernel): lets bench.py query the tile of a unit */
-int mpdx_unet_unit_layer(const mpdx_unet* u, int i) {
+int mpdx_unet_unit_layer(const mpdx_unet* u, int B, int i) {
     if (!u) return -1;
-    const auto units = current_units(u, nullptr);
+    const auto units = current_units(u, B, nullptr);
     if (i < 0 || i >= (int)units.size()) return -1;
     return units[i].fused >= 0 ? -1 : units[i].layer;
 }
