@@ -189,6 +189,10 @@ int mpdx_unet_profile(mpdx_unet* u, const float* packed_dev, const float* timeta
 /* dev tool: per-phase s_memtime stamps (workgroup 0, wave 0) of one launch of fused segment `seg` */
 int mpdx_fused_trace(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, const float* x, int seg, int B,
                      float* ws, void* stream, long long* stamps_out, int cap, int* n_out, int* nops_out);
+/* in-situ timing of launch units [unit_first, unit_last] inside `reps` real U-Net passes (one event pair per pass around the
+ * run: real predecessors and cold weights, event cost amortised over the run); *ms_avg = bracketed time per pass. */
+int mpdx_unet_time_units(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, int T, const float* x, int t, int B,
+                         float* ws, void* stream, int unit_first, int unit_last, int reps, float* ms_avg);
 /* layer index behind launch unit i of mpdx_unet_profile at batch B (-1: fused whole-trajectory segment or the final kernel) */
 int mpdx_unet_unit_layer(const mpdx_unet* u, int B, int i);
 /* `reps` back-to-back launches of layer `layer` between two events; dbg = ablation mask (1 skip staging, 2 skip

@@ -1235,6 +1235,48 @@ int mpdx_fused_trace(mpdx_unet* u, const float* packed, const float* timetab, co
     return rc;
 }
 
+/* in-situ timing: `reps` full U-Net passes; ONE event pair brackets launch units [unit_first, unit_last] of each pass
+ * (so the bracketed kernels run in their real context - cold weights, real predecessor - and the event cost is
+ * amortised over the run).  *ms_avg = average bracketed time per pass.  Synchronises. */
+int mpdx_unet_time_units(mpdx_unet* u, const float* packed, const float* timetab, int T, const float* x, int t, int B, float* ws,
+                         void* stream, int unit_first, int unit_last, int reps, float* ms_avg) {
+    if (!u || !packed || !timetab || !x || !ws || !ms_avg || reps < 1) return fail(MPDX_E_INVALID, "bad argument");
+    if (int rc = check_ready(u)) return rc;
+    if (t < 0 || t >= T) return fail(MPDX_E_INVALID, "timestep %d outside [0,%d)", t, T);
+    hipStream_t st = (hipStream_t)stream;
+    const auto units = current_units(u, B, nullptr);
+    if (unit_first < 0 || unit_last >= (int)units.size() || unit_first > unit_last) return fail(MPDX_E_INVALID, "bad unit range");
+    static float* scratch = nullptr;
+    static size_t scratch_n = 0;
+    const size_t need = (size_t)B * u->cfg.n_support_points * u->cfg.state_dim;
+    if (scratch_n < need) { if (scratch) (void)hipFree(scratch); HIP_TRY(hipMalloc(&scratch, need * sizeof(float))); scratch_n = need; }
+    FinalArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.out = scratch; fa.mode = 0; fa.n_per_ctx = 1;
+    const float* row = timetab + (size_t)t * u->tt_row;
+    std::vector<hipEvent_t> ev(2 * reps);
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    int rc = 0;
+    for (int r = 0; r < reps && !rc; ++r) {
+        bool final_done = false;
+        for (int i = 0; i < (int)units.size() && !rc; ++i) {
+            if (i == unit_first) HIP_TRY(hipEventRecord(ev[2 * r], st));
+            if (units[i].fused >= 0) {
+                rc = run_fused(u, u->fused[units[i].fused], packed, row, x, ws, B, &fa, st);
+                final_done |= u->fused[units[i].fused].has_final;
+            } else rc = run_layer(u, u->layers[units[i].layer], packed, row, x, ws, B, st);
+            if (i == unit_last) HIP_TRY(hipEventRecord(ev[2 * r + 1], st));
+        }
+        if (!rc && !final_done) rc = run_final(u, packed, fa, B, ws, st);
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    double tot = 0.0;
+    for (int r = 0; r < reps && !rc; ++r) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1])); tot += ms; }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    *ms_avg = (float)(tot / reps);
+    return rc;
+}
+
 /* layer index of launch unit i (-1 for a fused unit / the final kernel): lets bench.py query the tile of a unit */
 int mpdx_unet_unit_layer(const mpdx_unet* u, int B, int i) {
     if (!u) return -1;
