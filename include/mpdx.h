@@ -81,12 +81,16 @@ typedef struct mpdx_step_coefs {
     float noise_std_extra;              /* noise_std_extra_schedule_fn(t) (0.5 at inference.py:243), 1 if None */
     int32_t predict_epsilon;            /* :121-132 */
     int32_t clip_denoised;              /* :149-150 */
+    float ddim_k1;                      /* ddim_sample (:184-259): sqrt(alphas_cumprod[t_next]), 1 on the last pair */
+    float ddim_k2;                      /* sqrt(1 - alphas_cumprod[t_next] - sigma^2) with eta = 0, 0 on the last pair */
 } mpdx_step_coefs;
 
 /* x_io[B,H,D] is updated in place to  hard_cond( mean + noise_scale*noise*noise_std_extra ).
  * noise may be NULL (treated as 0).  hard_start/hard_goal: [B,D] values written at horizon index 0 / H-1
- * (NULL = no hard conditioning).  If mean_only != 0 the posterior mean (before noise, before hard conditioning)
- * is written instead - the point where the reference inserts the guide (sample_functions.py:39-48).
+ * (NULL = no hard conditioning).  mean_only == 1: the posterior mean (before noise, before hard conditioning) is
+ * written instead - the point where the reference inserts the guide (sample_functions.py:39-48).
+ * mean_only == 2: the DDIM update of ddim_sample (diffusion_model_base.py:216-237, eta = 0):
+ *   x <- hard_cond( ddim_k1 * x_start + ddim_k2 * pred_noise ), x_start NOT clamped (as the reference).
  * chain_out (optional): a second [B,H,D] destination that receives the same values (chain.append, :175-176).
  * absmax_out (optional, uint32 per context): atomicMax of the bit pattern of max|x| over each context's
  * n_per_ctx trajectories - the whole-tensor range test of LimitsNormalizer.unnormalize (normalization.py:160). */

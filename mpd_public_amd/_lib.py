@@ -22,7 +22,7 @@ class StepCoefs(C.Structure):
     _fields_ = [("sqrt_recip_alphas_cumprod", C.c_float), ("sqrt_recipm1_alphas_cumprod", C.c_float),
                 ("posterior_mean_coef1", C.c_float), ("posterior_mean_coef2", C.c_float),
                 ("noise_scale", C.c_float), ("noise_std_extra", C.c_float),
-                ("predict_epsilon", C.c_int32), ("clip_denoised", C.c_int32)]
+                ("predict_epsilon", C.c_int32), ("clip_denoised", C.c_int32), ("ddim_k1", C.c_float), ("ddim_k2", C.c_float)]
 
 
 MAX_FIELDS = 4

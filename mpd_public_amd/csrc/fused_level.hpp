@@ -274,12 +274,21 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
                     float x0 = a.k.predict_epsilon
                                    ? __fsub_rn(__fmul_rn(a.k.sqrt_recip_alphas_cumprod, xv), __fmul_rn(a.k.sqrt_recipm1_alphas_cumprod, s))
                                    : s;
-                    if (a.k.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-                    r = __fadd_rn(__fmul_rn(a.k.posterior_mean_coef1, x0), __fmul_rn(a.k.posterior_mean_coef2, xv));
-                    if (a.fmode == 1) {
-                        if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, a.noise[o]), a.k.noise_std_extra));
+                    if (a.fmode == 3) {  // ddim_sample (diffusion_model_base.py:216-237): x_start is not clamped there
+                        const float pn = a.k.predict_epsilon
+                                             ? s
+                                             : __fdiv_rn(__fsub_rn(__fmul_rn(a.k.sqrt_recip_alphas_cumprod, xv), s), a.k.sqrt_recipm1_alphas_cumprod);
+                        r = __fadd_rn(__fmul_rn(x0, a.k.ddim_k1), __fmul_rn(a.k.ddim_k2, pn));
                         if (a.hs && p == 0) r = a.hs[(size_t)b * a.D + d];
                         if (a.hg && p == H - 1) r = a.hg[(size_t)b * a.D + d];
+                    } else {
+                        if (a.k.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+                        r = __fadd_rn(__fmul_rn(a.k.posterior_mean_coef1, x0), __fmul_rn(a.k.posterior_mean_coef2, xv));
+                        if (a.fmode == 1) {
+                            if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, a.noise[o]), a.k.noise_std_extra));
+                            if (a.hs && p == 0) r = a.hs[(size_t)b * a.D + d];
+                            if (a.hg && p == H - 1) r = a.hg[(size_t)b * a.D + d];
+                        }
                     }
                 }
                 a.out[o] = r;

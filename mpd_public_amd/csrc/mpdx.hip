@@ -97,7 +97,7 @@ struct FinalArgs {
     float* chain;        // optional second destination
     uint32_t* absmax;    // optional per-context max|out| (bit pattern)
     int B, H, D, C;
-    int mode;            // 0: eps only; 1: full step; 2: posterior mean only (guide insertion point)
+    int mode;            // 0: eps only; 1: full step; 2: posterior mean only (guide insertion point); 3: DDIM update
     int n_per_ctx;
     mpdx_step_coefs k;
 };
@@ -134,12 +134,21 @@ __global__ __launch_bounds__(256) void final_step_kernel(const FinalArgs a) {
                     x0 = __fsub_rn(__fmul_rn(a.k.sqrt_recip_alphas_cumprod, xv), __fmul_rn(a.k.sqrt_recipm1_alphas_cumprod, s));
                 else
                     x0 = s;
-                if (a.k.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-                r = __fadd_rn(__fmul_rn(a.k.posterior_mean_coef1, x0), __fmul_rn(a.k.posterior_mean_coef2, xv));
-                if (a.mode == 1) {
-                    if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, a.noise[o]), a.k.noise_std_extra));
+                if (a.mode == 3) {  // ddim_sample (diffusion_model_base.py:216-237): x_start is not clamped there
+                    const float pn = a.k.predict_epsilon
+                                         ? s
+                                         : __fdiv_rn(__fsub_rn(__fmul_rn(a.k.sqrt_recip_alphas_cumprod, xv), s), a.k.sqrt_recipm1_alphas_cumprod);
+                    r = __fadd_rn(__fmul_rn(x0, a.k.ddim_k1), __fmul_rn(a.k.ddim_k2, pn));
                     if (a.hs && l == 0) r = a.hs[(size_t)b * a.D + d];
                     if (a.hg && l == a.H - 1) r = a.hg[(size_t)b * a.D + d];
+                } else {
+                    if (a.k.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+                    r = __fadd_rn(__fmul_rn(a.k.posterior_mean_coef1, x0), __fmul_rn(a.k.posterior_mean_coef2, xv));
+                    if (a.mode == 1) {
+                        if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, a.noise[o]), a.k.noise_std_extra));
+                        if (a.hs && l == 0) r = a.hs[(size_t)b * a.D + d];
+                        if (a.hg && l == a.H - 1) r = a.hg[(size_t)b * a.D + d];
+                    }
                 }
             }
             a.out[o] = r;
@@ -1048,7 +1057,7 @@ int mpdx_ddpm_step(mpdx_unet* u, const float* packed, const float* timetab, int 
     memset(&fa, 0, sizeof(fa));
     fa.x_in = x_io; fa.out = x_io; fa.noise = noise; fa.hs = hard_start; fa.hg = hard_goal;
     fa.chain = chain_out; fa.absmax = absmax_out; fa.n_per_ctx = n_per_ctx > 0 ? n_per_ctx : B;
-    fa.mode = mean_only ? 2 : 1;
+    fa.mode = mean_only == 2 ? 3 : (mean_only ? 2 : 1);
     fa.k = *coefs;
     if (int rc = run_unet_and_final(u, packed, timetab, T, x_io, t, B, ws, fa, st)) return rc;
     HIP_TRY(hipGetLastError());

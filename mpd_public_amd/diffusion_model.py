@@ -170,8 +170,54 @@ class GaussianDiffusionModel(nn.Module):
         return x
 
     @torch.no_grad()
-    def ddim_sample(self, shape, hard_conds, **kwargs):
-        raise NotImplementedError("ddim_sample (diffusion_model_base.py:184-259) is outside the accelerated hot path (SURVEY.md 8f-1)")
+    def ddim_sample(self, shape, hard_conds, context=None, return_chain=False, t_start_guide=torch.inf, guide=None, n_guide_steps=1,
+                    noise=None, **sample_kwargs):
+        """DDIM sampler, drop-in for diffusion_model_base.py:184-259 (sampling_timesteps = T // 5, eta = 0): per time pair
+        one U-Net pass + DDIM update (mpdx_ddpm_step mode 2), optional guide steps when t_next < t_start_guide, hard
+        conditioning.  `noise` ([1+pairs, B, H, D], optional) injects x_T for parity runs (eta = 0: no other draw matters)."""
+        if context is not None:
+            raise NotImplementedError("context is always None on this path")
+        device = self.betas.device
+        B, H, D = shape
+        total, sampling = self.n_diffusion_steps, self.n_diffusion_steps // 5
+        times = torch.linspace(0, total - 1, steps=sampling + 1)
+        times = list(reversed(torch.cat((torch.tensor([-1.0]), times)).int().tolist()))
+        pairs = list(zip(times[:-1], times[1:]))
+        if noise is not None:
+            x = noise[0].to(device=device, dtype=torch.float32).clone()
+        else:
+            x = self.fill_randn(torch.empty(shape, device=device, dtype=torch.float32))
+        x = apply_hard_conditioning(x, hard_conds)
+        chain = [x.clone()] if return_chain else None
+        hdl, packed, tab, ws = self.model.engine(total, B)
+        lib, hb = _lib.load(), self.host_buffers()
+        keys = set(hard_conds.keys())
+        native_hc = keys <= {0, H - 1}
+        hs = hard_conds.get(0).contiguous().float() if (native_hc and 0 in hard_conds) else None
+        hg = hard_conds.get(H - 1).contiguous().float() if (native_hc and (H - 1) in hard_conds) else None
+        for time, time_next in pairs:
+            guided = guide is not None and time_next >= 0 and time_next < t_start_guide
+            c = step_coefs(self, time)
+            if time_next < 0:
+                c.ddim_k1, c.ddim_k2 = 1.0, 0.0          # x = x_start  (:221-226)
+            else:
+                a_next = torch.tensor(float(hb["alphas_cumprod"][time_next]), dtype=torch.float32)
+                c.ddim_k1 = float(a_next.sqrt())
+                c.ddim_k2 = float((1 - a_next - torch.tensor(0.0) ** 2).sqrt())   # eta = 0 -> sigma = 0 (:231-234)
+            in_kernel_hc = native_hc and not guided
+            _lib.check(lib.mpdx_ddpm_step(hdl, packed.data_ptr(), tab.data_ptr(), self.model._timetab_T, x.data_ptr(), None,
+                                          _lib.ptr(hs) if in_kernel_hc else None, _lib.ptr(hg) if in_kernel_hc else None, c, time, 2,
+                                          None, None, B, B, ws.data_ptr(), _lib.current_stream()), "mpdx_ddpm_step(ddim)")
+            if guided:
+                from .sample_functions import guide_gradient_steps
+                x = guide_gradient_steps(x, hard_conds=hard_conds, guide=guide, n_guide_steps=n_guide_steps, **sample_kwargs)
+            if not in_kernel_hc:
+                x = apply_hard_conditioning(x, hard_conds)
+            if return_chain:
+                chain.append(x.clone())
+        if return_chain:
+            return x, torch.stack(chain, dim=1)
+        return x
 
     @torch.no_grad()
     def conditional_sample(self, hard_conds, horizon=None, batch_size=1, ddim=False, **sample_kwargs):

@@ -42,7 +42,7 @@ def step_coefs(model, t: int, noise_std_extra: float = 1.0) -> "_lib.StepCoefs":
     scale = 0.0 if t == 0 else float(c["noise_scale"][t])  # noise[t == 0] = 0  (sample_functions.py:52)
     return _lib.StepCoefs(float(c["sqrt_recip_alphas_cumprod"][t]), float(c["sqrt_recipm1_alphas_cumprod"][t]),
                           float(c["posterior_mean_coef1"][t]), float(c["posterior_mean_coef2"][t]), scale,
-                          float(noise_std_extra), int(bool(model.predict_epsilon)), int(bool(model.clip_denoised)))
+                          float(noise_std_extra), int(bool(model.predict_epsilon)), int(bool(model.clip_denoised)), 1.0, 0.0)
 
 
 @torch.no_grad()

@@ -80,3 +80,38 @@ def run_inference(sd: dict, hard_conds: dict, noise: torch.Tensor, T: int, varia
     B = noise.shape[1]
     hc = {k: (v[None, :].expand(B, -1).clone() if v.dim() == 1 else v.clone()) for k, v in hard_conds.items()}
     return p_sample_loop(buf, sd, hc, noise, T, n_diffusion_steps_without_noise, **kw)
+
+
+def ddim_sample(sd: dict, hard_conds: dict, x_T: torch.Tensor, T: int, variance_schedule: str = "exponential",
+                guide=None, n_guide_steps: int = 1, t_start_guide: float = float("inf"), predict_epsilon: bool = True,
+                dtype=torch.float32) -> torch.Tensor:
+    """diffusion_model_base.py:184-259 with eta = 0 (sigma = 0: the randn_like draws do not matter).  Returns the
+    chain [pairs+1, B, H, D] in 'diffsteps b h d' order.  x_start is NOT clamped on this path (the reference does not)."""
+    buf = {k: v.to(dtype) for k, v in _sched.make_buffers(T, variance_schedule).items()}
+    B = x_T.shape[0]
+    hc = {k: (v[None, :].expand(B, -1).clone() if v.dim() == 1 else v.clone()) for k, v in hard_conds.items()}
+    sampling = T // 5
+    times = torch.linspace(0, T - 1, steps=sampling + 1)
+    times = list(reversed(torch.cat((torch.tensor([-1.0]), times)).int().tolist()))
+    x = apply_hard_conditioning(x_T.clone(), hc)
+    chain = [x.clone()]
+    for time, time_next in zip(times[:-1], times[1:]):
+        tt = torch.full((B,), time, dtype=torch.long)
+        out = unet_forward(sd, x, tt)
+        a_t, b_t = buf["sqrt_recip_alphas_cumprod"][time], buf["sqrt_recipm1_alphas_cumprod"][time]
+        if predict_epsilon:
+            x_start, pred_noise = a_t * x - b_t * out, out
+        else:
+            x_start, pred_noise = out, (a_t * x - out) / b_t
+        if time_next < 0:
+            x = apply_hard_conditioning(x_start, hc)
+            chain.append(x.clone())
+            break
+        alpha_next = buf["alphas_cumprod"][time_next]
+        c = (1 - alpha_next).sqrt()
+        x = x_start * alpha_next.sqrt() + c * pred_noise
+        if guide is not None and time_next < t_start_guide:
+            x = guide_gradient_steps(x, hc, guide, n_guide_steps)
+        x = apply_hard_conditioning(x, hc)
+        chain.append(x.clone())
+    return torch.stack(chain, dim=0)

@@ -121,3 +121,18 @@ def test_guide_descriptor_compiles_to_params_on_cpu():
     assert [gp.fields[i].kind for i in range(4)] == [2, 0, 1, 0]
     assert gp.fields[1].n_spheres == 15 and gp.fields[3].n_spheres == 2 and gp.n_prim_floats == 17 * 4
     assert abs(gp.dt - 5.0 / 64) < 1e-9 and abs(gp.gp_weight - 1e-7) < 1e-12
+
+
+def test_checkpoint_layout_matches_reference(golden_dir):
+    """Every key/shape of the reference's GaussianDiffusionModel.state_dict() (fixture made by importing the reference)
+    exists with the same shape in ours, and nothing else: a reference .pth loads with strict=True (inference.py:145-148)."""
+    import mpd_public_amd as m
+    want = {}
+    for line in (golden_dir / "state_dict_keys.txt").read_text().splitlines():
+        cfg, key, shape = line.split()
+        want.setdefault(cfg, {})[key] = tuple(int(s) for s in shape.split("x")) if shape else ()
+    for cfg, (D, mults) in {"D4_opt1": (4, (1, 2, 4, 8)), "D14_opt0": (14, (1, 2, 4))}.items():
+        dm = m.GaussianDiffusionModel(model=m.TemporalUnet(n_support_points=64, state_dim=D, dim_mults=mults), n_diffusion_steps=25,
+                                      predict_epsilon=True)
+        got = {k: tuple(v.shape) for k, v in dm.state_dict().items()}
+        assert got == want[cfg], sorted(set(got.items()) ^ set(want[cfg].items()))[:5]

@@ -58,3 +58,29 @@ def test_experiment_entry_runs_and_reports(tmp_path, model_id, planner):
     xs = r["trajs_iters"]
     assert torch.equal(xs[:, :, 0, :], xs[0:1, 0:1, 0, :].expand(steps, n, -1))
     assert torch.equal(xs[:, :, -1, :], xs[0:1, 0:1, -1, :].expand(steps, n, -1))
+
+
+def test_experiment_loads_reference_format_checkpoint(tmp_path):
+    """model_dir with args.yaml + checkpoints/ema_model_current_state_dict.pth (the layout trainer.py:29-37 writes)."""
+    import yaml
+    import mpd_public_amd as m
+    from mpd_public_amd import synthetic as syn
+    from mpd_public_amd.inference import experiment
+    md = tmp_path / "EnvSimple2D-RobotPointMass"
+    (md / "checkpoints").mkdir(parents=True)
+    (md / "args.yaml").write_text(yaml.safe_dump(dict(variance_schedule="exponential", n_diffusion_steps=25, predict_epsilon=True,
+                                                      unet_input_dim=32, unet_dim_mults_option=0, use_ema=True, include_velocity=True)))
+    dm = m.GaussianDiffusionModel(model=m.TemporalUnet(n_support_points=64, state_dim=4, dim_mults=(1, 2, 4)), n_diffusion_steps=25,
+                                  predict_epsilon=True)
+    sd = dm.state_dict()
+    for k in sd:  # weights that differ from the synthetic default, so that loading is observable
+        if k.startswith("model."):
+            sd[k] = torch.from_numpy(syn.synth_param("ckpt/" + k, tuple(sd[k].shape)))
+    torch.save(sd, md / "checkpoints" / "ema_model_current_state_dict.pth")
+    kw = dict(model_id="EnvSimple2D-RobotPointMass", n_samples=6, debug=False, results_dir=str(tmp_path / "out"), seed=5,
+              planner_alg="diffusion_prior")
+    a = experiment(model_dir=str(md), **kw)
+    b = experiment(model_dir=None, model_args=dict(unet_dim_mults_option=0), **kw)
+    assert a["trajs_iters"].shape == b["trajs_iters"].shape == (31, 6, 64, 4)
+    assert torch.isfinite(a["trajs_iters"]).all()
+    assert not torch.allclose(a["trajs_iters"][-1], b["trajs_iters"][-1])   # the checkpoint's weights were used

@@ -158,3 +158,21 @@ def test_fused_plan_equals_stepwise_protocol():
     assert a.shape == (T + n0 + 1, B, 64, D)
     assert torch.equal(a, b)
     assert torch.isfinite(a).all()
+
+
+@pytest.mark.parametrize("opt", [0, 1])
+def test_ddim_chain_vs_reference_golden(golden_dir, opt):
+    """ddim_sample (diffusion_model_base.py:184-259, eta=0): run_inference(ddim=True) against the reference's chain."""
+    g = load_npz(golden_dir / "ddim.npz")
+    D, T, B = 4, 25, 4
+    dm = _gpu_model(D, opt, T)
+    noise = t("ddim_noise", (8, B, 64, D)).cuda()
+    hc = {0: t("chain_hc0", (D,), "uniform").cuda(), 63: t("chain_hc1", (D,), "uniform").cuda()}
+    chain = dm.run_inference(None, hc, n_samples=B, horizon=64, return_chain=True, ddim=True, noise=noise).cpu().numpy()
+    ref = g[f"ddim_chain_opt{opt}"]
+    assert chain.shape == ref.shape == (7, B, 64, D)
+    # no clamp on this path: the first update is O(1e3) (eps amplified by sqrt(1/alpha_bar - 1) = 4.6e3); relative tolerance
+    scale = np.abs(ref).reshape(7, -1).max(1)
+    err = np.abs(chain - ref).reshape(7, -1).max(1)
+    assert (err <= 3e-5 * np.maximum(scale, 1.0) + 2e-4).all(), (err, scale)
+    np.testing.assert_array_equal(chain[:, :, 0, :], ref[:, :, 0, :])

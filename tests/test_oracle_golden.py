@@ -111,3 +111,17 @@ def test_guided_chain_matches_reference(golden_dir):
     chain = diffusion.run_inference(sd, hc, noise, T, n_diffusion_steps_without_noise=n0, noise_std=0.5,
                                     guide=gm, n_guide_steps=5, t_start_guide=ceil(0.25 * T)).numpy()
     np.testing.assert_allclose(chain, g["guided_chain_opt0"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("opt", [0, 1])
+def test_ddim_chain_matches_reference(golden_dir, opt):
+    """ddim_sample (diffusion_model_base.py:184-259), eta=0, T=25 -> 6 updates."""
+    g = load_npz(golden_dir / "ddim.npz")
+    D, T, B = 4, 25, 4
+    x_T = t("ddim_noise", (8, B, 64, D))[0]
+    hc = {0: t("chain_hc0", (D,), "uniform"), 63: t("chain_hc1", (D,), "uniform")}
+    chain = diffusion.ddim_sample(synth_sd(D, opt), hc, x_T, T).numpy()
+    ref = g[f"ddim_chain_opt{opt}"]
+    assert chain.shape == ref.shape == (7, B, 64, D)
+    # the first update amplifies eps by 4.6e3 WITHOUT a clamp on this path: values are O(1e3); compare relatively
+    np.testing.assert_allclose(chain, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
