@@ -67,6 +67,7 @@ SIGNATURES = {
     "mpdx_absmax": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "mpdx_unet_profile": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(C.c_double),
                                 C.POINTER(C.c_char_p), C.POINTER(C.c_int)]),
+    "mpdx_layer_trace": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, C.POINTER(C.c_longlong)]),
     "mpdx_fused_trace": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, C.POINTER(C.c_longlong), _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mpdx_unet_time_units": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float)]),
     "mpdx_unet_unit_layer": (_i, [_vp, _i, _i]),

@@ -52,6 +52,7 @@ struct ConvArgs {
     int n_tiles_n;       // ceil(B*L_out / NT)
     int lg_c4n, lg_Lin, lg_Lout, lg_gs;  // log2 of cin_pad/4, L_in, L_out, gs (all powers of two): no integer division on device
     int dbg;             // ablation mask for mpdx_bench_layer: 1 skip staging, 2 skip MFMA loop, 4 skip epilogue
+    long long* trace;    // dev tool: s_memtime stamps of workgroups 0 and last / wave 0 (null in production)
 };
 
 // wave64 all-reduce (sum) with DPP row operations + 4 readlanes instead of a 6-step ds_bpermute butterfly:
@@ -109,6 +110,8 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WN, wk = wave / WN;
+    int tr_i = 0;
+#define CB_STAMP() do { if (a.trace && tid == 0 && (block_id == 0 || block_id == (int)gridDim.x - 1)) a.trace[(block_id ? 16 : 0) + tr_i] = (long long)__builtin_readcyclecounter(); ++tr_i; } while (0)
     const int n_mt = a.C_out / MT;   // MT is a compile-time power of two; one uniform division per workgroup
     const int mt = block_id % n_mt, nt = block_id / n_mt;
     const int L_in = a.L_in, L_out = a.L_out;
@@ -120,6 +123,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
     const int cin = a.c1 + a.c2;
     const int c4n = a.cin_pad >> 2;
 
+    CB_STAMP();  // 0: kernel entry
     // ------------------------------------------------------------------ weight prefetch (independent of LDS)
     // Each wave owns k-groups wk, wk+WK, ...; their A fragments are streamed from L2/HBM through a PF-deep register
     // ring so that the ~1-2 us load latency is paid once per kernel, under the staging phase, not once per iteration.
@@ -187,16 +191,19 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
         }
         // zero halo rows (conv padding): 2*PAD rows per trajectory
         if (PAD > 0) {
-            const int htot = (spt * 2 * PAD) << a.lg_c4n;
+            constexpr int P2 = PAD > 0 ? 2 * PAD : 1;
+            const int htot = (spt * P2) << a.lg_c4n;
             for (int idx = tid; idx < htot; idx += NTHR) {
                 const int hr = idx >> a.lg_c4n, c4 = idx & (c4n - 1);
-                const int s = hr / (2 * PAD), k = hr - s * (2 * PAD);          // compile-time divisor
+                const int s = hr / P2, k = hr - s * P2;                         // compile-time divisor
                 const int lp = (k < PAD) ? k : (L_in + k);                      // rows 0..PAD-1 and L_in+PAD..L_in+2PAD-1
                 smem4[(s * LP + lp) * RS4 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
     }
+    CB_STAMP();  // 1: own staging loads issued/written
     __syncthreads();
+    CB_STAMP();  // 2: window staged (all waves)
 
     // ------------------------------------------------------------------ MFMA main loop (K split over wk)
     const int j = lane & 15, q = lane >> 4;
@@ -225,33 +232,52 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
 #pragma unroll
         for (int i = 0; i < NSW; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // B fragments are software-pipelined one k-group ahead (explicit register double buffer): the ds_reads of k-group
+    // i+1 are issued before the MFMAs of k-group i, so their LDS latency hides under 16 MFMAs instead of being paid every
+    // k-group.  The body has no data-dependent control flow: k-group indices are clamped and a k-group past the end of
+    // this wave's range (ragged K split) contributes a zero A fragment.
+    auto load_b = [&](int it, f32x4 (&dst)[NSW]) {
+        const int g = ring_g(it);
+        const int c16 = g / NTAP, ts = g - c16 * NTAP;
+#pragma unroll
+        for (int i = 0; i < NSW; ++i) {
+            const int p = (MODE == CONV_UPT) ? (i & 1) : 0;
+            // row offset of this tap in the staged (zero-haloed) window:
+            //   conv/down: staged row (l*stride + tap) holds true index l*stride + tap - PAD;
+            //   convT:     boff already points at input m; even outputs use (m, m-1), odd outputs (m, m+1).
+            const int roff = (MODE == CONV_UPT) ? ((ts == 0) ? 0 : (p == 0 ? -1 : 1)) : ts;
+            dst[i] = smem4[boff[i] + roff * RS4 + c16 * 4];
+        }
+    };
+    f32x4 bcur[NSW], bnext[NSW];
+    load_b(0, bcur);
     for (int it0 = 0; it0 < niter && !(a.dbg & 2); it0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const int g = wk + (it0 + u) * WK;
-            if (g < ngroups) {  // wave-uniform; only LDS reads + MFMAs are conditional
-                const int c16 = g / NTAP, ts = g - c16 * NTAP;
+            const int it = it0 + u;
+            if (it < niter) {  // uniform over the workgroup
+                load_b(it + 1, bnext);
+                const bool live = (wk + it * WK) < ngroups;  // wave-uniform (ragged K split)
 #pragma unroll
                 for (int i = 0; i < NSW; ++i) {
                     const int p = (MODE == CONV_UPT) ? (i & 1) : 0;
-                    // row offset of this tap in the staged (zero-haloed) window:
-                    //   conv/down: staged row (l*stride + tap) holds true index l*stride + tap - PAD;
-                    //   convT:     boff already points at input m; even outputs use (m, m-1), odd outputs (m, m+1).
-                    const int roff = (MODE == CONV_UPT) ? ((ts == 0) ? 0 : (p == 0 ? -1 : 1)) : ts;
-                    const f32x4 bf = smem4[boff[i] + roff * RS4 + c16 * 4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
                         for (int m = 0; m < MS; ++m)
-                            acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][m][p][e], bf[e], acc[m][i], 0, 0, 0);
+                            acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(live ? af[u][m][p][e] : 0.0f, bcur[i][e], acc[m][i], 0, 0, 0);
                 }
+                load_a(ring_g(it + PF), af[u]);  // refill this ring slot (unconditional, clamped)
+#pragma unroll
+                for (int i = 0; i < NSW; ++i) bcur[i] = bnext[i];
             }
-            load_a(ring_g(it0 + u + PF), af[u]);  // refill this ring slot (unconditional, clamped)
         }
     }
 
     // ------------------------------------------------------------------ K-partials -> LDS (fixed-order reduction)
-    __syncthreads();  // every wave is done reading the staged window; reuse the memory
+    CB_STAMP();  // 3: this wave's MFMA loop done
+    __syncthreads();
+    CB_STAMP();  // 4: all waves done  // every wave is done reading the staged window; reuse the memory
     float* red = smem;
 #pragma unroll
     for (int m = 0; m < MS; ++m)
@@ -259,6 +285,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
         for (int i = 0; i < NSW; ++i)
             smem4[(wk * NT + npos[i]) * MTP4 + m * 4 + q] = acc[m][i];
     __syncthreads();
+    CB_STAMP();  // 5: partials visible
 
     // ------------------------------------------------------------------ epilogue
     if (a.dbg & 4) {
@@ -341,6 +368,8 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
             if (b < a.B) *(f32x4*)(a.dst + ((size_t)b * L_out + l) * a.C_out + co) = v;
         }
     }
+    CB_STAMP();  // 6: epilogue done (wave 0)
+#undef CB_STAMP
 }
 
 template <int MODE, int KS, int EPI, int MT, int NT, int WN, int WK>

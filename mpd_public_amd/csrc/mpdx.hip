@@ -34,6 +34,8 @@ static int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail((int)e_, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+static long long* g_conv_trace = nullptr;   // dev tool (mpdx_layer_trace)
+
 // ------------------------------------------------------------------------------------------------ small kernels
 
 // TimeEncoder (layers.py:229-255) and every ResidualTemporalBlock.cond_mlp (layers.py:336-340) depend only on the
@@ -759,6 +761,7 @@ static int make_conv_args(const mpdx_unet* u, const Layer& l, const float* packe
     a.dst = ws + slot * l.dst;
     a.B = B; a.L_in = l.L_in; a.L_out = l.L_out; a.C_out = l.cout;
     a.cin_pad = l.cin_pad; a.rs = l.rs; a.gs = l.gs; a.dbg = dbg;
+    a.trace = g_conv_trace;
     auto lg2 = [](int v) { int k = 0; while ((1 << k) < v) ++k; return k; };
     a.lg_c4n = lg2(l.cin_pad / 4); a.lg_Lin = lg2(l.L_in); a.lg_Lout = lg2(l.L_out); a.lg_gs = l.gs > 0 ? lg2(l.gs) : 0;
     if ((1 << a.lg_c4n) != l.cin_pad / 4 || (1 << a.lg_Lin) != l.L_in || (1 << a.lg_Lout) != l.L_out || (l.gs > 0 && (1 << a.lg_gs) != l.gs))
@@ -1215,6 +1218,24 @@ int mpdx_unet_profile(mpdx_unet* u, const float* packed, const float* timetab, i
     for (int i = 0; i < nl && !rc; ++i) HIP_TRY(hipEventElapsedTime(&ms_out[i], ev[2 * i], ev[2 * i + 1]));
     for (auto& e : ev) (void)hipEventDestroy(e);
     *n_out = nl;
+    return rc;
+}
+
+/* dev tool: one launch of layer `layer` with s_memtime stamps (7 per workgroup) of the first and the last workgroup */
+int mpdx_layer_trace(mpdx_unet* u, const float* packed, const float* timetab, const float* x, int layer, int B, float* ws, void* stream,
+                     long long* stamps32) {
+    if (!u || layer < 0 || layer >= (int)u->layers.size() || !stamps32) return fail(MPDX_E_INVALID, "bad argument");
+    if (int rc = check_ready(u)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    long long* dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, 32 * sizeof(long long)));
+    HIP_TRY(hipMemsetAsync(dev, 0, 32 * sizeof(long long), st));
+    g_conv_trace = dev;
+    int rc = run_layer(u, u->layers[layer], packed, timetab, x, ws, B, st);
+    g_conv_trace = nullptr;
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(stamps32, dev, 32 * sizeof(long long), hipMemcpyDeviceToHost));
+    (void)hipFree(dev);
     return rc;
 }
 
