@@ -140,7 +140,7 @@ def roofline_leg(dm, B, T, reps=20):
     return roof, table, sum(fl[i] for i in range(n.value))
 
 
-def cpu_baseline_leg(sd, D, T, B, n0, min_seconds=10.0, max_plans=3):
+def cpu_baseline_leg(sd, D, T, B, n0, min_seconds=10.0, max_plans=12):
     """The CPU oracle (oracle/, a port of the reference's algorithm validated against it) timed on this box's host
     cores on the SAME workload: whole plans until >= min_seconds of CPU work (bounded sample)."""
     from oracle import diffusion as odiff

@@ -128,7 +128,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
     // Each wave owns k-groups wk, wk+WK, ...; their A fragments are streamed from L2/HBM through a PF-deep register
     // ring so that the ~1-2 us load latency is paid once per kernel, under the staging phase, not once per iteration.
     constexpr int NCLS = (MODE == CONV_UPT) ? 2 : 1;
-    constexpr int PF = 4;
+    constexpr int PF = 4;   // ring depth in k-groups (8 measured worse: the staging loads queue behind 16 weight loads)
     const int nc16 = a.cin_pad >> 4;
     const int ngroups = nc16 * NTAP;
     const float* wbase = a.wp + (size_t)(mt * MS) * nc16 * NSLOT * 256 + lane * 4;
@@ -267,10 +267,12 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                         for (int m = 0; m < MS; ++m)
                             acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(live ? af[u][m][p][e] : 0.0f, bcur[i][e], acc[m][i], 0, 0, 0);
                 }
-                load_a(ring_g(it + PF), af[u]);  // refill this ring slot (unconditional, clamped)
 #pragma unroll
                 for (int i = 0; i < NSW; ++i) bcur[i] = bnext[i];
             }
+            // refill this ring slot OUTSIDE the guard: a conditional load makes hipcc drain the ring (vmcnt(0)) at
+            // every k-group; unconditional clamped loads keep the counted vmcnt((PF-1)*MS*NCLS) waits
+            load_a(ring_g(it + PF), af[u]);
         }
     }
 
