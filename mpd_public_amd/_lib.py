@@ -7,7 +7,10 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-_LIB_PATH = Path(__file__).resolve().parent / "libmpdx.so"
+import os as _os
+
+# MPDX_LIB=<path> selects another build of the library (A/B comparisons of kernel variants)
+_LIB_PATH = Path(_os.environ["MPDX_LIB"]) if _os.environ.get("MPDX_LIB") else Path(__file__).resolve().parent / "libmpdx.so"
 _lib = None
 
 MAX_LEVELS = 8
