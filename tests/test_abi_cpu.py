@@ -68,7 +68,8 @@ def test_handle_parameter_table_matches_reference_tree(lib, D, mults):
 
 def test_invalid_configurations_are_rejected_with_messages(lib):
     for kw in (dict(n_levels=1), dict(state_dim=0), dict(time_emb_dim=16), dict(unet_input_dim=24), dict(n_support_points=48),
-               dict(n_support_points=16)):
+               dict(n_support_points=16),
+               dict(n_support_points=32, n_levels=3, dim_mults=(1, 2, 4))):   # a 64-element GroupNorm region on the up path
         rc, _ = _create(lib, **kw)
         assert rc < 0, kw
         assert lib.mpdx_last_error()
