@@ -43,9 +43,8 @@ HBM_PEAK_GBS = 8000.0
 def build_model(D, mults, T, device):
     import mpd_public_amd as m
     from mpd_public_amd import synthetic as syn
-    from oracle.unet import unet_param_shapes  # shapes only (name->shape table); weights come from synthetic
-    sd = syn.synth_state_dict(unet_param_shapes(D, 32, mults))
     net = m.TemporalUnet(n_support_points=64, state_dim=D, unet_input_dim=32, dim_mults=mults)
+    sd = syn.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})  # formula-defined weights
     net.load_state_dict(sd, strict=True)
     dm = m.GaussianDiffusionModel(model=net, variance_schedule="exponential", n_diffusion_steps=T, predict_epsilon=True)
     return dm.to(device).eval(), sd

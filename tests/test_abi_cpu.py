@@ -137,3 +137,15 @@ def test_checkpoint_layout_matches_reference(golden_dir):
                                       predict_epsilon=True)
         got = {k: tuple(v.shape) for k, v in dm.state_dict().items()}
         assert got == want[cfg], sorted(set(got.items()) ^ set(want[cfg].items()))[:5]
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it."""
+    pkg = ROOT / "mpd_public_amd"
+    for f in list(pkg.glob("*.py")) + list((pkg / "csrc").glob("*")):
+        text = f.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+    bench = (ROOT / "bench.py").read_text()
+    hits = [m.start() for m in re.finditer(r"^\s*(from|import)\s+oracle\b", bench, flags=re.M)]
+    lo = bench.index("def cpu_baseline_leg"); hi = bench.index("def main")
+    assert hits and all(lo < h < hi for h in hits), "bench.py may import oracle only inside cpu_baseline_leg"
