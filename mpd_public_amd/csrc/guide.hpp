@@ -47,6 +47,10 @@ struct GuideArgs {
     const uint32_t* amax_in;   // per-context max|x| bit pattern of the INPUT (range test)
     uint32_t* amax_out;        // per-context max|x| of the OUTPUT (next iteration), or null
     int B, H, D, n_per_ctx;
+    // last guide iteration of a step: also finish the step (sample_functions.py:51-62 + hard conditioning + chain.append)
+    const float* noise;     // [B][H][D] or null
+    float noise_scale, noise_extra;
+    float* chain;           // optional second destination
 };
 
 template <int DIM>
@@ -272,7 +276,8 @@ __global__ __launch_bounds__(64) void traj_metrics_kernel(const mpdx_guide_param
 // QD = configuration-space dim (2, 3 point mass; 7 Panda), DIM = workspace dim, ROBOT as in mpdx.h.
 // WPT = waves per trajectory.  The collision part (FK + SDF + Jacobian transpose per interpolated point and per field) is
 // split over WPT waves as (point slice) x (field): PW = min(WPT,2) point slices, WPT/PW field slots; wave 0 then gathers,
-// clips, adds the GP term and applies the update.  Point mass: WPT = 1; Panda: WPT = 8 (2 point halves x 4 fields).
+// clips, adds the GP term and applies the update.  WPT = 8 for every robot (2 point halves x up to 4 fields): the single-wave
+// version is a long serial latency chain (2-D: 19 us per launch; 8 waves: see DESIGN.md).
 template <int QD, int DIM, int ROBOT, int WPT>
 __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a) {
     constexpr int D = 2 * QD;
@@ -504,9 +509,11 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
                 a.grad_out[base + d] = inc;
             } else {
                 float r = __fadd_rn(xn[d], inc);
+                if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.noise_scale, a.noise[base + d]), a.noise_extra));
                 if (a.hs && lane == 0) r = a.hs[(size_t)b * D + d];
                 if (a.hg && lane == H - 1) r = a.hg[(size_t)b * D + d];
                 a.x[base + d] = r;
+                if (a.chain) a.chain[base + d] = r;
                 vmax = fmaxf(vmax, fabsf(r));
             }
         }

@@ -921,7 +921,8 @@ static int run_unet_and_final(mpdx_unet* u, const float* packed, const float* ti
 }
 
 static int launch_guide(const mpdx_guide_params* gp, float* x, float* grad_out, const float* hs, const float* hg,
-                        const uint32_t* amax_in, uint32_t* amax_out, int n_per_ctx, int B, int H, int D, hipStream_t st) {
+                        const uint32_t* amax_in, uint32_t* amax_out, int n_per_ctx, int B, int H, int D, hipStream_t st,
+                        const float* noise = nullptr, float noise_scale = 0.f, float noise_extra = 0.f, float* chain = nullptr) {
     if (!gp || !x || !amax_in) return fail(MPDX_E_INVALID, "null argument");
     if (H > 64 || H < 2) return fail(MPDX_E_INVALID, "guide kernel maps one support point per lane: H=%d unsupported (max 64)", H);
     if (D != 2 * gp->q_dim || D > 16) return fail(MPDX_E_INVALID, "state dim %d != 2*q_dim (%d)", D, gp->q_dim);
@@ -931,12 +932,13 @@ static int launch_guide(const mpdx_guide_params* gp, float* x, float* grad_out, 
     GuideArgs a;
     a.gp = *gp; a.x = x; a.grad_out = grad_out; a.hs = hs; a.hg = hg; a.amax_in = amax_in; a.amax_out = amax_out;
     a.B = B; a.H = H; a.D = D; a.n_per_ctx = n_per_ctx > 0 ? n_per_ctx : B;
+    a.noise = noise; a.noise_scale = noise_scale; a.noise_extra = noise_extra; a.chain = chain;
     const size_t lds = guide_lds_bytes(*gp, H, D);
     if (lds > 64 * 1024) return fail(MPDX_E_INVALID, "guide needs %zu B of LDS", lds);
     if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 2 && gp->ws_dim == 2)
-        hipLaunchKernelGGL((guide_step_kernel<2, 2, MPDX_ROBOT_POINTMASS, 1>), dim3(B), dim3(64), lds, st, a);
+        hipLaunchKernelGGL((guide_step_kernel<2, 2, MPDX_ROBOT_POINTMASS, 8>), dim3(B), dim3(512), lds, st, a);
     else if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 3 && gp->ws_dim == 3)
-        hipLaunchKernelGGL((guide_step_kernel<3, 3, MPDX_ROBOT_POINTMASS, 1>), dim3(B), dim3(64), lds, st, a);
+        hipLaunchKernelGGL((guide_step_kernel<3, 3, MPDX_ROBOT_POINTMASS, 8>), dim3(B), dim3(512), lds, st, a);
     else if (gp->robot == MPDX_ROBOT_PANDA && gp->q_dim == 7 && gp->ws_dim == 3)
         hipLaunchKernelGGL((guide_step_kernel<7, 3, MPDX_ROBOT_PANDA, 8>), dim3(B), dim3(512), lds, st, a);
     else
@@ -1153,12 +1155,12 @@ int mpdx_plan(mpdx_unet* u, const float* packed, const float* timetab, int T, co
             uint32_t* fl = guide_flags + (size_t)k * (n_guide_steps + 1) * n_ctx;
             fa.mode = 2; fa.absmax = fl;  // posterior mean + its max|.| per context
             if (int rc = run_unet_and_final(u, packed, timetab, T, x, t, B, ws, fa, st)) return rc;
-            for (int j = 0; j < n_guide_steps; ++j)
+            for (int j = 0; j < n_guide_steps; ++j) {
+                const bool last = j == n_guide_steps - 1;  // the last iteration also adds the noise term and appends to the chain
                 if (int rc = launch_guide(guide, x, nullptr, hard_start, hard_goal, fl + (size_t)j * n_ctx, fl + (size_t)(j + 1) * n_ctx, npc, B, H,
-                                          D, st))
+                                          D, st, last ? nz : nullptr, coefs[t].noise_scale, coefs[t].noise_std_extra, last ? ch : nullptr))
                     return rc;
-            hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, x, nz, hard_start,
-                               hard_goal, coefs[t].noise_scale, coefs[t].noise_std_extra, ch, B, H, D);
+            }
         }
     }
     HIP_TRY(hipGetLastError());
