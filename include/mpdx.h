@@ -153,6 +153,9 @@ typedef struct mpdx_guide_params {
  * test of LimitsNormalizer.unnormalize, normalization.py:160). */
 int mpdx_guide_step(const mpdx_guide_params* gp, float* x, float* grad_out, const float* hard_start, const float* hard_goal,
                     const uint32_t* absmax_in, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, void* stream);
+/* dev tool: s_memtime stamps (8 per wave x 8 waves, workgroup 0) of one guide launch (gradient-only mode) */
+int mpdx_guide_trace(const mpdx_guide_params* gp, float* x, const uint32_t* absmax_in, int B, int H, int D, void* stream,
+                     long long* stamps64);
 /* absmax_out[ctx] <- atomicMax over the context's trajectories (caller zeroes absmax_out first) */
 int mpdx_absmax(const float* x, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, void* stream);
 

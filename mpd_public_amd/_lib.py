@@ -67,6 +67,7 @@ SIGNATURES = {
                         C.POINTER(GuideParams), _i, _i, _vp, _i, _vp]),
     "mpdx_guide_step": (_i, [C.POINTER(GuideParams), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mpdx_traj_metrics": (_i, [C.POINTER(GuideParams), _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mpdx_guide_trace": (_i, [C.POINTER(GuideParams), _vp, _vp, _i, _i, _i, _vp, C.POINTER(C.c_longlong)]),
     "mpdx_absmax": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "mpdx_unet_profile": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(C.c_double),
                                 C.POINTER(C.c_char_p), C.POINTER(C.c_int)]),

@@ -51,60 +51,97 @@ struct GuideArgs {
     const float* noise;     // [B][H][D] or null
     float noise_scale, noise_extra;
     float* chain;           // optional second destination
+    long long* trace;       // dev tool: s_memtime stamps, 8 per wave of workgroup 0 (null in production)
 };
 
+// d cost / d p  for  cost = relu(margin - min_prims sdf(p)).
+// The scan over primitives only tracks the minimum signed distance and its index: batched (4 primitives' data are read
+// back to back: one LDS wait per batch), branch-free (selects), hardware v_sqrt_f32 (1 ulp) instead of the IEEE-exact
+// sqrtf sequence.  The gradient is evaluated once, for the arg-min primitive, after the scan.  (The first version -
+// per primitive: load, exact sqrt, exact divide, compare, divergent branch - cost ~330 cycles per primitive and made
+// the 15-sphere objects field of the Panda 60-70 k cycles per launch.)
 template <int DIM>
 __device__ __forceinline__ void objects_force(const float* __restrict__ prims, const mpdx_field& f, const float (&p)[DIM], float margin,
                                               float (&force)[DIM]) {
-    // d cost / d p  for  cost = relu(margin - min_prims sdf(p))
     float best = 3.0e38f;
-    float g[DIM];
-#pragma unroll
-    for (int j = 0; j < DIM; ++j) g[j] = 0.f;
+    int bi = -1;  // arg-min: sphere index, or n_spheres + box index
     const float* sp = prims + f.sphere_off;
-    for (int s = 0; s < f.n_spheres; ++s) {
-        float d[DIM], n2 = 0.f;
+    for (int s0 = 0; s0 < f.n_spheres; s0 += 4) {
+        float c[4][4];
 #pragma unroll
-        for (int j = 0; j < DIM; ++j) { d[j] = p[j] - sp[s * 4 + j]; n2 += d[j] * d[j]; }
-        const float n = sqrtf(n2);
-        const float sd = n - sp[s * 4 + 3];
-        if (sd < best) {
-            best = sd;
-            const float inv = n > 0.f ? 1.0f / n : 0.f;
+        for (int u = 0; u < 4; ++u) {
+            const int si = (s0 + u < f.n_spheres) ? s0 + u : f.n_spheres - 1;
 #pragma unroll
-            for (int j = 0; j < DIM; ++j) g[j] = d[j] * inv;
+            for (int j = 0; j < 4; ++j) c[u][j] = sp[si * 4 + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float n2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) { const float d = p[j] - c[u][j]; n2 += d * d; }
+            const float sd = (s0 + u < f.n_spheres) ? __builtin_amdgcn_sqrtf(n2) - c[u][3] : 3.0e38f;
+            const bool better = sd < best;
+            best = better ? sd : best;
+            bi = better ? s0 + u : bi;
         }
     }
     const float* bp = prims + f.box_off;
-    for (int s = 0; s < f.n_boxes; ++s) {
-        float d[DIM], sg[DIM], mx = -3.0e38f, n2 = 0.f;
-        int jm = 0;
+    for (int s0 = 0; s0 < f.n_boxes; s0 += 2) {
+        float c[2][6];
 #pragma unroll
-        for (int j = 0; j < DIM; ++j) {
-            const float c = p[j] - bp[s * 6 + j];
-            sg[j] = c > 0.f ? 1.f : (c < 0.f ? -1.f : 0.f);
-            d[j] = fabsf(c) - bp[s * 6 + 3 + j];
-            if (d[j] > mx) { mx = d[j]; jm = j; }
-            const float r = fmaxf(d[j], 0.f);
-            n2 += r * r;
+        for (int u = 0; u < 2; ++u) {
+            const int si = (s0 + u < f.n_boxes) ? s0 + u : f.n_boxes - 1;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) c[u][j] = bp[si * 6 + j];
         }
-        const float n = sqrtf(n2);
-        const float sd = fminf(mx, 0.f) + n;
-        if (sd < best) {
-            best = sd;
-            if (mx > 0.f) {  // outside: gradient of |relu(d)|
-                const float inv = 1.0f / n;
 #pragma unroll
-                for (int j = 0; j < DIM; ++j) g[j] = sg[j] * fmaxf(d[j], 0.f) * inv;
-            } else {  // inside (or on the surface): gradient of max_j d_j
+        for (int u = 0; u < 2; ++u) {
+            float mx = -3.0e38f, n2 = 0.f;
 #pragma unroll
-                for (int j = 0; j < DIM; ++j) g[j] = (j == jm) ? sg[j] : 0.f;
+            for (int j = 0; j < DIM; ++j) {
+                const float d = fabsf(p[j] - c[u][j]) - c[u][3 + j];
+                mx = fmaxf(mx, d);
+                const float r = fmaxf(d, 0.f);
+                n2 += r * r;
             }
+            const float sd = (s0 + u < f.n_boxes) ? fminf(mx, 0.f) + __builtin_amdgcn_sqrtf(n2) : 3.0e38f;
+            const bool better = sd < best;
+            best = better ? sd : best;
+            bi = better ? f.n_spheres + s0 + u : bi;
         }
     }
-    const bool active = (margin - best) > 0.f;
+    // gradient of the arg-min primitive (only if the hinge is active)
 #pragma unroll
-    for (int j = 0; j < DIM; ++j) force[j] = active ? -g[j] : 0.f;
+    for (int j = 0; j < DIM; ++j) force[j] = 0.f;
+    if ((margin - best) > 0.f && bi >= 0) {
+        if (bi < f.n_spheres) {
+            float d[DIM], n2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) { d[j] = p[j] - sp[bi * 4 + j]; n2 += d[j] * d[j]; }
+            const float inv = n2 > 0.f ? __builtin_amdgcn_rsqf(n2) : 0.f;
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) force[j] = -d[j] * inv;
+        } else {
+            const int bb = bi - f.n_spheres;
+            float d[DIM], sg[DIM], mx = -3.0e38f, n2 = 0.f;
+            int jm = 0;
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) {
+                const float cc = p[j] - bp[bb * 6 + j];
+                sg[j] = cc > 0.f ? 1.f : (cc < 0.f ? -1.f : 0.f);
+                d[j] = fabsf(cc) - bp[bb * 6 + 3 + j];
+                jm = d[j] > mx ? j : jm;
+                mx = fmaxf(mx, d[j]);
+                const float r = fmaxf(d[j], 0.f);
+                n2 += r * r;
+            }
+            const bool outside = mx > 0.f;
+            const float inv = outside ? __builtin_amdgcn_rsqf(n2) : 0.f;
+#pragma unroll
+            for (int j = 0; j < DIM; ++j)  // outside: gradient of |relu(d)|; inside (or on the surface): gradient of max_j d_j
+                force[j] = -(outside ? sg[j] * fmaxf(d[j], 0.f) * inv : (j == jm ? sg[j] : 0.f));
+        }
+    }
 }
 
 template <int DIM>
@@ -291,6 +328,9 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
     const int H = a.H;
     const int N = gp.interpolate ? gp.n_interp : H;
     const bool live = lane < H;
+    int tr_i = 0;
+#define G_STAMP() do { if (a.trace && b == 0 && lane == 0) a.trace[wv * 8 + tr_i] = (long long)__builtin_readcyclecounter(); ++tr_i; } while (0)
+    G_STAMP();  // 0 entry
     // LDS carve: unnormalised state [H][D] | point forces A,B [MAXF][N][QD] each | primitive table
     float* sx = sm;
     float* sA = sx + H * D;
@@ -312,6 +352,7 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
         if (live && wv == 0) sx[lane * D + d] = xu[d];
     }
     __syncthreads();
+    G_STAMP();  // 1 state unnormalised + staged
 
     // ---- collision terms on the interpolated positions
     const float scale = (N > 1) ? (float)(H - 1) / (float)(N - 1) : 0.f;  // align_corners=True
@@ -353,63 +394,88 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
         } else {
             float O[7][3], Z[7][3];
             panda_fk(q, O, Z);
-            float P[kPandaNS][3];
-#pragma unroll
-            for (int s = 0; s < kPandaNS; ++s) {
-                const int fr = kPandaSF[s] - 1;
-#pragma unroll
-                for (int r = 0; r < 3; ++r) P[s][r] = O[fr][r] + kPandaSO[s] * Z[fr][r];
-            }
             for (int f = 0; f < gp.n_fields; ++f) {
                 if ((f % FW) != wv / PW) continue;
-                float F[kPandaNS][3];
+                // Per frame: total force on its spheres and their total moment about the world origin.  The
+                // Jacobian transpose d P_s / d theta_j = z_j x (P_s - O_j), j <= frame(s), then folds to
+                //     g_j = z_j . ( sum_{s: frame(s) >= j} P_s x F_s  -  O_j x sum_{s: frame(s) >= j} F_s ).
+                float FF[7][3], FM[7][3];
 #pragma unroll
-                for (int s = 0; s < kPandaNS; ++s) { F[s][0] = 0.f; F[s][1] = 0.f; F[s][2] = 0.f; }
+                for (int k = 0; k < 7; ++k) { FF[k][0] = FF[k][1] = FF[k][2] = 0.f; FM[k][0] = FM[k][1] = FM[k][2] = 0.f; }
                 const int kind = gp.fields[f].kind;
                 if (kind == MPDX_FIELD_OBJECTS || kind == MPDX_FIELD_WORKSPACE) {
-#pragma unroll
+                    // ONE copy of the field code, rolled over the link spheres: the kernel runs once per launch with a
+                    // cold instruction cache, so straight-line code is paid for in instruction fetch (11 inlined
+                    // copies of the scan made this slice 68 k cycles).  s is wave-uniform: frame selection is scalar.
+#pragma unroll 1
                     for (int s = 0; s < kPandaNS; ++s) {
-                        const float margin = kPandaSR[s] + gp.cutoff_margin;
-                        float p3[3] = {P[s][0], P[s][1], P[s][2]}, fo[3];
+                        const int fr = kPandaSF[s] - 1;
+                        const float off = kPandaSO[s], margin = kPandaSR[s] + gp.cutoff_margin;
+                        float o3[3], z3[3];
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            o3[r] = fr == 0 ? O[0][r] : fr == 2 ? O[2][r] : fr == 3 ? O[3][r] : fr == 4 ? O[4][r] : O[6][r];
+                            z3[r] = fr == 0 ? Z[0][r] : fr == 2 ? Z[2][r] : fr == 3 ? Z[3][r] : fr == 4 ? Z[4][r] : Z[6][r];
+                        }
+                        float p3[3] = {o3[0] + off * z3[0], o3[1] + off * z3[1], o3[2] + off * z3[2]}, fo[3];
                         if (kind == MPDX_FIELD_OBJECTS) objects_force<3>(sprim, gp.fields[f], p3, margin, fo);
                         else workspace_force<3>(gp.fields[f], p3, margin, fo);
-                        F[s][0] = fo[0]; F[s][1] = fo[1]; F[s][2] = fo[2];
+                        const float m3[3] = {p3[1] * fo[2] - p3[2] * fo[1], p3[2] * fo[0] - p3[0] * fo[2], p3[0] * fo[1] - p3[1] * fo[0]};
+#pragma unroll
+                        for (int k = 0; k < 7; ++k) {
+                            if (k == 0 || k == 2 || k == 3 || k == 4 || k == 6) {
+                                const float on = fr == k ? 1.f : 0.f;
+#pragma unroll
+                                for (int r = 0; r < 3; ++r) { FF[k][r] += on * fo[r]; FM[k][r] += on * m3[r]; }
+                            }
+                        }
                     }
                 } else if (kind == MPDX_FIELD_SELF) {
+                    float P[kPandaNS][3];
+#pragma unroll
+                    for (int s = 0; s < kPandaNS; ++s) {
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) P[s][r] = O[kPandaSF[s] - 1][r] + kPandaSO[s] * Z[kPandaSF[s] - 1][r];
+                    }
 #pragma unroll
                     for (int pr = 0; pr < kPandaNP; ++pr) {
                         const int sa_ = kPandaPA[pr], sb_ = kPandaPB[pr];
+                        const int fa = kPandaSF[sa_] - 1, fb = kPandaSF[sb_] - 1;
                         const float dx = P[sa_][0] - P[sb_][0], dy = P[sa_][1] - P[sb_][1], dz = P[sa_][2] - P[sb_][2];
-                        const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
-                        if (kPandaSR[sa_] + kPandaSR[sb_] - dist > 0.f && dist > 0.f) {
-                            const float inv = 1.0f / dist;
-                            F[sa_][0] -= dx * inv; F[sa_][1] -= dy * inv; F[sa_][2] -= dz * inv;
-                            F[sb_][0] += dx * inv; F[sb_][1] += dy * inv; F[sb_][2] += dz * inv;
-                        }
+                        const float d2 = dx * dx + dy * dy + dz * dz;
+                        const float dist = __builtin_amdgcn_sqrtf(d2);
+                        const float inv = (kPandaSR[sa_] + kPandaSR[sb_] - dist > 0.f && dist > 0.f) ? __builtin_amdgcn_rsqf(d2) : 0.f;
+                        const float fx = dx * inv, fy = dy * inv, fz = dz * inv;  // force on b; -f on a
+                        FF[fa][0] -= fx; FF[fa][1] -= fy; FF[fa][2] -= fz;
+                        FF[fb][0] += fx; FF[fb][1] += fy; FF[fb][2] += fz;
+                        // moments: P_b x f - P_a x f = (P_b - P_a) x f ... kept per frame because fa != fb
+                        FM[fa][0] -= P[sa_][1] * fz - P[sa_][2] * fy; FM[fa][1] -= P[sa_][2] * fx - P[sa_][0] * fz; FM[fa][2] -= P[sa_][0] * fy - P[sa_][1] * fx;
+                        FM[fb][0] += P[sb_][1] * fz - P[sb_][2] * fy; FM[fb][1] += P[sb_][2] * fx - P[sb_][0] * fz; FM[fb][2] += P[sb_][0] * fy - P[sb_][1] * fx;
                     }
                 }
-                // Jacobian transpose: d P_s / d theta_j = z_j x (P_s - O_j) for j <= frame(s)
+                float Ft[3] = {0.f, 0.f, 0.f}, Mt[3] = {0.f, 0.f, 0.f};
+                float g[7];
+#pragma unroll
+                for (int jn = 6; jn >= 0; --jn) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) { Ft[r] += FF[jn][r]; Mt[r] += FM[jn][r]; }
+                    const float cx = O[jn][1] * Ft[2] - O[jn][2] * Ft[1], cy = O[jn][2] * Ft[0] - O[jn][0] * Ft[2],
+                                cz = O[jn][0] * Ft[1] - O[jn][1] * Ft[0];
+                    g[jn] = Z[jn][0] * (Mt[0] - cx) + Z[jn][1] * (Mt[1] - cy) + Z[jn][2] * (Mt[2] - cz);
+                }
 #pragma unroll
                 for (int jn = 0; jn < 7; ++jn) {
-                    float g = 0.f;
-#pragma unroll
-                    for (int s = 0; s < kPandaNS; ++s) {
-                        if (jn <= kPandaSF[s] - 1) {
-                            const float rx = P[s][0] - O[jn][0], ry = P[s][1] - O[jn][1], rz = P[s][2] - O[jn][2];
-                            const float cx = Z[jn][1] * rz - Z[jn][2] * ry, cy = Z[jn][2] * rx - Z[jn][0] * rz,
-                                        cz = Z[jn][0] * ry - Z[jn][1] * rx;
-                            g += F[s][0] * cx + F[s][1] * cy + F[s][2] * cz;
-                        }
-                    }
                     if (jn < QD) {
-                        sA[(f * N + i) * QD + jn] = l0 * g;
-                        sB[(f * N + i) * QD + jn] = l1 * g;
+                        sA[(f * N + i) * QD + jn] = l0 * g[jn];
+                        sB[(f * N + i) * QD + jn] = l1 * g[jn];
                     }
                 }
             }
         }
     }
+    G_STAMP();  // 2 this wave's (point slice, field) done
     __syncthreads();
+    G_STAMP();  // 3 all waves done
     if (wv != 0) return;   // wave 0 finishes the trajectory (no further workgroup barriers below)
 
     // ---- gather to support points (transpose of the interpolation), clip, zero ends, weight
@@ -462,6 +528,7 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
         }
     }
 
+    G_STAMP();  // 4 gathered + clipped
     // ---- GP prior (constant-velocity, GPMP2): 3-point stencil over the horizon
     if (gp.use_gp) {
         const float dt = gp.dt, s2 = 1.0f / (gp.sigma_gp * gp.sigma_gp);
@@ -499,6 +566,7 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
         }
     }
 
+    G_STAMP();  // 5 GP term
     // ---- apply:  x = x + (-grad);  hard conditioning;  max|x| for the next range test
     float vmax = 0.f;
     if (live) {
@@ -523,6 +591,8 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
         for (int s = 32; s >= 1; s >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, s, 64));
         if (lane == 0) atomicMax(a.amax_out + ctx, __float_as_uint(vmax));
     }
+    G_STAMP();  // 6 applied
+#undef G_STAMP
 }
 
 // per-context max|x| (the range test of LimitsNormalizer.unnormalize) for the API path

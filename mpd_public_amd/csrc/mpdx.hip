@@ -35,6 +35,7 @@ static int fail(int code, const char* fmt, ...) {
     } while (0)
 
 static long long* g_conv_trace = nullptr;   // dev tool (mpdx_layer_trace)
+static long long* g_guide_trace = nullptr;  // dev tool (mpdx_guide_trace)
 
 // ------------------------------------------------------------------------------------------------ small kernels
 
@@ -933,6 +934,7 @@ static int launch_guide(const mpdx_guide_params* gp, float* x, float* grad_out, 
     a.gp = *gp; a.x = x; a.grad_out = grad_out; a.hs = hs; a.hg = hg; a.amax_in = amax_in; a.amax_out = amax_out;
     a.B = B; a.H = H; a.D = D; a.n_per_ctx = n_per_ctx > 0 ? n_per_ctx : B;
     a.noise = noise; a.noise_scale = noise_scale; a.noise_extra = noise_extra; a.chain = chain;
+    a.trace = g_guide_trace;
     const size_t lds = guide_lds_bytes(*gp, H, D);
     if (lds > 64 * 1024) return fail(MPDX_E_INVALID, "guide needs %zu B of LDS", lds);
     if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 2 && gp->ws_dim == 2)
@@ -1103,6 +1105,26 @@ int mpdx_traj_metrics(const mpdx_guide_params* gp, const float* x_unnormalised, 
         return fail(MPDX_E_INVALID, "unsupported robot %d / q_dim %d / ws_dim %d", gp->robot, gp->q_dim, gp->ws_dim);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+/* dev tool: one guide launch with s_memtime stamps (8 per wave, 8 waves) of workgroup 0 */
+int mpdx_guide_trace(const mpdx_guide_params* gp, float* x, const uint32_t* absmax_in, int B, int H, int D, void* stream, long long* stamps64) {
+    if (!stamps64) return fail(MPDX_E_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    long long* dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, 64 * sizeof(long long)));
+    HIP_TRY(hipMemsetAsync(dev, 0, 64 * sizeof(long long), st));
+    static float* scratch = nullptr;
+    static size_t scratch_n = 0;
+    const size_t need = (size_t)B * H * D;
+    if (scratch_n < need) { if (scratch) (void)hipFree(scratch); HIP_TRY(hipMalloc(&scratch, need * sizeof(float))); scratch_n = need; }
+    g_guide_trace = dev;
+    int rc = launch_guide(gp, x, scratch, nullptr, nullptr, absmax_in, nullptr, B, B, H, D, st);
+    g_guide_trace = nullptr;
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(stamps64, dev, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+    (void)hipFree(dev);
+    return rc;
 }
 
 int mpdx_absmax(const float* x, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, void* stream) {
