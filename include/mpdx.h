@@ -155,7 +155,7 @@ int mpdx_guide_step(const mpdx_guide_params* gp, float* x, float* grad_out, cons
                     const uint32_t* absmax_in, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, void* stream);
 /* dev tool: s_memtime stamps (8 per wave x 8 waves, workgroup 0) of one guide launch (gradient-only mode) */
 int mpdx_guide_trace(const mpdx_guide_params* gp, float* x, const uint32_t* absmax_in, int B, int H, int D, void* stream,
-                     long long* stamps64);
+                     long long* stamps128);
 /* absmax_out[ctx] <- atomicMax over the context's trajectories (caller zeroes absmax_out first) */
 int mpdx_absmax(const float* x, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, void* stream);
 

@@ -51,7 +51,7 @@ struct GuideArgs {
     const float* noise;     // [B][H][D] or null
     float noise_scale, noise_extra;
     float* chain;           // optional second destination
-    long long* trace;       // dev tool: s_memtime stamps, 8 per wave of workgroup 0 (null in production)
+    long long* trace;       // dev tool: cycle stamps, 16 slots per wave of workgroup 0 (null in production)
 };
 
 // d cost / d p  for  cost = relu(margin - min_prims sdf(p)).
@@ -310,13 +310,86 @@ __global__ __launch_bounds__(64) void traj_metrics_kernel(const mpdx_guide_param
     }
 }
 
-// QD = configuration-space dim (2, 3 point mass; 7 Panda), DIM = workspace dim, ROBOT as in mpdx.h.
-// WPT = waves per trajectory.  The collision part (FK + SDF + Jacobian transpose per interpolated point and per field) is
-// split over WPT waves as (point slice) x (field): PW = min(WPT,2) point slices, WPT/PW field slots; wave 0 then gathers,
-// clips, adds the GP term and applies the update.  WPT = 8 for every robot (2 point halves x up to 4 fields): the single-wave
-// version is a long serial latency chain (2-D: 19 us per launch; 8 waves: see DESIGN.md).
+// GP prior (constant-velocity, GPMP2: 3-point stencil over the horizon) added to the gathered collision gradient, then
+//     x = x + (-grad);  [+ the step's noise term on the last guide iteration];  hard conditioning;  max|x| for the next
+// range test.  One wave, lane = support point.  tr: optional two cycle stamps (dev tool).
+template <int QD>
+__device__ __forceinline__ void guide_gp_apply(const GuideArgs& a, int b, int ctx, int lane, int H, bool live, const float (&xn)[2 * QD],
+                                               const float (&xu)[2 * QD], const float* sx, float (&total)[2 * QD], size_t base, long long* tr) {
+    constexpr int D = 2 * QD;
+    const bool interior = live && lane > 0 && lane < H - 1;
+    if (a.gp.use_gp) {
+        const float dt = a.gp.dt, s2 = 1.0f / (a.gp.sigma_gp * a.gp.sigma_gp);
+        const float c_qq = 24.0f / (dt * dt * dt), c_qv = 12.0f / (dt * dt), c_vv = 8.0f / dt;
+        float av[QD], bv[QD];  // a_h = d c_h / d e_q,  b_h = d c_h / d e_v  for the segment (h, h+1)
+#pragma unroll
+        for (int j = 0; j < QD; ++j) {
+            float eq = 0.f, ev = 0.f;
+            if (live && lane < H - 1) {
+                eq = sx[(lane + 1) * D + j] - xu[j] - dt * xu[QD + j];
+                ev = sx[(lane + 1) * D + QD + j] - xu[QD + j];
+            }
+            av[j] = (c_qq * eq - c_qv * ev) * s2;
+            bv[j] = (-c_qv * eq + c_vv * ev) * s2;
+        }
+        float g[D];
+#pragma unroll
+        for (int j = 0; j < QD; ++j) {
+            float ap = __shfl_up(av[j], 1, 64), bp = __shfl_up(bv[j], 1, 64);
+            if (lane == 0) { ap = 0.f; bp = 0.f; }
+            g[j] = ap - av[j];
+            g[QD + j] = bp - bv[j] - dt * av[j];
+        }
+        float n2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) n2 += (g[d] + 1e-6f) * (g[d] + 1e-6f);
+        float ratio = 1.f;
+        if (a.gp.clip_grad) {
+            const float n = sqrtf(n2);
+            ratio = fminf(fmaxf(n, 0.f), a.gp.max_grad_norm) / n;
+        }
+        if (interior) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) total[d] += a.gp.gp_weight * (ratio * g[d]);
+        }
+    }
+
+    if (tr) tr[0] = (long long)__builtin_readcyclecounter();  // GP term done
+    // ---- apply:  x = x + (-grad);  hard conditioning;  max|x| for the next range test
+    float vmax = 0.f;
+    if (live) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float inc = -1.0f * total[d];
+            if (a.grad_out) {
+                a.grad_out[base + d] = inc;
+            } else {
+                float r = __fadd_rn(xn[d], inc);
+                if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.noise_scale, a.noise[base + d]), a.noise_extra));
+                if (a.hs && lane == 0) r = a.hs[(size_t)b * D + d];
+                if (a.hg && lane == H - 1) r = a.hg[(size_t)b * D + d];
+                a.x[base + d] = r;
+                if (a.chain) a.chain[base + d] = r;
+                vmax = fmaxf(vmax, fabsf(r));
+            }
+        }
+    }
+    if (a.amax_out && !a.grad_out) {
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, s, 64));
+        if (lane == 0) atomicMax(a.amax_out + ctx, __float_as_uint(vmax));
+    }
+    if (tr) tr[1] = (long long)__builtin_readcyclecounter();  // applied
+}
+
+// Point-mass robots (QD = DIM = 2 or 3).  WPT = waves per trajectory.  The collision part (SDF force per interpolated point
+// and per field) is split over WPT waves as (point slice) x (field): PW = min(WPT,2) point slices, WPT/PW field slots;
+// wave 0 then gathers, clips, adds the GP term and applies the update.  WPT = 8 (2 point halves x up to 4 fields): the
+// single-wave version is a long serial latency chain (2-D: 19 us per launch; 8 waves: 9 us).  The Panda has its own
+// kernel below (guide_step_panda_kernel).
 template <int QD, int DIM, int ROBOT, int WPT>
 __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a) {
+    static_assert(ROBOT == MPDX_ROBOT_POINTMASS, "the Panda has its own kernel (guide_step_panda_kernel)");
     constexpr int D = 2 * QD;
     constexpr int MAXF = MPDX_MAX_FIELDS;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -329,7 +402,7 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
     const int N = gp.interpolate ? gp.n_interp : H;
     const bool live = lane < H;
     int tr_i = 0;
-#define G_STAMP() do { if (a.trace && b == 0 && lane == 0) a.trace[wv * 8 + tr_i] = (long long)__builtin_readcyclecounter(); ++tr_i; } while (0)
+#define G_STAMP() do { if (a.trace && b == 0 && lane == 0) a.trace[wv * 16 + tr_i] = (long long)__builtin_readcyclecounter(); ++tr_i; } while (0)
     G_STAMP();  // 0 entry
     // LDS carve: unnormalised state [H][D] | point forces A,B [MAXF][N][QD] each | primitive table
     float* sx = sm;
@@ -391,86 +464,6 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
                     sB[(f * N + i) * QD + j] = l1 * force[j];
                 }
             }
-        } else {
-            float O[7][3], Z[7][3];
-            panda_fk(q, O, Z);
-            for (int f = 0; f < gp.n_fields; ++f) {
-                if ((f % FW) != wv / PW) continue;
-                // Per frame: total force on its spheres and their total moment about the world origin.  The
-                // Jacobian transpose d P_s / d theta_j = z_j x (P_s - O_j), j <= frame(s), then folds to
-                //     g_j = z_j . ( sum_{s: frame(s) >= j} P_s x F_s  -  O_j x sum_{s: frame(s) >= j} F_s ).
-                float FF[7][3], FM[7][3];
-#pragma unroll
-                for (int k = 0; k < 7; ++k) { FF[k][0] = FF[k][1] = FF[k][2] = 0.f; FM[k][0] = FM[k][1] = FM[k][2] = 0.f; }
-                const int kind = gp.fields[f].kind;
-                if (kind == MPDX_FIELD_OBJECTS || kind == MPDX_FIELD_WORKSPACE) {
-                    // ONE copy of the field code, rolled over the link spheres: the kernel runs once per launch with a
-                    // cold instruction cache, so straight-line code is paid for in instruction fetch (11 inlined
-                    // copies of the scan made this slice 68 k cycles).  s is wave-uniform: frame selection is scalar.
-#pragma unroll 1
-                    for (int s = 0; s < kPandaNS; ++s) {
-                        const int fr = kPandaSF[s] - 1;
-                        const float off = kPandaSO[s], margin = kPandaSR[s] + gp.cutoff_margin;
-                        float o3[3], z3[3];
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) {
-                            o3[r] = fr == 0 ? O[0][r] : fr == 2 ? O[2][r] : fr == 3 ? O[3][r] : fr == 4 ? O[4][r] : O[6][r];
-                            z3[r] = fr == 0 ? Z[0][r] : fr == 2 ? Z[2][r] : fr == 3 ? Z[3][r] : fr == 4 ? Z[4][r] : Z[6][r];
-                        }
-                        float p3[3] = {o3[0] + off * z3[0], o3[1] + off * z3[1], o3[2] + off * z3[2]}, fo[3];
-                        if (kind == MPDX_FIELD_OBJECTS) objects_force<3>(sprim, gp.fields[f], p3, margin, fo);
-                        else workspace_force<3>(gp.fields[f], p3, margin, fo);
-                        const float m3[3] = {p3[1] * fo[2] - p3[2] * fo[1], p3[2] * fo[0] - p3[0] * fo[2], p3[0] * fo[1] - p3[1] * fo[0]};
-#pragma unroll
-                        for (int k = 0; k < 7; ++k) {
-                            if (k == 0 || k == 2 || k == 3 || k == 4 || k == 6) {
-                                const float on = fr == k ? 1.f : 0.f;
-#pragma unroll
-                                for (int r = 0; r < 3; ++r) { FF[k][r] += on * fo[r]; FM[k][r] += on * m3[r]; }
-                            }
-                        }
-                    }
-                } else if (kind == MPDX_FIELD_SELF) {
-                    float P[kPandaNS][3];
-#pragma unroll
-                    for (int s = 0; s < kPandaNS; ++s) {
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) P[s][r] = O[kPandaSF[s] - 1][r] + kPandaSO[s] * Z[kPandaSF[s] - 1][r];
-                    }
-#pragma unroll
-                    for (int pr = 0; pr < kPandaNP; ++pr) {
-                        const int sa_ = kPandaPA[pr], sb_ = kPandaPB[pr];
-                        const int fa = kPandaSF[sa_] - 1, fb = kPandaSF[sb_] - 1;
-                        const float dx = P[sa_][0] - P[sb_][0], dy = P[sa_][1] - P[sb_][1], dz = P[sa_][2] - P[sb_][2];
-                        const float d2 = dx * dx + dy * dy + dz * dz;
-                        const float dist = __builtin_amdgcn_sqrtf(d2);
-                        const float inv = (kPandaSR[sa_] + kPandaSR[sb_] - dist > 0.f && dist > 0.f) ? __builtin_amdgcn_rsqf(d2) : 0.f;
-                        const float fx = dx * inv, fy = dy * inv, fz = dz * inv;  // force on b; -f on a
-                        FF[fa][0] -= fx; FF[fa][1] -= fy; FF[fa][2] -= fz;
-                        FF[fb][0] += fx; FF[fb][1] += fy; FF[fb][2] += fz;
-                        // moments: P_b x f - P_a x f = (P_b - P_a) x f ... kept per frame because fa != fb
-                        FM[fa][0] -= P[sa_][1] * fz - P[sa_][2] * fy; FM[fa][1] -= P[sa_][2] * fx - P[sa_][0] * fz; FM[fa][2] -= P[sa_][0] * fy - P[sa_][1] * fx;
-                        FM[fb][0] += P[sb_][1] * fz - P[sb_][2] * fy; FM[fb][1] += P[sb_][2] * fx - P[sb_][0] * fz; FM[fb][2] += P[sb_][0] * fy - P[sb_][1] * fx;
-                    }
-                }
-                float Ft[3] = {0.f, 0.f, 0.f}, Mt[3] = {0.f, 0.f, 0.f};
-                float g[7];
-#pragma unroll
-                for (int jn = 6; jn >= 0; --jn) {
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) { Ft[r] += FF[jn][r]; Mt[r] += FM[jn][r]; }
-                    const float cx = O[jn][1] * Ft[2] - O[jn][2] * Ft[1], cy = O[jn][2] * Ft[0] - O[jn][0] * Ft[2],
-                                cz = O[jn][0] * Ft[1] - O[jn][1] * Ft[0];
-                    g[jn] = Z[jn][0] * (Mt[0] - cx) + Z[jn][1] * (Mt[1] - cy) + Z[jn][2] * (Mt[2] - cz);
-                }
-#pragma unroll
-                for (int jn = 0; jn < 7; ++jn) {
-                    if (jn < QD) {
-                        sA[(f * N + i) * QD + jn] = l0 * g[jn];
-                        sB[(f * N + i) * QD + jn] = l1 * g[jn];
-                    }
-                }
-            }
         }
     }
     G_STAMP();  // 2 this wave's (point slice, field) done
@@ -529,69 +522,238 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
     }
 
     G_STAMP();  // 4 gathered + clipped
-    // ---- GP prior (constant-velocity, GPMP2): 3-point stencil over the horizon
-    if (gp.use_gp) {
-        const float dt = gp.dt, s2 = 1.0f / (gp.sigma_gp * gp.sigma_gp);
-        const float c_qq = 24.0f / (dt * dt * dt), c_qv = 12.0f / (dt * dt), c_vv = 8.0f / dt;
-        float av[QD], bv[QD];  // a_h = d c_h / d e_q,  b_h = d c_h / d e_v  for the segment (h, h+1)
+    guide_gp_apply<QD>(a, b, ctx, lane, H, live, xn, xu, sx, total, base, (a.trace && b == 0 && lane == 0) ? a.trace + wv * 16 + 5 : nullptr);
+#undef G_STAMP
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Panda variant of the guide update.  Same arithmetic as guide_step_kernel<7,3,PANDA,8>, different work split:
+// stamps of that kernel showed all four SIMDs of the CU saturated with VALU work for ~75 k cycles, most of it redundant
+// (every (point half, field) wave recomputed the full FK) or badly balanced (the 15-obstacle field is 3x the others).
+//   phase 1  FK once per interpolated point (2 of the 8 waves), frame origins / z axes / link-sphere centres -> LDS
+//   phase 2  wave = (point half, sphere group): for EVERY field, the forces on its 2-3 link spheres (or 3 self-collision
+//            pairs), folded per joint j into total force / moment of the spheres that joint moves,
+//                g_j = z_j . ( sum P_s x F_s  -  O_j x sum F_s ),     s over spheres with frame(s) >= j
+//            (d P_s / d theta_j = z_j x (P_s - O_j)); partial joint gradients per (field, group) -> LDS
+//   phase 3  wave f gathers field f to the support points (transpose of the interpolation, summing the groups in a fixed
+//            order), clips by norm, weights
+//   phase 4  wave 0: sum over fields, GP prior, apply (guide_gp_apply)
+constexpr int kPandaFKS = 75;   // floats per interpolated point in LDS: O[7][3] | Z[7][3] | P[11][3]  (odd stride: no bank conflicts)
+constexpr int kPandaParts = 4;  // sphere groups {0-2, 3-5, 6-8, 9-10}; pair groups of 3
+
+// phase 2 of guide_step_panda_kernel for sphere / pair group PART and point half `half`
+template <int PART>
+__device__ __forceinline__ void panda_group_forces(const mpdx_guide_params& gp, const float* sprim, const float* sfk, float* sG, int half, int lane, int N,
+                                                   long long* tr) {
+    constexpr int QD = 7, NP = kPandaParts;
+    constexpr int s_beg = PART * 3, s_end = (s_beg + 3 < kPandaNS) ? s_beg + 3 : kPandaNS;
+    constexpr int p_beg = PART * 3, p_end = (p_beg + 3 < kPandaNP) ? p_beg + 3 : kPandaNP;
+    for (int i = half * 64 + lane; i < N; i += 128) {
+        const float* fk = sfk + i * kPandaFKS;
+        float O[7][3], Z[7][3], P[kPandaNS][3];
 #pragma unroll
-        for (int j = 0; j < QD; ++j) {
-            float eq = 0.f, ev = 0.f;
-            if (live && lane < H - 1) {
-                eq = sx[(lane + 1) * D + j] - xu[j] - dt * xu[QD + j];
-                ev = sx[(lane + 1) * D + QD + j] - xu[QD + j];
+        for (int k = 0; k < 7; ++k) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { O[k][r] = fk[k * 3 + r]; Z[k][r] = fk[21 + k * 3 + r]; }
+        }
+#pragma unroll
+        for (int s = 0; s < kPandaNS; ++s) {  // only the spheres this group touches stay live
+#pragma unroll
+            for (int r = 0; r < 3; ++r) P[s][r] = fk[42 + s * 3 + r];
+        }
+        for (int f = 0; f < gp.n_fields; ++f) {
+            float FF[7][3], FM[7][3];  // per frame: force on its spheres, their moment about the world origin
+#pragma unroll
+            for (int k = 0; k < 7; ++k) { FF[k][0] = FF[k][1] = FF[k][2] = 0.f; FM[k][0] = FM[k][1] = FM[k][2] = 0.f; }
+            const int kind = gp.fields[f].kind;
+            if (kind == MPDX_FIELD_OBJECTS || kind == MPDX_FIELD_WORKSPACE) {
+#pragma unroll
+                for (int s = s_beg; s < s_end; ++s) {
+                    const int fr = kPandaSF[s] - 1;
+                    const float margin = kPandaSR[s] + gp.cutoff_margin;
+                    float p3[3] = {P[s][0], P[s][1], P[s][2]}, fo[3];
+                    if (kind == MPDX_FIELD_OBJECTS) objects_force<3>(sprim, gp.fields[f], p3, margin, fo);
+                    else workspace_force<3>(gp.fields[f], p3, margin, fo);
+                    FF[fr][0] += fo[0]; FF[fr][1] += fo[1]; FF[fr][2] += fo[2];
+                    FM[fr][0] += p3[1] * fo[2] - p3[2] * fo[1]; FM[fr][1] += p3[2] * fo[0] - p3[0] * fo[2]; FM[fr][2] += p3[0] * fo[1] - p3[1] * fo[0];
+                }
+            } else if (kind == MPDX_FIELD_SELF) {
+#pragma unroll
+                for (int pr = p_beg; pr < p_end; ++pr) {
+                    const int sa_ = kPandaPA[pr], sb_ = kPandaPB[pr];
+                    const int fa = kPandaSF[sa_] - 1, fb = kPandaSF[sb_] - 1;
+                    const float dx = P[sa_][0] - P[sb_][0], dy = P[sa_][1] - P[sb_][1], dz = P[sa_][2] - P[sb_][2];
+                    const float d2 = dx * dx + dy * dy + dz * dz;
+                    const float dist = __builtin_amdgcn_sqrtf(d2);
+                    const float inv = (kPandaSR[sa_] + kPandaSR[sb_] - dist > 0.f && dist > 0.f) ? __builtin_amdgcn_rsqf(d2) : 0.f;
+                    const float fx = dx * inv, fy = dy * inv, fz = dz * inv;  // d cost / d P_b = +f,  d cost / d P_a = -f
+                    FF[fa][0] -= fx; FF[fa][1] -= fy; FF[fa][2] -= fz;
+                    FF[fb][0] += fx; FF[fb][1] += fy; FF[fb][2] += fz;
+                    FM[fa][0] -= P[sa_][1] * fz - P[sa_][2] * fy; FM[fa][1] -= P[sa_][2] * fx - P[sa_][0] * fz; FM[fa][2] -= P[sa_][0] * fy - P[sa_][1] * fx;
+                    FM[fb][0] += P[sb_][1] * fz - P[sb_][2] * fy; FM[fb][1] += P[sb_][2] * fx - P[sb_][0] * fz; FM[fb][2] += P[sb_][0] * fy - P[sb_][1] * fx;
+                }
             }
-            av[j] = (c_qq * eq - c_qv * ev) * s2;
-            bv[j] = (-c_qv * eq + c_vv * ev) * s2;
-        }
-        float g[D];
+            float Ft[3] = {0.f, 0.f, 0.f}, Mt[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < QD; ++j) {
-            float ap = __shfl_up(av[j], 1, 64), bp = __shfl_up(bv[j], 1, 64);
-            if (lane == 0) { ap = 0.f; bp = 0.f; }
-            g[j] = ap - av[j];
-            g[QD + j] = bp - bv[j] - dt * av[j];
-        }
-        float n2 = 0.f;
+            for (int k = 6; k >= 0; --k) {  // joint k moves every sphere on frames >= k
 #pragma unroll
-        for (int d = 0; d < D; ++d) n2 += (g[d] + 1e-6f) * (g[d] + 1e-6f);
+                for (int r = 0; r < 3; ++r) { Ft[r] += FF[k][r]; Mt[r] += FM[k][r]; }
+                const float cx = O[k][1] * Ft[2] - O[k][2] * Ft[1], cy = O[k][2] * Ft[0] - O[k][0] * Ft[2], cz = O[k][0] * Ft[1] - O[k][1] * Ft[0];
+                sG[((f * NP + PART) * N + i) * QD + k] = Z[k][0] * (Mt[0] - cx) + Z[k][1] * (Mt[1] - cy) + Z[k][2] * (Mt[2] - cz);
+            }
+            if (tr) tr[f] = (long long)__builtin_readcyclecounter();
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void guide_step_panda_kernel(const GuideArgs a) {
+    constexpr int QD = 7, D = 14, MAXF = MPDX_MAX_FIELDS, NP = kPandaParts, WPT = 8;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const mpdx_guide_params& gp = a.gp;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
+    const int H = a.H;
+    const int N = gp.interpolate ? gp.n_interp : H;
+    const bool live = lane < H;
+    int tr_i = 0;
+#define G_STAMP() do { if (a.trace && b == 0 && lane == 0) a.trace[wv * 16 + tr_i] = (long long)__builtin_readcyclecounter(); ++tr_i; } while (0)
+    G_STAMP();  // 0 entry
+    float* sx = sm;                           // [H][D]  unnormalised state
+    float* sfk = sx + H * D;                  // [N][kPandaFKS]
+    float* sG = sfk + N * kPandaFKS;          // [MAXF][NP][N][QD]  partial joint gradients
+    float* sC = sG + MAXF * NP * N * QD;      // [MAXF][H][QD]      clipped, weighted per-field support-point gradients
+    float* sprim = sC + MAXF * H * QD;
+    for (int i = threadIdx.x; i < gp.n_prim_floats; i += 64 * WPT) sprim[i] = gp.prims[i];
+
+    // ---- load + unnormalise (normalization.py:156-167)
+    const int ctx = b / a.n_per_ctx;
+    const bool clipall = __uint_as_float(a.amax_in[ctx]) > 1.0001f;
+    float xn[D], xu[D];
+    const size_t base = ((size_t)b * H + (live ? lane : 0)) * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        xn[d] = live ? a.x[base + d] : 0.f;
+        const float c = clipall ? fminf(fmaxf(xn[d], -1.f), 1.f) : xn[d];
+        const float u01 = __fadd_rn(c, 1.0f) * 0.5f;
+        xu[d] = __fadd_rn(__fmul_rn(u01, __fsub_rn(gp.maxs[d], gp.mins[d])), gp.mins[d]);
+        if (live && wv == 0) sx[lane * D + d] = xu[d];
+    }
+    __syncthreads();
+    G_STAMP();  // 1 state unnormalised + staged
+
+    // ---- phase 1: interpolate + FK, once per point
+    const float scale = (N > 1) ? (float)(H - 1) / (float)(N - 1) : 0.f;  // align_corners=True
+    for (int i = wv * 64 + lane; i < N; i += 64 * WPT) {
+        int i0 = i, i1 = i;
+        float l0 = 1.f, l1 = 0.f;
+        if (gp.interpolate) {
+            const float u = scale * (float)i;
+            i0 = (int)u;
+            if (i0 > H - 1) i0 = H - 1;
+            i1 = i0 + 1 < H ? i0 + 1 : H - 1;
+            l1 = u - (float)i0;
+            l0 = 1.0f - l1;
+        }
+        float q[QD];
+#pragma unroll
+        for (int j = 0; j < QD; ++j) q[j] = l0 * sx[i0 * D + j] + l1 * sx[i1 * D + j];
+        float O[7][3], Z[7][3];
+        panda_fk(q, O, Z);
+        float* fk = sfk + i * kPandaFKS;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { fk[k * 3 + r] = O[k][r]; fk[21 + k * 3 + r] = Z[k][r]; }
+        }
+#pragma unroll
+        for (int s = 0; s < kPandaNS; ++s) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) fk[42 + s * 3 + r] = O[kPandaSF[s] - 1][r] + kPandaSO[s] * Z[kPandaSF[s] - 1][r];
+        }
+    }
+    __syncthreads();
+    G_STAMP();  // 2 FK in LDS
+
+    // ---- phase 2: forces of this wave's sphere / pair group, every field, folded to joint gradients
+    {
+        const int half = wv & 1;
+        long long* trf = (a.trace && b == 0 && lane == 0) ? a.trace + wv * 16 + 8 : nullptr;  // slots 8..: per-field stamps
+        switch (wv >> 1) {  // the group is a template parameter: sphere -> frame is static, no per-joint masks
+            case 0: panda_group_forces<0>(gp, sprim, sfk, sG, half, lane, N, trf); break;
+            case 1: panda_group_forces<1>(gp, sprim, sfk, sG, half, lane, N, trf); break;
+            case 2: panda_group_forces<2>(gp, sprim, sfk, sG, half, lane, N, trf); break;
+            default: panda_group_forces<3>(gp, sprim, sfk, sG, half, lane, N, trf); break;
+        }
+    }
+    G_STAMP();  // 3 this wave's forces done
+    __syncthreads();
+    G_STAMP();  // 4 all waves done
+
+    // ---- phase 3: wave f gathers field f to the support points, clips, weights
+    const bool interior = live && lane > 0 && lane < H - 1;
+    if (wv < gp.n_fields && live) {
+        const int f = wv;
+        int ilo = lane, ihi = lane;
+        if (gp.interpolate && scale > 0.f) {
+            ilo = (int)((float)lane / scale) - 2;
+            ihi = (int)((float)(lane + 1) / scale) + 2;
+            if (ilo < 0) ilo = 0;
+            if (ihi > N - 1) ihi = N - 1;
+        }
+        float g[QD];
+#pragma unroll
+        for (int j = 0; j < QD; ++j) g[j] = 0.f;
+        for (int i = ilo; i <= ihi; ++i) {
+            int i0 = i, i1 = i;
+            float l0 = 1.f, l1 = 0.f;
+            if (gp.interpolate) {
+                const float u = scale * (float)i;
+                i0 = (int)u;
+                if (i0 > H - 1) i0 = H - 1;
+                i1 = i0 + 1 < H ? i0 + 1 : H - 1;
+                l1 = u - (float)i0;
+                l0 = 1.0f - l1;
+            }
+            const bool m0 = i0 == lane, m1 = i1 == lane && gp.interpolate;
+            if (m0 || m1) {
+#pragma unroll
+                for (int j = 0; j < QD; ++j) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int pt = 0; pt < NP; ++pt) v += sG[((f * NP + pt) * N + i) * QD + j];
+                    if (m0) g[j] += l0 * v;
+                    if (m1) g[j] += l1 * v;
+                }
+            }
+        }
+        // clip_grad_by_norm over ALL D dims of (g + 1e-6): the velocity dims of a collision gradient are 0
+        float n2 = (float)QD * (1e-6f * 1e-6f);
+#pragma unroll
+        for (int j = 0; j < QD; ++j) n2 += (g[j] + 1e-6f) * (g[j] + 1e-6f);
         float ratio = 1.f;
         if (gp.clip_grad) {
             const float n = sqrtf(n2);
             ratio = fminf(fmaxf(n, 0.f), gp.max_grad_norm) / n;
         }
-        if (interior) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) total[d] += gp.gp_weight * (ratio * g[d]);
-        }
+        for (int j = 0; j < QD; ++j) sC[(f * H + lane) * QD + j] = interior ? gp.fields[f].weight * (ratio * g[j]) : 0.f;
     }
+    __syncthreads();
+    G_STAMP();  // 5 gathered + clipped
+    if (wv != 0) return;
 
-    G_STAMP();  // 5 GP term
-    // ---- apply:  x = x + (-grad);  hard conditioning;  max|x| for the next range test
-    float vmax = 0.f;
-    if (live) {
+    // ---- phase 4: sum over fields, GP prior, apply
+    float total[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float inc = -1.0f * total[d];
-            if (a.grad_out) {
-                a.grad_out[base + d] = inc;
-            } else {
-                float r = __fadd_rn(xn[d], inc);
-                if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.noise_scale, a.noise[base + d]), a.noise_extra));
-                if (a.hs && lane == 0) r = a.hs[(size_t)b * D + d];
-                if (a.hg && lane == H - 1) r = a.hg[(size_t)b * D + d];
-                a.x[base + d] = r;
-                if (a.chain) a.chain[base + d] = r;
-                vmax = fmaxf(vmax, fabsf(r));
-            }
+    for (int d = 0; d < D; ++d) total[d] = 0.f;
+    if (live) {
+        for (int f = 0; f < gp.n_fields; ++f) {
+#pragma unroll
+            for (int j = 0; j < QD; ++j) total[j] += sC[(f * H + lane) * QD + j];
         }
     }
-    if (a.amax_out && !a.grad_out) {
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, s, 64));
-        if (lane == 0) atomicMax(a.amax_out + ctx, __float_as_uint(vmax));
-    }
-    G_STAMP();  // 6 applied
+    guide_gp_apply<QD>(a, b, ctx, lane, H, live, xn, xu, sx, total, base, (a.trace && b == 0 && lane == 0) ? a.trace + wv * 16 + 6 : nullptr);
 #undef G_STAMP
 }
 
@@ -608,6 +770,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 
 inline size_t guide_lds_bytes(const mpdx_guide_params& gp, int H, int D) {
     const int N = gp.interpolate ? gp.n_interp : H;
+    if (gp.robot == MPDX_ROBOT_PANDA)
+        return (size_t)(H * D + N * kPandaFKS + MPDX_MAX_FIELDS * kPandaParts * N * 7 + MPDX_MAX_FIELDS * H * 7 + gp.n_prim_floats) * sizeof(float);
     return (size_t)(H * D + 2 * MPDX_MAX_FIELDS * N * (D / 2) + gp.n_prim_floats) * sizeof(float);
 }
 

@@ -936,13 +936,19 @@ static int launch_guide(const mpdx_guide_params* gp, float* x, float* grad_out, 
     a.noise = noise; a.noise_scale = noise_scale; a.noise_extra = noise_extra; a.chain = chain;
     a.trace = g_guide_trace;
     const size_t lds = guide_lds_bytes(*gp, H, D);
-    if (lds > 64 * 1024) return fail(MPDX_E_INVALID, "guide needs %zu B of LDS", lds);
+    if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "guide needs %zu B of LDS (n_interp %d too large)", lds, gp->n_interp);
     if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 2 && gp->ws_dim == 2)
         hipLaunchKernelGGL((guide_step_kernel<2, 2, MPDX_ROBOT_POINTMASS, 8>), dim3(B), dim3(512), lds, st, a);
     else if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 3 && gp->ws_dim == 3)
         hipLaunchKernelGGL((guide_step_kernel<3, 3, MPDX_ROBOT_POINTMASS, 8>), dim3(B), dim3(512), lds, st, a);
-    else if (gp->robot == MPDX_ROBOT_PANDA && gp->q_dim == 7 && gp->ws_dim == 3)
-        hipLaunchKernelGGL((guide_step_kernel<7, 3, MPDX_ROBOT_PANDA, 8>), dim3(B), dim3(512), lds, st, a);
+    else if (gp->robot == MPDX_ROBOT_PANDA && gp->q_dim == 7 && gp->ws_dim == 3) {
+        static bool raised = false;
+        if (!raised) {
+            HIP_TRY(hipFuncSetAttribute((const void*)guide_step_panda_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+        hipLaunchKernelGGL(guide_step_panda_kernel, dim3(B), dim3(512), lds, st, a);
+    }
     else
         return fail(MPDX_E_INVALID, "unsupported robot %d / q_dim %d / ws_dim %d", gp->robot, gp->q_dim, gp->ws_dim);
     return 0;
@@ -1107,13 +1113,13 @@ int mpdx_traj_metrics(const mpdx_guide_params* gp, const float* x_unnormalised, 
     return 0;
 }
 
-/* dev tool: one guide launch with s_memtime stamps (8 per wave, 8 waves) of workgroup 0 */
+/* dev tool: one guide launch with s_memtime stamps (16 slots per wave, 8 waves -> 128 values) of workgroup 0 */
 int mpdx_guide_trace(const mpdx_guide_params* gp, float* x, const uint32_t* absmax_in, int B, int H, int D, void* stream, long long* stamps64) {
     if (!stamps64) return fail(MPDX_E_INVALID, "null argument");
     hipStream_t st = (hipStream_t)stream;
     long long* dev = nullptr;
-    HIP_TRY(hipMalloc(&dev, 64 * sizeof(long long)));
-    HIP_TRY(hipMemsetAsync(dev, 0, 64 * sizeof(long long), st));
+    HIP_TRY(hipMalloc(&dev, 128 * sizeof(long long)));
+    HIP_TRY(hipMemsetAsync(dev, 0, 128 * sizeof(long long), st));
     static float* scratch = nullptr;
     static size_t scratch_n = 0;
     const size_t need = (size_t)B * H * D;
@@ -1122,7 +1128,7 @@ int mpdx_guide_trace(const mpdx_guide_params* gp, float* x, const uint32_t* absm
     int rc = launch_guide(gp, x, scratch, nullptr, nullptr, absmax_in, nullptr, B, B, H, D, st);
     g_guide_trace = nullptr;
     HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipMemcpy(stamps64, dev, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(stamps64, dev, 128 * sizeof(long long), hipMemcpyDeviceToHost));
     (void)hipFree(dev);
     return rc;
 }
