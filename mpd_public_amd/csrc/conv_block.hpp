@@ -58,6 +58,26 @@ struct ConvArgs {
 // wave64 all-reduce (sum) with DPP row operations + 4 readlanes instead of a 6-step ds_bpermute butterfly:
 // quad_perm xor1, quad_perm xor2, row_half_mirror, row_mirror give every lane its 16-lane row sum in registers
 // (no LDS crossbar round trips), then the four row sums are combined through SGPRs.
+// Kernel arguments are read with scalar loads, and hipcc sinks each s_load next to its first use: a kernel with a large
+// argument block (or one it indexes dynamically) then pays one cold scalar-cache miss (~1 k cycles to HBM) after another,
+// in series.  warm_kernarg<BYTES>() touches every 64-byte line of the argument block with a dummy s_load at kernel entry
+// and waits once: one round trip, after which every argument read is a scalar-cache hit.  Used by fused_level_kernel
+// (1.9 KB of arguments, indexed per op); measured no effect on kernels whose arguments are read at static offsets.
+template <int OFF, int END>
+__device__ __forceinline__ void warm_kernarg_lines(unsigned long long kp, int& t) {
+    if constexpr (OFF < END) {
+        asm volatile("s_load_dword %0, %1, %2" : "+s"(t) : "s"(kp), "n"(OFF));
+        warm_kernarg_lines<OFF + 64, END>(kp, t);
+    }
+}
+template <int BYTES>
+__device__ __forceinline__ void warm_kernarg() {
+    const unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    int t = 0;
+    warm_kernarg_lines<0, BYTES>(kp, t);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]

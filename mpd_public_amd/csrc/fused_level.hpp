@@ -137,6 +137,7 @@ __device__ __forceinline__ void fused_mfma(const f32x4* __restrict__ wrow, const
 }
 
 __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
+    warm_kernarg<(int)sizeof(FusedArgs)>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* const sm4 = (f32x4*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -155,32 +156,44 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
     const int n_in = a.L0 * c4n;
     constexpr int IK = 4;   // input float4 per thread (<= 2048 float4 per trajectory window)
     f32x4 iv[IK];
-    int idst[IK];
+    int idst[IK], ck[IK];
+    const bool vec_ok = ((a.gc1 & 3) == 0) && ((a.gc2 & 3) == 0);
     {
-        const bool vec_ok = ((a.gc1 & 3) == 0) && ((a.gc2 & 3) == 0);
+        // Unconditional loads from clamped addresses, zeros selected afterwards: a conditional load into a
+        // zero-initialised register makes hipcc wait (vmcnt(0)) for the previous load before issuing the next one,
+        // which serialised these four round trips (~6 k cycles per launch).
+        int lk[IK];
+        bool vk[IK];
 #pragma unroll
         for (int k = 0; k < IK; ++k) {
             const int idx = tid + k * 512;
-            iv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            idst[k] = -1;
-            if (idx < n_in) {
-                const int l = a.lg_c4n >= 0 ? (idx >> a.lg_c4n) : (idx / c4n);
-                const int c = (idx - l * c4n) << 2;
-                const size_t pos = (size_t)b * a.L0 + l;
-                idst[k] = ib.off4 + (l + 2) * ib.rs4 + (c >> 2);
-                if (vec_ok) {
-                    iv[k] = (c < a.gc1) ? *(const f32x4*)(a.gsrc1 + pos * a.gc1 + c) : *(const f32x4*)(a.gsrc2 + pos * a.gc2 + (c - a.gc1));
-                } else {
+            vk[k] = idx < n_in;
+            const int idc = vk[k] ? idx : 0;
+            lk[k] = a.lg_c4n >= 0 ? (idc >> a.lg_c4n) : (idc / c4n);
+            ck[k] = (idc - lk[k] * c4n) << 2;
+            idst[k] = vk[k] ? ib.off4 + (lk[k] + 2) * ib.rs4 + (ck[k] >> 2) : -1;
+        }
+        if (vec_ok) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int ce = c + e;
-                        if (ce < a.gc1) iv[k][e] = a.gsrc1[pos * a.gc1 + ce];
-                        else if (ce < cin) iv[k][e] = a.gsrc2[pos * a.gc2 + (ce - a.gc1)];
-                    }
+            for (int k = 0; k < IK; ++k) {
+                const size_t pos = (size_t)b * a.L0 + lk[k];
+                const float* src = (ck[k] < a.gc1) ? a.gsrc1 + pos * a.gc1 + ck[k] : a.gsrc2 + pos * a.gc2 + (ck[k] - a.gc1);
+                iv[k] = *(const f32x4*)src;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < IK; ++k) {   // channel padding (ce >= cin) is masked to zero at the LDS store below
+                const size_t pos = (size_t)b * a.L0 + lk[k];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ce = ck[k] + e;
+                    const float* src = (ce < a.gc1) ? a.gsrc1 + pos * a.gc1 + ce : (ce < cin) ? a.gsrc2 + pos * a.gc2 + (ce - a.gc1) : a.gsrc1 + pos * a.gc1;
+                    iv[k][e] = *src;
                 }
             }
         }
     }
+    FUSED_STAMP();   // input loads issued
     // parameter vectors [bias | gamma | beta | tbias] x C_out of every op: run r is handled by wave r % 8, lane = channel
     float* par = smem + (size_t)a.par_off4 * 4;
     constexpr int RK = 7;   // runs per wave (<= 14 ops * 4 / 8)
@@ -201,9 +214,11 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
             if (src) pvv[k] = src[lane];
         }
     }
+    FUSED_STAMP();   // parameter loads issued
     // weights of the first op
     FusedWork wk = fused_work(a.ops[0], wave);
     fused_dma_weights(a, a.ops[0], 0, a.ops[0].cchunk, wave, lane, smem);
+    FUSED_STAMP();   // first op's weight DMA issued
     // zeros: the 2+2 halo rows of every buffer (interiors are fully overwritten before they are read) and the
     // channel padding of the staged input rows (disjoint from what the staging writes below)
     {
@@ -225,8 +240,13 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
     }
     FUSED_STAMP();
 #pragma unroll
-    for (int k = 0; k < IK; ++k)
+    for (int k = 0; k < IK; ++k) {
+        if (!vec_ok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) iv[k][e] = (ck[k] + e < cin) ? iv[k][e] : 0.f;
+        }
         if (idst[k] >= 0) sm4[idst[k]] = iv[k];
+    }
     for (int idx = tid + IK * 512; idx < n_in; idx += 512) {   // (not reached for the supported shapes; kept for safety)
         const int l = idx / c4n, c = (idx - l * c4n) << 2;
         const size_t pos = (size_t)b * a.L0 + l;
