@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace mpdx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -176,38 +178,62 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
         const int total = (spt << a.lg_Lin) << a.lg_c4n;
         const bool vec_ok = ((a.c1 & 3) == 0) && ((a.c2 & 3) == 0);
         constexpr int SB = 4;  // loads in flight per thread
-        for (int base = tid; base < total; base += NTHR * SB) {
+        // The loads are UNCONDITIONAL (addresses clamped to something valid, zeros selected at the LDS store): a load inside
+        // a branch into a zero-initialised register makes hipcc wait for ALL outstanding loads (vmcnt(0)) before it issues
+        // it, which put the weight-ring round trip and the SB staging round trips in series (5 x ~1.5 k cycles per launch).
+        // The first pass is peeled out of the loop (for the B <= 512 shapes it is the only one): inside a loop the
+        // compiler's wait insertion is conservative across the back edge and makes the first pass wait for most of the
+        // weight ring before it issues its own loads.
+        // The vector and the scalar variant are separate code paths with their own registers: sharing them makes the wait
+        // counts of one path include the (never issued) loads of the other.
+        auto stage_pass = [&](int base, auto vec) {
+            constexpr bool VEC = decltype(vec)::value;
             f32x4 v[SB];
-            int dsto[SB];
+            int dsto[SB], cc[SB];
+            bool ok[SB];
+            size_t pos[SB];
 #pragma unroll
             for (int u = 0; u < SB; ++u) {
                 const int idx = base + u * NTHR;
-                v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                dsto[u] = -1;
-                if (idx < total) {
-                    const int rowi = idx >> a.lg_c4n, c = (idx & (c4n - 1)) << 2;
-                    const int s = rowi >> a.lg_Lin, li = rowi & (L_in - 1);
-                    const int b = s0 + s;
-                    dsto[u] = (s * LP + li + PAD) * RS4 + (c >> 2);
-                    if (b < a.B && c < cin) {
-                        const size_t pos = (size_t)b * L_in + li;
-                        if (vec_ok) {
-                            v[u] = (c < a.c1) ? *(const f32x4*)(a.src1 + pos * a.c1 + c)
-                                              : *(const f32x4*)(a.src2 + pos * a.c2 + (c - a.c1));
-                        } else {
+                const bool in = idx < total;
+                const int idc = in ? idx : 0;
+                const int rowi = idc >> a.lg_c4n, c = (idc & (c4n - 1)) << 2;
+                const int s = rowi >> a.lg_Lin, li = rowi & (L_in - 1);
+                const int b = s0 + s;
+                dsto[u] = in ? (s * LP + li + PAD) * RS4 + (c >> 2) : -1;
+                ok[u] = in && b < a.B && c < cin;
+                cc[u] = c < cin ? c : 0;
+                pos[u] = (size_t)(b < a.B ? b : a.B - 1) * L_in + li;
+            }
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int ce = c + e;
-                                if (ce < a.c1) v[u][e] = a.src1[pos * a.c1 + ce];
-                                else if (ce < cin) v[u][e] = a.src2[pos * a.c2 + (ce - a.c1)];
-                            }
-                        }
+            for (int u = 0; u < SB; ++u) {
+                if constexpr (VEC) {
+                    const float* src = (cc[u] < a.c1) ? a.src1 + pos[u] * a.c1 + cc[u] : a.src2 + pos[u] * a.c2 + (cc[u] - a.c1);
+                    v[u] = *(const f32x4*)src;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ce = cc[u] + e;
+                        const float* src = (ce < a.c1) ? a.src1 + pos[u] * a.c1 + ce : (ce < cin) ? a.src2 + pos[u] * a.c2 + (ce - a.c1) : a.src1 + pos[u] * a.c1;
+                        v[u][e] = *src;
                     }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < SB; ++u)
-                if (dsto[u] >= 0) smem4[dsto[u]] = v[u];
+            for (int u = 0; u < SB; ++u) {
+                if constexpr (!VEC) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[u][e] = (cc[u] + e < cin) ? v[u][e] : 0.f;
+                }
+                if (dsto[u] >= 0) smem4[dsto[u]] = ok[u] ? v[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        if (vec_ok) {
+            stage_pass(tid, std::true_type{});
+            for (int base = tid + NTHR * SB; base < total; base += NTHR * SB) stage_pass(base, std::true_type{});
+        } else {
+            stage_pass(tid, std::false_type{});
+            for (int base = tid + NTHR * SB; base < total; base += NTHR * SB) stage_pass(base, std::false_type{});
         }
         // zero halo rows (conv padding): 2*PAD rows per trajectory
         if (PAD > 0) {
