@@ -49,7 +49,7 @@ struct FusedOp {
 };
 
 constexpr int kMaxFusedOps = 14;
-constexpr int kMaxFusedBufs = 8;
+constexpr int kMaxFusedBufs = 16;
 
 struct FusedArgs {
     const float* packed;
@@ -198,13 +198,15 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
     float* par = smem + (size_t)a.par_off4 * 4;
     constexpr int RK = 7;   // runs per wave (<= 14 ops * 4 / 8)
     float pvv[RK];
-    const int cout_seg = 1 << a.lg_cout;
+    int pdst[RK];   // LDS destination (floats from the start of the parameter area), -1: nothing to store
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
         const int r = wave + k * 8;
         pvv[k] = 0.f;
-        if (r < a.n_runs && lane < cout_seg) {
+        pdst[k] = -1;
+        if (r < a.n_runs && lane < a.ops[r >> 2].cout) {
             const FusedOp& op = a.ops[r >> 2];
+            pdst[k] = op.p_off + (r & 3) * op.cout + lane;
             const int which = r & 3;
             const float* src = (which == 0) ? a.packed + op.b_off
                                : (op.kind != FOP_CONV_GN) ? nullptr
@@ -219,16 +221,14 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
     FusedWork wk = fused_work(a.ops[0], wave);
     fused_dma_weights(a, a.ops[0], 0, a.ops[0].cchunk, wave, lane, smem);
     FUSED_STAMP();   // first op's weight DMA issued
-    // zeros: the 2+2 halo rows of every buffer (interiors are fully overwritten before they are read) and the
-    // channel padding of the staged input rows (disjoint from what the staging writes below)
+    // zeros: the 2+2 halo rows of the staged input buffer and the channel padding of its rows (disjoint from what the
+    // staging writes below).  Every other buffer gets its halo rows zeroed by the op that writes it (buffers with disjoint
+    // live ranges share LDS addresses, so they cannot all be prepared here); interiors are fully overwritten before use.
     {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        for (int bi = 0; bi < a.nbufs; ++bi) {
-            const FusedBuf bb = a.bufs[bi];
-            for (int i = tid; i < 2 * bb.rs4; i += 512) {
-                sm4[bb.off4 + i] = z;
-                sm4[bb.off4 + (bb.rows - 2) * bb.rs4 + i] = z;
-            }
+        for (int i = tid; i < 2 * ib.rs4; i += 512) {
+            sm4[ib.off4 + i] = z;
+            sm4[ib.off4 + (ib.rows - 2) * ib.rs4 + i] = z;
         }
         if (ib.clear_all) {
             const int padw = ib.rs4 - c4n;   // float4 columns beyond the staged channels
@@ -260,10 +260,8 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
         sm4[ib.off4 + (l + 2) * ib.rs4 + (c >> 2)] = v;
     }
 #pragma unroll
-    for (int k = 0; k < RK; ++k) {
-        const int r = wave + k * 8;
-        if (r < a.n_runs && lane < cout_seg) par[(r >> 2) * 4 * cout_seg + (r & 3) * cout_seg + lane] = pvv[k];
-    }
+    for (int k = 0; k < RK; ++k)
+        if (pdst[k] >= 0) par[pdst[k]] = pvv[k];
     __builtin_amdgcn_s_waitcnt(0);  // this wave's DMA blocks have landed
     __syncthreads();
     FUSED_STAMP();
@@ -431,6 +429,14 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
                 v += *(const f32x4*)(bias + c4 * 4);
                 if (op.dst >= 0) sm4[a.bufs[op.dst].off4 + (l + 2) * a.bufs[op.dst].rs4 + c4] = v;
                 if (op.gdst >= 0) *(f32x4*)(a.gout[op.gdst] + ((size_t)b * N + l) * op.cout + c4 * 4) = v;
+            }
+        }
+        if (op.dst >= 0) {   // halo rows of the buffer this op defines (2 above, 2 below its L_out interior rows)
+            const FusedBuf hb = a.bufs[op.dst];
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            for (int i = tid; i < 2 * hb.rs4; i += 512) {
+                sm4[hb.off4 + i] = z;
+                sm4[hb.off4 + (N + 2) * hb.rs4 + i] = z;
             }
         }
         FUSED_STAMP();   // epilogue done (this wave)

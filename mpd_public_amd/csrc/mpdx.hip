@@ -3,6 +3,7 @@
 // gfx950 only.  No CUDA shims, no dual paths.  All device memory is caller-owned; nothing here synchronises.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -454,6 +455,12 @@ static void build_model(mpdx_unet* u) {
 // ------------------------------------------------------------------------------------------------ fused segments
 // Try to turn layers [i0, i1) (an outer U-Net level: 2 residual blocks + resample [+ final_conv[0]]) into one
 // fused_level_kernel program.  Returns false (and leaves the per-layer path) if any shape constraint fails.
+// MPDX_DEBUG_FUSE=1 prints which shape constraint rejected a fused segment (dev aid)
+static bool fuse_reject(int line) {
+    if (getenv("MPDX_DEBUG_FUSE")) fprintf(stderr, "[mpdx] fused segment rejected at mpdx.hip:%d\n", line);
+    return false;
+}
+
 static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
     mpdx_unet::Fused f;
     f.first = i0; f.count = i1 - i0; f.has_final = with_final;
@@ -462,16 +469,27 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
     const Layer& l0 = u->layers[i0];
     f.in1 = l0.src1; f.in2 = l0.src2;
     a.gc1 = l0.c1; a.gc2 = l0.c2; a.L0 = l0.L_in;
-    if (f.count + (with_final ? 1 : 0) > kMaxFusedOps) return false;
+    if (f.count + (with_final ? 1 : 0) > kMaxFusedOps) return fuse_reject(__LINE__);
     int nbuf = 0;
     size_t off4 = 0;
     std::unordered_map<long, int> bufmap;  // (slot, L) -> LDS buffer
+    // LDS activation buffers are placed AFTER the op list is known, by live range [first write, last read] in op indices
+    // (-1 = staged by the prologue): buffers whose ranges do not intersect share addresses, which is what lets two U-Net
+    // levels run as one program within 160 KB.
+    size_t buf_size4[kMaxFusedBufs];
+    int buf_def[kMaxFusedBufs], buf_last[kMaxFusedBufs];
     auto new_buf = [&](int cpad, int L) {
         if (nbuf >= kMaxFusedBufs) return -1;
         const int rs = pick_row_stride(cpad, CONV_S1, L, L, L + 4);
-        a.bufs[nbuf].off4 = (int)off4; a.bufs[nbuf].rs4 = rs / 4; a.bufs[nbuf].rows = L + 4; a.bufs[nbuf].clear_all = 0;
-        off4 += (size_t)(L + 4) * (rs / 4);
+        a.bufs[nbuf].off4 = -1; a.bufs[nbuf].rs4 = rs / 4; a.bufs[nbuf].rows = L + 4; a.bufs[nbuf].clear_all = 0;
+        buf_size4[nbuf] = (size_t)(L + 4) * (rs / 4);
+        buf_def[nbuf] = 1 << 30; buf_last[nbuf] = -1;
         return nbuf++;
+    };
+    auto touch = [&](int id, int opi, bool write) {
+        if (id < 0) return;
+        if (write) buf_def[id] = std::min(buf_def[id], opi);
+        buf_last[id] = std::max(buf_last[id], opi);
     };
     auto buf_for = [&](int slot, int L, int cpad) {
         const long key = (long)(slot + 8) * 4096 + L;
@@ -482,8 +500,9 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         return id;
     };
     a.in_buf = new_buf(l0.cin_pad, l0.L_in);
-    if (a.in_buf < 0) return false;
+    if (a.in_buf < 0) return fuse_reject(__LINE__);
     a.bufs[a.in_buf].clear_all = (l0.cin_pad != l0.c1 + l0.c2) ? 1 : 0;  // channel padding of the staged input
+    touch(a.in_buf, -1, true);
     bufmap[(long)(l0.src1 + 8) * 4096 + l0.L_in] = a.in_buf;
     size_t red4 = 0;
     int ng = 0;
@@ -494,20 +513,20 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         op.mode = l.mode; op.ks = l.ks;
         const int MSn = l.cout / 16, NSn = (l.mode == CONV_UPT) ? (l.L_in / 16) * 2 : l.L_out / 16;
         const int T = MSn * NSn;
-        if (l.cout % 16 || l.L_out % 16 || (T != 4 && T != 8) || (l.mode == CONV_UPT && l.L_in % 16)) return false;
-        if (op.kind == FOP_CONV_GN && (l.cout / l.gs != 8 || (l.gs * l.L_out != 128 && l.gs * l.L_out != 256))) return false;
+        if (l.cout % 16 || l.L_out % 16 || (T != 4 && T != 8) || (l.mode == CONV_UPT && l.L_in % 16)) return fuse_reject(__LINE__);
+        if (op.kind == FOP_CONV_GN && (l.cout / l.gs != 8 || (l.gs * l.L_out != 128 && l.gs * l.L_out != 256))) return fuse_reject(__LINE__);
         // source: the first layers read the staged input; later ones an LDS buffer produced in this segment
         if (i == i0 || (l.src1 == l0.src1 && l.src2 == l0.src2 && l.L_in == l0.L_in)) op.src = a.in_buf;
         else {
-            if (l.src2 != SRC_NONE) return false;
+            if (l.src2 != SRC_NONE) return fuse_reject(__LINE__);
             const long key = (long)(l.src1 + 8) * 4096 + l.L_in;
-            if (!bufmap.count(key)) return false;
+            if (!bufmap.count(key)) return fuse_reject(__LINE__);
             op.src = bufmap[key];
         }
         op.res = -1;
         if (l.res != SRC_NONE) {
             const long key = (long)(l.res + 8) * 4096 + l.L_out;
-            if (!bufmap.count(key)) return false;
+            if (!bufmap.count(key)) return fuse_reject(__LINE__);
             op.res = bufmap[key];
         }
         // destination: LDS if a later layer of the segment (or the final op) reads it; global if someone outside does
@@ -528,24 +547,25 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         }
         if (i == i1 - 1 && !with_final) read_outside = true;
         op.dst = read_inside ? buf_for(l.dst, l.L_out, l.cout) : -1;
-        if (read_inside && op.dst < 0) return false;
-        if (op.dst >= 0 && (op.dst == op.src || op.dst == op.res)) return false;
+        if (read_inside && op.dst < 0) return fuse_reject(__LINE__);
+        if (op.dst >= 0 && (op.dst == op.src || op.dst == op.res)) return fuse_reject(__LINE__);
         op.gdst = -1;
         if (read_outside) {
-            if (ng >= 3) return false;
+            if (ng >= 3) return fuse_reject(__LINE__);
             f.gout_slot[ng] = l.dst;
             op.gdst = ng++;
         }
+        touch(op.src, a.nops, false); touch(op.res, a.nops, false); touch(op.dst, a.nops, true);
         op.cin_pad = l.cin_pad; op.cout = l.cout; op.L_in = l.L_in; op.L_out = l.L_out; op.gs = l.gs;
         op.w_off = (int)u->params[l.w].off; op.b_off = (int)u->params[l.b].off;
         op.ga_off = l.gamma >= 0 ? (int)u->params[l.gamma].off : 0;
         op.be_off = l.beta >= 0 ? (int)u->params[l.beta].off : 0;
         op.tb_off = l.tb_off;
         auto lg2 = [](int v) { int k = 0; while ((1 << k) < v) ++k; return k; };
-        if ((1 << lg2(MSn)) != MSn || (1 << lg2(l.cout / 4)) != l.cout / 4) return false;
+        if ((1 << lg2(MSn)) != MSn || (1 << lg2(l.cout / 4)) != l.cout / 4) return fuse_reject(__LINE__);
         op.lg_T = lg2(T); op.lg_MSn = lg2(MSn); op.lg_M4 = lg2(l.cout / 4);
         op.lg_gs = op.kind == FOP_CONV_GN ? lg2(l.gs) : 0;
-        if (op.kind == FOP_CONV_GN && (1 << op.lg_gs) != l.gs) return false;
+        if (op.kind == FOP_CONV_GN && (1 << op.lg_gs) != l.gs) return fuse_reject(__LINE__);
         op.ntap = (l.mode == CONV_UPT) ? 2 : l.ks;
         op.nslot = (l.mode == CONV_UPT) ? 4 : l.ks;
         op.nc16 = l.cin_pad / 16;
@@ -558,12 +578,35 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         memset(&op, 0, sizeof(op));
         op.kind = FOP_FINAL;
         op.src = bufmap[(long)(lf.dst + 8) * 4096 + lf.L_out];
+        touch(op.src, a.nops - 1, false);
         op.L_in = lf.L_out;
         a.Cf = u->cfg.unet_input_dim; a.D = u->cfg.state_dim;
         a.fw_off = (int)u->params[u->pidx.at("final_conv.1.weight")].off;
         a.fb_off = (int)u->params[u->pidx.at("final_conv.1.bias")].off;
     }
     a.nbufs = nbuf;
+    {   // first-fit placement in order of definition; two buffers may share addresses iff one is dead strictly before the
+        // op that first writes the other
+        std::vector<int> order(nbuf);
+        for (int i = 0; i < nbuf; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return buf_def[x] < buf_def[y]; });
+        for (int oi = 0; oi < nbuf; ++oi) {
+            const int bi = order[oi];
+            if (buf_last[bi] < buf_def[bi]) buf_last[bi] = buf_def[bi];
+            size_t cand = 0;
+            for (bool moved = true; moved;) {
+                moved = false;
+                for (int oj = 0; oj < oi; ++oj) {
+                    const int bj = order[oj];
+                    const bool live_overlap = !(buf_last[bj] < buf_def[bi] || buf_last[bi] < buf_def[bj]);
+                    const size_t lo = (size_t)a.bufs[bj].off4, hi = lo + buf_size4[bj];
+                    if (live_overlap && cand < hi && lo < cand + buf_size4[bi]) { cand = hi; moved = true; }
+                }
+            }
+            a.bufs[bi].off4 = (int)cand;
+            off4 = std::max(off4, cand + buf_size4[bi]);
+        }
+    }
     a.red_off4 = (int)off4;
     off4 += red4;
     a.lds_float4 = (int)off4;   // cleared at kernel start (activation buffers + partials); parameters follow
@@ -572,24 +615,20 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
     for (int k = 0; k < a.nops; ++k)
         if (a.ops[k].kind != FOP_FINAL) { a.ops[k].p_off = poff; poff += 4 * a.ops[k].cout; }
     a.par_floats = poff;
-    {   // uniform C_out per segment (parameter runs are indexed by lane = channel), at most 64 channels
-        int co = 0, nconv = 0;
+    {   // parameter runs are indexed by lane = channel: at most 64 output channels per op; conv ops come first (FINAL last)
+        int nconv = 0;
         for (int k = 0; k < a.nops; ++k)
             if (a.ops[k].kind != FOP_FINAL) {
-                if (co && a.ops[k].cout != co) return false;
-                co = a.ops[k].cout;
-                if (a.ops[k].p_off != nconv * 4 * co) return false;
+                if (a.ops[k].cout > 64 || k != nconv) return fuse_reject(__LINE__);
                 ++nconv;
             }
-        int lg = 0;
-        while ((1 << lg) < co) ++lg;
-        if ((1 << lg) != co || co > 64 || nconv * 4 > 56) return false;
-        a.lg_cout = lg; a.n_runs = nconv * 4;
+        if (nconv * 4 > 56) return fuse_reject(__LINE__);
+        a.lg_cout = 0; a.n_runs = nconv * 4;
         const int c4n = (a.gc1 + a.gc2 + 3) / 4;
         int l4 = 0;
         while ((1 << l4) < c4n) ++l4;
         a.lg_c4n = ((1 << l4) == c4n) ? l4 : -1;
-        if ((size_t)a.L0 * c4n > 4 * 512) return false;   // prologue holds the input window in 4 float4 per thread
+        if ((size_t)a.L0 * c4n > 4 * 512) return fuse_reject(__LINE__);   // prologue holds the input window in 4 float4 per thread
     }
     off4 += (size_t)(poff + 3) / 4;
     // LDS weight window: as large as the remaining LDS allows (<= the largest op), in 1-KiB blocks; an op that
@@ -602,8 +641,8 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         need_blocks = std::max(need_blocks, per_c16 * (op.cin_pad / 16));
         min_blocks = std::max(min_blocks, per_c16);
     }
-    const size_t budget_bytes = 150 * 1024;
-    if (off4 * 16 + min_blocks * 1024 > budget_bytes) return false;
+    const size_t budget_bytes = 158 * 1024;
+    if (off4 * 16 + min_blocks * 1024 > budget_bytes) return fuse_reject(__LINE__);
     const size_t cap = std::min(need_blocks, (budget_bytes - off4 * 16) / 1024);
     a.w_off4 = (int)off4;
     a.w_cap_blocks = (int)cap;
@@ -615,12 +654,15 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         int fit = (int)(cap / per_c16);
         if (fit >= op.nc16) fit = op.nc16;
         else if ((8 >> op.lg_T) == 2) fit &= ~1;  // K is split in two over 16-channel chunks: keep chunks even
-        if (fit < 1) return false;
+        if (fit < 1) return fuse_reject(__LINE__);
         op.cchunk = fit;
     }
     f.lds_bytes = off4 * 16;
-    if (f.lds_bytes > 160 * 1024) return false;
+    if (f.lds_bytes > 160 * 1024) return fuse_reject(__LINE__);
     u->fused.push_back(f);
+    if (getenv("MPDX_DEBUG_FUSE"))
+        fprintf(stderr, "[mpdx] fused segment %zu: layers [%d,%d) %s..%s  %d ops  %d buffers  LDS %zu B (window %d KiB)\n", u->fused.size() - 1, i0, i1,
+                u->layers[i0].name.c_str(), u->layers[i1 - 1].name.c_str(), a.nops, a.nbufs, f.lds_bytes, a.w_cap_blocks);
     return true;
 }
 
@@ -645,8 +687,19 @@ static void build_units(mpdx_unet* u) {
         if (build_fused_segment(u, i0, i1, with_final))
             for (int i = i0; i < i1; ++i) owner[i] = (int)u->fused.size() - 1;
     };
-    try_seg("downs.0.", false);
-    if (nl >= 3) try_seg("downs.1.", false);
+    // the two outer down levels as ONE program if it fits (one launch boundary and one prologue less per step)
+    bool merged_down = false;
+    if (nl >= 3 && !getenv("MPDX_NO_MERGE")) {
+        int a0, a1, b0, b1;
+        if (range_of("downs.0.", a0, a1) && range_of("downs.1.", b0, b1) && a1 == b0 && build_fused_segment(u, a0, b1, false)) {
+            for (int i = a0; i < b1; ++i) owner[i] = (int)u->fused.size() - 1;
+            merged_down = true;
+        }
+    }
+    if (!merged_down) {
+        try_seg("downs.0.", false);
+        if (nl >= 3) try_seg("downs.1.", false);
+    }
     if (nl >= 3) try_seg("ups." + std::to_string(nl - 3) + ".", false);
     try_seg("ups." + std::to_string(nl - 2) + ".", true);
     u->owner = owner;

@@ -16,8 +16,9 @@ dm.model(x, torch.full((B,), 50, device="cuda", dtype=torch.long))
 st = torch.cuda.current_stream().cuda_stream
 for seg in range(4):
     stamps = (C.c_longlong * 256)(); n = C.c_int(); nops = C.c_int()
-    for rep in range(2):
-        _lib.check(lib.mpdx_fused_trace(hdl, packed.data_ptr(), tab.data_ptr(), x.data_ptr(), seg, B, ws.data_ptr(), st, stamps, 256, C.byref(n), C.byref(nops)))
+    if lib.mpdx_fused_trace(hdl, packed.data_ptr(), tab.data_ptr(), x.data_ptr(), seg, B, ws.data_ptr(), st, stamps, 256, C.byref(n), C.byref(nops)):
+        break   # no such segment
+    _lib.check(lib.mpdx_fused_trace(hdl, packed.data_ptr(), tab.data_ptr(), x.data_ptr(), seg, B, ws.data_ptr(), st, stamps, 256, C.byref(n), C.byref(nops)))
     v = [stamps[i] for i in range(256) if stamps[i]]
     d = [b - a for a, b in zip(v, v[1:])]
     print(f"segment {seg}: {nops.value} ops, total {v[-1]-v[0]} cycles; prologue: input loads issued {d[0]}, parameter loads issued {d[1]}, weight DMA issued {d[2]}, halo zeros {d[3]}, loads landed + barrier {d[4]}")
