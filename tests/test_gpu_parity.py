@@ -201,3 +201,38 @@ def test_chain_other_model_options_vs_oracle(sched, pred_eps):
     # x <- model(x) with random weights; that map expands the 1e-6 summation-order differences a few-fold per step
     # (measured 5e-4 at the end).  Same fp32-rounding class, looser bound on the result.
     assert err.max() < 2e-3 and err[-1] < (5e-4 if pred_eps else 2e-3), err
+
+
+_VARIANT_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path[:0] = [sys.argv[1], sys.argv[1] + "/tests"]
+import mpd_public_amd as m
+from helpers import synth_sd, t, DIM_MULTS
+out = {}
+for D in (4, 14):
+    net = m.TemporalUnet(n_support_points=64, state_dim=D, unet_input_dim=32, dim_mults=DIM_MULTS[1])
+    net.load_state_dict(synth_sd(D, 1), strict=True)
+    net = net.cuda().eval()
+    x = t(f"variants_x_D{D}", (5, 64, D)).cuda()
+    out[f"D{D}"] = net(x, torch.full((5,), 41, dtype=torch.long, device="cuda"), None).cpu().numpy()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_fused_program_variants_agree(tmp_path):
+    """The launch-structure switches are read once per process, so each variant runs in its own interpreter:
+    default (the two outer down levels merged into one fused program), MPDX_NO_MERGE=1 (one program per level) and
+    MPDX_FUSED=0 (one launch per layer).  Merged vs unmerged: same ops in the same order -> bit-identical.
+    Fused vs per-layer: different K split -> the eps tolerance of the golden test."""
+    import os, subprocess, sys
+    from pathlib import Path
+    root = str(Path(__file__).resolve().parent.parent)
+    res = {}
+    for name, env in (("merged", {}), ("unmerged", {"MPDX_NO_MERGE": "1"}), ("per_layer", {"MPDX_FUSED": "0"})):
+        f = tmp_path / f"{name}.npz"
+        e = dict(os.environ); e.update(env)
+        subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT, root, str(f)], check=True, env=e, timeout=600)
+        res[name] = load_npz(f)
+    for k in ("D4", "D14"):
+        assert np.array_equal(res["merged"][k], res["unmerged"][k]), k
+        np.testing.assert_allclose(res["merged"][k], res["per_layer"][k], rtol=0, atol=2e-5, err_msg=k)
