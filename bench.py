@@ -223,13 +223,16 @@ def main():
             return dm.run_inference(None, hc, n_samples=B, horizon=64, return_chain=True, n_diffusion_steps_without_noise=n0,
                                     noise_std_extra_schedule_fn=extra, **guide_kw)
     else:  # per-rank shard of independent contexts; per-trajectory hard conditions
-        from mpd_public_amd.parallel import expand_contexts
+        from mpd_public_amd.parallel import expand_contexts, gather_trajectories
         st = torch.from_numpy(syn.synth_tensor(f"bench_ctx_s{rank}", (n_ctx, D), "uniform", 0.6)).cuda()
         gl = torch.from_numpy(syn.synth_tensor(f"bench_ctx_g{rank}", (n_ctx, D), "uniform", 0.6)).cuda()
         hs, hg = expand_contexts(st, gl, B // n_ctx)
 
         def one_plan():
             x, chain = dm.plan({0: hs, 63: hg}, B, 64, n0, None, extra, return_chain=True, n_per_context=B // n_ctx, **guide_kw)
+            if world > 1:   # the path's one exchange step: all-gather of the planned trajectories (RCCL over xGMI), timed
+                gathered = gather_trajectories(x, n_ctx * world, B // n_ctx)
+                assert gathered.shape[0] == world * B
             return chain
 
     def fence():
@@ -261,7 +264,9 @@ def main():
         "config": {"workload": f"{args.config}: {env_id}-{robot} shape, {B} trajectories ({n_ctx} context(s)) x H=64 x D={D}, T={T} (+{n0}) "
                                f"reverse steps, {'guided (collision + GP prior, 5 guide steps on the last T/4+5 iterations)' if guided else 'unguided'}, "
                                f"U-Net dim_mults {mults}, one plan = one bench step",
-                   "parallelism": "replicas" if world > 1 else "single", "denoising_steps_per_plan": steps_per_plan,
+                   "parallelism": ("single" if world == 1 else "replicas (no collective)" if n_ctx == 1
+                                   else "contexts sharded over ranks, one all_gather of the final trajectories per plan"),
+                   "denoising_steps_per_plan": steps_per_plan,
                    "trajectory_steps_per_s": round(value * B, 1)},
         "plan_wall_clock_ms": round(dt / args.steps * 1e3, 3),
     }
