@@ -11,8 +11,10 @@
 // The arithmetic per layer is the same as conv_block.hpp (same packed weights, same fp32 MFMA, same GroupNorm/Mish);
 // only the schedule differs: activations never leave the CU between layers.
 //
-// Structure.  One workgroup (8 waves) = one trajectory.  LDS holds a few activation buffers in the zero-haloed
-// channel-last layout [L+4 rows][C + pad] (rows 0,1 and L+2,L+3 stay zero: conv padding), plus the K-partial buffer.
+// Structure.  One workgroup (8 waves) = one trajectory.  LDS holds the activation buffers in the zero-haloed
+// channel-last layout [L+4 rows][C + pad] (rows 0,1 and L+2,L+3 are zero: conv padding; written by the op that defines
+// the buffer), plus the K-partial buffer.  The host places the buffers by live range (buffers whose lives do not
+// intersect share addresses), which lets the two outer down levels run as ONE program of 12 ops within 160 KB.
 // A tiny op list (kernel argument) is interpreted: each conv is M = C_out (all), N = L positions, K = C_in*taps;
 // the (C_out/16)*(L/16) = 8 (or 4) MFMA sub-tiles map one per wave (K split in two when there are 4), partials meet
 // in LDS, then wave g normalises GroupNorm group g of the trajectory.
@@ -21,7 +23,7 @@
 // shape (wave-uniform base + lane*16).  The blocks of op i+1 are DMA'd right after op i's MFMA barrier, so their
 // HBM/L2 latency hides under op i's GroupNorm epilogue; the k-loop itself reads A and B fragments from LDS only
 // (no vmcnt waits inside it - the register-ring version of this loop was serialised by hipcc to ~2 loads in flight).
-// Ops whose weights exceed the LDS weight window (the 256->64 k5 block: 320 KiB) run in c16 chunks.
+// Ops whose weights exceed the LDS weight window (the 128->64 k5 block of ups: 160 KiB) run in c16 chunks.
 #pragma once
 #include "conv_block.hpp"
 
@@ -65,7 +67,6 @@ struct FusedArgs {
     int w_off4;          // LDS weight window (float4 units)
     int w_cap_blocks;    // its capacity in 1-KiB A-fragment blocks
     int lg_c4n;          // log2(float4 per staged input row) or -1 (generic division path)
-    int lg_cout;         // log2(C_out) of the segment's ops (uniform per segment)
     int n_runs;          // parameter runs = 4 * (#conv ops): run r = op (r>>2), vector (r&3)
     int lds_float4;      // total LDS in float4 units (zeroed at start)
     FusedOp ops[kMaxFusedOps];

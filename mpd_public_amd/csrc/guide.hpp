@@ -11,11 +11,12 @@
 // The cost arithmetic itself (CostCollision / CostGPTrajectory / robot FK / SDF fields) lives in un-vendored
 // submodules of the reference; it is restated from the published formulas (oracle/costs.py header) - PARITY UNPINNED.
 //
-// Mapping.  One 64-lane wave per trajectory, lane h = support point h (H <= 64).  The [H, D] state is read with
-// coalesced loads; the horizon window needed by the interpolation and by the GP prior's 3-point finite-difference
-// stencil is staged in LDS; interpolated points are processed lane-strided (i = lane, lane+64, ...); the transpose
-// of the interpolation (scatter of point gradients to support points) is a deterministic LDS gather (no atomics);
-// max|x| for the next iteration's range test is a wave reduction + one atomicMax per trajectory.
+// Mapping.  One 512-thread workgroup (8 waves) per trajectory; lane h of wave 0 = support point h (H <= 64).  The [H, D]
+// state is read with coalesced loads; the horizon window needed by the interpolation and by the GP prior's 3-point
+// finite-difference stencil is staged in LDS; the collision work on the interpolated points (lane = point) is split over
+// the 8 waves (point mass: point half x field; Panda: point half x link-sphere group, FK once per point in LDS); the
+// transpose of the interpolation (scatter of point gradients to support points) is a deterministic LDS gather (no
+// atomics); max|x| for the next iteration's range test is a wave reduction + one atomicMax per trajectory.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -623,7 +623,7 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
                 ++nconv;
             }
         if (nconv * 4 > 56) return fuse_reject(__LINE__);
-        a.lg_cout = 0; a.n_runs = nconv * 4;
+        a.n_runs = nconv * 4;
         const int c4n = (a.gc1 + a.gc2 + 3) / 4;
         int l4 = 0;
         while ((1 << l4) < c4n) ++l4;
