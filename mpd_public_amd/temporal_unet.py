@@ -166,18 +166,37 @@ class TemporalUnet(nn.Module):
 
     # ------------------------------------------------------------------------------------------- model protocol
     def forward(self, x, time, context=None):
-        """x: [B,H,D] fp32, time: [B] int64 (batch-constant, as every caller in the reference passes it) -> eps [B,H,D]."""
+        """x: [B,H,D] fp32, time: [B] int64 -> eps [B,H,D].  Batch-constant `time` (every caller on the planning path) is one
+        kernel sequence; mixed timesteps run as one sequence per distinct value."""
         if context is not None:
             raise NotImplementedError("context conditioning is not supported (context is always None on this path, inference.py:182)")
         b, h, d = x.shape
         if h != self.n_support_points or d != self.state_dim:
             raise ValueError(f"expected [B,{self.n_support_points},{self.state_dim}], got {tuple(x.shape)}")
-        t0 = int(time.reshape(-1)[0])  # one host sync, as sample_functions.py:28-29 has
-        if time.numel() > 1 and not bool((time == t0).all()):
-            raise NotImplementedError("per-sample timesteps are not supported on the tabulated-time path")
-        hdl, packed, tab, ws = self.engine(t0 + 1, b)
         x = x.to(torch.float32).contiguous()
+        tl = time.reshape(-1).tolist()  # one host sync, as sample_functions.py:28-29 has
+        if len(tl) not in (1, b):
+            raise ValueError(f"time must have 1 or {b} entries, got {len(tl)}")
         out = torch.empty_like(x)
-        _lib.check(_lib.load().mpdx_unet_forward(hdl, packed.data_ptr(), tab.data_ptr(), self._timetab_T, x.data_ptr(), t0,
-                                                 out.data_ptr(), b, ws.data_ptr(), _lib.current_stream()), "mpdx_unet_forward")
+        lib = _lib.load()
+
+        def run(xg, t0, og):
+            hdl, packed, tab, ws = self.engine(t0 + 1, xg.shape[0])
+            _lib.check(lib.mpdx_unet_forward(hdl, packed.data_ptr(), tab.data_ptr(), self._timetab_T, xg.data_ptr(), t0,
+                                             og.data_ptr(), xg.shape[0], ws.data_ptr(), _lib.current_stream()), "mpdx_unet_forward")
+
+        distinct = sorted(set(int(v) for v in tl))
+        if len(distinct) == 1:   # every caller on the planning path: one timestep for the whole batch
+            run(x, distinct[0], out)
+            return out
+        # per-sample timesteps (the reference's training path): the time-conditioning tables are per integer t, and
+        # trajectories are independent, so the batch is run in groups of equal t
+        self.engine(distinct[-1] + 1, b)
+        tt = torch.as_tensor(tl, device=x.device)
+        for t0 in distinct:
+            idx = (tt == t0).nonzero(as_tuple=True)[0]
+            xg = x.index_select(0, idx).contiguous()
+            og = torch.empty_like(xg)
+            run(xg, t0, og)
+            out.index_copy_(0, idx, og)
         return out

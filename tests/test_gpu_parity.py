@@ -236,3 +236,19 @@ def test_fused_program_variants_agree(tmp_path):
     for k in ("D4", "D14"):
         assert np.array_equal(res["merged"][k], res["unmerged"][k]), k
         np.testing.assert_allclose(res["merged"][k], res["per_layer"][k], rtol=0, atol=2e-5, err_msg=k)
+
+
+def test_unet_forward_per_sample_timesteps_vs_oracle():
+    """model(x, t[B]) with mixed t (the reference's training-time call, diffusion_model_base.py:342): equals the oracle and
+    equals batch-constant calls row by row (bit-exact: trajectories are independent)."""
+    from oracle.unet import unet_forward
+    D, opt = 4, 1
+    net = _gpu_model(D, opt)
+    x = t("mixed_t_x", (6, 64, D))
+    tt = torch.tensor([3, 50, 3, 99, 0, 50], dtype=torch.long)
+    y = net(x.cuda(), tt.cuda(), None).cpu()
+    ref = unet_forward(synth_sd(D, opt), x, tt)
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=0, atol=2e-5)
+    for i in range(6):
+        yi = net(x[i:i + 1].cuda(), tt[i:i + 1].cuda(), None).cpu()
+        assert torch.equal(yi[0], y[i]), i
