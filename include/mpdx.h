@@ -103,6 +103,17 @@ int mpdx_ddpm_step(mpdx_unet* u, const float* packed_dev, const float* timetab_d
 int mpdx_add_noise(float* x_io, const float* noise, const float* hard_start, const float* hard_goal,
                    float noise_scale, float noise_std_extra, float* chain_out, int B, int H, int D, void* stream);
 
+/* ---- forward loss (what the reference's validation loop evaluates under no_grad; the backward pass is out of scope).
+ * q_sample (diffusion_model_base.py:320-330) followed by apply_hard_conditioning (:335): per-trajectory timesteps t_dev[B]
+ * (int64, clamped to [0,T)), schedule buffers on the device. */
+int mpdx_q_sample(const float* x_start, const float* noise, const long long* t_dev, const float* sqrt_alphas_cumprod_dev,
+                  const float* sqrt_one_minus_alphas_cumprod_dev, const float* hard_start, const float* hard_goal, float* out, int B, int H,
+                  int D, int T, void* stream);
+/* WeightedL2 (l1 = 0) / WeightedL1 (l1 = 1) of helpers.py:71-99 applied to apply_hard_conditioning(pred) vs targ
+ * (diffusion_model_base.py:343-350): out1[0] = mean over B*H*D of the (optionally weights_hd[H*D]-weighted) error. */
+int mpdx_weighted_loss(const float* pred, const float* targ, const float* weights_hd, const float* hard_start, const float* hard_goal,
+                       int l1, float* out1, int B, int H, int D, void* stream);
+
 /* standard-normal generator for the production path (Philox4x32-10 + Box-Muller); replaces torch.randn /
  * torch.randn_like (diffusion_model_base.py:165, sample_functions.py:51).  Parity runs inject noise instead. */
 int mpdx_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
@@ -153,7 +164,7 @@ typedef struct mpdx_guide_params {
  * test of LimitsNormalizer.unnormalize, normalization.py:160). */
 int mpdx_guide_step(const mpdx_guide_params* gp, float* x, float* grad_out, const float* hard_start, const float* hard_goal,
                     const uint32_t* absmax_in, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, void* stream);
-/* dev tool: s_memtime stamps (8 per wave x 8 waves, workgroup 0) of one guide launch (gradient-only mode) */
+/* dev tool: cycle stamps (16 slots per wave x 8 waves, workgroup 0) of one guide launch (gradient-only mode) */
 int mpdx_guide_trace(const mpdx_guide_params* gp, float* x, const uint32_t* absmax_in, int B, int H, int D, void* stream,
                      long long* stamps128);
 /* absmax_out[ctx] <- atomicMax over the context's trajectories (caller zeroes absmax_out first) */

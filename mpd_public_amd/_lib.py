@@ -63,6 +63,8 @@ SIGNATURES = {
     "mpdx_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "mpdx_ddpm_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, C.POINTER(StepCoefs), _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "mpdx_add_noise": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _i, _i, _i, _vp]),
+    "mpdx_q_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mpdx_weighted_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "mpdx_plan": (_i, [_vp, _vp, _vp, _i, C.POINTER(StepCoefs), _i, _vp, _vp, _vp, _vp, _vp, _i, _vp,
                         C.POINTER(GuideParams), _i, _i, _vp, _i, _vp]),
     "mpdx_guide_step": (_i, [C.POINTER(GuideParams), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

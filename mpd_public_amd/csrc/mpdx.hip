@@ -192,6 +192,58 @@ __global__ __launch_bounds__(256) void add_noise_kernel(float* x, const float* n
     }
 }
 
+// q_sample (diffusion_model_base.py:320-330) + apply_hard_conditioning (:335): per-trajectory timestep, schedule rows
+// looked up on the device.  x_t = sqrt(acp[t_b]) * x0 + sqrt(1 - acp[t_b]) * noise
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* x0, const float* noise, const long long* t, const float* sqrt_ac,
+                                                        const float* sqrt_1mac, const float* hs, const float* hg, float* out, int B, int H,
+                                                        int D, int T) {
+    const size_t n = (size_t)B * H * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = i % D;
+        const size_t p = i / D;
+        const int l = p % H;
+        const size_t b = p / H;
+        long long tb = t[b];
+        tb = tb < 0 ? 0 : (tb >= T ? T - 1 : tb);
+        float r = __fadd_rn(__fmul_rn(sqrt_ac[tb], x0[i]), __fmul_rn(sqrt_1mac[tb], noise[i]));
+        if (hs && l == 0) r = hs[b * D + d];
+        if (hg && l == H - 1) r = hg[b * D + d];
+        out[i] = r;
+    }
+}
+
+// WeightedL1 / WeightedL2 (helpers.py:71-99) of apply_hard_conditioning(pred) against targ: mean over all B*H*D elements
+// of |.| or (.)^2, optionally times weights[H*D].  One workgroup, fixed summation order (deterministic); validation-sized
+// inputs (B*H*D ~ 1e5 - 1e7).
+__global__ __launch_bounds__(1024) void weighted_loss_kernel(const float* pred, const float* targ, const float* weights, const float* hs,
+                                                             const float* hg, int l1, float* out, int B, int H, int D) {
+    __shared__ double part[16];
+    const size_t n = (size_t)B * H * D;
+    double acc = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += 1024) {
+        const int d = i % D;
+        const size_t p = i / D;
+        const int l = p % H;
+        const size_t b = p / H;
+        float v = pred[i];
+        if (hs && l == 0) v = hs[b * D + d];
+        if (hg && l == H - 1) v = hg[b * D + d];
+        const float e = __fsub_rn(v, targ[i]);
+        float q = l1 ? fabsf(e) : __fmul_rn(e, e);
+        if (weights) q = __fmul_rn(q, weights[(size_t)l * D + d]);
+        acc += (double)q;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int k = 0; k < 16; ++k) tot += part[k];
+        out[0] = (float)(tot / (double)n);
+    }
+}
+
 // Philox4x32-10 counter-based generator + Box-Muller: 4 normals per counter.
 __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
@@ -1136,6 +1188,27 @@ int mpdx_add_noise(float* x_io, const float* noise, const float* hard_start, con
     const size_t n = (size_t)B * H * D;
     hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream,
                        x_io, noise, hard_start, hard_goal, noise_scale, noise_std_extra, chain_out, B, H, D);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mpdx_q_sample(const float* x_start, const float* noise, const long long* t_dev, const float* sqrt_alphas_cumprod_dev,
+                  const float* sqrt_one_minus_alphas_cumprod_dev, const float* hard_start, const float* hard_goal, float* out, int B, int H,
+                  int D, int T, void* stream) {
+    if (!x_start || !noise || !t_dev || !sqrt_alphas_cumprod_dev || !sqrt_one_minus_alphas_cumprod_dev || !out || B <= 0 || T <= 0)
+        return fail(MPDX_E_INVALID, "bad argument");
+    const size_t n = (size_t)B * H * D;
+    hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, x_start, noise,
+                       t_dev, sqrt_alphas_cumprod_dev, sqrt_one_minus_alphas_cumprod_dev, hard_start, hard_goal, out, B, H, D, T);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mpdx_weighted_loss(const float* pred, const float* targ, const float* weights_hd, const float* hard_start, const float* hard_goal,
+                       int l1, float* out1, int B, int H, int D, void* stream) {
+    if (!pred || !targ || !out1 || B <= 0) return fail(MPDX_E_INVALID, "bad argument");
+    hipLaunchKernelGGL(weighted_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, targ, weights_hd, hard_start, hard_goal, l1, out1,
+                       B, H, D);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -2,9 +2,9 @@
 (diffusion_model_base.py:46-316): same constructor, same registered buffers (state-dict compatible), same
 ``run_inference / conditional_sample / p_sample_loop / p_mean_variance / warmup`` protocol.
 
-The sampling half runs on libmpdx.so.  The training half (q_sample / p_losses / loss, :320-357) and ddim_sample
-(:184-259) are outside the hot path this package accelerates: signatures are kept and
-raise NotImplementedError.
+The sampling half (DDPM and DDIM) runs on libmpdx.so.  Of the training half (:320-357) the FORWARD value is provided:
+q_sample / p_losses / loss return the loss the reference's validation pass computes under no_grad (per-sample timesteps,
+hard conditioning, WeightedL1/L2); there is no backward pass - the returned loss carries no autograd history.
 """
 from __future__ import annotations
 
@@ -264,11 +264,68 @@ class GaussianDiffusionModel(nn.Module):
         return chain[-1]
 
     # ---------------------------------------------------------------------------------------------- training (out of scope)
-    def q_sample(self, x_start, t, noise=None):
-        raise NotImplementedError("training path (diffusion_model_base.py:320-357) is out of scope of mpd_public_amd")
+    # ------------------------------------------------------------------------------ forward loss (no backward pass)
+    def _hard_tables(self, hard_conds, B, H, D, device):
+        """{0: v, H-1: v} (v [D] or [B,D]) -> ([B,D] start table or None, [B,D] goal table or None)."""
+        out = []
+        for key in (0, H - 1):
+            v = (hard_conds or {}).get(key)
+            if v is None:
+                out.append(None)
+                continue
+            v = v.to(device=device, dtype=torch.float32)
+            out.append((v.expand(B, D) if v.dim() == 1 else v).contiguous())
+        extra = set((hard_conds or {}).keys()) - {0, H - 1}
+        if extra:
+            raise NotImplementedError(f"hard conditions at horizon indices {sorted(extra)}: only 0 and H-1 are supported")
+        return out
 
-    def p_losses(self, x_start, context, t, hard_conds):
-        raise NotImplementedError("training path (diffusion_model_base.py:320-357) is out of scope of mpd_public_amd")
+    def q_sample(self, x_start, t, noise=None, hard_conds=None):
+        """diffusion_model_base.py:320-330 (per-sample t).  `hard_conds` optionally folds the apply_hard_conditioning of
+        p_losses (:335) into the same kernel.  Noise defaults to the device generator (mpdx_randn)."""
+        if not x_start.is_cuda:
+            raise RuntimeError("q_sample / p_losses run on the GPU (libmpdx); there is no CPU fallback")
+        x_start = x_start.to(torch.float32).contiguous()
+        B, H, D = x_start.shape
+        if noise is None:
+            noise = self.fill_randn(torch.empty((B, H, D), device=x_start.device, dtype=torch.float32))
+        noise = noise.to(torch.float32).contiguous()
+        t = t.to(device=x_start.device, dtype=torch.long).reshape(-1).contiguous()
+        if t.numel() != B:
+            raise ValueError(f"t must have {B} entries")
+        hs, hg = self._hard_tables(hard_conds, B, H, D, x_start.device)
+        out = torch.empty_like(x_start)
+        _lib.check(_lib.load().mpdx_q_sample(x_start.data_ptr(), noise.data_ptr(), t.data_ptr(), self.sqrt_alphas_cumprod.data_ptr(),
+                                             self.sqrt_one_minus_alphas_cumprod.data_ptr(), hs.data_ptr() if hs is not None else None,
+                                             hg.data_ptr() if hg is not None else None, out.data_ptr(), B, H, D, self.n_diffusion_steps,
+                                             _lib.current_stream()), "mpdx_q_sample")
+        return out
+
+    def p_losses(self, x_start, context, t, hard_conds, noise=None):
+        """diffusion_model_base.py:331-352, forward value only: (loss, info) with loss a 0-dim tensor WITHOUT autograd history
+        (what the reference's validation pass computes under no_grad; the backward pass / optimiser are out of scope)."""
+        if context is not None:
+            raise NotImplementedError("context is always None on this path")
+        if not x_start.is_cuda:
+            raise RuntimeError("q_sample / p_losses run on the GPU (libmpdx); there is no CPU fallback")
+        x_start = x_start.to(torch.float32).contiguous()
+        B, H, D = x_start.shape
+        if noise is None:
+            noise = self.fill_randn(torch.empty((B, H, D), device=x_start.device, dtype=torch.float32))
+        noise = noise.to(torch.float32).contiguous()
+        x_noisy = self.q_sample(x_start, t, noise, hard_conds)
+        x_recon = self.model(x_noisy, t, None)
+        hs, hg = self._hard_tables(hard_conds, B, H, D, x_start.device)
+        target = noise if self.predict_epsilon else x_start
+        if self.loss_type not in ("l1", "l2"):
+            raise NotImplementedError(self.loss_type)
+        out = torch.empty(1, dtype=torch.float32, device=x_start.device)
+        _lib.check(_lib.load().mpdx_weighted_loss(x_recon.data_ptr(), target.data_ptr(), None, hs.data_ptr() if hs is not None else None,
+                                                  hg.data_ptr() if hg is not None else None, 1 if self.loss_type == "l1" else 0, out.data_ptr(),
+                                                  B, H, D, _lib.current_stream()), "mpdx_weighted_loss")
+        return out[0], {}
 
     def loss(self, x, context, *args):
-        raise NotImplementedError("training path (diffusion_model_base.py:320-357) is out of scope of mpd_public_amd")
+        """diffusion_model_base.py:354-357: uniform random timestep per sample, then p_losses."""
+        t = torch.randint(0, self.n_diffusion_steps, (x.shape[0],), device=x.device).long()
+        return self.p_losses(x, context, t, *args)

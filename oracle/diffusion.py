@@ -115,3 +115,22 @@ def ddim_sample(sd: dict, hard_conds: dict, x_T: torch.Tensor, T: int, variance_
         x = apply_hard_conditioning(x, hc)
         chain.append(x.clone())
     return torch.stack(chain, dim=0)
+
+
+# ------------------------------------------------------------------------------------------------ forward loss
+def q_sample(buf: dict, x_start: torch.Tensor, t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """diffusion_model_base.py:320-330 (extract = gather + reshape to [B,1,1], sample_functions.py:11-14)."""
+    a = buf["sqrt_alphas_cumprod"].gather(-1, t).reshape(-1, 1, 1)
+    b = buf["sqrt_one_minus_alphas_cumprod"].gather(-1, t).reshape(-1, 1, 1)
+    return a * x_start + b * noise
+
+
+def p_losses(sd: dict, x_start: torch.Tensor, t: torch.Tensor, hard_conds: dict, noise: torch.Tensor, T: int,
+             variance_schedule: str = "exponential", predict_epsilon: bool = True, loss_type: str = "l2") -> torch.Tensor:
+    """diffusion_model_base.py:331-352 with the unweighted WeightedL1 / WeightedL2 of helpers.py:71-99 (loss.mean())."""
+    buf = _sched.make_buffers(T, variance_schedule)
+    x_noisy = apply_hard_conditioning(q_sample(buf, x_start, t, noise), hard_conds)
+    x_recon = apply_hard_conditioning(unet_forward(sd, x_noisy, t), hard_conds)
+    targ = noise if predict_epsilon else x_start
+    err = (x_recon - targ).abs() if loss_type == "l1" else torch.nn.functional.mse_loss(x_recon, targ, reduction="none")
+    return err.mean()

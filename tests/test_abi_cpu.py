@@ -105,8 +105,10 @@ def test_model_state_dict_and_loud_cpu_failure():
         net(torch.zeros(2, 64, 4), torch.zeros(2, dtype=torch.long))
     with pytest.raises(NotImplementedError):
         m.TemporalUnet(n_support_points=64, state_dim=4, conditioning_type="attention")
+    with pytest.raises(RuntimeError, match="GPU"):   # the forward loss runs on libmpdx only
+        dm.loss(torch.zeros(1, 64, 4), None, {})
     with pytest.raises(NotImplementedError):
-        dm.loss(torch.zeros(1, 64, 4), None)
+        dm.p_losses(torch.zeros(1, 64, 4), torch.zeros(1, 3), torch.zeros(1, dtype=torch.long), {})   # context models: not on this path
     c = m.sample_functions.step_coefs(dm, 0, 0.5)
     assert c.noise_scale == 0.0 and c.noise_std_extra == 0.5 and c.predict_epsilon == 1
 

@@ -252,3 +252,34 @@ def test_unet_forward_per_sample_timesteps_vs_oracle():
     for i in range(6):
         yi = net(x[i:i + 1].cuda(), tt[i:i + 1].cuda(), None).cpu()
         assert torch.equal(yi[0], y[i]), i
+
+
+@pytest.mark.parametrize("D,opt", [(4, 1), (14, 0)])
+def test_forward_loss_vs_reference_golden(golden_dir, D, opt):
+    """q_sample / p_losses forward value (mpdx_q_sample -> U-Net groups of equal t -> mpdx_weighted_loss) against the
+    reference's own numbers (tests/golden/loss.npz): q_sample bit-exact against the same formula, loss to 2e-5 relative (eps tolerance 2e-5 of
+    |eps| ~ 0.3 averaged over 1e4 elements, fp64 accumulation on the device)."""
+    import mpd_public_amd as m
+    g = load_npz(golden_dir / "loss.npz")
+    T, B = 25, 6
+    tt = torch.tensor([3, 24, 0, 12, 12, 7], dtype=torch.long).cuda()
+    x0, noise = t(f"loss_x0_D{D}", (B, 64, D), "uniform", 0.8).cuda(), t(f"loss_noise_D{D}", (B, 64, D)).cuda()
+    hc = {0: t(f"loss_hc0_D{D}", (B, D), "uniform", 0.7).cuda(), 63: t(f"loss_hc1_D{D}", (B, D), "uniform", 0.7).cuda()}
+    net = _gpu_model(D, opt)
+    for pe in (True, False):
+        for lt in ("l2", "l1"):
+            dm = m.GaussianDiffusionModel(model=net, variance_schedule="exponential", n_diffusion_steps=T, predict_epsilon=pe, loss_type=lt).cuda().eval()
+            if pe and lt == "l2":
+                xq = dm.q_sample(x0, tt, noise)
+                a_ = dm.sqrt_alphas_cumprod[tt].reshape(-1, 1, 1)
+                b_ = dm.sqrt_one_minus_alphas_cumprod[tt].reshape(-1, 1, 1)
+                assert torch.equal(xq, a_ * x0 + b_ * noise)   # the reference's three elementwise ops, same buffers: bit-exact
+                # vs the reference's run: the schedule buffers come from the HOST's vectorised torch.exp / cumprod, which differ
+                # by 1 ulp between CPUs (the golden was made in the build container), so 2 ulp of O(1) values here
+                np.testing.assert_allclose(xq.cpu().numpy(), g[f"D{D}_x_noisy"], rtol=0, atol=3e-7)
+            loss, info = dm.p_losses(x0, None, tt, hc, noise=noise)
+            assert loss.dim() == 0 and not loss.requires_grad and info == {}
+            want = float(g[f"D{D}_eps{int(pe)}_{lt}"])
+            assert abs(float(loss) - want) <= 2e-5 * abs(want), (pe, lt, float(loss), want)
+    l2, _ = dm.loss(x0, None, hc)   # random timesteps + device noise: finite, positive
+    assert bool(torch.isfinite(l2)) and float(l2) > 0

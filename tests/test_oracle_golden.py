@@ -125,3 +125,19 @@ def test_ddim_chain_matches_reference(golden_dir, opt):
     assert chain.shape == ref.shape == (7, B, 64, D)
     # the first update amplifies eps by 4.6e3 WITHOUT a clamp on this path: values are O(1e3); compare relatively
     np.testing.assert_allclose(chain, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("D,opt", [(4, 1), (14, 0)])
+def test_forward_loss_vs_reference_golden(golden_dir, D, opt):
+    """q_sample + p_losses (diffusion_model_base.py:320-352): per-sample timesteps, per-sample hard conditions, injected noise."""
+    g = load_npz(golden_dir / "loss.npz")
+    T, B = 25, 6
+    tt = torch.tensor([3, 24, 0, 12, 12, 7], dtype=torch.long)
+    x0, noise = t(f"loss_x0_D{D}", (B, 64, D), "uniform", 0.8), t(f"loss_noise_D{D}", (B, 64, D))
+    hc = {0: t(f"loss_hc0_D{D}", (B, D), "uniform", 0.7), 63: t(f"loss_hc1_D{D}", (B, D), "uniform", 0.7)}
+    buf = schedules.make_buffers(T)
+    assert np.array_equal(diffusion.q_sample(buf, x0, tt, noise).numpy(), g[f"D{D}_x_noisy"])
+    for pe in (True, False):
+        for lt in ("l2", "l1"):
+            v = float(diffusion.p_losses(synth_sd(D, opt), x0, tt, hc, noise, T, predict_epsilon=pe, loss_type=lt))
+            assert abs(v - float(g[f"D{D}_eps{int(pe)}_{lt}"])) <= 2e-6 * abs(v), (pe, lt, v)
