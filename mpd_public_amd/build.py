@@ -11,7 +11,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libmpdx.so"
 SOURCES = [CSRC / "mpdx.hip"]
-HEADERS = [CSRC / "conv_block.hpp", PKG.parent / "include" / "mpdx.h"]
+HEADERS = sorted(CSRC.glob("*.hpp")) + [PKG.parent / "include" / "mpdx.h"]   # every header mpdx.hip includes
 
 
 def hipcc() -> str:
@@ -33,6 +33,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=on",
            "-Wall", "-Wno-unused-function", "-o", str(LIB)] + [str(s) for s in SOURCES]
+    cmd += os.environ.get("MPDX_BUILD_DEFS", "").split()   # dev builds, e.g. -DMPDX_LOOP_ABLATION (tools/ablate_loop.py)
     if verbose:
         print("[mpdx build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -53,8 +53,8 @@ struct ConvArgs {
     int gs;              // GroupNorm channels per group
     int n_tiles_n;       // ceil(B*L_out / NT)
     int lg_c4n, lg_Lin, lg_Lout, lg_gs;  // log2 of cin_pad/4, L_in, L_out, gs (all powers of two): no integer division on device
-    int dbg;             // ablation mask for mpdx_bench_layer: 1 skip staging, 2 skip MFMA loop, 4 skip epilogue,
-                         // 8 no weight-ring refills in the loop (MFMAs re-use the prefilled ring), 32 no B-fragment LDS reads
+    int dbg;             // ablation mask for mpdx_bench_layer: 1 skip staging, 2 skip MFMA loop, 4 skip epilogue; only in builds with
+                         // -DMPDX_LOOP_ABLATION: 8 no weight-ring refills in the loop, 32 no B-fragment LDS reads
     long long* trace;    // dev tool: s_memtime stamps of workgroups 0 and last / wave 0 (null in production)
 };
 
@@ -294,7 +294,11 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                     //   conv/down: staged row (l*stride + tap) holds true index l*stride + tap - PAD;
                     //   convT:     boff already points at input m; even outputs use (m, m-1), odd outputs (m, m+1).
                     const int roff = (MODE == CONV_UPT) ? ((ts == 0) ? 0 : (p == 0 ? -1 : 1)) : ts;
+#ifdef MPDX_LOOP_ABLATION
                     const f32x4 bf = (a.dbg & 32) ? (f32x4){1.f, 2.f, 3.f, 4.f} : smem4[boff[i] + roff * RS4 + c16 * 4];
+#else
+                    const f32x4 bf = smem4[boff[i] + roff * RS4 + c16 * 4];
+#endif
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -302,7 +306,11 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                             acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][m][p][e], bf[e], acc[m][i], 0, 0, 0);
                 }
             }
-            if (!(a.dbg & 8)) load_a(ring_g(it0 + u + PF), af[u]);  // refill this ring slot (unconditional, clamped)
+#ifdef MPDX_LOOP_ABLATION   // a CONDITIONAL refill serialises the ring (hipcc waits vmcnt(0)): never in the production build
+            if (!(a.dbg & 8)) load_a(ring_g(it0 + u + PF), af[u]);
+#else
+            load_a(ring_g(it0 + u + PF), af[u]);  // refill this ring slot (unconditional, clamped)
+#endif
         }
     }
 

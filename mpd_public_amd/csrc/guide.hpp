@@ -470,14 +470,17 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
     G_STAMP();  // 2 this wave's (point slice, field) done
     __syncthreads();
     G_STAMP();  // 3 all waves done
-    if (wv != 0) return;   // wave 0 finishes the trajectory (no further workgroup barriers below)
-
-    // ---- gather to support points (transpose of the interpolation), clip, zero ends, weight
-    float total[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) total[d] = 0.f;
+    // ---- gather to support points (transpose of the interpolation), clip, zero ends, weight: wave f handles field f and
+    //      leaves its clipped, weighted gradient in LDS; wave 0 then adds the fields in order (same additions as one wave
+    //      looping over the fields)
     const bool interior = live && lane > 0 && lane < H - 1;
-    if (live) {
+    float* sC = sB;   // [MAXF][H][QD]: overlays sB after the barrier below (every gatherer has its sums in registers by then)
+    float cg[QD];
+#pragma unroll
+    for (int j = 0; j < QD; ++j) cg[j] = 0.f;
+    const bool gatherer = wv < gp.n_fields;
+    if (gatherer && live) {
+        const int f = wv;
         int ilo = lane, ihi = lane;
         if (gp.interpolate && scale > 0.f) {
             ilo = (int)((float)lane / scale) - 2;
@@ -485,43 +488,57 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
             if (ilo < 0) ilo = 0;
             if (ihi > N - 1) ihi = N - 1;
         }
-        for (int f = 0; f < gp.n_fields; ++f) {
-            float g[QD];
+        float g[QD];
 #pragma unroll
-            for (int j = 0; j < QD; ++j) g[j] = 0.f;
-            for (int i = ilo; i <= ihi; ++i) {
-                int i0 = i, i1 = i;
-                if (gp.interpolate) {
-                    const float u = scale * (float)i;
-                    i0 = (int)u;
-                    if (i0 > H - 1) i0 = H - 1;
-                    i1 = i0 + 1 < H ? i0 + 1 : H - 1;
-                }
-                if (i0 == lane) {
-#pragma unroll
-                    for (int j = 0; j < QD; ++j) g[j] += sA[(f * N + i) * QD + j];
-                }
-                if (i1 == lane && gp.interpolate) {
-#pragma unroll
-                    for (int j = 0; j < QD; ++j) g[j] += sB[(f * N + i) * QD + j];
-                }
+        for (int j = 0; j < QD; ++j) g[j] = 0.f;
+        for (int i = ilo; i <= ihi; ++i) {
+            int i0 = i, i1 = i;
+            if (gp.interpolate) {
+                const float u = scale * (float)i;
+                i0 = (int)u;
+                if (i0 > H - 1) i0 = H - 1;
+                i1 = i0 + 1 < H ? i0 + 1 : H - 1;
             }
-            // clip_grad_by_norm over ALL D dims of (g + 1e-6): the velocity dims of a collision gradient are 0
-            float n2 = (float)QD * (1e-6f * 1e-6f);
+            if (i0 == lane) {
 #pragma unroll
-            for (int j = 0; j < QD; ++j) n2 += (g[j] + 1e-6f) * (g[j] + 1e-6f);
-            float ratio = 1.f;
-            if (gp.clip_grad) {
-                const float n = sqrtf(n2);
-                ratio = fminf(fmaxf(n, 0.f), gp.max_grad_norm) / n;
+                for (int j = 0; j < QD; ++j) g[j] += sA[(f * N + i) * QD + j];
             }
-            if (interior) {
+            if (i1 == lane && gp.interpolate) {
 #pragma unroll
-                for (int j = 0; j < QD; ++j) total[j] += gp.fields[f].weight * (ratio * g[j]);
+                for (int j = 0; j < QD; ++j) g[j] += sB[(f * N + i) * QD + j];
             }
         }
+        // clip_grad_by_norm over ALL D dims of (g + 1e-6): the velocity dims of a collision gradient are 0
+        float n2 = (float)QD * (1e-6f * 1e-6f);
+#pragma unroll
+        for (int j = 0; j < QD; ++j) n2 += (g[j] + 1e-6f) * (g[j] + 1e-6f);
+        float ratio = 1.f;
+        if (gp.clip_grad) {
+            const float n = sqrtf(n2);
+            ratio = fminf(fmaxf(n, 0.f), gp.max_grad_norm) / n;
+        }
+        if (interior) {
+#pragma unroll
+            for (int j = 0; j < QD; ++j) cg[j] = gp.fields[f].weight * (ratio * g[j]);
+        }
     }
-
+    static_assert(WPT >= MAXF, "one gathering wave per field");
+    __syncthreads();   // every gatherer has read its sA / sB slabs
+    if (gatherer && live) {
+#pragma unroll
+        for (int j = 0; j < QD; ++j) sC[(wv * H + lane) * QD + j] = cg[j];
+    }
+    __syncthreads();
+    if (wv != 0) return;   // wave 0 finishes the trajectory (no further workgroup barriers below)
+    float total[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) total[d] = 0.f;
+    if (live) {
+        for (int f = 0; f < gp.n_fields; ++f) {
+#pragma unroll
+            for (int j = 0; j < QD; ++j) total[j] += sC[(f * H + lane) * QD + j];
+        }
+    }
     G_STAMP();  // 4 gathered + clipped
     guide_gp_apply<QD>(a, b, ctx, lane, H, live, xn, xu, sx, total, base, (a.trace && b == 0 && lane == 0) ? a.trace + wv * 16 + 5 : nullptr);
 #undef G_STAMP
