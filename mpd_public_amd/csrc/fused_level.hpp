@@ -138,7 +138,9 @@ __device__ __forceinline__ void fused_mfma(const f32x4* __restrict__ wrow, const
 }
 
 __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
+#ifndef MPDX_NO_WARM_KERNARG   // dev A/B switch
     warm_kernarg<(int)sizeof(FusedArgs)>();
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* const sm4 = (f32x4*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
