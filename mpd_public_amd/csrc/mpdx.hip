@@ -798,11 +798,12 @@ static void choose_tile(const Layer& l, int B, int& MT, int& NT) {
         return std::max(stage, red);
     };
     const int mts[2] = {32, 16}, nts[3] = {64, 32, 16};
-    // largest tile that fits LDS (<= 96 KiB so that a second workgroup can co-reside) and still yields >= target
-    // workgroups; else the smallest legal tile
+    // largest tile that fits LDS (<= 96 KiB so that a second workgroup can co-reside; MPDX_LDS_CAP_KB overrides) and still
+    // yields >= target workgroups; else the smallest legal tile
+    static const size_t cap = (size_t)(getenv("MPDX_LDS_CAP_KB") ? atoi(getenv("MPDX_LDS_CAP_KB")) : 96) * 1024;
     for (int nt : nts)
         for (int mt : mts) {
-            if (mt < min_mt || nt < min_nt || l.cout % mt || lds(mt, nt) > 96 * 1024) continue;
+            if (mt < min_mt || nt < min_nt || l.cout % mt || lds(mt, nt) > cap) continue;
             if (wgs(mt, nt) >= target) { MT = mt; NT = nt; return; }
         }
     MT = (min_mt <= 16 && l.cout % 16 == 0) ? 16 : 32;
