@@ -155,3 +155,20 @@ def test_multi_context_batch_equals_separate_plans():
     for c in range(C):
         x, _ = dm.plan({0: starts[c], 63: goals[c]}, n, 64, noise=noise[:, c * n:(c + 1) * n].contiguous(), return_chain=False, **kw)
         assert torch.equal(batched[c * n:(c + 1) * n], x), c
+
+
+def test_panda_guide_rejects_interpolation_that_exceeds_lds():
+    """The Panda kernel keeps FK results and per-group gradients of every interpolated point in LDS: 512 points do not fit
+    160 KB.  The C ABI must refuse (error code + message), not launch."""
+    import mpd_public_amd as m
+    ds = m.TrajectoryDataset("EnvSpheres3D", "RobotPanda", tensor_args={"device": "cuda", "dtype": torch.float32})
+    costs = [m.CostCollision(ds.robot, 64, field=f, sigma_coll=1.0) for f in ds.task.get_collision_fields()]
+    comp = m.CostComposite(ds.robot, 64, costs, weights_cost_l=[1e-2] * len(costs))
+    g = m.GuideManagerTrajectoriesWithVelocity(ds, comp, clip_grad=True, interpolate_trajectories_for_collision=True,
+                                               num_interpolated_points_for_collision=512).cuda()
+    x = obstacle_hugging_trajs(ds, 3, seed="lds_cap").cuda()
+    with pytest.raises(RuntimeError, match="LDS"):
+        g(x)
+    ok = m.GuideManagerTrajectoriesWithVelocity(ds, comp, clip_grad=True, interpolate_trajectories_for_collision=True,
+                                                num_interpolated_points_for_collision=192).cuda()
+    assert bool(torch.isfinite(ok(x)).all())   # 192 points fit (3 passes of the 64-lane point loop)

@@ -283,3 +283,23 @@ def test_forward_loss_vs_reference_golden(golden_dir, D, opt):
             assert abs(float(loss) - want) <= 2e-5 * abs(want), (pe, lt, float(loss), want)
     l2, _ = dm.loss(x0, None, hc)   # random timesteps + device noise: finite, positive
     assert bool(torch.isfinite(l2)) and float(l2) > 0
+
+
+def test_weighted_loss_kernel_vs_formula():
+    """mpdx_weighted_loss with a [H*D] weight table and hard conditioning of the prediction (helpers.py:71-99 with weights,
+    sample_functions.py:5-8): against the same formula in torch ops (fp64), both loss types."""
+    import ctypes as C
+    from mpd_public_amd import _lib
+    lib = _lib.load()
+    B, H, D = 7, 64, 14
+    pred, targ = t("wl_pred", (B, H, D)).cuda(), t("wl_targ", (B, H, D)).cuda()
+    w = (t("wl_w", (H, D), "uniform").abs() + 0.1).cuda()
+    hs, hg = t("wl_hs", (B, D), "uniform").cuda(), t("wl_hg", (B, D), "uniform").cuda()
+    p2 = pred.clone(); p2[:, 0] = hs; p2[:, H - 1] = hg
+    out = torch.empty(1, device="cuda")
+    for l1 in (0, 1):
+        _lib.check(lib.mpdx_weighted_loss(pred.data_ptr(), targ.data_ptr(), w.data_ptr(), hs.data_ptr(), hg.data_ptr(), l1, out.data_ptr(),
+                                          B, H, D, _lib.current_stream()))
+        e = (p2 - targ).double()
+        want = ((e.abs() if l1 else e * e) * w.double()).mean()
+        assert abs(float(out) - float(want)) <= 1e-6 * float(want), (l1, float(out), float(want))
