@@ -151,7 +151,9 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
     // Each wave owns k-groups wk, wk+WK, ...; their A fragments are streamed from L2/HBM through a PF-deep register
     // ring so that the ~1-2 us load latency is paid once per kernel, under the staging phase, not once per iteration.
     constexpr int NCLS = (MODE == CONV_UPT) ? 2 : 1;
-    constexpr int PF = 4;   // ring depth in k-groups (8 measured worse: the staging loads queue behind 16 weight loads)
+    constexpr int PF = 2;   // ring depth in k-groups.  Measured (cfg2 / cfg5 plan, ms): PF 1: 27.90 / 739, 2: 27.70 / 745, 3: 27.95 / 760,
+                            // 4: 28.22 / 797, 6: 28.65 / 856 - a deeper ring only adds unrolled code and registers, the loads are
+                            // L2 hits that two k-groups of MFMAs (1-2 k cycles) already cover
     const int nc16 = a.cin_pad >> 4;
     const int ngroups = nc16 * NTAP;
     const float* wbase = a.wp + (size_t)(mt * MS) * nc16 * NSLOT * 256 + lane * 4;
