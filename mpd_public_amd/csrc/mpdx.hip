@@ -813,6 +813,8 @@ static void choose_tile(const Layer& l, int B, int& MT, int& NT) {
 static int layer_ntap(const Layer& l) { return l.mode == CONV_UPT ? 2 : l.ks; }
 static bool layer_ksplit(const Layer& l) {
     if (!(l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH)) return true;
+    static const int forced = getenv("MPDX_KSPLIT") ? atoi(getenv("MPDX_KSPLIT")) : -1;   // dev: 0 = (NT/16) x (8/(NT/16)) waves, 1 = 1 x 8
+    if (forced >= 0) return forced != 0;
     return (l.cin_pad / 16) * layer_ntap(l) >= 16;  // enough K to feed 8 K-split waves
 }
 static double layer_flops(const Layer& l, int B) {
