@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """bench.py - denoising-steps/s and plan wall-clock of the reverse-diffusion planning loop on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched under torch.distributed.run,
-one rank per GPU.  A "step" here is ONE FULL PLAN = the region the reference times (scripts/inference/inference.py:
-248-258): initial noise, all T+5 reverse updates of the whole batch, chain materialisation.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 one rank per GPU under torch.distributed.run
+(a plain `python bench.py --gpus N` re-executes itself under it).  A "step" here is ONE FULL PLAN = the region the
+reference times (scripts/inference/inference.py:248-258): initial noise, all T+5 reverse updates of the whole batch,
+chain materialisation.
   metric  = denoising-steps/s = (T+5) * plans / wall ; ms_per_step = plan wall-clock in ms.
 Workload (BASELINE.json configs[1]): EnvDense2D-RobotPointMass shape - 100 trajectories x H=64 x D=4 (pos+vel),
 T=100 diffusion steps (+5 without noise), U-Net dim_mults (1,2,4,8), unguided, fp32, synthetic formula-defined weights.
-N>1: the single-context plan does not shard (B=100 does not fill a GPU): N independent replicas, no collective
-in the data path (SURVEY.md 8e "replicas only"); value is the aggregate over ranks.
+N>1: the single-context plan does not shard (B=100 does not fill a GPU): N independent replicas, no collective in the
+data path (SURVEY.md 8e "replicas only"); value is the aggregate over ranks.  The path that DOES shard (BASELINE
+configs[4]: independent start/goal contexts, one all-gather at the end) is reported beside it in the `sharded` sub-record.
 """
 from __future__ import annotations
 
@@ -16,17 +18,17 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-from collections import defaultdict
+from collections import OrderedDict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
-import torch  # noqa: E402
 
 CONFIGS = {
     # name: (env, robot, D, dim_mults, T, B, n_without_noise, guided, n_contexts)
@@ -50,9 +52,50 @@ def build_model(D, mults, T, device):
     return dm.to(device).eval(), sd
 
 
-def roofline_leg(dm, B, T, reps=20):
-    """Per-launch durations of one U-Net pass measured with HIP event pairs on the launch stream (mpdx_unet_profile),
-    averaged over `reps` passes.  Returns the roofline object for the dominant kernel class + a per-class table."""
+def build_guide(env_id, robot, T, device):
+    """The guide exactly as inference.py:188-236 builds it (weights 1e-2 / 1e-7, 5 guide steps, last quarter of the loop)."""
+    import torch
+    import mpd_public_amd as m
+    from math import ceil
+    ds = m.TrajectoryDataset(env_id, robot, tensor_args={"device": torch.device(device), "dtype": torch.float32})
+    H_, dt_ = 64, 5.0 / 64
+    cl = [m.CostCollision(ds.robot, H_, field=f, sigma_coll=1.0) for f in ds.task.get_collision_fields()]
+    wl = [1e-2] * len(cl)
+    cl.append(m.CostGPTrajectory(ds.robot, H_, dt_, sigma_gp=1.0)); wl.append(1e-7)
+    guide = m.GuideManagerTrajectoriesWithVelocity(ds, m.CostComposite(ds.robot, H_, cl, weights_cost_l=wl), clip_grad=True,
+                                                   interpolate_trajectories_for_collision=True).to(device)
+    return dict(guide=guide, n_guide_steps=5, t_start_guide=ceil(0.25 * T))
+
+
+# ------------------------------------------------------------------------------------------------------ roofline leg
+def _unit_classes(lib, hdl, B, names, flops, n):
+    """launch unit -> (class key, kernel name as rocprofv3 prints it)."""
+    buf = C.create_string_buffer(64)
+    out = []
+    for i in range(n):
+        nm = names[i].decode()
+        li = lib.mpdx_unet_unit_layer(hdl, B, i)
+        if li >= 0:
+            lib.mpdx_unet_layer_tile(hdl, li, B, buf, 64)
+            tile = buf.value.decode()
+            kind = "conv_k5_gn_mish" if ".block.0." in nm else ("conv_k1" if "residual" in nm else ("down_k3s2" if "downs" in nm else "up_k4s2"))
+            if lib.mpdx_unet_unit_is_pair(hdl, B, i):
+                out.append((f"conv_k5_gn_mish+conv_k1 pair[{tile}] {flops[i]:.3e} flop", "conv_pair_kernel"))
+            else:
+                out.append((f"{kind}[{tile}] {flops[i]:.3e} flop", "conv_block_kernel"))
+        elif nm.startswith("fused"):
+            out.append(("fused_level_kernel (whole-trajectory level programs)", "fused_level_kernel"))
+        else:
+            out.append((nm, "final_step_kernel"))
+    return out
+
+
+def roofline_leg(dm, B, T, reps=30):
+    """Where the time of one U-Net pass (= one denoising step, unguided) goes, per launch class, measured IN SITU: for every
+    maximal run of consecutive launches of one class, one HIP-event pair on the launch stream brackets that run inside
+    `reps` real passes (mpdx_unet_time_units) - real predecessors, cold weights, event cost amortised over the run.
+    The `roofline` object describes the class with the LARGEST share of the pass; `classes` lists all of them."""
+    import torch
     from mpd_public_amd import _lib
     lib = _lib.load()
     hdl, packed, tab, ws = dm.model.engine(T, B)
@@ -62,96 +105,83 @@ def roofline_leg(dm, B, T, reps=20):
     fl = (C.c_double * cap)()
     names = (C.c_char_p * cap)()
     n = C.c_int()
-    acc = None
     st = torch.cuda.current_stream().cuda_stream
-    for r in range(reps + 2):
-        _lib.check(lib.mpdx_unet_profile(hdl, packed.data_ptr(), tab.data_ptr(), dm.model._timetab_T, x.data_ptr(), T // 2, B,
-                                         ws.data_ptr(), st, cap, ms, fl, names, C.byref(n)), "mpdx_unet_profile")
-        if r < 2:
-            continue
-        cur = [ms[i] for i in range(n.value)]
-        acc = cur if acc is None else [a + b for a, b in zip(acc, cur)]
-    avg_ms = [a / reps for a in acc]
-    buf = C.create_string_buffer(64)
-    classes = defaultdict(lambda: [0.0, 0.0, 0])  # key -> [ms, flops, launches]
-    for i in range(n.value):
-        nm = names[i].decode()
-        li = lib.mpdx_unet_unit_layer(hdl, B, i)
-        if li >= 0:
-            lib.mpdx_unet_layer_tile(hdl, li, B, buf, 64)
-            kind = "conv_k5_gn_mish" if ".block.0." in nm else ("conv_k1" if "residual" in nm else ("down_k3s2" if "downs" in nm else "up_k4s2"))
-            key = f"{kind}[{buf.value.decode()}] flops/launch={fl[i]:.3e}"
-        else:
-            key = nm
-        c = classes[key]
-        c[0] += avg_ms[i]; c[1] += fl[i]; c[2] += 1
-    table = sorted(((k, v[0], v[1], v[2]) for k, v in classes.items()), key=lambda r: -r[1])
-    dom = max((r for r in table if r[2] > 0 and not r[0].startswith("fused")), key=lambda r: r[1])
-    per_launch_flops = dom[2] / dom[3]
-    # The per-launch event pairs above carry the event records' own cost (14.6 us vs 11.8 us under rocprofv3 for the
-    # dominant class), and back-to-back launches of one layer re-read warm weights (10.3 us).  For the roofline number the
-    # dominant class is timed IN SITU: one HIP-event pair on the launch stream brackets the longest run of consecutive
-    # launches of that class inside real U-Net passes (6 launches for the 256->256 blocks), 50 passes.  This is the
-    # figure that agrees with the rocprofv3 --kernel-trace --stats average committed under profiles/.
-    keys = []
-    for i in range(n.value):
-        li = lib.mpdx_unet_unit_layer(hdl, B, i)
-        k = None
-        if li >= 0:
-            lib.mpdx_unet_layer_tile(hdl, li, B, buf, 64)
-            nm = names[i].decode()
-            kind = "conv_k5_gn_mish" if ".block.0." in nm else ("conv_k1" if "residual" in nm else ("down_k3s2" if "downs" in nm else "up_k4s2"))
-            k = f"{kind}[{buf.value.decode()}] flops/launch={fl[i]:.3e}"
-        keys.append(k)
-    best = (0, 0, -1)
-    i = 0
-    while i < len(keys):
-        if keys[i] == dom[0]:
-            j = i
-            while j + 1 < len(keys) and keys[j + 1] == dom[0]:
-                j += 1
-            if j - i + 1 > best[0]:
-                best = (j - i + 1, i, j)
-            i = j + 1
-        else:
-            i += 1
+    tt = T // 2
+    _lib.check(lib.mpdx_unet_profile(hdl, packed.data_ptr(), tab.data_ptr(), dm.model._timetab_T, x.data_ptr(), tt, B, ws.data_ptr(), st,
+                                     cap, ms, fl, names, C.byref(n)), "mpdx_unet_profile")
+    n = n.value
+    cls = _unit_classes(lib, hdl, B, names, fl, n)
+    n_units = n if lib.mpdx_unet_unit_layer(hdl, B, n - 1) >= 0 or names[n - 1].decode().startswith("fused") else n - 1  # final kernel is not a unit
+    runs, i = [], 0
+    while i < n_units:
+        j = i
+        while j + 1 < n_units and cls[j + 1][0] == cls[i][0]:
+            j += 1
+        runs.append((i, j))
+        i = j + 1
     out = C.c_float()
-    if best[0] > 0:
-        _lib.check(lib.mpdx_unet_time_units(hdl, packed.data_ptr(), tab.data_ptr(), dm.model._timetab_T, x.data_ptr(), T // 2, B,
-                                            ws.data_ptr(), st, best[1], best[2], 50, C.byref(out)), "mpdx_unet_time_units")
-        per_launch_ms = out.value / best[0]
-    else:
-        per_launch_ms = dom[1] / dom[3]
-    achieved = per_launch_flops / (per_launch_ms * 1e-3) / 1e12
-    # HBM-side traffic per launch of the dominant kernel: PMC counters cannot be collected from inside this process;
-    # the value measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction) is
-    # committed under profiles/ and quoted here when it is for this kernel and batch.
-    traffic = None
-    pmc = ROOT / "profiles" / "r01_pmc_dominant.json"
-    if pmc.exists() and B == 100 and "32x32/1x8" in dom[0] and "conv_k5_gn_mish" in dom[0]:
-        traffic = json.loads(pmc.read_text()).get("traffic_bytes_per_launch")
-    roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
-            "kernel": dom[0], "launches_per_unet_pass": dom[3], "avg_launch_us": round(per_launch_ms * 1e3, 2),
-            "timed": f"in situ, one event pair around {best[0]} consecutive launches, 50 passes",
-            "unet_pass_us_sum_of_launches": round(sum(avg_ms) * 1e3, 1),
-            "unet_pass_tflops": round(sum(fl[i] for i in range(n.value)) / (sum(avg_ms) * 1e-3) / 1e12, 3)}
-    return roof, table, sum(fl[i] for i in range(n.value))
+    table = OrderedDict()
+    whole = C.c_float()
+    _lib.check(lib.mpdx_unet_time_units(hdl, packed.data_ptr(), tab.data_ptr(), dm.model._timetab_T, x.data_ptr(), tt, B, ws.data_ptr(), st,
+                                        0, n_units - 1, reps, C.byref(whole)), "mpdx_unet_time_units")
+    for (a, b) in runs:
+        _lib.check(lib.mpdx_unet_time_units(hdl, packed.data_ptr(), tab.data_ptr(), dm.model._timetab_T, x.data_ptr(), tt, B, ws.data_ptr(), st,
+                                            a, b, reps, C.byref(out)), "mpdx_unet_time_units")
+        e = table.setdefault(cls[a][0], {"us": 0.0, "flop": 0.0, "launches": 0, "kernel": cls[a][1], "longest_run": 0})
+        e["us"] += out.value * 1e3
+        e["flop"] += sum(fl[k] for k in range(a, b + 1))
+        e["launches"] += b - a + 1
+        e["longest_run"] = max(e["longest_run"], b - a + 1)
+    tot_us = sum(e["us"] for e in table.values())
+    classes = []
+    for k, e in sorted(table.items(), key=lambda kv: -kv[1]["us"]):
+        tf = e["flop"] / (e["us"] * 1e-6) / 1e12 if e["us"] > 0 else 0.0
+        classes.append({"class": k, "kernel": e["kernel"], "launches_per_pass": e["launches"], "us_per_pass": round(e["us"], 2),
+                        "share": round(e["us"] / tot_us, 4), "avg_launch_us": round(e["us"] / e["launches"], 2),
+                        "flop_per_pass": e["flop"], "tflops": round(tf, 2), "frac": round(tf / FP32_PEAK_TFLOPS, 4)})
+    dom = classes[0]
+    # HBM-side traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process; they are
+    # collected by tools/r02_evidence.sh (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, gfx950 x2 fetch
+    # correction, MI355X_MICROARCH.md section HBM) on this same command and committed under profiles/.
+    traffic, traffic_src = None, None
+    for f in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
+        try:
+            rec = json.loads(f.read_text())
+        except Exception:
+            continue
+        if rec.get("batch") != B:
+            continue
+        hit = [v for k, v in rec.get("kernels", {}).items() if dom["kernel"].split(" ")[0] in k]
+        if hit:
+            nl = sum(v["launches"] for v in hit)
+            traffic = int(sum(v["traffic_bytes_per_launch"] * v["launches"] for v in hit) / nl)
+            traffic_src = f.name
+            break
+    roof = {"bound": "mfma", "achieved": dom["tflops"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
+            "traffic": traffic, "traffic_source": traffic_src, "kernel": dom["kernel"], "class": dom["class"],
+            "launches_per_unet_pass": dom["launches_per_pass"], "avg_launch_us": dom["avg_launch_us"], "share_of_pass": dom["share"],
+            "algorithmic_flop_per_launch": dom["flop_per_pass"] / dom["launches_per_pass"],
+            "timed": f"in situ: one HIP-event pair per run of consecutive launches of the class inside {reps} real U-Net passes",
+            "unet_pass_us": round(whole.value * 1e3, 1), "unet_pass_us_sum_of_classes": round(tot_us, 1),
+            "unet_pass_tflops": round(sum(fl[k] for k in range(n)) / (whole.value * 1e-3) / 1e12, 3),
+            "classes": classes}
+    return roof, sum(fl[k] for k in range(n))
 
 
 def cpu_baseline_leg(sd, D, T, B, n0, min_seconds=10.0, max_plans=12):
     """The CPU oracle (oracle/, a port of the reference's algorithm validated against it) timed on this box's host
     cores on the SAME workload: whole plans until >= min_seconds of CPU work (bounded sample)."""
+    import torch
     from oracle import diffusion as odiff
     from mpd_public_amd import synthetic as syn
     # thread count: torch's default (all logical cores) oversubscribes these small per-layer ops badly on big hosts
     # (measured: 128 threads -> 5.9 steps/s, slower than 8 threads); probe a few settings on 2 steps and keep the best.
-    import os as _os
+    host_cores = os.cpu_count() or 8
     probe_noise = torch.randn((4, B, 64, D))
     hc0 = {0: torch.zeros(D), 63: torch.zeros(D)}
     best = (1e30, torch.get_num_threads())
-    for nthr in sorted({8, 16, 32, 64, min(_os.cpu_count() or 8, 128)}):
-        if nthr > (_os.cpu_count() or 8):
+    for nthr in sorted({8, 16, 32, 64, min(host_cores, 128)}):
+        if nthr > host_cores:
             continue
         torch.set_num_threads(nthr)
         odiff.run_inference(sd, hc0, probe_noise, 2, n_diffusion_steps_without_noise=1, noise_std=0.5)
@@ -171,9 +201,96 @@ def cpu_baseline_leg(sd, D, T, B, n0, min_seconds=10.0, max_plans=12):
         odiff.run_inference(sd, hc, noise, T, n_diffusion_steps_without_noise=n0, noise_std=0.5)
         plans += 1
     dt = time.perf_counter() - t0
-    return {"value": round(plans * (T + n0) / dt, 2), "unit": "denoising-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{plans} full plan(s) of {T + n0} steps, B={B}, torch-CPU fp32 oracle, {dt:.1f} s",
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(plans * (T + n0) / dt, 2), "unit": "denoising-steps/s", "cores": cores, "host_cores": host_cores,
+            "host_cpu": cpu_model, "kind": "port",
+            "sample": f"{plans} full plan(s) of {T + n0} steps, B={B}, torch-CPU fp32 oracle on {cores} threads (best of a probe over "
+                      f"8..{min(host_cores, 128)} on this {host_cores}-logical-core host), {dt:.1f} s",
             "plan_wall_s": round(dt / plans, 3)}
+
+
+# ------------------------------------------------------------------------------------------------------ sub-records
+def sharded_leg(rank, world, dist, device, plans=2):
+    """BASELINE configs[4] per-GPU shard: 128 start/goal contexts x 50 Panda trajectories per rank (weak scaling: 128*N contexts in
+    total), guided, per-trajectory hard conditions, per-context range tests, zero exchange during the loop, ONE all-gather of the
+    planned trajectories at the end (RCCL over xGMI when N > 1)."""
+    import torch
+    from mpd_public_amd import synthetic as syn
+    from mpd_public_amd.parallel import expand_contexts, gather_trajectories
+    env_id, robot, D, mults, T, B, n0, _, n_ctx = CONFIGS["cfg5"]
+    dm, _sd = build_model(D, mults, T, device)
+    dm.manual_seed(1000 + rank)
+    gk = build_guide(env_id, robot, T, device)
+    st = torch.from_numpy(syn.synth_tensor(f"bench_ctx_s{rank}", (n_ctx, D), "uniform", 0.6)).to(device)
+    gl = torch.from_numpy(syn.synth_tensor(f"bench_ctx_g{rank}", (n_ctx, D), "uniform", 0.6)).to(device)
+    hs, hg = expand_contexts(st, gl, B // n_ctx)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    plan_ms, gather_ms = [], []
+    for it in range(plans + 1):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev[0].record()
+        x, _ = dm.plan({0: hs, 63: hg}, B, 64, n0, None, lambda t: 0.5, return_chain=False, n_per_context=B // n_ctx, **gk)
+        ev[1].record()
+        g = gather_trajectories(x, n_ctx * world, B // n_ctx, force_collective=dist is not None)
+        ev[2].record()
+        torch.cuda.synchronize()
+        assert g.shape[0] == world * B and bool(torch.isfinite(g[-1]).all())
+        if it > 0:
+            plan_ms.append(ev[0].elapsed_time(ev[1])); gather_ms.append(ev[1].elapsed_time(ev[2]))
+    pm, gm = max(plan_ms), max(gather_ms)
+    if dist is not None:
+        tt = torch.tensor([pm, gm], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        pm, gm = float(tt[0]), float(tt[1])
+    return {"workload": f"cfg5 shard per rank: {n_ctx} contexts x {B // n_ctx} = {B} Panda trajectories, T={T} (+{n0}), guided; {n_ctx * world} contexts in total",
+            "ranks": world, "backend": (dist.get_backend() if dist is not None else None),
+            "collective": "all_gather_into_tensor of the final trajectories" if dist is not None else None,
+            "plan_ms_per_rank_max": round(pm, 2), "all_gather_ms_max": round(gm, 3), "all_gather_bytes_per_rank": int(B * 64 * D * 4),
+            "denoising_steps_per_s": round(world * (T + n0) / ((pm + gm) * 1e-3), 2),
+            "trajectory_steps_per_s": round(world * B * (T + n0) / ((pm + gm) * 1e-3), 1), "scaling": "weak"}
+
+
+def serving_leg(dm, D, T, n0, n_ctx=16, n=100, plans=3):
+    """Several start/goal contexts BATCHED into one plan (per-trajectory hard conditions): the single-context chain is
+    latency-bound and leaves most of the GPU idle, so a planning server batches queued requests."""
+    import torch
+    from mpd_public_amd import synthetic as syn
+    from mpd_public_amd.parallel import expand_contexts
+    st = torch.from_numpy(syn.synth_tensor("mc_s", (n_ctx, D), "uniform", 0.6)).cuda()
+    gl = torch.from_numpy(syn.synth_tensor("mc_g", (n_ctx, D), "uniform", 0.6)).cuda()
+    hs, hg = expand_contexts(st, gl, n)
+    B = n_ctx * n
+
+    def one():
+        return dm.plan({0: hs, 63: hg}, B, 64, n0, None, lambda t: 0.5, return_chain=True, n_per_context=n)
+    one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(plans):
+        one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / plans
+    return {"workload": f"{n_ctx} contexts x {n} trajectories in ONE plan (cfg2 shape, unguided)", "plan_ms": round(dt * 1e3, 2),
+            "ms_per_context": round(dt * 1e3 / n_ctx, 2), "context_denoising_steps_per_s": round((T + n0) * n_ctx / dt, 1)}
+
+
+def _respawn(args):
+    """`python bench.py --gpus N` without a torch.distributed.run environment: start the N ranks ourselves."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
 
 
 def main():
@@ -184,14 +301,19 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `sharded` / `serving` sub-records")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        _respawn(args)
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU, RCCL over xGMI
         import torch.distributed as dist
@@ -199,22 +321,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
 
     env_id, robot, D, mults, T, B, n0, guided, n_ctx = CONFIGS[args.config]
-    dm, sd = build_model(D, mults, T, f"cuda:{local_rank}")
+    dm, sd = build_model(D, mults, T, device)
     dm.manual_seed(30 + rank)
     from mpd_public_amd import synthetic as syn
-    import mpd_public_amd as m
-    from math import ceil
     extra = lambda t: 0.5  # noqa: E731  inference.py:243
-    guide_kw = {}
-    if guided:  # guide built exactly as inference.py:188-236 builds it (weights 1e-2 / 1e-7, 5 guide steps, last quarter)
-        ds = m.TrajectoryDataset(env_id, robot, tensor_args={"device": torch.device("cuda", local_rank), "dtype": torch.float32})
-        H_, dt_ = 64, 5.0 / 64
-        cl = [m.CostCollision(ds.robot, H_, field=f, sigma_coll=1.0) for f in ds.task.get_collision_fields()]
-        wl = [1e-2] * len(cl)
-        cl.append(m.CostGPTrajectory(ds.robot, H_, dt_, sigma_gp=1.0)); wl.append(1e-7)
-        guide = m.GuideManagerTrajectoriesWithVelocity(ds, m.CostComposite(ds.robot, H_, cl, weights_cost_l=wl), clip_grad=True,
-                                                       interpolate_trajectories_for_collision=True).cuda()
-        guide_kw = dict(guide=guide, n_guide_steps=5, t_start_guide=ceil(0.25 * T))
+    guide_kw = build_guide(env_id, robot, T, device) if guided else {}
     if n_ctx == 1:
         hc = {0: torch.from_numpy(syn.synth_tensor("bench_hc0", (D,), "uniform", 0.6)).cuda(),
               63: torch.from_numpy(syn.synth_tensor("bench_hc1", (D,), "uniform", 0.6)).cuda()}
@@ -271,7 +382,7 @@ def main():
         "plan_wall_clock_ms": round(dt / args.steps * 1e3, 3),
     }
     if rank == 0 and not args.no_roofline:
-        roof, table, unet_flops = roofline_leg(dm, B, T)
+        roof, unet_flops = roofline_leg(dm, B, T)
         out["roofline"] = roof
         # whole-plan view: algorithmic bytes (weights once per step + 4 tensor passes) and FLOPs
         w_bytes = sum(int(v.numel()) for v in sd.values()) * 4
@@ -283,8 +394,23 @@ def main():
             "algorithmic_flops_per_step": unet_flops, "fp32_TFLOPs": round(unet_flops * steps_per_plan / plan_s / 1e12, 3),
             "fp32_peak_frac": round(unet_flops * steps_per_plan / plan_s / 1e12 / FP32_PEAK_TFLOPS, 4)}
         if os.environ.get("MPDX_BENCH_TABLE"):
-            for k, ms, fl, nl in table:
-                print(f"# {ms*1e3:9.1f} us  {nl:3d} launches  {fl/ (ms*1e-3)/1e12 if ms > 0 else 0:7.2f} TF/s  {k}", file=sys.stderr)
+            for c in roof["classes"]:
+                print(f"# {c['us_per_pass']:9.1f} us {c['share']*100:5.1f}%  {c['launches_per_pass']:3d} launches  {c['tflops']:7.2f} TF/s "
+                      f"({c['frac']*100:4.1f}% of peak)  {c['class']}", file=sys.stderr)
+    if not args.no_extras and args.config == "cfg2":
+        # every rank takes part in the sharded sub-record (it ends in a collective when N > 1)
+        try:
+            rec = sharded_leg(rank, world, dist, device)
+            if rank == 0:
+                out["sharded"] = rec
+        except Exception as e:  # the headline line must survive a failing sub-record
+            if rank == 0:
+                out["sharded"] = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0 and world == 1:
+            try:
+                out["serving"] = serving_leg(dm, D, T, n0)
+            except Exception as e:
+                out["serving"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_leg(sd, D, T, B, n0)
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -83,6 +83,8 @@ typedef struct mpdx_step_coefs {
     int32_t clip_denoised;              /* :149-150 */
     float ddim_k1;                      /* ddim_sample (:184-259): sqrt(alphas_cumprod[t_next]), 1 on the last pair */
     float ddim_k2;                      /* sqrt(1 - alphas_cumprod[t_next] - sigma^2) with eta = 0, 0 on the last pair */
+    float guide_scale;                  /* factor on every guide increment of this step: 1, or model_var = exp(posterior_log_variance_clipped[t])
+                                         * when scale_grad_by_std (sample_functions.py:77-78) */
 } mpdx_step_coefs;
 
 /* x_io[B,H,D] is updated in place to  hard_cond( mean + noise_scale*noise*noise_std_extra ).
@@ -156,6 +158,10 @@ typedef struct mpdx_guide_params {
     float   sigma_gp;                   /* 1.0 */
     const float* prims;                 /* device pointer: primitive table */
     int32_t n_prim_floats;
+    /* --- switches for what the reference's empty submodules leave undecidable / for options of guides.py --- */
+    int32_t clip_rule;                  /* 0: clip_grad_rule 'norm' (guides.py:224-230); 1: 'value' (guides.py:232-236) */
+    float   max_grad_value;             /* 0.1 (guides.py:151) */
+    int32_t gp_half_factor;             /* 0: cost_GP = sum e^T Qinv e (default);  1: 1/2 sum e^T Qinv e (GPMP2's convention) */
 } mpdx_guide_params;
 
 /* one guide iteration on x[B,H,D] (normalised).  grad_out == NULL: x <- hard_cond(x + guide(x)) in place and
@@ -164,6 +170,10 @@ typedef struct mpdx_guide_params {
  * test of LimitsNormalizer.unnormalize, normalization.py:160). */
 int mpdx_guide_step(const mpdx_guide_params* gp, float* x, float* grad_out, const float* hard_start, const float* hard_goal,
                     const uint32_t* absmax_in, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, void* stream);
+/* the same with the increment multiplied by guide_scale before it is added (scale_grad_by_std, sample_functions.py:77-78) */
+int mpdx_guide_step_scaled(const mpdx_guide_params* gp, float* x, float* grad_out, const float* hard_start, const float* hard_goal,
+                           const uint32_t* absmax_in, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, float guide_scale,
+                           void* stream);
 /* dev tool: cycle stamps (16 slots per wave x 8 waves, workgroup 0) of one guide launch (gradient-only mode) */
 int mpdx_guide_trace(const mpdx_guide_params* gp, float* x, const uint32_t* absmax_in, int B, int H, int D, void* stream,
                      long long* stamps128);
@@ -187,7 +197,8 @@ int mpdx_traj_metrics(const mpdx_guide_params* gp, const float* x_unnormalised, 
  *   chain  : NULL or [T + n_without_noise + 1, B,H,D] <- x after every iteration, index 0 = conditioned x_T
  *            (the 'diffsteps b h d' layout run_inference returns, :310)
  *   guide  : NULL (planner_alg 'diffusion_prior') or the cost guide; applied n_guide_steps times on the posterior
- *            mean of every iteration whose loop index i < t_start_guide (sample_functions.py:39-48)
+ *            mean of every iteration whose loop index i < t_start_guide (sample_functions.py:39-48), each increment times
+ *            coefs[t].guide_scale; n_guide_steps == 0 skips guidance (the reference's empty range(0) loop)
  *   guide_flags : device scratch, (T + n_without_noise) * (n_guide_steps + 1) * ceil(B / n_per_ctx) uint32
  *   n_per_ctx   : trajectories per start/goal context (n_samples); contexts are consecutive blocks of the batch   */
 int mpdx_plan(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, int T, const mpdx_step_coefs* coefs,
@@ -216,6 +227,8 @@ int mpdx_unet_time_units(mpdx_unet* u, const float* packed_dev, const float* tim
                          float* ws, void* stream, int unit_first, int unit_last, int reps, float* ms_avg);
 /* layer index behind launch unit i of mpdx_unet_profile at batch B (-1: fused whole-trajectory segment or the final kernel) */
 int mpdx_unet_unit_layer(const mpdx_unet* u, int B, int i);
+/* 1 when launch unit i is a paired launch (blocks[0] + the same block's residual 1x1 conv in one conv_pair_kernel) */
+int mpdx_unet_unit_is_pair(const mpdx_unet* u, int B, int i);
 /* `reps` back-to-back launches of layer `layer` between two events; dbg = ablation mask (1 skip staging, 2 skip
  * MFMA loop, 4 skip epilogue, 8 skip weight loads); synchronises. */
 int mpdx_bench_layer(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, const float* x, int layer, int B,

@@ -25,7 +25,8 @@ class StepCoefs(C.Structure):
     _fields_ = [("sqrt_recip_alphas_cumprod", C.c_float), ("sqrt_recipm1_alphas_cumprod", C.c_float),
                 ("posterior_mean_coef1", C.c_float), ("posterior_mean_coef2", C.c_float),
                 ("noise_scale", C.c_float), ("noise_std_extra", C.c_float),
-                ("predict_epsilon", C.c_int32), ("clip_denoised", C.c_int32), ("ddim_k1", C.c_float), ("ddim_k2", C.c_float)]
+                ("predict_epsilon", C.c_int32), ("clip_denoised", C.c_int32), ("ddim_k1", C.c_float), ("ddim_k2", C.c_float),
+                ("guide_scale", C.c_float)]
 
 
 MAX_FIELDS = 4
@@ -43,7 +44,8 @@ class GuideParams(C.Structure):
                 ("n_interp", C.c_int32), ("clip_grad", C.c_int32), ("max_grad_norm", C.c_float),
                 ("mins", C.c_float * 16), ("maxs", C.c_float * 16), ("cutoff_margin", C.c_float), ("link_margin", C.c_float),
                 ("n_fields", C.c_int32), ("fields", Field * MAX_FIELDS), ("use_gp", C.c_int32), ("gp_weight", C.c_float),
-                ("dt", C.c_float), ("sigma_gp", C.c_float), ("prims", C.c_void_p), ("n_prim_floats", C.c_int32)]
+                ("dt", C.c_float), ("sigma_gp", C.c_float), ("prims", C.c_void_p), ("n_prim_floats", C.c_int32),
+                ("clip_rule", C.c_int32), ("max_grad_value", C.c_float), ("gp_half_factor", C.c_int32)]
 
 
 # every symbol include/mpdx.h declares: name -> (restype, argtypes)
@@ -68,6 +70,7 @@ SIGNATURES = {
     "mpdx_plan": (_i, [_vp, _vp, _vp, _i, C.POINTER(StepCoefs), _i, _vp, _vp, _vp, _vp, _vp, _i, _vp,
                         C.POINTER(GuideParams), _i, _i, _vp, _i, _vp]),
     "mpdx_guide_step": (_i, [C.POINTER(GuideParams), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mpdx_guide_step_scaled": (_i, [C.POINTER(GuideParams), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mpdx_traj_metrics": (_i, [C.POINTER(GuideParams), _vp, _vp, _i, _i, _i, _i, _vp]),
     "mpdx_guide_trace": (_i, [C.POINTER(GuideParams), _vp, _vp, _i, _i, _i, _vp, C.POINTER(C.c_longlong)]),
     "mpdx_absmax": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -77,6 +80,7 @@ SIGNATURES = {
     "mpdx_fused_trace": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, C.POINTER(C.c_longlong), _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mpdx_unet_time_units": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float)]),
     "mpdx_unet_unit_layer": (_i, [_vp, _i, _i]),
+    "mpdx_unet_unit_is_pair": (_i, [_vp, _i, _i]),
     "mpdx_bench_layer": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, C.POINTER(C.c_float)]),
     "mpdx_unet_layer_tile": (_i, [_vp, _i, _i, C.c_char_p, _sz]),
     "mpdx_randn": (_i, [_vp, _sz, C.c_uint64, C.c_uint64, _vp]),

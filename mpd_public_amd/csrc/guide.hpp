@@ -51,6 +51,7 @@ struct GuideArgs {
     // last guide iteration of a step: also finish the step (sample_functions.py:51-62 + hard conditioning + chain.append)
     const float* noise;     // [B][H][D] or null
     float noise_scale, noise_extra;
+    float guide_scale;      // factor on the increment (1, or model_var when scale_grad_by_std: sample_functions.py:77-78)
     float* chain;           // optional second destination
     long long* trace;       // dev tool: cycle stamps, 16 slots per wave of workgroup 0 (null in production)
 };
@@ -311,6 +312,26 @@ __global__ __launch_bounds__(64) void traj_metrics_kernel(const mpdx_guide_param
     }
 }
 
+// clip_gradient (guides.py:213-236) of one waypoint's gradient g[0..N) (the remaining D - N dims of the term are zero):
+//   rule 'norm'  : g * clip(|g + 1e-6|, 0, max_norm) / |g + 1e-6|, norm over ALL D dims
+//   rule 'value' : clip(g, -max_value, max_value) per element
+template <int N>
+__device__ __forceinline__ void clip_waypoint_grad(const mpdx_guide_params& gp, float (&g)[N], int n_zero_dims) {
+    if (!gp.clip_grad) return;
+    if (gp.clip_rule == 1) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) g[j] = fminf(fmaxf(g[j], -gp.max_grad_value), gp.max_grad_value);
+        return;
+    }
+    float n2 = (float)n_zero_dims * (1e-6f * 1e-6f);
+#pragma unroll
+    for (int j = 0; j < N; ++j) n2 += (g[j] + 1e-6f) * (g[j] + 1e-6f);
+    const float n = sqrtf(n2);
+    const float ratio = fminf(fmaxf(n, 0.f), gp.max_grad_norm) / n;
+#pragma unroll
+    for (int j = 0; j < N; ++j) g[j] = ratio * g[j];
+}
+
 // GP prior (constant-velocity, GPMP2: 3-point stencil over the horizon) added to the gathered collision gradient, then
 //     x = x + (-grad);  [+ the step's noise term on the last guide iteration];  hard conditioning;  max|x| for the next
 // range test.  One wave, lane = support point.  tr: optional two cycle stamps (dev tool).
@@ -320,7 +341,7 @@ __device__ __forceinline__ void guide_gp_apply(const GuideArgs& a, int b, int ct
     constexpr int D = 2 * QD;
     const bool interior = live && lane > 0 && lane < H - 1;
     if (a.gp.use_gp) {
-        const float dt = a.gp.dt, s2 = 1.0f / (a.gp.sigma_gp * a.gp.sigma_gp);
+        const float dt = a.gp.dt, s2 = (a.gp.gp_half_factor ? 0.5f : 1.0f) / (a.gp.sigma_gp * a.gp.sigma_gp);
         const float c_qq = 24.0f / (dt * dt * dt), c_qv = 12.0f / (dt * dt), c_vv = 8.0f / dt;
         float av[QD], bv[QD];  // a_h = d c_h / d e_q,  b_h = d c_h / d e_v  for the segment (h, h+1)
 #pragma unroll
@@ -341,17 +362,10 @@ __device__ __forceinline__ void guide_gp_apply(const GuideArgs& a, int b, int ct
             g[j] = ap - av[j];
             g[QD + j] = bp - bv[j] - dt * av[j];
         }
-        float n2 = 0.f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) n2 += (g[d] + 1e-6f) * (g[d] + 1e-6f);
-        float ratio = 1.f;
-        if (a.gp.clip_grad) {
-            const float n = sqrtf(n2);
-            ratio = fminf(fmaxf(n, 0.f), a.gp.max_grad_norm) / n;
-        }
+        clip_waypoint_grad<D>(a.gp, g, 0);
         if (interior) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) total[d] += a.gp.gp_weight * (ratio * g[d]);
+            for (int d = 0; d < D; ++d) total[d] += a.gp.gp_weight * g[d];
         }
     }
 
@@ -361,7 +375,7 @@ __device__ __forceinline__ void guide_gp_apply(const GuideArgs& a, int b, int ct
     if (live) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const float inc = -1.0f * total[d];
+            const float inc = __fmul_rn(a.guide_scale, -1.0f * total[d]);
             if (a.grad_out) {
                 a.grad_out[base + d] = inc;
             } else {
@@ -508,18 +522,11 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
                 for (int j = 0; j < QD; ++j) g[j] += sB[(f * N + i) * QD + j];
             }
         }
-        // clip_grad_by_norm over ALL D dims of (g + 1e-6): the velocity dims of a collision gradient are 0
-        float n2 = (float)QD * (1e-6f * 1e-6f);
-#pragma unroll
-        for (int j = 0; j < QD; ++j) n2 += (g[j] + 1e-6f) * (g[j] + 1e-6f);
-        float ratio = 1.f;
-        if (gp.clip_grad) {
-            const float n = sqrtf(n2);
-            ratio = fminf(fmaxf(n, 0.f), gp.max_grad_norm) / n;
-        }
+        // clip over ALL D dims of (g + 1e-6): the velocity dims of a collision gradient are 0
+        clip_waypoint_grad<QD>(gp, g, QD);
         if (interior) {
 #pragma unroll
-            for (int j = 0; j < QD; ++j) cg[j] = gp.fields[f].weight * (ratio * g[j]);
+            for (int j = 0; j < QD; ++j) cg[j] = gp.fields[f].weight * g[j];
         }
     }
     static_assert(WPT >= MAXF, "one gathering wave per field");
@@ -745,17 +752,10 @@ __global__ __launch_bounds__(512) void guide_step_panda_kernel(const GuideArgs a
                 }
             }
         }
-        // clip_grad_by_norm over ALL D dims of (g + 1e-6): the velocity dims of a collision gradient are 0
-        float n2 = (float)QD * (1e-6f * 1e-6f);
+        // clip over ALL D dims of (g + 1e-6): the velocity dims of a collision gradient are 0
+        clip_waypoint_grad<QD>(gp, g, QD);
 #pragma unroll
-        for (int j = 0; j < QD; ++j) n2 += (g[j] + 1e-6f) * (g[j] + 1e-6f);
-        float ratio = 1.f;
-        if (gp.clip_grad) {
-            const float n = sqrtf(n2);
-            ratio = fminf(fmaxf(n, 0.f), gp.max_grad_norm) / n;
-        }
-#pragma unroll
-        for (int j = 0; j < QD; ++j) sC[(f * H + lane) * QD + j] = interior ? gp.fields[f].weight * (ratio * g[j]) : 0.f;
+        for (int j = 0; j < QD; ++j) sC[(f * H + lane) * QD + j] = interior ? gp.fields[f].weight * g[j] : 0.f;
     }
     __syncthreads();
     G_STAMP();  // 5 gathered + clipped

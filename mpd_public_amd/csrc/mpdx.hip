@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -34,6 +36,27 @@ static int fail(int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                       \
         if (e_ != hipSuccess) return fail((int)e_, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) must be applied once per (device, kernel): guarded by a mutex and keyed by
+// the current device, so that several host threads / several GPUs in one process are safe.
+static int raise_lds_limit(const void* kern) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, kern})) return 0;
+    HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done.insert({dev, kern});
+    return 0;
+}
+
+// MPDX_DEBUG=1: check hipGetLastError() after every launch group of mpdx_plan (2: also synchronise the stream there, so
+// that an asynchronous fault is attributed to the step that caused it).  Off by default: the plan never synchronises.
+static int debug_level() {
+    static const int lv = getenv("MPDX_DEBUG") ? atoi(getenv("MPDX_DEBUG")) : 0;
+    return lv;
+}
 
 static long long* g_conv_trace = nullptr;   // dev tool (mpdx_layer_trace)
 static long long* g_guide_trace = nullptr;  // dev tool (mpdx_guide_trace)
@@ -331,7 +354,7 @@ struct mpdx_unet {
         mpdx::FusedArgs tmpl;
     };
     std::vector<Fused> fused;
-    struct Unit { int fused; int layer; };   // fused >= 0: fused[fused]; else layers[layer]
+    struct Unit { int fused; int layer; bool pair; };   // fused >= 0: fused[fused]; else layers[layer] (pair: + layers[layer+1] in one launch)
     std::vector<int> owner;                  // layer -> fused segment (-1: per-layer launch)
 };
 
@@ -763,13 +786,8 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     const size_t lds = conv_block_lds_bytes<MODE, KS, MT, NT, WK>(a.L_in, a.L_out, a.rs);
     if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "conv tile needs %zu B of LDS", lds);
     auto kern = conv_block_kernel<MODE, KS, EPI, MT, NT, WN, WK>;
-    if (lds > 64 * 1024) {
-        static thread_local bool raised = false;  // per instantiation
-        if (!raised) {
-            HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
-        }
-    }
+    if (lds > 64 * 1024)
+        if (int rc = raise_lds_limit((const void*)kern)) return rc;
     const int grid = (a.C_out / MT) * a.n_tiles_n;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WN * WK), lds, st, a);
     return 0;
@@ -897,34 +915,39 @@ static int launch_pair(const ConvArgs& a1, const ConvArgs& a2, const Layer& l1, 
                                 conv_block_lds_bytes<CONV_S1, 1, MT, NT, 8>(l2.L_in, l2.L_out, l2.rs));
     if (lds > 160 * 1024) return 0;
     auto kern = conv_pair_kernel<MT, NT>;
-    static thread_local bool raised = false;
-    if (lds > 64 * 1024 && !raised) {
-        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        raised = true;
-    }
+    if (lds > 64 * 1024)
+        if (raise_lds_limit((const void*)kern)) return -1;
     const int n1 = (a1.C_out / MT) * a1.n_tiles_n, n2 = (a2.C_out / MT) * a2.n_tiles_n;
     hipLaunchKernelGGL(kern, dim3(n1 + n2), dim3(512), lds, st, a1, a2, n1);
     return 1;
 }
 
-static int run_pair(const mpdx_unet* u, const Layer& l1, const Layer& l2, const float* packed, const float* tt_row, const float* x, float* ws,
-                    int B, hipStream_t st) {
+// blocks[0] + residual 1x1 conv of one ResidualTemporalBlock qualify for ONE launch (conv_pair_kernel)?  On success the tile.
+static bool pair_tile(const Layer& l1, const Layer& l2, int B, int& MT, int& NT) {
     static const bool off = getenv("MPDX_PAIR") && atoi(getenv("MPDX_PAIR")) == 0;
-    if (off) return 0;
-    if (!(l1.mode == CONV_S1 && l1.ks == 5 && l1.epi == EPI_GN_MISH && l2.mode == CONV_S1 && l2.ks == 1 && l2.epi == EPI_BIAS)) return 0;
-    if (l1.src1 != l2.src1 || l1.src2 != l2.src2 || l1.cout != l2.cout || l1.L_out != l2.L_out || !layer_ksplit(l1)) return 0;
-    int MT, NT;
+    if (off) return false;
+    if (!(l1.mode == CONV_S1 && l1.ks == 5 && l1.epi == EPI_GN_MISH && l2.mode == CONV_S1 && l2.ks == 1 && l2.epi == EPI_BIAS)) return false;
+    if (l1.src1 != l2.src1 || l1.src2 != l2.src2 || l1.cout != l2.cout || l1.L_out != l2.L_out || !layer_ksplit(l1)) return false;
     choose_tile(l1, B, MT, NT);   // the k5 block decides the tile; the 1x1 conv has no constraint beyond it
     if (l1.cout % MT) MT = 16;
-    if (l1.cout % MT || NT % l1.L_out) return 0;
+    if (l1.cout % MT || NT % l1.L_out) return false;
+    const size_t lds = std::max({(size_t)(NT / l1.L_out) * (l1.L_in + 4) * l1.rs * sizeof(float), (size_t)(NT / l2.L_out) * l2.L_in * l2.rs * sizeof(float),
+                                 (size_t)8 * NT * (MT + 4) * sizeof(float)});   // as launch_pair computes it
+    return lds <= 160 * 1024;
+}
+
+static int run_pair(const mpdx_unet* u, const Layer& l1, const Layer& l2, const float* packed, const float* tt_row, const float* x, float* ws,
+                    int B, hipStream_t st) {
+    int MT, NT;
+    if (!pair_tile(l1, l2, B, MT, NT)) return fail(MPDX_E_STATE, "layers %s / %s do not pair", l1.name.c_str(), l2.name.c_str());
     ConvArgs a1, a2;
     if (int rc = make_conv_args(u, l1, packed, tt_row, x, ws, B, 0, a1)) return rc;
     if (int rc = make_conv_args(u, l2, packed, tt_row, x, ws, B, 0, a2)) return rc;
     a1.n_tiles_n = a2.n_tiles_n = (int)(((long)B * l1.L_out + NT - 1) / NT);
-#define MPDX_PAIR_TILE(mt, nt) if (MT == mt && NT == nt) return launch_pair<mt, nt>(a1, a2, l1, l2, st);
+#define MPDX_PAIR_TILE(mt, nt) if (MT == mt && NT == nt) return launch_pair<mt, nt>(a1, a2, l1, l2, st) == 1 ? 0 : fail(MPDX_E_INVALID, "pair launch failed");
     MPDX_PAIR_TILE(32, 64) MPDX_PAIR_TILE(32, 32) MPDX_PAIR_TILE(16, 64) MPDX_PAIR_TILE(16, 32) MPDX_PAIR_TILE(32, 16) MPDX_PAIR_TILE(16, 16)
 #undef MPDX_PAIR_TILE
-    return 0;
+    return fail(MPDX_E_INVALID, "no pair instantiation for tile %dx%d", MT, NT);
 }
 
 static int check_ready(const mpdx_unet* u) {
@@ -951,11 +974,21 @@ static std::vector<mpdx_unet::Unit> current_units(const mpdx_unet* u, int B, boo
     std::vector<mpdx_unet::Unit> out;
     const unsigned m = fused_mask(B);
     bool fin = false;
-    for (int i = 0; i < (int)u->layers.size(); ++i) {
+    const int nlay = (int)u->layers.size();
+    auto fused_on = [&](int i) { const int o = u->owner[i]; return o >= 0 && ((m >> o) & 1u); };
+    for (int i = 0; i < nlay; ++i) {
         const int o = u->owner[i];
-        if (o >= 0 && ((m >> o) & 1u)) {
-            if (i == u->fused[o].first) { out.push_back({o, i}); fin |= u->fused[o].has_final; }
-        } else out.push_back({-1, i});
+        if (fused_on(i)) {
+            if (i == u->fused[o].first) { out.push_back({o, i, false}); fin |= u->fused[o].has_final; }
+            continue;
+        }
+        int MT, NT;
+        if (i + 1 < nlay && !fused_on(i + 1) && pair_tile(u->layers[i], u->layers[i + 1], B, MT, NT)) {
+            out.push_back({-1, i, true});   // blocks[0] followed by the same block's residual 1x1 conv: one launch
+            ++i;
+            continue;
+        }
+        out.push_back({-1, i, false});
     }
     if (final_in_fused) *final_in_fused = fin;
     return out;
@@ -990,13 +1023,26 @@ static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packe
         a.x_in = fa->x_in; a.noise = fa->noise; a.hs = fa->hs; a.hg = fa->hg; a.out = fa->out; a.chain = fa->chain;
         a.absmax = fa->absmax; a.fmode = fa->mode; a.n_per_ctx = fa->n_per_ctx > 0 ? fa->n_per_ctx : B; a.k = fa->k;
     }
-    static bool raised = false;
-    if (!raised) {
-        HIP_TRY(hipFuncSetAttribute((const void*)fused_level_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        raised = true;
-    }
+    if (int rc = raise_lds_limit((const void*)fused_level_kernel)) return rc;
     hipLaunchKernelGGL(fused_level_kernel, dim3(B), dim3(512), f.lds_bytes, st, a);
     return 0;
+}
+
+// one launch unit of the pass (the SAME function serves the planning path, the profiler and the in-situ timer)
+static int run_unit(mpdx_unet* u, const mpdx_unet::Unit& un, const float* packed, const float* row, const float* x, float* ws, int B,
+                    const FinalArgs* fa, hipStream_t st) {
+    if (un.fused >= 0) return run_fused(u, u->fused[un.fused], packed, row, x, ws, B, fa, st);
+    if (un.pair) return run_pair(u, u->layers[un.layer], u->layers[un.layer + 1], packed, row, x, ws, B, st);
+    return run_layer(u, u->layers[un.layer], packed, row, x, ws, B, st);
+}
+static double unit_flops(const mpdx_unet* u, const mpdx_unet::Unit& un, int B) {
+    if (un.fused >= 0) {
+        const auto& f = u->fused[un.fused];
+        double fl = 0.0;
+        for (int k = f.first; k < f.first + f.count; ++k) fl += layer_flops(u->layers[k], B);
+        return fl;
+    }
+    return layer_flops(u->layers[un.layer], B) + (un.pair ? layer_flops(u->layers[un.layer + 1], B) : 0.0);
 }
 
 // one U-Net pass + the final 1x1 conv / DDPM step described by `fa` (fa.mode 0: eps only)
@@ -1008,21 +1054,9 @@ static int run_unet_and_final(mpdx_unet* u, const float* packed, const float* ti
     const float* row = timetab + (size_t)t * u->tt_row;
     const auto units = current_units(u, B, nullptr);
     bool final_done = false;
-    for (size_t k = 0; k < units.size(); ++k) {
-        const auto& un = units[k];
-        if (un.fused >= 0) {
-            const auto& f = u->fused[un.fused];
-            if (int rc = run_fused(u, f, packed, row, x, ws, B, &fa, st)) return rc;
-            final_done |= f.has_final;
-            continue;
-        }
-        // blocks[0] followed by the same block's residual 1x1 conv: one launch
-        if (k + 1 < units.size() && units[k + 1].fused < 0 && units[k + 1].layer == un.layer + 1) {
-            const int pr = run_pair(u, u->layers[un.layer], u->layers[un.layer + 1], packed, row, x, ws, B, st);
-            if (pr < 0) return pr;
-            if (pr == 1) { ++k; continue; }
-        }
-        if (int rc = run_layer(u, u->layers[un.layer], packed, row, x, ws, B, st)) return rc;
+    for (const auto& un : units) {
+        if (int rc = run_unit(u, un, packed, row, x, ws, B, &fa, st)) return rc;
+        if (un.fused >= 0) final_done |= u->fused[un.fused].has_final;
     }
     if (!final_done)
         if (int rc = run_final(u, packed, fa, B, ws, st)) return rc;
@@ -1031,7 +1065,8 @@ static int run_unet_and_final(mpdx_unet* u, const float* packed, const float* ti
 
 static int launch_guide(const mpdx_guide_params* gp, float* x, float* grad_out, const float* hs, const float* hg,
                         const uint32_t* amax_in, uint32_t* amax_out, int n_per_ctx, int B, int H, int D, hipStream_t st,
-                        const float* noise = nullptr, float noise_scale = 0.f, float noise_extra = 0.f, float* chain = nullptr) {
+                        const float* noise = nullptr, float noise_scale = 0.f, float noise_extra = 0.f, float* chain = nullptr,
+                        float guide_scale = 1.0f) {
     if (!gp || !x || !amax_in) return fail(MPDX_E_INVALID, "null argument");
     if (H > 64 || H < 2) return fail(MPDX_E_INVALID, "guide kernel maps one support point per lane: H=%d unsupported (max 64)", H);
     if (D != 2 * gp->q_dim || D > 16) return fail(MPDX_E_INVALID, "state dim %d != 2*q_dim (%d)", D, gp->q_dim);
@@ -1042,6 +1077,8 @@ static int launch_guide(const mpdx_guide_params* gp, float* x, float* grad_out, 
     a.gp = *gp; a.x = x; a.grad_out = grad_out; a.hs = hs; a.hg = hg; a.amax_in = amax_in; a.amax_out = amax_out;
     a.B = B; a.H = H; a.D = D; a.n_per_ctx = n_per_ctx > 0 ? n_per_ctx : B;
     a.noise = noise; a.noise_scale = noise_scale; a.noise_extra = noise_extra; a.chain = chain;
+    a.guide_scale = guide_scale;
+    if (gp->clip_grad && gp->clip_rule != 0 && gp->clip_rule != 1) return fail(MPDX_E_INVALID, "clip_rule %d (0 = 'norm', 1 = 'value')", gp->clip_rule);
     a.trace = g_guide_trace;
     const size_t lds = guide_lds_bytes(*gp, H, D);
     if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "guide needs %zu B of LDS (n_interp %d too large)", lds, gp->n_interp);
@@ -1050,11 +1087,7 @@ static int launch_guide(const mpdx_guide_params* gp, float* x, float* grad_out, 
     else if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 3 && gp->ws_dim == 3)
         hipLaunchKernelGGL((guide_step_kernel<3, 3, MPDX_ROBOT_POINTMASS, 8>), dim3(B), dim3(512), lds, st, a);
     else if (gp->robot == MPDX_ROBOT_PANDA && gp->q_dim == 7 && gp->ws_dim == 3) {
-        static bool raised = false;
-        if (!raised) {
-            HIP_TRY(hipFuncSetAttribute((const void*)guide_step_panda_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
-        }
+        if (int rc = raise_lds_limit((const void*)guide_step_panda_kernel)) return rc;
         hipLaunchKernelGGL(guide_step_panda_kernel, dim3(B), dim3(512), lds, st, a);
     }
     else
@@ -1223,6 +1256,15 @@ int mpdx_guide_step(const mpdx_guide_params* gp, float* x, float* grad_out, cons
     return 0;
 }
 
+int mpdx_guide_step_scaled(const mpdx_guide_params* gp, float* x, float* grad_out, const float* hard_start, const float* hard_goal,
+                           const uint32_t* absmax_in, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, float guide_scale, void* stream) {
+    if (int rc = launch_guide(gp, x, grad_out, hard_start, hard_goal, absmax_in, absmax_out, n_per_ctx, B, H, D, (hipStream_t)stream, nullptr, 0.f,
+                              0.f, nullptr, guide_scale))
+        return rc;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int mpdx_traj_metrics(const mpdx_guide_params* gp, const float* x_unnormalised, float* out4, int n_check, int B, int H, int D, void* stream) {
     if (!gp || !x_unnormalised || !out4 || B <= 0) return fail(MPDX_E_INVALID, "bad argument");
     if (H > 64 || H < 2) return fail(MPDX_E_INVALID, "H=%d unsupported (max 64)", H);
@@ -1286,8 +1328,11 @@ int mpdx_plan(mpdx_unet* u, const float* packed, const float* timetab, int T, co
     const int npc = n_per_ctx > 0 ? n_per_ctx : B;
     const int n_ctx = (B + npc - 1) / npc;
     const int steps = T + n_without_noise;
+    if (n_guide_steps < 0) return fail(MPDX_E_INVALID, "n_guide_steps %d", n_guide_steps);
+    if (n_guide_steps == 0) guide = nullptr;   // range(0): the reference runs no guide iteration (sample_functions.py:74)
+    const int dbg = debug_level();
     if (guide) {
-        if (!guide_flags || n_guide_steps < 1) return fail(MPDX_E_INVALID, "guide needs guide_flags and n_guide_steps >= 1");
+        if (!guide_flags) return fail(MPDX_E_INVALID, "guide needs guide_flags");
         if (B % npc) return fail(MPDX_E_INVALID, "B=%d is not a multiple of n_per_ctx=%d", B, npc);
         HIP_TRY(hipMemsetAsync(guide_flags, 0, (size_t)steps * (n_guide_steps + 1) * n_ctx * sizeof(uint32_t), st));
     }
@@ -1315,9 +1360,18 @@ int mpdx_plan(mpdx_unet* u, const float* packed, const float* timetab, int T, co
             for (int j = 0; j < n_guide_steps; ++j) {
                 const bool last = j == n_guide_steps - 1;  // the last iteration also adds the noise term and appends to the chain
                 if (int rc = launch_guide(guide, x, nullptr, hard_start, hard_goal, fl + (size_t)j * n_ctx, fl + (size_t)(j + 1) * n_ctx, npc, B, H,
-                                          D, st, last ? nz : nullptr, coefs[t].noise_scale, coefs[t].noise_std_extra, last ? ch : nullptr))
+                                          D, st, last ? nz : nullptr, coefs[t].noise_scale, coefs[t].noise_std_extra, last ? ch : nullptr,
+                                          coefs[t].guide_scale))
                     return rc;
             }
+        }
+        if (dbg) {   // MPDX_DEBUG: attribute launch / execution errors to the loop iteration that caused them
+            if (dbg >= 2) {
+                hipError_t e = hipStreamSynchronize(st);
+                if (e != hipSuccess) return fail((int)e, "mpdx_plan: loop iteration %d (t=%d%s) faulted: %s", k, t, guided ? ", guided" : "", hipGetErrorString(e));
+            }
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail((int)e, "mpdx_plan: launch in loop iteration %d (t=%d%s) failed: %s", k, t, guided ? ", guided" : "", hipGetErrorString(e));
         }
     }
     HIP_TRY(hipGetLastError());
@@ -1350,19 +1404,14 @@ int mpdx_unet_profile(mpdx_unet* u, const float* packed, const float* timetab, i
     int rc = 0;
     for (int i = 0; i < (int)units.size() && !rc; ++i) {
         HIP_TRY(hipEventRecord(ev[2 * i], st));
-        double fl = 0.0;
+        const double fl = unit_flops(u, units[i], B);
+        rc = run_unit(u, units[i], packed, row, x, ws, B, &fa, st);
         if (units[i].fused >= 0) {
             const auto& f = u->fused[units[i].fused];
-            rc = run_fused(u, f, packed, row, x, ws, B, &fa, st);
-            for (int k = f.first; k < f.first + f.count; ++k) fl += layer_flops(u->layers[k], B);
             fused_names[units[i].fused] = "fused[" + u->layers[f.first].name.substr(0, u->layers[f.first].name.find(".blocks")) + "..+" +
                                           std::to_string(f.count) + (f.has_final ? " layers+final_conv.1+ddpm_step]" : " layers]");
             if (names_out) names_out[i] = fused_names[units[i].fused].c_str();
-        } else {
-            rc = run_layer(u, u->layers[units[i].layer], packed, row, x, ws, B, st);
-            fl = layer_flops(u->layers[units[i].layer], B);
-            if (names_out) names_out[i] = u->layers[units[i].layer].name.c_str();
-        }
+        } else if (names_out) names_out[i] = u->layers[units[i].layer].name.c_str();
         HIP_TRY(hipEventRecord(ev[2 * i + 1], st));
         if (flops_out) flops_out[i] = fl;
     }
@@ -1450,10 +1499,8 @@ int mpdx_unet_time_units(mpdx_unet* u, const float* packed, const float* timetab
         bool final_done = false;
         for (int i = 0; i < (int)units.size() && !rc; ++i) {
             if (i == unit_first) HIP_TRY(hipEventRecord(ev[2 * r], st));
-            if (units[i].fused >= 0) {
-                rc = run_fused(u, u->fused[units[i].fused], packed, row, x, ws, B, &fa, st);
-                final_done |= u->fused[units[i].fused].has_final;
-            } else rc = run_layer(u, u->layers[units[i].layer], packed, row, x, ws, B, st);
+            rc = run_unit(u, units[i], packed, row, x, ws, B, &fa, st);
+            if (units[i].fused >= 0) final_done |= u->fused[units[i].fused].has_final;
             if (i == unit_last) HIP_TRY(hipEventRecord(ev[2 * r + 1], st));
         }
         if (!rc && !final_done) rc = run_final(u, packed, fa, B, ws, st);
@@ -1472,6 +1519,13 @@ int mpdx_unet_unit_layer(const mpdx_unet* u, int B, int i) {
     const auto units = current_units(u, B, nullptr);
     if (i < 0 || i >= (int)units.size()) return -1;
     return units[i].fused >= 0 ? -1 : units[i].layer;
+}
+
+/* 1 when launch unit i is a paired launch (blocks[0] + the block's residual 1x1 conv in one conv_pair_kernel) */
+int mpdx_unet_unit_is_pair(const mpdx_unet* u, int B, int i) {
+    if (!u) return 0;
+    const auto units = current_units(u, B, nullptr);
+    return (i >= 0 && i < (int)units.size() && units[i].fused < 0 && units[i].pair) ? 1 : 0;
 }
 
 int mpdx_bench_layer(mpdx_unet* u, const float* packed, const float* timetab, const float* x, int layer, int B, float* ws,

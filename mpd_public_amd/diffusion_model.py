@@ -33,6 +33,7 @@ class GaussianDiffusionModel(nn.Module):
         self.clip_denoised = clip_denoised
         self.predict_epsilon = predict_epsilon
         self.loss_type = loss_type
+        self.loss_fn = {"l1": "WeightedL1", "l2": "WeightedL2"}.get(loss_type, loss_type)  # the reference keeps the loss module here
         for name, value in diffusion_buffers(variance_schedule, n_diffusion_steps).items():
             self.register_buffer(name, value)
         self._host = None
@@ -49,6 +50,7 @@ class GaussianDiffusionModel(nn.Module):
             host = {k: v.detach().to("cpu", torch.float32) for k, v in self.named_buffers() if "." not in k}
             # model_std = exp(0.5 * posterior_log_variance_clipped[t])  (sample_functions.py:35-36), fp32 like the reference
             host["noise_scale"] = torch.exp(0.5 * host["posterior_log_variance_clipped"])
+            host["model_var"] = torch.exp(host["posterior_log_variance_clipped"])   # sample_functions.py:36 (scale_grad_by_std)
             self._host = {k: v.numpy() for k, v in host.items()}
             self._host_stamp = stamp
             self._coef_cache = {}
@@ -66,23 +68,24 @@ class GaussianDiffusionModel(nn.Module):
         return out
 
     # ---------------------------------------------------------------------------------------------- fused loop
-    def _coef_table(self, noise_std_extra_schedule_fn):
-        """ctypes array [T] of mpdx_step_coefs, cached per (schedule buffers, extra-noise schedule values)."""
+    def _coef_table(self, noise_std_extra_schedule_fn, scale_grad_by_std=False):
+        """ctypes array [T] of mpdx_step_coefs, cached per (schedule buffers, extra-noise schedule values, guide scaling)."""
         T = self.n_diffusion_steps
         self.host_buffers()
         extras = tuple(1.0 if noise_std_extra_schedule_fn is None else float(noise_std_extra_schedule_fn(t)) for t in range(T))
-        arr = self._coef_cache.get(extras)
+        key = (extras, bool(scale_grad_by_std))
+        arr = self._coef_cache.get(key)
         if arr is None:
             arr = (_lib.StepCoefs * T)()
             for t in range(T):
-                arr[t] = step_coefs(self, t, extras[t])
-            self._coef_cache[extras] = arr
+                arr[t] = step_coefs(self, t, extras[t], scale_grad_by_std)
+            self._coef_cache[key] = arr
         return arr
 
     @torch.no_grad()
     def plan(self, hard_conds, n_samples, horizon=None, n_diffusion_steps_without_noise=0, noise=None,
              noise_std_extra_schedule_fn=None, return_chain=True, guide=None, n_guide_steps=1, t_start_guide=float("inf"),
-             n_per_context=None):
+             n_per_context=None, scale_grad_by_std=False):
         """The whole reverse loop of p_sample_loop (diffusion_model_base.py:157-182) enqueued by ONE mpdx_plan call,
         without host synchronisation.  hard_conds: {0: start[B,D] or [D], H-1: goal}.  Returns (x_final, chain or None)
         with chain laid out [steps+1, B, H, D] (run_inference's order).
@@ -110,11 +113,13 @@ class GaussianDiffusionModel(nn.Module):
         else:
             noise = noise.to(device=dev, dtype=torch.float32).contiguous()
             assert tuple(noise.shape) == (steps + 1, B, H, D), noise.shape
-        coefs = self._coef_table(noise_std_extra_schedule_fn)
+        coefs = self._coef_table(noise_std_extra_schedule_fn, scale_grad_by_std)
         x = noise[0].clone()
         chain = torch.empty((steps + 1, B, H, D), device=dev, dtype=torch.float32) if return_chain else None
         npc = int(n_per_context or B)
         gp_ref, flags, n_gs, t_sg = None, None, 0, 0
+        if int(n_guide_steps) <= 0:
+            guide = None   # range(0): the reference runs no guide iteration
         if guide is not None:
             import ctypes as C
             gp_ref = C.byref(guide.device_params(dev))
@@ -143,6 +148,19 @@ class GaussianDiffusionModel(nn.Module):
                                               _lib.current_stream()), "mpdx_ddpm_step")
         return mean, extract(self.posterior_variance, t, x.shape), extract(self.posterior_log_variance_clipped, t, x.shape)
 
+    def _normalise_hard_conds(self, hard_conds, B, device):
+        """{t: [D] or [B,D] on any device} -> {t: contiguous fp32 [B,D] on `device`} (what the kernels index as hs[b*D+d];
+        the reference's `x[:, t, :] = val` broadcasts a [D] value)."""
+        out = {}
+        for k, v in (hard_conds or {}).items():
+            v = torch.as_tensor(v).to(device=device, dtype=torch.float32)
+            if v.dim() == 1:
+                v = v.reshape(1, -1).expand(B, -1)
+            if v.shape != (B, self.state_dim):
+                raise ValueError(f"hard condition at horizon index {k}: expected [{self.state_dim}] or [{B},{self.state_dim}], got {tuple(v.shape)}")
+            out[k] = v.contiguous()
+        return out
+
     @torch.no_grad()
     def p_sample_loop(self, shape, hard_conds, context=None, return_chain=False, sample_fn=ddpm_sample_fn,
                       n_diffusion_steps_without_noise=0, noise=None, **sample_kwargs):
@@ -150,9 +168,11 @@ class GaussianDiffusionModel(nn.Module):
         device = self.betas.device
         batch_size = shape[0]
         if noise is not None:
-            x = noise[0].to(device=device, dtype=torch.float32).clone()
+            noise = noise.to(device=device, dtype=torch.float32).contiguous()   # converted once: noise[k] is handed to the kernels
+            x = noise[0].clone()
         else:
             x = self.fill_randn(torch.empty(shape, device=device, dtype=torch.float32))
+        hard_conds = self._normalise_hard_conds(hard_conds, batch_size, device)
         x = apply_hard_conditioning(x, hard_conds)
         chain = [x] if return_chain else None
         k = 1
@@ -187,14 +207,15 @@ class GaussianDiffusionModel(nn.Module):
             x = noise[0].to(device=device, dtype=torch.float32).clone()
         else:
             x = self.fill_randn(torch.empty(shape, device=device, dtype=torch.float32))
+        hard_conds = self._normalise_hard_conds(hard_conds, B, device)   # [D] values broadcast, CPU values moved: the kernel reads hs[b*D+d]
         x = apply_hard_conditioning(x, hard_conds)
         chain = [x.clone()] if return_chain else None
         hdl, packed, tab, ws = self.model.engine(total, B)
         lib, hb = _lib.load(), self.host_buffers()
         keys = set(hard_conds.keys())
         native_hc = keys <= {0, H - 1}
-        hs = hard_conds.get(0).contiguous().float() if (native_hc and 0 in hard_conds) else None
-        hg = hard_conds.get(H - 1).contiguous().float() if (native_hc and (H - 1) in hard_conds) else None
+        hs = hard_conds.get(0) if native_hc else None
+        hg = hard_conds.get(H - 1) if native_hc else None
         for time, time_next in pairs:
             guided = guide is not None and time_next >= 0 and time_next < t_start_guide
             c = step_coefs(self, time)
@@ -210,7 +231,9 @@ class GaussianDiffusionModel(nn.Module):
                                           None, None, B, B, ws.data_ptr(), _lib.current_stream()), "mpdx_ddpm_step(ddim)")
             if guided:
                 from .sample_functions import guide_gradient_steps
-                x = guide_gradient_steps(x, hard_conds=hard_conds, guide=guide, n_guide_steps=n_guide_steps, **sample_kwargs)
+                # the reference names n_guide_steps in ddim_sample's signature and never forwards it (:240-246): ONE guide step per
+                # time pair whatever the caller passed - reproduced
+                x = guide_gradient_steps(x, hard_conds=hard_conds, guide=guide, **sample_kwargs)
             if not in_kernel_hc:
                 x = apply_hard_conditioning(x, hard_conds)
             if return_chain:
@@ -246,16 +269,21 @@ class GaussianDiffusionModel(nn.Module):
         fused = diffusion_kwargs.pop("fused", True)  # extension: fused=False forces the step-by-step protocol loop
         kw.pop("fused", None)
         from .guides import GuideManagerTrajectoriesWithVelocity as _NativeGuide
-        if fused and kw.pop("sample_fn", ddpm_sample_fn) is ddpm_sample_fn \
-                and (kw.get("guide") is None or isinstance(kw.get("guide"), _NativeGuide)) and not kw.get("ddim", False) \
-                and not kw.get("scale_grad_by_std", False) and set(hard_conds.keys()) <= {0, (horizon or self.model.n_support_points) - 1}:
-            # fused path: one mpdx_plan call for the whole loop
+        g = kw.get("guide")
+        native_guide = g is None or (isinstance(g, _NativeGuide) and g.is_native)
+        if fused and kw.pop("sample_fn", ddpm_sample_fn) is ddpm_sample_fn and native_guide and not kw.get("ddim", False) \
+                and set(hard_conds.keys()) <= {0, (horizon or self.model.n_support_points) - 1}:
+            # fused path: one mpdx_plan call for the whole loop.  What stays on the step-by-step protocol loop below (same
+            # kernels, one call per step): a caller-supplied sample_fn, DDIM, a guide around an arbitrary Python cost
+            # (torch autograd), hard conditions at horizon indices other than 0 / H-1.
             x, chain = self.plan(hard_conds, n_samples, horizon, kw.get("n_diffusion_steps_without_noise", 0), kw.get("noise"),
-                                 kw.get("noise_std_extra_schedule_fn"), return_chain=True, guide=kw.get("guide"),
-                                 n_guide_steps=kw.get("n_guide_steps", 1), t_start_guide=kw.get("t_start_guide", float("inf")))
+                                 kw.get("noise_std_extra_schedule_fn"), return_chain=True, guide=g,
+                                 n_guide_steps=kw.get("n_guide_steps", 1), t_start_guide=kw.get("t_start_guide", float("inf")),
+                                 scale_grad_by_std=bool(kw.get("scale_grad_by_std", False)))
             return chain if return_chain else chain[-1]
         for k, v in hard_conds.items():
-            hard_conds[k] = v.reshape(1, -1).expand(n_samples, -1).contiguous()  # 'd -> b d'
+            if v.dim() == 1:
+                hard_conds[k] = v.reshape(1, -1).expand(n_samples, -1).contiguous()  # 'd -> b d'
         samples, chain = self.conditional_sample(hard_conds, context=None, batch_size=n_samples, return_chain=True,
                                                  **diffusion_kwargs)
         chain = chain.permute(1, 0, 2, 3)  # 'b diffsteps h d -> diffsteps b h d'

@@ -17,13 +17,17 @@ from . import _lib
 from .planning import CostCollision, CostComposite, CostGPTrajectory
 
 
-def build_device_params(robot, ws_dim, cutoff_margin, mins, maxs, cost_l, weight_l, interpolate, n_interp, clip_grad, max_grad_norm, device):
+def build_device_params(robot, ws_dim, cutoff_margin, mins, maxs, cost_l, weight_l, interpolate, n_interp, clip_grad, max_grad_norm, device,
+                        clip_grad_rule="norm", max_grad_value=0.1):
     """Compile cost descriptors into the `mpdx_guide_params` block the HIP kernels take.  Returns (params, primitive
     table tensor) - the caller keeps the tensor alive (params holds its raw device pointer)."""
     gp = _lib.GuideParams()
     gp.robot, gp.q_dim, gp.ws_dim = robot.robot_id, robot.q_dim, ws_dim
     gp.interpolate, gp.n_interp = int(bool(interpolate)), int(n_interp)
     gp.clip_grad, gp.max_grad_norm = int(bool(clip_grad)), float(max_grad_norm)
+    if clip_grad_rule not in ("norm", "value"):
+        raise NotImplementedError(f"clip_grad_rule={clip_grad_rule!r}")   # as guides.py:219-220
+    gp.clip_rule, gp.max_grad_value = (1 if clip_grad_rule == "value" else 0), float(max_grad_value)
     D = 2 * robot.q_dim
     if mins is not None:
         mins, maxs = torch.as_tensor(mins).cpu().numpy(), torch.as_tensor(maxs).cpu().numpy()
@@ -53,6 +57,7 @@ def build_device_params(robot, ws_dim, cutoff_margin, mins, maxs, cost_l, weight
             if gp.use_gp:
                 raise NotImplementedError("one CostGPTrajectory term")
             gp.use_gp, gp.gp_weight, gp.dt, gp.sigma_gp = 1, float(w), float(c.dt), float(c.sigma_gp)
+            gp.gp_half_factor = int(bool(getattr(c, "half_factor", False)))
         else:
             raise NotImplementedError(type(c))
     gp.n_fields = nf
@@ -68,11 +73,16 @@ class GuideManagerTrajectoriesWithVelocity(nn.Module):
                  interpolate_trajectories_for_collision=False, num_interpolated_points_for_collision=128,
                  start_state_pos=None, goal_state_pos=None, num_steps=100, robot=None, n_samples=1, tensor_args=None, **kwargs):
         super().__init__()
-        if not isinstance(cost, CostComposite):
-            raise TypeError("cost must be a mpd_public_amd.planning.CostComposite (arbitrary Python costs need autograd; "
-                            "the device guide has hand-derived gradients for the reference's cost terms only)")
-        if clip_grad and clip_grad_rule != "norm":
-            raise NotImplementedError("clip_grad_rule='value' is never used by the reference entry (inference.py:229-236)")
+        # A CostComposite of the reference's cost terms is compiled into the HIP guide kernel (hand-derived gradients).
+        # Any other callable with the call-site contract of guides.py:190,
+        #     cost(x, x_interpolated=..., return_invidual_costs_and_weights=True) -> ([B] tensors, [weights]),
+        # is differentiated with torch autograd ON THE GPU exactly as the reference's manager does (guides.py:173-211);
+        # such a guide runs on the step-by-step protocol loop, not inside mpdx_plan.
+        self.is_native = isinstance(cost, CostComposite)
+        if not self.is_native and not callable(cost):
+            raise TypeError("cost must be a CostComposite or a callable with the contract of guides.py:190")
+        if clip_grad_rule not in ("norm", "value"):
+            raise NotImplementedError(f"clip_grad_rule={clip_grad_rule!r}")   # as guides.py:219-220
         self.cost, self.dataset = cost, dataset
         self.interpolate_trajectories_for_collision = interpolate_trajectories_for_collision
         self.num_interpolated_points_for_collision = num_interpolated_points_for_collision
@@ -92,12 +102,43 @@ class GuideManagerTrajectoriesWithVelocity(nn.Module):
         self._params, self._prims = build_device_params(
             ds.robot, ds.env.dim, ds.task.obstacle_cutoff_margin, ds.normalizer.mins, ds.normalizer.maxs, self.cost.cost_l,
             self.cost.weight_cost_l, self.interpolate_trajectories_for_collision, self.num_interpolated_points_for_collision,
-            self.clip_grad, self.max_grad_norm, device)
+            self.clip_grad, self.max_grad_norm, device, clip_grad_rule=self.clip_grad_rule, max_grad_value=self.max_grad_value)
         return self._params
 
     # ------------------------------------------------------------------------------------------- guide protocol
+    def _forward_autograd(self, x_normalized):
+        """guides.py:173-211 verbatim in behaviour, for a Python cost callable: torch autograd on the device."""
+        if not x_normalized.is_cuda:
+            raise RuntimeError("the guide runs on the GPU; there is no CPU fallback")
+        x = x_normalized.detach().clone()
+        with torch.enable_grad():
+            x.requires_grad_(True)
+            x = self.dataset.unnormalize_trajectories(x)
+            if self.interpolate_trajectories_for_collision:
+                xi = torch.nn.functional.interpolate(x.transpose(-2, -1), self.num_interpolated_points_for_collision, mode="linear",
+                                                     align_corners=True).transpose(-2, -1)
+            else:
+                xi = x
+            cost_l, w_l = self.cost(x, x_interpolated=xi, return_invidual_costs_and_weights=True)
+            grad = 0
+            for c, w in zip(cost_l, w_l):
+                if torch.is_tensor(c):
+                    g = torch.autograd.grad([c.sum()], [x], retain_graph=True)[0]
+                    if self.clip_grad:
+                        if self.clip_grad_rule == "norm":
+                            n = torch.linalg.norm(g + 1e-6, dim=-1, keepdims=True)
+                            g = torch.clip(n, 0.0, self.max_grad_norm) / n * g
+                        else:
+                            g = torch.clip(g, -self.max_grad_value, self.max_grad_value)
+                    g[..., 0, :] = 0.0
+                    g[..., -1, :] = 0.0
+                    grad = grad + w * g
+        return (-1.0 * grad).detach()
+
     @torch.no_grad()
     def forward(self, x_normalized):
+        if not self.is_native:
+            return self._forward_autograd(x_normalized)
         x = x_normalized.to(torch.float32).contiguous()
         B, H, D = x.shape
         gp = self.device_params(x.device)

@@ -70,6 +70,27 @@ def experiment(model_id: str = "EnvSpheres3D-RobotPanda", planner_alg: str = "mp
                                    predict_epsilon=args["predict_epsilon"])
     if ckpt is not None and os.path.exists(ckpt):
         model.load_state_dict(torch.load(ckpt, map_location="cpu"))
+        # The reference derives the normaliser limits from the training dataset (normalization.py:92-93) and the obstacles /
+        # link spheres from torch_robotics; neither travels with a checkpoint.  `model_dir/limits.yaml`
+        # ({mins: [D], maxs: [D]}) supplies the limits; without it trained weights would be run against SYNTHETIC
+        # normalisation - refuse unless the caller opts in.
+        lim = os.path.join(model_dir, "limits.yaml")
+        if os.path.exists(lim):
+            import yaml
+            with open(lim) as f:
+                lm = yaml.safe_load(f)
+            from .datasets import LimitsNormalizer
+            if len(lm["mins"]) != dataset.state_dim or len(lm["maxs"]) != dataset.state_dim:
+                raise ValueError(f"{lim}: expected {dataset.state_dim} mins/maxs")
+            dataset.normalizer = LimitsNormalizer(lm["mins"], lm["maxs"]).to(tensor_args["device"])
+        elif not kwargs.get("allow_synthetic_limits", False):
+            raise RuntimeError(f"{model_dir} holds trained weights but no limits.yaml: the normaliser limits (and the environment "
+                               "geometry) of this package are synthetic stand-ins (DESIGN.md section 5) and would not match the "
+                               "training data.  Provide model_dir/limits.yaml {mins, maxs} or pass allow_synthetic_limits=True.")
+        else:
+            import warnings
+            warnings.warn("trained checkpoint combined with SYNTHETIC normaliser limits / environment geometry: plans and metrics "
+                          "are not comparable with the reference's", RuntimeWarning)
     else:
         unet.load_state_dict(syn.synth_state_dict({k: tuple(v.shape) for k, v in unet.state_dict().items()}))
     model = model.to(tensor_args["device"]).eval()
@@ -132,7 +153,7 @@ def experiment(model_id: str = "EnvSpheres3D-RobotPanda", planner_alg: str = "mp
     fraction_free_trajs = task.compute_fraction_free_trajs(trajs_final)
     collision_intensity_trajs = task.compute_collision_intensity_trajs(trajs_final)
     if debug:
-        print(f"success: {success_free_trajs}\\npercentage free trajs: {fraction_free_trajs*100:.2f}\\n"
+        print(f"success: {success_free_trajs}\npercentage free trajs: {fraction_free_trajs*100:.2f}\n"
               f"percentage collision intensity: {collision_intensity_trajs*100:.2f}")
 
     traj_final_free_best = idx_best_traj = cost_best_free_traj = cost_smoothness = cost_path_length = cost_all = None

@@ -55,11 +55,14 @@ def plan_contexts(model, start: torch.Tensor, goal: torch.Tensor, n_samples: int
     return torch.cat(outs, dim=0), (lo, hi)
 
 
-def gather_trajectories(local: torch.Tensor, n_contexts: int, n_samples: int, group=None) -> torch.Tensor:
+def gather_trajectories(local: torch.Tensor, n_contexts: int, n_samples: int, group=None, force_collective: bool = False) -> torch.Tensor:
     """All-gather the per-rank trajectory blocks into [n_contexts*n_samples, H, D] on every rank (one collective).
-    Blocks may differ by one context in size: they are padded to the largest block for the collective."""
+    Blocks may differ by one context in size: they are padded to the largest block for the collective.
+    force_collective: issue the all-gather even in a world of one rank (exercises the RCCL path on a single GPU)."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
+        return local
+    if dist.get_world_size(group) == 1 and not force_collective:
         return local
     world = dist.get_world_size(group)
     sizes = [(shard_range(n_contexts, world, r)[1] - shard_range(n_contexts, world, r)[0]) * n_samples for r in range(world)]

@@ -240,12 +240,22 @@ def compute_path_length(trajs, robot):
     return torch.linalg.norm(torch.diff(q, dim=-2), dim=-1).sum(-1)
 
 
-def compute_variance_waypoints(trajs, robot):
-    """sum over waypoints of the variance of the positions across trajectories (restated)."""
+def compute_variance_waypoints(trajs, robot, definition="position_variance"):
+    """Diversity of a batch of trajectories, summed over the waypoints (torch_robotics.trajectory.metrics.compute_variance_waypoints,
+    un-vendored: restated; the definition is undecidable from the reference tree, so both plausible ones are offered):
+      'position_variance' (default): sum_h sum_j Var_b[q_{b,h,j}]  (unbiased variance of each coordinate across the batch)
+      'pairwise_distance'          : sum_h Var over unordered trajectory pairs of |q_{a,h} - q_{b,h}|  (SURVEY.md A20's recollection)"""
     q = robot.get_position(trajs)
     if q.shape[0] < 2:
         return 0.0
-    return float(q.var(dim=0).sum(-1).sum())
+    if definition == "position_variance":
+        return float(q.var(dim=0).sum(-1).sum())
+    if definition == "pairwise_distance":
+        B = q.shape[0]
+        ia, ib = torch.triu_indices(B, B, offset=1, device=q.device)
+        d = torch.linalg.norm(q[ia] - q[ib], dim=-1)     # [pairs, H]
+        return float(d.var(dim=0).sum()) if d.shape[0] > 1 else 0.0
+    raise ValueError(definition)
 
 
 # ------------------------------------------------------------------------------------------------ cost descriptors
@@ -259,8 +269,13 @@ class CostCollision:
 
 
 class CostGPTrajectory:
-    def __init__(self, robot, n_support_points, dt, sigma_gp=1.0, tensor_args=None, **kw):
+    """half_factor (extension, default False): whether the GP cost carries GPMP2's 1/2 (1/2 sum e^T Qinv e).  The reference's
+    implementation lives in an empty submodule, so the convention is undecidable here; it only matters where the per-waypoint
+    gradient norm is below max_grad_norm."""
+
+    def __init__(self, robot, n_support_points, dt, sigma_gp=1.0, tensor_args=None, half_factor=False, **kw):
         self.robot, self.n_support_points, self.dt, self.sigma_gp = robot, n_support_points, float(dt), float(sigma_gp)
+        self.half_factor = bool(half_factor)
 
 
 class CostComposite:

@@ -36,13 +36,15 @@ def extract(a, t, x_shape):
     return out.reshape(b, *((1,) * (len(x_shape) - 1)))
 
 
-def step_coefs(model, t: int, noise_std_extra: float = 1.0) -> "_lib.StepCoefs":
-    """The t-th entries of the model's registered buffers as the scalar block mpdx_ddpm_step takes."""
+def step_coefs(model, t: int, noise_std_extra: float = 1.0, scale_grad_by_std: bool = False) -> "_lib.StepCoefs":
+    """The t-th entries of the model's registered buffers as the scalar block mpdx_ddpm_step takes.
+    scale_grad_by_std: guide increments of this step are multiplied by model_var[t] (sample_functions.py:41-43,77-78)."""
     c = model.host_buffers()
     scale = 0.0 if t == 0 else float(c["noise_scale"][t])  # noise[t == 0] = 0  (sample_functions.py:52)
     return _lib.StepCoefs(float(c["sqrt_recip_alphas_cumprod"][t]), float(c["sqrt_recipm1_alphas_cumprod"][t]),
                           float(c["posterior_mean_coef1"][t]), float(c["posterior_mean_coef2"][t]), scale,
-                          float(noise_std_extra), int(bool(model.predict_epsilon)), int(bool(model.clip_denoised)), 1.0, 0.0)
+                          float(noise_std_extra), int(bool(model.predict_epsilon)), int(bool(model.clip_denoised)), 1.0, 0.0,
+                          float(c["model_var"][t]) if scale_grad_by_std else 1.0)
 
 
 @torch.no_grad()
@@ -64,6 +66,8 @@ def ddpm_sample_fn(model, x, hard_conds, context, t, guide=None, n_guide_steps=1
     if noise is None and tt != 0:
         noise = torch.empty_like(x)
         model.fill_randn(noise)
+    elif noise is not None:
+        noise = noise.to(device=x.device, dtype=torch.float32).contiguous()
     st = _lib.current_stream()
     use_guide = guide is not None and t_single < t_start_guide
     nz = _lib.ptr(noise) if tt != 0 else None
@@ -73,8 +77,8 @@ def ddpm_sample_fn(model, x, hard_conds, context, t, guide=None, n_guide_steps=1
                                   ws.data_ptr(), st), "mpdx_ddpm_step")
     if use_guide:
         model_var = None
-        if scale_grad_by_std:
-            model_var = torch.exp(extract(model.posterior_log_variance_clipped, torch.full((B,), tt, device=x.device, dtype=torch.long), x.shape))
+        if scale_grad_by_std:  # exp(posterior_log_variance_clipped[t]) (sample_functions.py:36); the host-side fp32 value, so that
+            model_var = float(model.host_buffers()["model_var"][tt])  # this loop and the fused mpdx_plan multiply by the same bits
         out = guide_gradient_steps(out, hard_conds=hard_conds, guide=guide, n_guide_steps=n_guide_steps,
                                    scale_grad_by_std=scale_grad_by_std, model_var=model_var)
         _lib.check(lib.mpdx_add_noise(out.data_ptr(), nz, None, None, coefs.noise_scale, extra, None, B, H, D, st), "mpdx_add_noise")
@@ -84,7 +88,7 @@ def ddpm_sample_fn(model, x, hard_conds, context, t, guide=None, n_guide_steps=1
 def guide_gradient_steps(x, hard_conds=None, guide=None, n_guide_steps=1, scale_grad_by_std=False, model_var=None,
                          debug=False, **kwargs):
     """sample_functions.py:65-83."""
-    for _ in range(n_guide_steps):
+    for _ in range(int(n_guide_steps)):
         grad_scaled = guide(x)
         if scale_grad_by_std:
             grad_scaled = model_var * grad_scaled

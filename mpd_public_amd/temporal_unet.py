@@ -111,6 +111,20 @@ class TemporalUnet(nn.Module):
         self._stamp = None
 
     # ------------------------------------------------------------------------------------------- engine plumbing
+    _DEVICE_STATE = {"_h": None, "_packed": None, "_timetab": None, "_timetab_T": 0, "_ws": None, "_ws_B": 0, "_stamp": None}
+
+    def __getstate__(self):
+        """copy.deepcopy (the reference's EMA pattern, trainer.py:67-85) and pickling copy the PARAMETERS only: the native
+        handle (a ctypes pointer owned by this instance), the repacked weights, the time table and the workspace are
+        dropped and rebuilt lazily by the copy's first engine() call - never shared, never double-freed."""
+        state = dict(self.__dict__)
+        state.update(self._DEVICE_STATE)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.__dict__.update(self._DEVICE_STATE)
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

@@ -162,8 +162,12 @@ class CostCollision:
 
 
 class CostGPTrajectory:
-    def __init__(self, robot, n_support_points, dt, sigma_gp=1.0, **kw):
+    """half_factor: GPMP2 writes the prior as 1/2 sum e^T Qinv e; whether mp_baselines keeps the 1/2 is undecidable from the
+    reference tree (empty submodule), so it is a switch (default False), mirrored by mpdx_guide_params.gp_half_factor."""
+
+    def __init__(self, robot, n_support_points, dt, sigma_gp=1.0, half_factor=False, **kw):
         self.robot, self.dt, self.sigma = robot, float(dt), sigma_gp
+        self.half_factor = bool(half_factor)
 
     def __call__(self, trajs):
         qd, dt = self.robot.q_dim, self.dt
@@ -171,7 +175,7 @@ class CostGPTrajectory:
         eq = q[:, 1:] - q[:, :-1] - dt * v[:, :-1]
         ev = v[:, 1:] - v[:, :-1]
         c = (12.0 / dt ** 3) * (eq * eq).sum(-1) - (12.0 / dt ** 2) * (eq * ev).sum(-1) + (4.0 / dt) * (ev * ev).sum(-1)
-        return c.sum(-1) / (self.sigma ** 2)
+        return (0.5 if self.half_factor else 1.0) * c.sum(-1) / (self.sigma ** 2)
 
 
 class CostComposite:

@@ -34,23 +34,28 @@ def p_mean(buf: dict, sd: dict, x: torch.Tensor, t: int, predict_epsilon: bool =
     return buf["posterior_mean_coef1"][t] * x0 + buf["posterior_mean_coef2"][t] * x
 
 
-def guide_gradient_steps(x: torch.Tensor, hard_conds: dict, guide, n_guide_steps: int) -> torch.Tensor:
-    # sample_functions.py:65-83 (scale_grad_by_std=False as inference.py:240-244 leaves the default)
+def guide_gradient_steps(x: torch.Tensor, hard_conds: dict, guide, n_guide_steps: int, scale_grad_by_std: bool = False,
+                         model_var=None) -> torch.Tensor:
+    # sample_functions.py:65-83 (inference.py:240-244 leaves scale_grad_by_std at its default False)
     for _ in range(n_guide_steps):
-        x = x + guide(x)
+        g = guide(x)
+        if scale_grad_by_std:  # :77-78
+            g = model_var * g
+        x = x + g
         x = apply_hard_conditioning(x, hard_conds)
     return x
 
 
 def ddpm_step(buf: dict, sd: dict, x: torch.Tensor, hard_conds: dict, i: int, noise: torch.Tensor,
               guide=None, n_guide_steps: int = 1, t_start_guide: float = float("inf"),
-              noise_std: float = 1.0, predict_epsilon: bool = True, eps_fn=None) -> torch.Tensor:
+              noise_std: float = 1.0, predict_epsilon: bool = True, eps_fn=None, scale_grad_by_std: bool = False) -> torch.Tensor:
     """One ddpm_sample_fn call at loop index i (may be negative). sample_functions.py:17-62."""
     t = max(i, 0)  # :28-30
     x = p_mean(buf, sd, x, t, predict_epsilon, eps_fn)
     std = torch.exp(0.5 * buf["posterior_log_variance_clipped"][t])  # :35-36
     if guide is not None and i < t_start_guide:  # :39 compares t_single (the un-clamped index)
-        x = guide_gradient_steps(x, hard_conds, guide, n_guide_steps)
+        model_var = torch.exp(buf["posterior_log_variance_clipped"][t])  # :36
+        x = guide_gradient_steps(x, hard_conds, guide, n_guide_steps, scale_grad_by_std, model_var)
     n = noise.clone()
     if t == 0:  # :52
         n.zero_()
@@ -111,7 +116,9 @@ def ddim_sample(sd: dict, hard_conds: dict, x_T: torch.Tensor, T: int, variance_
         c = (1 - alpha_next).sqrt()
         x = x_start * alpha_next.sqrt() + c * pred_noise
         if guide is not None and time_next < t_start_guide:
-            x = guide_gradient_steps(x, hc, guide, n_guide_steps)
+            # the reference names n_guide_steps in ddim_sample's signature but does not forward it to guide_gradient_steps
+            # (diffusion_model_base.py:240-246): always ONE guide step per time pair
+            x = guide_gradient_steps(x, hc, guide, 1)
         x = apply_hard_conditioning(x, hc)
         chain.append(x.clone())
     return torch.stack(chain, dim=0)

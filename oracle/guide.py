@@ -22,10 +22,17 @@ def clip_grad_by_norm(g: torch.Tensor, max_grad_norm: float = 1.0) -> torch.Tens
     return torch.clip(n, 0.0, max_grad_norm) / n * g
 
 
+def clip_grad_by_value(g: torch.Tensor, max_grad_value: float = 0.1) -> torch.Tensor:
+    # guides.py:232-236
+    return torch.clip(g, -max_grad_value, max_grad_value)
+
+
 class GuideManager:
-    def __init__(self, normalizer, cost, clip_grad=True, max_grad_norm=1.0, interpolate=True, n_interp=128):
+    def __init__(self, normalizer, cost, clip_grad=True, max_grad_norm=1.0, interpolate=True, n_interp=128, clip_grad_rule="norm",
+                 max_grad_value=0.1):
         self.normalizer, self.cost = normalizer, cost
         self.clip_grad, self.max_grad_norm = clip_grad, max_grad_norm
+        self.clip_grad_rule, self.max_grad_value = clip_grad_rule, max_grad_value
         self.interpolate, self.n_interp = interpolate, n_interp
 
     def __call__(self, x_normalized: torch.Tensor) -> torch.Tensor:
@@ -39,8 +46,13 @@ class GuideManager:
             for c, w in zip(cost_l, w_l):
                 if torch.is_tensor(c):
                     g = torch.autograd.grad([c.sum()], [x], retain_graph=True)[0]  # :196
-                    if self.clip_grad:
-                        g = clip_grad_by_norm(g, self.max_grad_norm)
+                    if self.clip_grad:  # guides.py:213-222
+                        if self.clip_grad_rule == "norm":
+                            g = clip_grad_by_norm(g, self.max_grad_norm)
+                        elif self.clip_grad_rule == "value":
+                            g = clip_grad_by_value(g, self.max_grad_value)
+                        else:
+                            raise NotImplementedError
                     g[..., 0, :] = 0.0  # :202-203
                     g[..., -1, :] = 0.0
                     grad = grad + w * g

@@ -29,7 +29,8 @@ def load_npz(path):
 
 
 # ---------------------------------------------------------------------------------------------- guidance helpers
-def oracle_guide(dataset, w_coll=1e-2, w_smooth=1e-7, clip_grad=True, interpolate=True, n_interp=128, dtype=torch.float32):
+def oracle_guide(dataset, w_coll=1e-2, w_smooth=1e-7, clip_grad=True, interpolate=True, n_interp=128, dtype=torch.float32,
+                 clip_grad_rule="norm", max_grad_value=0.1, gp_half_factor=False):
     """The oracle's guide (autograd over oracle/costs.py) for the same task as a product `TrajectoryDataset`."""
     from oracle import costs as oc
     from oracle.guide import GuideManager
@@ -52,26 +53,28 @@ def oracle_guide(dataset, w_coll=1e-2, w_smooth=1e-7, clip_grad=True, interpolat
         cl.append(oc.CostCollision(robot, 64, field=fld, sigma_coll=1.0, cutoff_margin=dataset.task.obstacle_cutoff_margin))
         wl.append(w_coll)
     dt = 5.0 / dataset.n_support_points
-    cl.append(oc.CostGPTrajectory(robot, 64, dt, sigma_gp=1.0))
+    cl.append(oc.CostGPTrajectory(robot, 64, dt, sigma_gp=1.0, half_factor=gp_half_factor))
     wl.append(w_smooth)
     comp = oc.CostComposite(robot, 64, cl, weights_cost_l=wl)
     nrm = LimitsNormalizer(dataset.normalizer.mins.cpu(), dataset.normalizer.maxs.cpu())
     nrm.mins, nrm.maxs = nrm.mins.to(dtype), nrm.maxs.to(dtype)
-    return GuideManager(nrm, comp, clip_grad=clip_grad, interpolate=interpolate, n_interp=n_interp), comp
+    return GuideManager(nrm, comp, clip_grad=clip_grad, interpolate=interpolate, n_interp=n_interp, clip_grad_rule=clip_grad_rule,
+                        max_grad_value=max_grad_value), comp
 
 
-def product_guide(dataset, w_coll=1e-2, w_smooth=1e-7, clip_grad=True, interpolate=True):
+def product_guide(dataset, w_coll=1e-2, w_smooth=1e-7, clip_grad=True, interpolate=True, clip_grad_rule="norm", max_grad_value=0.1,
+                  gp_half_factor=False):
     """The product guide built exactly as scripts/inference/inference.py:188-236 builds it."""
     import mpd_public_amd as m
     H = dataset.n_support_points
     dt = 5.0 / H
     costs = [m.CostCollision(dataset.robot, H, field=f, sigma_coll=1.0) for f in dataset.task.get_collision_fields()]
     weights = [w_coll] * len(costs)
-    costs.append(m.CostGPTrajectory(dataset.robot, H, dt, sigma_gp=1.0))
+    costs.append(m.CostGPTrajectory(dataset.robot, H, dt, sigma_gp=1.0, half_factor=gp_half_factor))
     weights.append(w_smooth)
     comp = m.CostComposite(dataset.robot, H, costs, weights_cost_l=weights)
     from math import ceil
-    return m.GuideManagerTrajectoriesWithVelocity(dataset, comp, clip_grad=clip_grad,
+    return m.GuideManagerTrajectoriesWithVelocity(dataset, comp, clip_grad=clip_grad, clip_grad_rule=clip_grad_rule, max_grad_value=max_grad_value,
                                                   interpolate_trajectories_for_collision=interpolate,
                                                   num_interpolated_points=ceil(H * 1.5))  # misspelt kwarg, as inference.py:234
 
@@ -120,3 +123,24 @@ def panda_probe_configs(dataset):
     assert selfc.max() > 0 and wsc.max() > 0
     _PROBE["panda"] = (q[selfc.argmax()], q[wsc.argmax()])
     return _PROBE["panda"]
+
+
+def oracle_plan_metrics(dataset, xu, n_check=256):
+    """The oracle's restatement of the post-loop metrics (inference.py:288-297,311-316) on UNNORMALISED trajectories xu [B,H,D]
+    (CPU tensor): (#colliding interpolated waypoints [B], path length [B], smoothness [B]).  A waypoint collides iff some hinge
+    with margin = link radius (no cutoff margin) is active on the n_check-point interpolation."""
+    from oracle import costs as oc
+    from oracle.guide import interpolate_points_v1
+    _, comp = oracle_guide(dataset, dtype=xu.dtype)
+    qd = dataset.state_dim // 2
+    q, v = xu[..., :qd], xu[..., qd:]
+    plen = torch.linalg.norm(q[:, 1:] - q[:, :-1], dim=-1).sum(-1)
+    smooth = torch.linalg.norm(v[:, 1:] - v[:, :-1], dim=-1).sum(-1)
+    xi = interpolate_points_v1(xu, n_check)
+    hit = torch.zeros(xi.shape[:2], dtype=torch.bool)
+    for term in comp.cost_l:
+        if isinstance(term, oc.CostCollision):
+            term.cutoff = 0.0
+            per_point = torch.stack([term(xi[:, i:i + 1]) for i in range(xi.shape[1])], 1)
+            hit |= per_point > 0
+    return hit.sum(1), plen, smooth

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import synth_sd, t, product_guide, DIM_MULTS
+from helpers import synth_sd, t, product_guide, oracle_guide, oracle_plan_metrics, DIM_MULTS
 
 pytestmark = pytest.mark.gpu
 
@@ -50,13 +50,69 @@ def test_cfg2_size_plan_properties_and_oracle_slice():
     np.testing.assert_allclose(chain[-1, :3].cpu().numpy(), ref[-1].numpy(), rtol=0, atol=5e-4)
 
 
-def test_cfg5_shard_size_matches_small_batch_plans():
+@pytest.mark.parametrize("env_id,robot_id", [("EnvNarrowPassageDense2D", "RobotPointMass"), ("EnvSpheres3D", "RobotPanda")])
+def test_cfg3_cfg4_full_size_guided_plan_vs_oracle(env_id, robot_id):
+    """BASELINE configs[2] / [3] at their full size: 100 trajectories x H=64, T=100 (+5), collision + GP guidance (30 guided steps
+    x 5 guide iterations), against the CPU oracle run on the SAME full batch with the same injected noise.
+    Checked: (1) hard conditions exact in every chain entry, fused mpdx_plan == step-by-step protocol loop bit for bit;
+    (2) the chain up to the first guided step within the unguided fp32 tolerance; (3) final trajectories: bulk within 2e-3,
+    isolated waypoints within a few clipped increments (hinge / arg-min flips, see test_gpu_guide.py); (4) north_star's own
+    criterion - collision-free rate, collision intensity, mean path length and mean smoothness of the planned batch,
+    HIP (metrics kernel on HIP trajectories) vs oracle (oracle metrics on oracle trajectories), identical to 3 s.f."""
+    import mpd_public_amd as m
+    from oracle import diffusion as odiff
+    T, B, n0 = 100, 100, 5
+    ds = m.TrajectoryDataset(env_id, robot_id, tensor_args={"device": "cuda", "dtype": torch.float32})
+    D = ds.state_dim
+    dm = _model(D, T)
+    noise = _randn((T + n0 + 1, B, 64, D), 4321)
+    qd = D // 2
+    start = ds.normalizer.normalize(torch.cat([t(f"fs3_s/{env_id}", (qd,), "uniform", 0.6).cuda(), torch.zeros(qd, device="cuda")]))
+    goal = ds.normalizer.normalize(torch.cat([t(f"fs3_g/{env_id}", (qd,), "uniform", 0.6).cuda(), torch.zeros(qd, device="cuda")]))
+    hc = {0: start, 63: goal}
+    w = (1e-2, 1e-7)   # inference.py:55-56
+    pg = product_guide(ds, *w).cuda()
+    kw = dict(n_samples=B, horizon=64, return_chain=True, sample_fn=m.ddpm_sample_fn, guide=pg, n_guide_steps=5,
+              t_start_guide=ceil(0.25 * T), n_diffusion_steps_without_noise=n0, noise_std_extra_schedule_fn=lambda tt: 0.5, noise=noise)
+    chain = dm.run_inference(None, hc, fused=True, **kw)
+    assert chain.shape == (T + n0 + 1, B, 64, D) and bool(torch.isfinite(chain).all())
+    assert torch.equal(chain[:, :, 0, :], start.expand(T + n0 + 1, B, D)) and torch.equal(chain[:, :, 63, :], goal.expand(T + n0 + 1, B, D))
+    assert torch.equal(chain, dm.run_inference(None, hc, fused=False, **kw))
+    og, _ = oracle_guide(ds, *w, dtype=torch.float32)
+    ref = odiff.run_inference(synth_sd(D, 1), {k: v.cpu() for k, v in hc.items()}, noise.cpu(), T, noise_std=0.5, guide=og, n_guide_steps=5,
+                              t_start_guide=ceil(0.25 * T), n_diffusion_steps_without_noise=n0)
+    got = chain.cpu()
+    k_guide = T - ceil(0.25 * T)
+    err = (got - ref).abs().reshape(got.shape[0], -1).amax(1).numpy()
+    assert err[: k_guide + 1].max() < 2e-3, err[: k_guide + 1].max()
+    d = (got[-1] - ref[-1]).abs().amax(-1).numpy()   # [B, H]
+    assert np.median(d) < 2e-3, np.median(d)
+    assert d.max() < 5e-2, d.max()
+    # plan-level figures (inference.py:285-297, 311-316)
+    xu_hip = ds.unnormalize_trajectories(chain[-1])
+    mh = ds.task.trajectory_metrics(xu_hip).cpu().numpy()
+    from oracle.normalizer import LimitsNormalizer
+    xu_ref = LimitsNormalizer(ds.normalizer.mins.cpu(), ds.normalizer.maxs.cpu()).unnormalize(ref[-1])
+    nc, plen, smooth = oracle_plan_metrics(ds, xu_ref, n_check=256)
+    figures = {
+        "fraction_free_trajs": (float((mh[:, 0] == 0).mean()), float((nc == 0).float().mean())),
+        "collision_intensity_trajs": (float((mh[:, 0] / mh[:, 3]).mean()), float((nc.float() / 256.0).mean())),
+        "mean_path_length": (float(mh[:, 1].mean()), float(plen.mean())),
+        "mean_smoothness": (float(mh[:, 2].mean()), float(smooth.mean())),
+    }
+    print(env_id, figures)
+    for name, (a_, b_) in figures.items():
+        assert abs(a_ - b_) <= 5e-3 * max(abs(b_), 1e-12), (name, a_, b_)   # identical to 3 significant figures
+
+
+@pytest.mark.parametrize("T", [25, 100])
+def test_cfg5_shard_size_matches_small_batch_plans(T):
     """BASELINE configs[4], one GPU's shard: 128 contexts x 50 = 6400 Panda trajectories (per-layer launches, per-context
     range tests, per-trajectory hard conditions).  Contexts planned alone (B=50: fused level programs) must agree:
     unguided to the fp32 tolerance of two different summation orders, guided to the statistics of the guided tests."""
     import mpd_public_amd as m
     from mpd_public_amd.parallel import expand_contexts
-    T, n0, C_, n = 25, 5, 128, 50
+    n0, C_, n = 5, 128, 50
     B = C_ * n
     ds = m.TrajectoryDataset("EnvSpheres3D", "RobotPanda", tensor_args={"device": "cuda", "dtype": torch.float32})
     D = ds.state_dim
@@ -94,3 +150,42 @@ def test_cfg5_shard_size_matches_small_batch_plans():
                 assert np.median(d) < 1e-5 and d.max() < 2e-3, (label, c, np.median(d), d.max())
             else:
                 assert np.median(d) < 2e-3 and d.max() < 5e-2, (label, c, np.median(d), d.max())
+
+
+def test_rccl_world_of_one_runs_real_planner_under_parallel():
+    """The N>1 code path with the REAL planner on hardware: init the `nccl` (= RCCL) backend in a world of one rank, plan a
+    block of contexts through parallel.plan_contexts (model.plan, guided, per-context range tests) and push the result through
+    gather_trajectories' all_gather_into_tensor.  The gathered tensor must equal the local block, and the block must equal
+    per-context plans (bit for bit)."""
+    import socket
+    import torch.distributed as dist
+    import mpd_public_amd as m
+    from mpd_public_amd.parallel import plan_contexts, gather_trajectories
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        assert dist.get_backend() == "nccl"
+        T, n, C_, n0 = 25, 10, 6, 5
+        ds = m.TrajectoryDataset("EnvSpheres3D", "RobotPanda", tensor_args={"device": "cuda", "dtype": torch.float32})
+        D = ds.state_dim
+        dm = _model(D, T)
+        pg = product_guide(ds, 1e-2, 1e-7).cuda()
+        zeros = torch.zeros(C_, D // 2, device="cuda")
+        starts = ds.normalizer.normalize(torch.cat([t("rc_s", (C_, D // 2), "uniform", 0.6).cuda(), zeros], 1))
+        goals = ds.normalizer.normalize(torch.cat([t("rc_g", (C_, D // 2), "uniform", 0.6).cuda(), zeros], 1))
+        noise = _randn((T + n0 + 1, C_ * n, 64, D), 99)
+        kw = dict(n_diffusion_steps_without_noise=n0, noise_std_extra_schedule_fn=lambda tt: 0.5, guide=pg, n_guide_steps=5,
+                  t_start_guide=ceil(0.25 * T))
+        local, (lo, hi) = plan_contexts(dm, starts, goals, n, rank=dist.get_rank(), world_size=dist.get_world_size(), horizon=64, noise=noise, **kw)
+        assert (lo, hi) == (0, C_)
+        full = gather_trajectories(local, C_, n, force_collective=True)   # RCCL all_gather_into_tensor, world of one
+        torch.cuda.synchronize()
+        assert full.data_ptr() != local.data_ptr() and torch.equal(full, local)
+        x3, _ = dm.plan({0: starts[3], 63: goals[3]}, n, 64, noise=noise[:, 3 * n:4 * n].contiguous(), return_chain=False, **kw)
+        assert torch.equal(full[3 * n:4 * n], x3)
+    finally:
+        dist.destroy_process_group()

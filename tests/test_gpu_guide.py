@@ -172,3 +172,202 @@ def test_panda_guide_rejects_interpolation_that_exceeds_lds():
     ok = m.GuideManagerTrajectoriesWithVelocity(ds, comp, clip_grad=True, interpolate_trajectories_for_collision=True,
                                                 num_interpolated_points_for_collision=192).cuda()
     assert bool(torch.isfinite(ok(x)).all())   # 192 points fit (3 passes of the 64-lane point loop)
+
+
+# ---------------------------------------------------------------------------------------------- options of the guide manager
+@pytest.mark.parametrize("env_id,robot_id", CASES[::2])
+def test_guide_clip_by_value_vs_oracle(env_id, robot_id):
+    """clip_grad_rule='value' (guides.py:232-236): per-element clip to +-max_grad_value instead of the per-waypoint norm clip."""
+    import mpd_public_amd as m
+    ds = m.TrajectoryDataset(env_id, robot_id, tensor_args={"device": "cuda", "dtype": torch.float32})
+    x = obstacle_hugging_trajs(ds, 6, seed=f"clipv/{env_id}", scale=0.95)
+    for mv in (0.1, 0.35):
+        og, _ = oracle_guide(ds, 1.0, 1e-4, dtype=torch.float64, clip_grad_rule="value", max_grad_value=mv)
+        ref = og(x.double()).numpy()
+        got = product_guide(ds, 1.0, 1e-4, clip_grad_rule="value", max_grad_value=mv).cuda()(x.cuda()).cpu().numpy()
+        norm_ref = product_guide(ds, 1.0, 1e-4).cuda()(x.cuda()).cpu().numpy()
+        assert np.abs(got - norm_ref).max() > 1e-3, "the two clip rules must differ on this input"
+        bad = _mismatch(got, ref, atol=2e-4).any(-1)
+        assert bad.mean() < 0.01, f"{bad.sum()} of {bad.size} waypoints differ; max|diff|={np.abs(got-ref).max():.3e}"
+        np.testing.assert_allclose(got[~bad], ref[~bad], rtol=1e-3, atol=2e-4)
+    with pytest.raises(NotImplementedError):
+        m.GuideManagerTrajectoriesWithVelocity(ds, product_guide(ds).cost, clip_grad=True, clip_grad_rule="median")
+
+
+def test_gp_half_factor_switch_vs_oracle():
+    """The GP prior with and without GPMP2's 1/2 (undecidable from the reference tree: explicit switch).
+    Un-clipped, the GP increment halves exactly; with the norm clip it only changes where |grad| < max_grad_norm."""
+    import mpd_public_amd as m
+    ds = m.TrajectoryDataset("EnvDense2D", "RobotPointMass", tensor_args={"device": "cuda", "dtype": torch.float32})
+    x = (0.02 * t("gph/x", (5, 64, 4))).contiguous()   # near-constant trajectories far from obstacles: only the GP term acts
+    x[..., :2] += 0.9
+    for clip in (False, True):
+        out = {}
+        for half in (False, True):
+            og, _ = oracle_guide(ds, 0.0, 1e-3, clip_grad=clip, dtype=torch.float64, gp_half_factor=half)
+            ref = og(x.double()).numpy()
+            got = product_guide(ds, 0.0, 1e-3, clip_grad=clip, gp_half_factor=half).cuda()(x.cuda()).cpu().numpy()
+            np.testing.assert_allclose(got, ref, rtol=2e-3, atol=1e-7)
+            out[half] = got
+        assert np.abs(out[False]).max() > 0
+        if not clip:
+            np.testing.assert_allclose(out[True], 0.5 * out[False], rtol=1e-6, atol=1e-12)
+
+
+def test_python_cost_callable_guide_vs_reference_golden(golden_dir):
+    """A guide around an ARBITRARY Python cost (guides.py:190's contract) takes the torch-autograd path on the GPU; the
+    reference's own manager produced these vectors with the same toy cost (tests/golden/make_golden.py)."""
+    import mpd_public_amd as m
+    from helpers import toy_cost, load_npz
+    g = load_npz(golden_dir / "guide.npz")
+    for robot, D, env in (("RobotPointMass", 4, "EnvSimple2D"), ("RobotPanda", 14, "EnvSpheres3D")):
+        ds = m.TrajectoryDataset(env, robot, tensor_args={"device": "cuda", "dtype": torch.float32})
+        gm = m.GuideManagerTrajectoriesWithVelocity(ds, toy_cost, clip_grad=True, interpolate_trajectories_for_collision=True).cuda()
+        assert not gm.is_native
+        for scale, tag in ((0.5, "inrange"), (0.9, "clipped")):
+            x = t(f"guide_x_D{D}", (5, 64, D), "uniform", scale=scale * 1.2).cuda()
+            np.testing.assert_allclose(gm(x).cpu().numpy(), g[f"guide_D{D}_{tag}"], rtol=2e-5, atol=2e-7)
+
+
+def test_python_cost_guided_chain_vs_reference_golden(golden_dir):
+    """run_inference with a Python-cost guide: the step-by-step protocol loop (HIP U-Net + step kernels, torch-autograd guide)
+    against the chain the real reference produced with the same toy cost."""
+    import mpd_public_amd as m
+    from helpers import toy_cost, load_npz
+    g = load_npz(golden_dir / "guide.npz")
+    D, T, B, n0, opt = 4, 25, 4, 5, 0
+    ds = m.TrajectoryDataset("EnvSimple2D", "RobotPointMass", tensor_args={"device": "cuda", "dtype": torch.float32})
+    net = m.TemporalUnet(n_support_points=64, state_dim=D, unet_input_dim=32, dim_mults=DIM_MULTS[opt])
+    net.load_state_dict(synth_sd(D, opt), strict=True)
+    dm = m.GaussianDiffusionModel(model=net, n_diffusion_steps=T, predict_epsilon=True).cuda().eval()
+    gm = m.GuideManagerTrajectoriesWithVelocity(ds, toy_cost, clip_grad=True, interpolate_trajectories_for_collision=True).cuda()
+    noise = t("chain_noise_guided", (T + n0 + 1, B, 64, D))
+    hc = {0: t("chain_hc0", (D,), "uniform").cuda(), 63: t("chain_hc1", (D,), "uniform").cuda()}
+    chain = dm.run_inference(None, hc, n_samples=B, horizon=64, return_chain=True, sample_fn=m.ddpm_sample_fn, guide=gm, n_guide_steps=5,
+                             t_start_guide=ceil(0.25 * T), n_diffusion_steps_without_noise=n0, noise_std_extra_schedule_fn=lambda tt: 0.5,
+                             noise=noise.cuda()).cpu().numpy()
+    ref = g["guided_chain_opt0"]
+    assert chain.shape == ref.shape
+    np.testing.assert_allclose(chain, ref, rtol=0, atol=2e-3)
+    np.testing.assert_allclose(chain[-1], ref[-1], rtol=0, atol=5e-4)
+
+
+def test_scale_grad_by_std_fused_equals_stepwise_and_oracle():
+    """scale_grad_by_std=True (sample_functions.py:41-43,77-78): every guide increment times model_var[t].  Stays on the fused
+    mpdx_plan path (coefs[t].guide_scale), bit-identical to the protocol loop, and follows the oracle."""
+    import mpd_public_amd as m
+    from oracle import diffusion as odiff
+    T, B = 25, 4
+    ds, dm, noise, hc, n0 = _guided_setup("EnvDense2D", "RobotPointMass", T, B, 0)
+    w = (1.0, 1e-4)   # model_var ~ 1e-2..1e-4 in the guided range: use un-attenuated weights so that the scaled increments matter
+    pg = product_guide(ds, *w).cuda()
+    kw = dict(n_samples=B, horizon=64, return_chain=True, sample_fn=m.ddpm_sample_fn, guide=pg, n_guide_steps=5,
+              t_start_guide=ceil(0.25 * T), n_diffusion_steps_without_noise=n0, noise_std_extra_schedule_fn=lambda tt: 0.5,
+              noise=noise.cuda(), scale_grad_by_std=True)
+    a = dm.run_inference(None, hc, fused=True, **kw)
+    b = dm.run_inference(None, hc, fused=False, **kw)
+    assert torch.equal(a, b)
+    plain = dm.run_inference(None, hc, fused=True, **dict(kw, scale_grad_by_std=False))
+    assert not torch.equal(a, plain)
+    og, _ = oracle_guide(ds, *w, dtype=torch.float32)
+    ref = odiff.run_inference(synth_sd(ds.state_dim, 0), {k: v.cpu() for k, v in hc.items()}, noise, T, noise_std=0.5, guide=og, n_guide_steps=5,
+                              t_start_guide=ceil(0.25 * T), n_diffusion_steps_without_noise=n0, scale_grad_by_std=True).numpy()
+    d = np.abs(a.cpu().numpy()[-1] - ref[-1]).max(-1)
+    assert np.median(d) < 2e-3 and d.max() < 5e-2, (np.median(d), d.max())
+
+
+def test_zero_guide_steps_is_unguided():
+    """n_guide_steps=0: the reference's `for _ in range(0)` runs no guide iteration; both paths must equal the unguided plan."""
+    import mpd_public_amd as m
+    T, B = 25, 3
+    ds, dm, noise, hc, n0 = _guided_setup("EnvDense2D", "RobotPointMass", T, B, 0)
+    pg = product_guide(ds).cuda()
+    kw = dict(n_samples=B, horizon=64, return_chain=True, sample_fn=m.ddpm_sample_fn, n_diffusion_steps_without_noise=n0,
+              noise_std_extra_schedule_fn=lambda tt: 0.5, noise=noise.cuda())
+    plain = dm.run_inference(None, hc, **kw)
+    for fused in (True, False):
+        z = dm.run_inference(None, hc, fused=fused, guide=pg, n_guide_steps=0, t_start_guide=ceil(0.25 * T), **kw)
+        assert torch.equal(z, plain), fused
+
+
+def test_ddim_accepts_unbatched_and_cpu_hard_conditions():
+    """ddim_sample / p_sample_loop normalise hard conditions ([D] broadcast, CPU -> device) before the kernels index them as
+    hs[b*D+d] (a [D] tensor was read out of bounds for b > 0)."""
+    import mpd_public_amd as m
+    D, T, B = 4, 25, 5
+    net = m.TemporalUnet(n_support_points=64, state_dim=D, unet_input_dim=32, dim_mults=DIM_MULTS[0])
+    net.load_state_dict(synth_sd(D, 0), strict=True)
+    dm = m.GaussianDiffusionModel(model=net, n_diffusion_steps=T, predict_epsilon=True).cuda().eval()
+    x_T = t("ddim_hc_noise", (8, B, 64, D))
+    hc1 = {0: t("chain_hc0", (D,), "uniform"), 63: t("chain_hc1", (D,), "uniform")}            # [D], on the CPU
+    hcB = {k: v.reshape(1, -1).expand(B, -1).contiguous().cuda() for k, v in hc1.items()}      # [B,D], on the GPU
+    xa, ca = dm.conditional_sample(hc1, horizon=64, batch_size=B, ddim=True, return_chain=True, noise=x_T)
+    xb, cb = dm.conditional_sample(hcB, horizon=64, batch_size=B, ddim=True, return_chain=True, noise=x_T)
+    assert torch.equal(ca, cb)
+    assert torch.equal(xa[:, 0], hcB[0]) and torch.equal(xa[:, 63], hcB[63])
+    pa, _ = dm.conditional_sample(hc1, horizon=64, batch_size=B, return_chain=True, noise=t("psl_noise", (T + 1, B, 64, D)))
+    assert torch.equal(pa[:, 0], hcB[0]) and torch.equal(pa[:, 63], hcB[63])
+    with pytest.raises(ValueError):
+        dm.conditional_sample({0: torch.zeros(3, D)}, horizon=64, batch_size=B, ddim=True, noise=x_T)
+
+
+def test_unet_deepcopy_rebuilds_its_own_engine():
+    """copy.deepcopy(model) (the reference's EMA pattern): parameters are copied, the native handle / packed weights are not
+    shared; both copies keep working and a parameter change in one does not leak into the other."""
+    import copy
+    import mpd_public_amd as m
+    D = 4
+    net = m.TemporalUnet(n_support_points=64, state_dim=D, unet_input_dim=32, dim_mults=DIM_MULTS[0])
+    net.load_state_dict(synth_sd(D, 0), strict=True)
+    net = net.cuda().eval()
+    x, tt = t("dc_x", (3, 64, D)).cuda(), torch.full((3,), 7, dtype=torch.long, device="cuda")
+    y0 = net(x, tt)
+    ema = copy.deepcopy(net)
+    assert ema._h is None and ema._packed is None
+    assert torch.equal(ema(x, tt), y0)
+    with torch.no_grad():
+        ema.final_conv[1].bias.add_(1.0)
+    assert torch.allclose(ema(x, tt), y0 + 1.0, atol=1e-6) and torch.equal(net(x, tt), y0)
+    del ema   # must not free the original's handle
+    assert torch.equal(net(x, tt), y0)
+
+
+def test_guide_options_and_sampler_options_vs_reference_golden(golden_dir):
+    """Vectors from the REAL reference (tests/golden/guide_opts.npz): clip_grad_rule='value', clip_grad=False, a
+    scale_grad_by_std=True chain and a guided DDIM chain (n_guide_steps=3 requested, one applied) - product on the GPU
+    (HIP U-Net / step kernels; the toy Python cost takes the torch-autograd guide path)."""
+    import mpd_public_amd as m
+    from helpers import toy_cost, load_npz
+    g = load_npz(golden_dir / "guide_opts.npz")
+    for robot, D, env in (("RobotPointMass", 4, "EnvSimple2D"), ("RobotPanda", 14, "EnvSpheres3D")):
+        ds = m.TrajectoryDataset(env, robot, tensor_args={"device": "cuda", "dtype": torch.float32})
+        x = t(f"guide_x_D{D}", (5, 64, D), "uniform", scale=0.6).cuda()
+        for mv in (0.1, 0.004):
+            gm = m.GuideManagerTrajectoriesWithVelocity(ds, toy_cost, clip_grad=True, clip_grad_rule="value", max_grad_value=mv,
+                                                        interpolate_trajectories_for_collision=True).cuda()
+            np.testing.assert_allclose(gm(x).cpu().numpy(), g[f"value_D{D}_mv{mv}"], rtol=2e-5, atol=2e-7)
+        gm = m.GuideManagerTrajectoriesWithVelocity(ds, toy_cost, clip_grad=False, interpolate_trajectories_for_collision=True).cuda()
+        np.testing.assert_allclose(gm(x).cpu().numpy(), g[f"noclip_D{D}"], rtol=2e-5, atol=2e-7)
+
+    def big_cost(x, x_interpolated=None, return_invidual_costs_and_weights=False, **kw):
+        cl, _ = toy_cost(x, x_interpolated=x_interpolated)
+        return cl, [1.0, 0.3]
+
+    D, T, B, n0, opt = 4, 25, 4, 5, 0
+    ds = m.TrajectoryDataset("EnvSimple2D", "RobotPointMass", tensor_args={"device": "cuda", "dtype": torch.float32})
+    net = m.TemporalUnet(n_support_points=64, state_dim=D, unet_input_dim=32, dim_mults=DIM_MULTS[opt])
+    net.load_state_dict(synth_sd(D, opt), strict=True)
+    dm = m.GaussianDiffusionModel(model=net, n_diffusion_steps=T, predict_epsilon=True).cuda().eval()
+    hc = {0: t("chain_hc0", (D,), "uniform").cuda(), 63: t("chain_hc1", (D,), "uniform").cuda()}
+    gm = m.GuideManagerTrajectoriesWithVelocity(ds, big_cost, clip_grad=True, interpolate_trajectories_for_collision=True).cuda()
+    chain = dm.run_inference(None, hc, n_samples=B, horizon=64, return_chain=True, sample_fn=m.ddpm_sample_fn, guide=gm, n_guide_steps=5,
+                             t_start_guide=ceil(0.25 * T), scale_grad_by_std=True, n_diffusion_steps_without_noise=n0,
+                             noise_std_extra_schedule_fn=lambda tt: 0.5, noise=t("chain_noise_guided", (T + n0 + 1, B, 64, D)).cuda()).cpu().numpy()
+    np.testing.assert_allclose(chain, g["scaled_chain_opt0"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(chain[-1], g["scaled_chain_opt0"][-1], rtol=0, atol=5e-4)
+    gm = m.GuideManagerTrajectoriesWithVelocity(ds, toy_cost, clip_grad=True, interpolate_trajectories_for_collision=True).cuda()
+    chain = dm.run_inference(None, hc, n_samples=B, horizon=64, return_chain=True, ddim=True, guide=gm, n_guide_steps=3, t_start_guide=13,
+                             noise=t("ddim_noise", (8, B, 64, D)).cuda()).cpu().numpy()
+    ref = g["ddim_guided_chain_opt0"]
+    assert chain.shape == ref.shape
+    np.testing.assert_allclose(chain, ref, rtol=2e-4, atol=2e-4 * np.abs(ref).max())

@@ -141,3 +141,43 @@ def test_forward_loss_vs_reference_golden(golden_dir, D, opt):
         for lt in ("l2", "l1"):
             v = float(diffusion.p_losses(synth_sd(D, opt), x0, tt, hc, noise, T, predict_epsilon=pe, loss_type=lt))
             assert abs(v - float(g[f"D{D}_eps{int(pe)}_{lt}"])) <= 2e-6 * abs(v), (pe, lt, v)
+
+
+def _big_cost(x, x_interpolated=None, return_invidual_costs_and_weights=False, **kw):
+    cl, _ = toy_cost(x, x_interpolated=x_interpolated)
+    return cl, [1.0, 0.3]
+
+
+@pytest.mark.parametrize("robot,D", [("RobotPointMass", 4), ("RobotPanda", 14)])
+def test_guide_options_match_reference(golden_dir, robot, D):
+    """clip_grad_rule='value' (guides.py:232-236) and clip_grad=False, vectors from the real reference (guide_opts.npz)."""
+    g = load_npz(golden_dir / "guide_opts.npz")
+    nrm = LimitsNormalizer(*syn.limits_for(robot))
+    x = t(f"guide_x_D{D}", (5, 64, D), "uniform", scale=0.6)
+    for mv in (0.1, 0.004):
+        gm = GuideManager(nrm, toy_cost, clip_grad=True, clip_grad_rule="value", max_grad_value=mv)
+        np.testing.assert_allclose(gm(x).numpy(), g[f"value_D{D}_mv{mv}"], rtol=1e-5, atol=1e-7)
+    assert np.abs(g[f"value_D{D}_mv0.004"]).max() <= 0.004 * 1e-2 * (1 + 1e-6) + 0.004 * 3e-3  # the clip was active
+    gm = GuideManager(nrm, toy_cost, clip_grad=False)
+    np.testing.assert_allclose(gm(x).numpy(), g[f"noclip_D{D}"], rtol=1e-5, atol=1e-7)
+
+
+def test_scaled_and_ddim_guided_chains_match_reference(golden_dir):
+    """scale_grad_by_std=True (increments times model_var[t]) and guided DDIM with n_guide_steps=3 requested (the reference's
+    ddim_sample never forwards it: one guide step per pair) - chains from the real reference."""
+    g = load_npz(golden_dir / "guide_opts.npz")
+    D, T, B, n0, opt = 4, 25, 4, 5, 0
+    sd = synth_sd(D, opt)
+    nrm = LimitsNormalizer(*syn.limits_for("RobotPointMass"))
+    hc = {0: t("chain_hc0", (D,), "uniform"), 63: t("chain_hc1", (D,), "uniform")}
+    noise = t("chain_noise_guided", (T + n0 + 1, B, 64, D))
+    chain = diffusion.run_inference(sd, hc, noise, T, n_diffusion_steps_without_noise=n0, noise_std=0.5, guide=GuideManager(nrm, _big_cost),
+                                    n_guide_steps=5, t_start_guide=ceil(0.25 * T), scale_grad_by_std=True).numpy()
+    np.testing.assert_allclose(chain, g["scaled_chain_opt0"], rtol=0, atol=2e-5)
+    unscaled = diffusion.run_inference(sd, hc, noise, T, n_diffusion_steps_without_noise=n0, noise_std=0.5, guide=GuideManager(nrm, _big_cost),
+                                       n_guide_steps=5, t_start_guide=ceil(0.25 * T)).numpy()
+    assert np.abs(unscaled[-1] - g["scaled_chain_opt0"][-1]).max() > 1e-2   # the scaling matters in this vector
+    x_T = t("ddim_noise", (8, B, 64, D))[0]
+    chain = diffusion.ddim_sample(sd, hc, x_T, T, guide=GuideManager(nrm, toy_cost), n_guide_steps=3, t_start_guide=13).numpy()
+    ref = g["ddim_guided_chain_opt0"]
+    np.testing.assert_allclose(chain, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
