@@ -1,29 +1,33 @@
-// fused_level.hpp - whole-trajectory fused kernels for the outer levels of TemporalUnet.
+// fused_level.hpp - whole-trajectory fused programs for the outer levels of TemporalUnet (round-2 design).
 //
-// Why.  At B=100 the per-layer path is bound by launch boundaries and per-kernel fixed phases (DESIGN.md section 3:
-// 44 dependent launches per denoising step, ~3 us boundary + ~2 us fixed cost each).  At the two outer resolutions one
-// workgroup can own ALL channels of a trajectory (C*L = 2048 floats, C <= 64), so GroupNorm statistics stay local and a
-// whole run of layers executes out of LDS in ONE launch:
+// Why.  At B=100 the per-layer path is bound by launch boundaries and per-kernel fixed phases.  At the
+// outer resolutions one workgroup can own ALL channels of a trajectory (C*L = 2048 floats, C <= 64), so GroupNorm statistics
+// stay local and a whole run of layers executes out of LDS in ONE launch:
 //     downs[i] (i = 0, 1):  ResidualTemporalBlock x2 -> Downsample1d                     (temporal_unet.py:141-150)
 //     ups[j]   (last two):  cat(x, skip) -> ResidualTemporalBlock x2 -> Upsample1d       (temporal_unet.py:158-165)
 //     and, after the last Upsample1d: final_conv (Conv1dBlock -> Conv1d 1x1) + the DDPM posterior step
 //                                                            (temporal_unet.py:167, diffusion_model_base.py:121-155)
-// The arithmetic per layer is the same as conv_block.hpp (same packed weights, same fp32 MFMA, same GroupNorm/Mish);
-// only the schedule differs: activations never leave the CU between layers.
+// The arithmetic per layer is the same as conv_block.hpp (same packed weights, same fp32 MFMA, GroupNorm, Mish).
 //
-// Structure.  One workgroup (8 waves) = one trajectory.  LDS holds the activation buffers in the zero-haloed
-// channel-last layout [L+4 rows][C + pad] (rows 0,1 and L+2,L+3 are zero: conv padding; written by the op that defines
-// the buffer), plus the K-partial buffer.  The host places the buffers by live range (buffers whose lives do not
-// intersect share addresses), which lets the two outer down levels run as ONE program of 12 ops within 160 KB.
-// A tiny op list (kernel argument) is interpreted: each conv is M = C_out (all), N = L positions, K = C_in*taps;
-// the (C_out/16)*(L/16) = 8 (or 4) MFMA sub-tiles map one per wave (K split in two when there are 4), partials meet
-// in LDS, then wave g normalises GroupNorm group g of the trajectory.
-// Weights reach the MFMAs through LDS-DMA (global_load_lds, 16 B per lane): the packed A-fragment layout
-// Wp[m16][c16][slot][lane][4] is already a sequence of lane-linear 1-KiB blocks, which is exactly the DMA's destination
-// shape (wave-uniform base + lane*16).  The blocks of op i+1 are DMA'd right after op i's MFMA barrier, so their
-// HBM/L2 latency hides under op i's GroupNorm epilogue; the k-loop itself reads A and B fragments from LDS only
-// (no vmcnt waits inside it - the register-ring version of this loop was serialised by hipcc to ~2 loads in flight).
-// Ops whose weights exceed the LDS weight window (the 128->64 k5 block of ups: 160 KiB) run in c16 chunks.
+// Structure.  One workgroup (8 waves) = one trajectory; LDS holds the activation buffers in the zero-haloed channel-last
+// layout [L+4 rows][C + pad] (placed by live range on the host).  A small op list (kernel argument) is walked; every conv is
+// M = C_out (all), N = L positions, K = C_in*taps as (C_out/16)*(L/16) = 8 or 4 MFMA tiles of 16x16.
+//
+// What round 2 changed (measured: the round-1 kernel spent 4.3 k of every ~7.7 k cycles per op outside the MFMA loop):
+//   * TILE OWNERSHIP: wave w owns tile w for the whole K range (ops with 4 tiles run on waves 0-3).  Accumulators never leave
+//     registers: no K-partials through LDS, no partial-sum re-reads.
+//   * GroupNorm statistics straight from the accumulators: per 16-lane DPP row (= 4 channels x 16 positions) a local
+//     two-pass (mean, M2), exchanged as 8 bytes per row through LDS and combined with Chan's formula (all parts have 64
+//     elements) - one barrier; normalise + Mish + time bias + residual in registers; ONE 16-byte LDS store per lane.
+//   * WEIGHTS BY REGISTER RING, prefetched ACROSS ops: a wave's A operand stream (its 16 output channels, all K) is a linear
+//     run of 1-KiB blocks of the packed weights; a 16-block ring (64 VGPRs) is refilled as blocks are consumed, and the first
+//     16 blocks of the NEXT op are requested before the current op's epilogue, so L2/MALL latency hides under the epilogue
+//     and the barriers.  No LDS weight window: the k-loop's LDS traffic halves (B fragments only) and LDS use drops to
+//     the activations (~40-60 KB).  Barriers are LDS-only (s_waitcnt lgkmcnt(0) + s_barrier): they do not drain the ring.
+//   * the k-loop is a compile-time shape (MODE, taps, C_in/16 [, C_in/16 of a folded residual conv]): fully unrolled, every
+//     ring slot and LDS offset static, exact s_waitcnt vmcnt counts.
+//   * a block's residual 1x1 conv is FOLDED into blocks[1]: its blocks follow blocks[1]'s own in the same ring stream and
+//     accumulate the block input into a second accumulator added after Mish (removes an op, a buffer and two barriers).
 #pragma once
 #include "conv_block.hpp"
 
@@ -39,19 +43,25 @@ struct FusedBuf {
 };
 
 struct FusedOp {
-    int kind;          // FOP_*
-    int mode, ks;      // CONV_S1 / CONV_DOWN / CONV_UPT, taps
-    int src, dst, res; // LDS buffer ids (-1: none)
-    int gdst;          // index into FusedArgs.gout (-1: none)
-    int cin_pad, cout, L_in, L_out, gs;
-    int w_off, b_off, ga_off, be_off, tb_off;  // float offsets into packed weights / the time-table row (-1: none)
-    int p_off;         // float offset of this op's staged [bias | gamma | beta | tbias] block (4*cout floats) in LDS
-    // host-precomputed so that the kernel needs no integer division (sub-tile counts and group sizes are powers of two)
-    int lg_T, lg_MSn, lg_gs, lg_M4, ntap, nslot, nc16, cchunk;
+    int kind;            // FOP_*
+    int shape;           // compile-time k-loop shape id (fused_shape_id), -1 for FOP_FINAL
+    int mode, ks;        // CONV_S1 / CONV_DOWN / CONV_UPT, taps
+    int nc16;            // C_in (padded) / 16
+    int src, dst, res;   // LDS buffer ids (-1: none); res = identity residual added after Mish
+    int gdst;            // index into FusedArgs.gout (-1: none)
+    int cout, L_in, L_out, gs;
+    int lg_MSn, T;       // log2(C_out/16); number of 16x16 tiles (4 or 8)
+    int NSn, lg_RB;      // tiles along positions; log2(DPP rows per GroupNorm group) = log2(gs/4)
+    int w_off;           // float offset of the packed conv weights
+    int b_off, ga_off, be_off, tb_off;  // sources of the parameter vectors (packed offsets; tb_off: offset in the time-table row, -1 none)
+    int p_off;           // float offset of this op's staged [bias | gamma | beta | tbias | rbias] block (5*cout floats) in LDS
+    // folded residual 1x1 conv of the block (blocks[1] only):  out += W_res * block_input + b_res
+    int rsrc, rnc16, rw_off, rb_off;    // rsrc = LDS buffer of the block input (-1: none)
 };
 
-constexpr int kMaxFusedOps = 14;
+constexpr int kMaxFusedOps = 16;
 constexpr int kMaxFusedBufs = 16;
+constexpr int kFusedRing = 16;   // ring depth in 1-KiB A-fragment blocks (4 VGPRs each)
 
 struct FusedArgs {
     const float* packed;
@@ -61,14 +71,11 @@ struct FusedArgs {
     float* gout[3];      // global outputs, channel-last [B][L][C]
     int gc1, gc2, L0, in_buf;
     int B, nops, nbufs;
-    int red_off4;        // K-partial buffer (float4 units)
+    int stat_off;        // GroupNorm exchange area (floats): [tile 0..7][q 0..3][mean, M2]
     int par_off4;        // staged per-op parameter vectors (float4 units)
-    int par_floats;      // their total length (<= 8*512)
-    int w_off4;          // LDS weight window (float4 units)
-    int w_cap_blocks;    // its capacity in 1-KiB A-fragment blocks
+    int par_floats;      // their total length
     int lg_c4n;          // log2(float4 per staged input row) or -1 (generic division path)
-    int n_runs;          // parameter runs = 4 * (#conv ops): run r = op (r>>2), vector (r&3)
-    int lds_float4;      // total LDS in float4 units (zeroed at start)
+    int n_runs;          // parameter runs = 5 * (#conv ops): run r = op (r / 5), vector (r % 5)
     FusedOp ops[kMaxFusedOps];
     FusedBuf bufs[kMaxFusedBufs];
     // FOP_FINAL extras (final 1x1 conv + DDPM step), as FinalArgs of mpdx.hip
@@ -79,62 +86,124 @@ struct FusedArgs {
     long long* trace;    // dev tool: s_memtime stamps of workgroup 0 / wave 0 (null in production)
 };
 
-struct FusedWork {   // one wave's share of a conv op
-    int ms, ns, kpart, ksplit, MSn;
+// ---- compile-time k-loop shapes: (MODE, KS, C_in/16, C_in/16 of the folded residual conv or 0) -----------------------------
+#define MPDX_FUSED_SHAPES(X)                                                                                      \
+    X(0, CONV_S1, 5, 1, 0) X(1, CONV_S1, 5, 2, 0) X(2, CONV_S1, 5, 4, 0) X(3, CONV_S1, 5, 8, 0) X(4, CONV_S1, 5, 16, 0) \
+    X(5, CONV_S1, 5, 2, 1) X(6, CONV_S1, 5, 4, 2) X(7, CONV_S1, 5, 4, 16) X(8, CONV_S1, 5, 2, 8) X(9, CONV_S1, 5, 8, 4)   \
+    X(10, CONV_S1, 1, 1, 0) X(11, CONV_S1, 1, 2, 0) X(12, CONV_S1, 1, 4, 0) X(13, CONV_S1, 1, 8, 0) X(14, CONV_S1, 1, 16, 0) \
+    X(15, CONV_DOWN, 3, 2, 0) X(16, CONV_DOWN, 3, 4, 0) X(17, CONV_DOWN, 3, 8, 0)                                  \
+    X(18, CONV_UPT, 4, 2, 0) X(19, CONV_UPT, 4, 4, 0) X(20, CONV_UPT, 4, 8, 0)
+
+inline int fused_shape_id(int mode, int ks, int nc16, int rnc16) {
+#define X(id, M, K, N, R) if (mode == M && ks == K && nc16 == N && rnc16 == R) return id;
+    MPDX_FUSED_SHAPES(X)
+#undef X
+    return -1;
+}
+
+// LDS-only workgroup barrier: waits for this wave's LDS traffic, NOT for its global loads (the weight ring stays in flight).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// block index (1-KiB units, relative to the wave's stream base) of the r-th block a wave consumes
+template <int MODE>
+__device__ __forceinline__ constexpr int fused_blk(int r) { return (MODE == CONV_UPT) ? ((r >> 1) * 4 + (r & 1)) : r; }
+
+// Request the first kFusedRing blocks of an op's stream (runtime shape: called one op ahead).  Unconditional loads from
+// clamped block indices: short streams just re-request their last block.
+__device__ __forceinline__ void fused_prefetch(f32x4 (&ring)[kFusedRing], const float* __restrict__ abase, int mode, int nblk,
+                                               const float* __restrict__ rbase, int rnblk) {
+#pragma unroll
+    for (int p = 0; p < kFusedRing; ++p) {
+        const int tot = nblk + rnblk;
+        const int r = p < tot ? p : tot - 1;
+        const float* src;
+        if (r < nblk) src = abase + (size_t)(mode == CONV_UPT ? ((r >> 1) * 4 + (r & 1)) : r) * 256;
+        else src = rbase + (size_t)(r - nblk) * 256;
+        ring[p] = *(const f32x4*)src;
+    }
+}
+
+// One wave's whole-K MFMA loop over its 16x16 tile.  ring[] holds blocks 0..kFusedRing-1 of the stream on entry (requested
+// one op ahead); every consumed slot is refilled with the block kFusedRing further down the stream.
+//   abase: packed weights of this wave's 16 output channels (+ parity slots for CONV_UPT) + lane*4
+//   brow : lane's B row in the source buffer (float4 units); tap offsets are multiples of rs4
+//   rbase / rrow / racc: the folded residual 1x1 conv's stream, B row and accumulator (NCR > 0)
+template <int MODE, int KS, int NC16, int NCR>
+__device__ __forceinline__ void fused_kloop(f32x4 (&ring)[kFusedRing], const float* __restrict__ abase, const f32x4* __restrict__ brow, int rs4,
+                                            int par, const float* __restrict__ rbase, const f32x4* __restrict__ rrow, f32x4& acc0, f32x4& acc1,
+                                            f32x4& racc0, f32x4& racc1) {
+    constexpr int NTAP = (MODE == CONV_UPT) ? 2 : KS;
+    constexpr int NBLK = NC16 * NTAP, TOT = NBLK + NCR, P = kFusedRing;
+    constexpr int DB = 2;   // B fragments are read DB blocks ahead of their MFMAs (LDS latency under two blocks of MFMAs)
+    auto read_b = [&](int r) -> f32x4 {
+        if (r < NBLK) {
+            const int c16 = r / NTAP, ts = r % NTAP;
+            const int roff = (MODE == CONV_UPT) ? ((ts == 0) ? 0 : (par == 0 ? -1 : 1)) : ts;
+            return brow[roff * rs4 + c16 * 4];
+        }
+        return rrow[(r - NBLK) * 4];
+    };
+    f32x4 bq[DB + 1];
+#pragma unroll
+    for (int r = 0; r < DB && r < TOT; ++r) bq[r] = read_b(r);
+    // hipcc's scheduler otherwise sinks every ring refill next to its use (2 loads in flight instead of 16) and issues each
+    // ds_read right before its MFMAs: the order below is PINNED block by block with sched_barrier(0); the s_waitcnt counts are
+    // still the compiler's (exact: the code is straight-line).
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < TOT; ++r) {
+        if (r + DB < TOT) bq[(r + DB) % (DB + 1)] = read_b(r + DB);
+        const f32x4 af = ring[r % P];
+        const f32x4 bf = bq[r % (DB + 1)];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {   // two independent accumulator chains (even / odd k)
+            if (r >= NBLK) {
+                if (e & 1) racc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], racc1, 0, 0, 0);
+                else racc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], racc0, 0, 0, 0);
+            } else {
+                if (e & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc0, 0, 0, 0);
+            }
+        }
+        if (r + P < TOT) {
+            const int rn = r + P;
+            ring[r % P] = (rn < NBLK) ? *(const f32x4*)(abase + (size_t)fused_blk<MODE>(rn) * 256) : *(const f32x4*)(rbase + (size_t)(rn - NBLK) * 256);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// sum over the 16 lanes of a DPP row (every lane of the row gets the sum)
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
+struct FusedTile {   // a wave's tile of the current op and where its operands live
+    int ms, ns, par, npos;
+    const float* abase;
+    const float* rbase;
+    int nblk, rnblk;
 };
 
-__device__ __forceinline__ FusedWork fused_work(const FusedOp& op, int wave) {
-    FusedWork w;
-    w.MSn = 1 << op.lg_MSn;
-    const int sub = wave & ((1 << op.lg_T) - 1);
-    w.kpart = wave >> op.lg_T;
-    w.ksplit = 8 >> op.lg_T;
-    w.ms = sub & (w.MSn - 1);
-    w.ns = sub >> op.lg_MSn;
-    return w;
-}
-
-// LDS-DMA the A-fragment blocks of input-channel chunk [c_lo, c_lo + cn) of `op` into the weight window.
-// Window layout [ms][c16_local][slot] x 1 KiB: for a fixed ms both the global source and the window are one contiguous
-// run of cn*nslot blocks, so the copy loop needs no index decoding.  Every wave issues its share; completion =
-// vmcnt(0) + barrier.
-__device__ __forceinline__ void fused_dma_weights(const FusedArgs& a, const FusedOp& op, int c_lo, int cn, int wave, int lane, float* smem) {
-    const int run = cn * op.nslot;
+__device__ __forceinline__ FusedTile fused_tile(const FusedArgs& a, const FusedOp& op, int wave, int lane) {
+    FusedTile t;
     const int MSn = 1 << op.lg_MSn;
-    for (int ms = 0; ms < MSn; ++ms) {
-        const float* src = a.packed + op.w_off + ((size_t)(ms * op.nc16 + c_lo) * op.nslot) * 256 + lane * 4;
-        float* dst = smem + (size_t)a.w_off4 * 4 + (size_t)(ms * run) * 256;
-        for (int r = wave; r < run; r += 8)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)r * 256),
-                                             (__attribute__((address_space(3))) void*)(dst + (size_t)r * 256), 16, 0, 0);
-    }
-}
-
-// K-loop of one wave over 16-input-channel chunks [cl_lo, cl_hi) of the weight window: taps are unrolled at compile
-// time and there is no per-k-group control flow, so hipcc software-pipelines the ds_reads against the MFMAs.
-// wrow: this wave's A blocks in the window (+lane), brow: its B row in the activation buffer (float4 units).
-template <int MODE, int KS>
-__device__ __forceinline__ void fused_mfma(const f32x4* __restrict__ wrow, const f32x4* __restrict__ brow, int rs4, int c_base, int cl_lo,
-                                           int cl_hi, int par, f32x4& acc0, f32x4& acc1) {
-    constexpr int NTAP = (MODE == CONV_UPT) ? 2 : KS;
-    constexpr int NSLOT = (MODE == CONV_UPT) ? 4 : KS;
-    for (int cl = cl_lo; cl < cl_hi; ++cl) {
-        f32x4 af[NTAP], bf[NTAP];
-#pragma unroll
-        for (int ts = 0; ts < NTAP; ++ts) {
-            const int roff = (MODE == CONV_UPT) ? ((ts == 0) ? 0 : (par == 0 ? -1 : 1)) : ts;
-            const int slot = (MODE == CONV_UPT) ? (par * 2 + ts) : ts;
-            af[ts] = wrow[(cl * NSLOT + slot) * 64];
-            bf[ts] = brow[roff * rs4 + (c_base + cl) * 4];
-        }
-#pragma unroll
-        for (int ts = 0; ts < NTAP; ++ts)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if ((ts & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ts][e], bf[ts][e], acc0, 0, 0, 0);
-                else acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ts][e], bf[ts][e], acc1, 0, 0, 0);
-            }
-    }
+    const int sub = wave & (op.T - 1);            // waves >= T alias a valid tile (their loads are harmless, their results unused)
+    t.ms = sub & (MSn - 1);
+    t.ns = sub >> op.lg_MSn;
+    t.par = t.ns & 1;
+    const int j = lane & 15;
+    const int nslot = (op.mode == CONV_UPT) ? 4 : op.ks;
+    t.abase = a.packed + op.w_off + (size_t)t.ms * op.nc16 * nslot * 256 + (op.mode == CONV_UPT ? t.par * 2 * 256 : 0) + lane * 4;
+    t.nblk = op.nc16 * ((op.mode == CONV_UPT) ? 2 : op.ks);
+    t.rnblk = op.rsrc >= 0 ? op.rnc16 : 0;
+    t.rbase = a.packed + (op.rsrc >= 0 ? op.rw_off + (size_t)t.ms * op.rnc16 * 256 : 0) + lane * 4;
+    t.npos = (op.mode == CONV_UPT) ? 2 * ((t.ns >> 1) * 16 + j) + t.par : t.ns * 16 + j;
+    return t;
 }
 
 __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
@@ -151,8 +220,13 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
 #define FUSED_STAMP() do { if (a.trace && b == 0 && tid == 0) a.trace[tr] = (long long)__builtin_readcyclecounter(); ++tr; } while (0)
     FUSED_STAMP();
 
-    // ---- prologue: every global load is issued first (input window, parameter vectors, weight DMA of the first op), the
-    //      halo / padding zeros are written while they fly, and ONE barrier closes it.
+    // ---- prologue: every global load is issued first (weight ring of op 0, input window, parameter vectors), the halo /
+    //      padding zeros are written while they fly, and ONE barrier closes it.
+    f32x4 ring[kFusedRing];
+    FusedTile tl = fused_tile(a, a.ops[0], wave, lane);
+    fused_prefetch(ring, tl.abase, a.ops[0].mode, tl.nblk, tl.rbase, tl.rnblk);
+    __builtin_amdgcn_sched_barrier(0);
+
     const FusedBuf ib = a.bufs[a.in_buf];
     const int cin = a.gc1 + a.gc2;
     const int c4n = (cin + 3) >> 2;
@@ -163,8 +237,7 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
     const bool vec_ok = ((a.gc1 & 3) == 0) && ((a.gc2 & 3) == 0);
     {
         // Unconditional loads from clamped addresses, zeros selected afterwards: a conditional load into a
-        // zero-initialised register makes hipcc wait (vmcnt(0)) for the previous load before issuing the next one,
-        // which serialised these four round trips (~6 k cycles per launch).
+        // zero-initialised register makes hipcc wait (vmcnt(0)) for the previous load before issuing the next one.
         int lk[IK];
         bool vk[IK];
 #pragma unroll
@@ -196,10 +269,10 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
             }
         }
     }
-    FUSED_STAMP();   // input loads issued
-    // parameter vectors [bias | gamma | beta | tbias] x C_out of every op: run r is handled by wave r % 8, lane = channel
+    FUSED_STAMP();   // ring + input loads issued
+    // parameter vectors [bias | gamma | beta | tbias | rbias] x C_out of every conv op: run r is handled by wave r % 8, lane = channel
     float* par = smem + (size_t)a.par_off4 * 4;
-    constexpr int RK = 7;   // runs per wave (<= 14 ops * 4 / 8)
+    constexpr int RK = 10;   // runs per wave (<= 16 ops * 5 / 8)
     float pvv[RK];
     int pdst[RK];   // LDS destination (floats from the start of the parameter area), -1: nothing to store
 #pragma unroll
@@ -207,11 +280,12 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
         const int r = wave + k * 8;
         pvv[k] = 0.f;
         pdst[k] = -1;
-        if (r < a.n_runs && lane < a.ops[r >> 2].cout) {
-            const FusedOp& op = a.ops[r >> 2];
-            pdst[k] = op.p_off + (r & 3) * op.cout + lane;
-            const int which = r & 3;
+        const int oi = r / 5, which = r - oi * 5;
+        if (r < a.n_runs && lane < a.ops[oi].cout) {
+            const FusedOp& op = a.ops[oi];
+            pdst[k] = op.p_off + which * op.cout + lane;
             const float* src = (which == 0) ? a.packed + op.b_off
+                               : (which == 4) ? (op.rsrc >= 0 ? a.packed + op.rb_off : nullptr)
                                : (op.kind != FOP_CONV_GN) ? nullptr
                                : (which == 1) ? a.packed + op.ga_off
                                : (which == 2) ? a.packed + op.be_off
@@ -220,13 +294,8 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
         }
     }
     FUSED_STAMP();   // parameter loads issued
-    // weights of the first op
-    FusedWork wk = fused_work(a.ops[0], wave);
-    fused_dma_weights(a, a.ops[0], 0, a.ops[0].cchunk, wave, lane, smem);
-    FUSED_STAMP();   // first op's weight DMA issued
     // zeros: the 2+2 halo rows of the staged input buffer and the channel padding of its rows (disjoint from what the
-    // staging writes below).  Every other buffer gets its halo rows zeroed by the op that writes it (buffers with disjoint
-    // live ranges share LDS addresses, so they cannot all be prepared here); interiors are fully overwritten before use.
+    // staging writes below).  Every other buffer gets its halo rows zeroed by the op that writes it.
     {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         for (int i = tid; i < 2 * ib.rs4; i += 512) {
@@ -250,23 +319,10 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
         }
         if (idst[k] >= 0) sm4[idst[k]] = iv[k];
     }
-    for (int idx = tid + IK * 512; idx < n_in; idx += 512) {   // (not reached for the supported shapes; kept for safety)
-        const int l = idx / c4n, c = (idx - l * c4n) << 2;
-        const size_t pos = (size_t)b * a.L0 + l;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ce = c + e;
-            if (ce < a.gc1) v[e] = a.gsrc1[pos * a.gc1 + ce];
-            else if (ce < cin) v[e] = a.gsrc2[pos * a.gc2 + (ce - a.gc1)];
-        }
-        sm4[ib.off4 + (l + 2) * ib.rs4 + (c >> 2)] = v;
-    }
 #pragma unroll
     for (int k = 0; k < RK; ++k)
         if (pdst[k] >= 0) par[pdst[k]] = pvv[k];
-    __builtin_amdgcn_s_waitcnt(0);  // this wave's DMA blocks have landed
-    __syncthreads();
+    lds_barrier();
     FUSED_STAMP();
 
     for (int oi = 0; oi < a.nops; ++oi) {
@@ -325,114 +381,94 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
             continue;
         }
 
-        // ------------------------------------------------------------------ conv: MFMA over this wave's k-groups
-        wk = fused_work(op, wave);
+        // ------------------------------------------------------------------ conv: this wave's tile, whole K
         const FusedBuf sb = a.bufs[op.src];
-        int boff, npos;
-        if (op.mode == CONV_UPT) {
-            const int m = (wk.ns >> 1) * 16 + j;
-            boff = sb.off4 + (m + 2) * sb.rs4 + q;
-            npos = 2 * m + (wk.ns & 1);
-        } else {
-            const int l = wk.ns * 16 + j;
-            const int pad = (op.mode == CONV_S1) ? (op.ks >> 1) : 1;
-            boff = sb.off4 + ((op.mode == CONV_DOWN ? 2 * l : l) + 2 - pad) * sb.rs4 + q;
-            npos = l;
-        }
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        const int par = wk.ns & 1;
-        const int cchunk = op.cchunk;
-        for (int c_lo = 0; c_lo < op.nc16; c_lo += cchunk) {
-            const int cn = min(cchunk, op.nc16 - c_lo);
-            if (c_lo > 0) {  // next chunk of a large op: the window is free once every wave finished the previous chunk
-                __syncthreads();
-                fused_dma_weights(a, op, c_lo, cn, wave, lane, smem);
-                __builtin_amdgcn_s_waitcnt(0);
-                __syncthreads();
+        const bool owner = wave < op.T;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, racc0 = {0.f, 0.f, 0.f, 0.f}, racc1 = {0.f, 0.f, 0.f, 0.f};
+        if (owner) {
+            int boff;
+            if (op.mode == CONV_UPT) boff = sb.off4 + ((tl.ns >> 1) * 16 + j + 2) * sb.rs4 + q;
+            else {
+                const int l = tl.ns * 16 + j;
+                const int pad = (op.mode == CONV_S1) ? (op.ks >> 1) : 1;
+                boff = sb.off4 + ((op.mode == CONV_DOWN ? 2 * l : l) + 2 - pad) * sb.rs4 + q;
             }
-            // K split over 16-channel chunks (host guarantees cn % ksplit == 0 or ksplit == 1)
-            const int per = (wk.ksplit == 1) ? cn : ((cn + 1) >> 1);   // ksplit is 1 or 2
-            const int cl_lo = wk.kpart * per, cl_hi = min(cn, cl_lo + per);
-            const f32x4* wrow = sm4 + a.w_off4 + (size_t)(wk.ms * cn) * op.nslot * 64 + lane;
             const f32x4* brow = sm4 + boff;
-            if (op.mode == CONV_S1 && op.ks == 5) fused_mfma<CONV_S1, 5>(wrow, brow, sb.rs4, c_lo, cl_lo, cl_hi, par, acc0, acc1);
-            else if (op.mode == CONV_S1) fused_mfma<CONV_S1, 1>(wrow, brow, sb.rs4, c_lo, cl_lo, cl_hi, par, acc0, acc1);
-            else if (op.mode == CONV_DOWN) fused_mfma<CONV_DOWN, 3>(wrow, brow, sb.rs4, c_lo, cl_lo, cl_hi, par, acc0, acc1);
-            else fused_mfma<CONV_UPT, 4>(wrow, brow, sb.rs4, c_lo, cl_lo, cl_hi, par, acc0, acc1);
+            const f32x4* rrow = sm4;
+            if (op.rsrc >= 0) rrow = sm4 + a.bufs[op.rsrc].off4 + (tl.ns * 16 + j + 2) * a.bufs[op.rsrc].rs4 + q;
+            switch (op.shape) {
+#define X(id, M, K, N, R) case id: fused_kloop<M, K, N, R>(ring, tl.abase, brow, sb.rs4, tl.par, tl.rbase, rrow, acc0, acc1, racc0, racc1); break;
+                MPDX_FUSED_SHAPES(X)
+#undef X
+                default: break;
+            }
         }
-        const f32x4 acc = acc0 + acc1;
-        FUSED_STAMP();   // MFMA loop done
-        const int MTP4 = (op.cout + 4) >> 2;
+        f32x4 acc = acc0 + acc1;
+        const f32x4 racc = racc0 + racc1;
+        FUSED_STAMP();   // k-loop issued
+        const FusedTile cur = tl;
+        // request the next conv's first ring blocks now: they arrive under this op's epilogue and barriers
+        if (oi + 1 < a.nops && a.ops[oi + 1].kind != FOP_FINAL) {
+            tl = fused_tile(a, a.ops[oi + 1], wave, lane);
+            fused_prefetch(ring, tl.abase, a.ops[oi + 1].mode, tl.nblk, tl.rbase, tl.rnblk);
+            __builtin_amdgcn_sched_barrier(0);   // the requests go out HERE, ahead of the epilogue
+        }
+
+        // ------------------------------------------------------------------ epilogue (registers -> destination buffer)
+        const float* par_op = smem + (size_t)a.par_off4 * 4 + op.p_off;  // [bias | gamma | beta | tbias | rbias] x cout
+        const int c0 = cur.ms * 16 + q * 4;   // this lane's 4 output channels
         const int N = op.L_out;
-        sm4[a.red_off4 + (wk.kpart * N + npos) * MTP4 + wk.ms * 4 + q] = acc;
-        const int ksplit_cur = wk.ksplit;
-        __syncthreads();
-        FUSED_STAMP();   // partials visible; the weight window is free
-
-        // DMA the next conv's weights now: the transfer overlaps this op's epilogue
-        if (oi + 1 < a.nops && a.ops[oi + 1].kind != FOP_FINAL)
-            fused_dma_weights(a, a.ops[oi + 1], 0, a.ops[oi + 1].cchunk, wave, lane, smem);
-
-        // ------------------------------------------------------------------ epilogue
-        const float* par_op = smem + (size_t)a.par_off4 * 4 + op.p_off;  // [bias | gamma | beta | tbias] x cout
-        const float* bias = par_op;
+        f32x4 y;
         if (op.kind == FOP_CONV_GN) {
-            // wave g normalises GroupNorm group g (8 groups per trajectory)
-            const int gs = op.gs, re = gs * N;
-            const float inv_re = (re == 256) ? (1.0f / 256.0f) : (1.0f / 128.0f);
-            const FusedBuf db = a.bufs[op.dst];
-            if (re == 256) {
-                const int e0 = lane * 4;
-                const int l = e0 >> op.lg_gs, c = wave * gs + (e0 & (gs - 1));
-                const f32x4 bi = *(const f32x4*)(bias + c);
-                const f32x4 ga = *(const f32x4*)(par_op + op.cout + c), be = *(const f32x4*)(par_op + 2 * op.cout + c);
-                const f32x4 tb = *(const f32x4*)(par_op + 3 * op.cout + c);
-                f32x4 v = sm4[a.red_off4 + l * MTP4 + (c >> 2)];
-                for (int k = 1; k < ksplit_cur; ++k) v += sm4[a.red_off4 + (k * N + l) * MTP4 + (c >> 2)];
-                v += bi;
-                const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * inv_re;
-                const f32x4 d = v - mean;
-                const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * inv_re;
-                const float rstd = 1.0f / sqrtf(var + 1e-5f);
-                f32x4 y;
+            const f32x4 bi = *(const f32x4*)(par_op + c0);
+            const f32x4 ga = *(const f32x4*)(par_op + op.cout + c0), be = *(const f32x4*)(par_op + 2 * op.cout + c0);
+            const f32x4 tb = *(const f32x4*)(par_op + 3 * op.cout + c0);
+            f32x4 rsd = {0.f, 0.f, 0.f, 0.f};
+            if (owner && op.res >= 0) rsd = sm4[a.bufs[op.res].off4 + (cur.npos + 2) * a.bufs[op.res].rs4 + (c0 >> 2)];
+            if (op.rsrc >= 0) rsd = racc + *(const f32x4*)(par_op + 4 * op.cout + c0);
+            acc += bi;
+            // local two-pass statistics of this DPP row (4 channels x 16 positions = 64 elements)
+            const float m_loc = row_sum16((acc[0] + acc[1]) + (acc[2] + acc[3])) * (1.0f / 64.0f);
+            const f32x4 dl = acc - m_loc;
+            const float m2_loc = row_sum16((dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]));
+            float* stat = smem + a.stat_off;
+            if (owner && j == 0) *(f32x2*)(stat + ((cur.ms * op.NSn + cur.ns) * 4 + q) * 2) = (f32x2){m_loc, m2_loc};
+            lds_barrier();
+            FUSED_STAMP();   // statistics exchanged
+            // combine the parts of this lane's group: rows q0 .. q0+RB-1 of the tiles (ms, 0..NSn-1); equal counts (64 each)
+            const int RB = 1 << op.lg_RB, q0 = q & ~(RB - 1);
+            const int nparts = op.NSn << op.lg_RB;   // 2 or 4
+            float pm[4], pM2[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = mish(d[e] * rstd * ga[e] + be[e]);
-                y += tb;
-                if (op.res >= 0) y += sm4[a.bufs[op.res].off4 + (l + 2) * a.bufs[op.res].rs4 + (c >> 2)];
-                sm4[db.off4 + (l + 2) * db.rs4 + (c >> 2)] = y;
-                if (op.gdst >= 0) *(f32x4*)(a.gout[op.gdst] + ((size_t)b * N + l) * op.cout + c) = y;
-            } else {  // re == 128
-                const int e0 = lane * 2;
-                const int l = e0 >> op.lg_gs, c = wave * gs + (e0 & (gs - 1));
-                const f32x2 bi = *(const f32x2*)(bias + c);
-                const f32x2 ga = *(const f32x2*)(par_op + op.cout + c), be = *(const f32x2*)(par_op + 2 * op.cout + c);
-                const f32x2 tb = *(const f32x2*)(par_op + 3 * op.cout + c);
-                const float* redf = smem + (size_t)a.red_off4 * 4;
-                f32x2 v = *(const f32x2*)(redf + (size_t)l * (MTP4 * 4) + c);
-                for (int k = 1; k < ksplit_cur; ++k) v += *(const f32x2*)(redf + (size_t)(k * N + l) * (MTP4 * 4) + c);
-                v += bi;
-                const float mean = wave_sum(v[0] + v[1]) * inv_re;
-                const f32x2 d = v - mean;
-                const float var = wave_sum(d[0] * d[0] + d[1] * d[1]) * inv_re;
-                const float rstd = 1.0f / sqrtf(var + 1e-5f);
-                f32x2 y;
+            for (int k = 0; k < 4; ++k) {
+                const int kk = k < nparts ? k : 0;
+                const int ns_k = kk >> op.lg_RB, q_k = q0 + (kk & (RB - 1));
+                const f32x2 v = *(const f32x2*)(stat + ((cur.ms * op.NSn + ns_k) * 4 + q_k) * 2);
+                pm[k] = v[0]; pM2[k] = v[1];
+            }
+            float mean, M2;
+            if (nparts == 4) {
+                mean = ((pm[0] + pm[1]) + (pm[2] + pm[3])) * 0.25f;
+                const float d0 = pm[0] - mean, d1 = pm[1] - mean, d2 = pm[2] - mean, d3 = pm[3] - mean;
+                M2 = ((pM2[0] + pM2[1]) + (pM2[2] + pM2[3])) + 64.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+            } else {
+                mean = (pm[0] + pm[1]) * 0.5f;
+                const float d0 = pm[0] - mean, d1 = pm[1] - mean;
+                M2 = (pM2[0] + pM2[1]) + 64.0f * (d0 * d0 + d1 * d1);
+            }
+            const float var = M2 * (nparts == 4 ? (1.0f / 256.0f) : (1.0f / 128.0f));
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
 #pragma unroll
-                for (int e = 0; e < 2; ++e) y[e] = mish(d[e] * rstd * ga[e] + be[e]);
-                y += tb;
-                if (op.res >= 0) y += *(const f32x2*)(smem + ((size_t)a.bufs[op.res].off4 + (size_t)(l + 2) * a.bufs[op.res].rs4) * 4 + c);
-                *(f32x2*)(smem + ((size_t)db.off4 + (size_t)(l + 2) * db.rs4) * 4 + c) = y;
-                if (op.gdst >= 0) *(f32x2*)(a.gout[op.gdst] + ((size_t)b * N + l) * op.cout + c) = y;
-            }
-        } else {  // bias only: residual 1x1 conv / Downsample1d / Upsample1d
-            const int M4 = op.cout >> 2;
-            for (int idx = tid; idx < N * M4; idx += 512) {
-                const int l = idx >> op.lg_M4, c4 = idx & (M4 - 1);
-                f32x4 v = sm4[a.red_off4 + l * MTP4 + c4];
-                for (int k = 1; k < ksplit_cur; ++k) v += sm4[a.red_off4 + (k * N + l) * MTP4 + c4];
-                v += *(const f32x4*)(bias + c4 * 4);
-                if (op.dst >= 0) sm4[a.bufs[op.dst].off4 + (l + 2) * a.bufs[op.dst].rs4 + c4] = v;
-                if (op.gdst >= 0) *(f32x4*)(a.gout[op.gdst] + ((size_t)b * N + l) * op.cout + c4 * 4) = v;
-            }
+            for (int e = 0; e < 4; ++e) y[e] = mish((acc[e] - mean) * rstd * ga[e] + be[e]);
+            y += tb;
+            y += rsd;
+        } else {  // bias only: Downsample1d / Upsample1d / a stand-alone 1x1 conv
+            y = acc + *(const f32x4*)(par_op + c0);
+            FUSED_STAMP();   // (keeps four stamps per op)
+        }
+        if (owner) {
+            if (op.dst >= 0) sm4[a.bufs[op.dst].off4 + (cur.npos + 2) * a.bufs[op.dst].rs4 + (c0 >> 2)] = y;
+            if (op.gdst >= 0) *(f32x4*)(a.gout[op.gdst] + ((size_t)b * N + cur.npos) * op.cout + c0) = y;
         }
         if (op.dst >= 0) {   // halo rows of the buffer this op defines (2 above, 2 below its L_out interior rows)
             const FusedBuf hb = a.bufs[op.dst];
@@ -443,8 +479,7 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
             }
         }
         FUSED_STAMP();   // epilogue done (this wave)
-        __builtin_amdgcn_s_waitcnt(0);  // the next op's weight blocks issued by this wave have landed
-        __syncthreads();
+        lds_barrier();
         FUSED_STAMP();
     }
 }

@@ -544,13 +544,11 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
     const Layer& l0 = u->layers[i0];
     f.in1 = l0.src1; f.in2 = l0.src2;
     a.gc1 = l0.c1; a.gc2 = l0.c2; a.L0 = l0.L_in;
-    if (f.count + (with_final ? 1 : 0) > kMaxFusedOps) return fuse_reject(__LINE__);
     int nbuf = 0;
     size_t off4 = 0;
     std::unordered_map<long, int> bufmap;  // (slot, L) -> LDS buffer
     // LDS activation buffers are placed AFTER the op list is known, by live range [first write, last read] in op indices
-    // (-1 = staged by the prologue): buffers whose ranges do not intersect share addresses, which is what lets two U-Net
-    // levels run as one program within 160 KB.
+    // (-1 = staged by the prologue): buffers whose ranges do not intersect share addresses.
     size_t buf_size4[kMaxFusedBufs];
     int buf_def[kMaxFusedBufs], buf_last[kMaxFusedBufs];
     auto new_buf = [&](int cpad, int L) {
@@ -574,36 +572,63 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         bufmap[key] = id;
         return id;
     };
+    auto lg2 = [](int v) { int k = 0; while ((1 << k) < v) ++k; return k; };
     a.in_buf = new_buf(l0.cin_pad, l0.L_in);
     if (a.in_buf < 0) return fuse_reject(__LINE__);
     a.bufs[a.in_buf].clear_all = (l0.cin_pad != l0.c1 + l0.c2) ? 1 : 0;  // channel padding of the staged input
     touch(a.in_buf, -1, true);
     bufmap[(long)(l0.src1 + 8) * 4096 + l0.L_in] = a.in_buf;
-    size_t red4 = 0;
+    auto src_buf = [&](const Layer& l, int i) -> int {   // LDS buffer a layer reads (-1: not available inside the segment)
+        if (i == i0 || (l.src1 == l0.src1 && l.src2 == l0.src2 && l.L_in == l0.L_in)) return a.in_buf;
+        if (l.src2 != SRC_NONE) return -1;
+        const long key = (long)(l.src1 + 8) * 4096 + l.L_in;
+        return bufmap.count(key) ? bufmap[key] : -1;
+    };
     int ng = 0;
+    int pending_res = -1;   // index of a residual 1x1 conv waiting to be folded into the block's blocks[1]
     for (int i = i0; i < i1; ++i) {
         const Layer& l = u->layers[i];
+        // a block's residual 1x1 conv is folded into blocks[1] (the next layer, which adds its output after Mish)
+        if (l.mode == CONV_S1 && l.ks == 1 && l.epi == EPI_BIAS && i + 1 < i1 && u->layers[i + 1].res == l.dst &&
+            u->layers[i + 1].epi == EPI_GN_MISH && u->layers[i + 1].L_out == l.L_out && u->layers[i + 1].cout == l.cout) {
+            pending_res = i;
+            continue;
+        }
+        if (a.nops >= kMaxFusedOps - (with_final ? 1 : 0)) return fuse_reject(__LINE__);
         FusedOp& op = a.ops[a.nops];
+        memset(&op, 0, sizeof(op));
         op.kind = (l.epi == EPI_GN_MISH) ? FOP_CONV_GN : FOP_CONV_BIAS;
-        op.mode = l.mode; op.ks = l.ks;
+        op.mode = l.mode; op.ks = l.ks; op.nc16 = l.cin_pad / 16;
         const int MSn = l.cout / 16, NSn = (l.mode == CONV_UPT) ? (l.L_in / 16) * 2 : l.L_out / 16;
         const int T = MSn * NSn;
         if (l.cout % 16 || l.L_out % 16 || (T != 4 && T != 8) || (l.mode == CONV_UPT && l.L_in % 16)) return fuse_reject(__LINE__);
-        if (op.kind == FOP_CONV_GN && (l.cout / l.gs != 8 || (l.gs * l.L_out != 128 && l.gs * l.L_out != 256))) return fuse_reject(__LINE__);
-        // source: the first layers read the staged input; later ones an LDS buffer produced in this segment
-        if (i == i0 || (l.src1 == l0.src1 && l.src2 == l0.src2 && l.L_in == l0.L_in)) op.src = a.in_buf;
-        else {
-            if (l.src2 != SRC_NONE) return fuse_reject(__LINE__);
-            const long key = (long)(l.src1 + 8) * 4096 + l.L_in;
-            if (!bufmap.count(key)) return fuse_reject(__LINE__);
-            op.src = bufmap[key];
+        if ((1 << lg2(MSn)) != MSn || l.cout > 64) return fuse_reject(__LINE__);   // parameter staging: lane = channel
+        op.lg_MSn = lg2(MSn); op.T = T; op.NSn = NSn; op.gs = l.gs;
+        if (op.kind == FOP_CONV_GN) {
+            // a GroupNorm group = RB DPP rows (4 channels each) of NSn tiles: 64 elements per part, 2 or 4 parts
+            if (l.gs != 4 && l.gs != 8 && l.gs != 16) return fuse_reject(__LINE__);
+            op.lg_RB = lg2(l.gs / 4);
+            const int parts = NSn << op.lg_RB;
+            if (parts != 2 && parts != 4) return fuse_reject(__LINE__);
+            if (l.mode != CONV_S1) return fuse_reject(__LINE__);
         }
-        op.res = -1;
-        if (l.res != SRC_NONE) {
+        op.src = src_buf(l, i);
+        if (op.src < 0) return fuse_reject(__LINE__);
+        op.res = -1; op.rsrc = -1;
+        if (pending_res >= 0) {
+            const Layer& r = u->layers[pending_res];
+            op.rsrc = src_buf(r, pending_res);
+            if (op.rsrc < 0) return fuse_reject(__LINE__);
+            op.rnc16 = r.cin_pad / 16;
+            op.rw_off = (int)u->params[r.w].off; op.rb_off = (int)u->params[r.b].off;
+            pending_res = -1;
+        } else if (l.res != SRC_NONE) {
             const long key = (long)(l.res + 8) * 4096 + l.L_out;
             if (!bufmap.count(key)) return fuse_reject(__LINE__);
             op.res = bufmap[key];
         }
+        op.shape = fused_shape_id(l.mode, l.ks, op.nc16, op.rsrc >= 0 ? op.rnc16 : 0);
+        if (op.shape < 0) return fuse_reject(__LINE__);
         // destination: LDS if a later layer of the segment (or the final op) reads it; global if someone outside does
         bool read_inside = with_final && i == i1 - 1;
         for (int k = i + 1; k < i1; ++k) {
@@ -623,35 +648,27 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         if (i == i1 - 1 && !with_final) read_outside = true;
         op.dst = read_inside ? buf_for(l.dst, l.L_out, l.cout) : -1;
         if (read_inside && op.dst < 0) return fuse_reject(__LINE__);
-        if (op.dst >= 0 && (op.dst == op.src || op.dst == op.res)) return fuse_reject(__LINE__);
+        if (op.dst >= 0 && (op.dst == op.src || op.dst == op.res || op.dst == op.rsrc)) return fuse_reject(__LINE__);
         op.gdst = -1;
         if (read_outside) {
             if (ng >= 3) return fuse_reject(__LINE__);
             f.gout_slot[ng] = l.dst;
             op.gdst = ng++;
         }
-        touch(op.src, a.nops, false); touch(op.res, a.nops, false); touch(op.dst, a.nops, true);
-        op.cin_pad = l.cin_pad; op.cout = l.cout; op.L_in = l.L_in; op.L_out = l.L_out; op.gs = l.gs;
+        touch(op.src, a.nops, false); touch(op.res, a.nops, false); touch(op.rsrc, a.nops, false); touch(op.dst, a.nops, true);
+        op.cout = l.cout; op.L_in = l.L_in; op.L_out = l.L_out;
         op.w_off = (int)u->params[l.w].off; op.b_off = (int)u->params[l.b].off;
         op.ga_off = l.gamma >= 0 ? (int)u->params[l.gamma].off : 0;
         op.be_off = l.beta >= 0 ? (int)u->params[l.beta].off : 0;
         op.tb_off = l.tb_off;
-        auto lg2 = [](int v) { int k = 0; while ((1 << k) < v) ++k; return k; };
-        if ((1 << lg2(MSn)) != MSn || (1 << lg2(l.cout / 4)) != l.cout / 4) return fuse_reject(__LINE__);
-        op.lg_T = lg2(T); op.lg_MSn = lg2(MSn); op.lg_M4 = lg2(l.cout / 4);
-        op.lg_gs = op.kind == FOP_CONV_GN ? lg2(l.gs) : 0;
-        if (op.kind == FOP_CONV_GN && (1 << op.lg_gs) != l.gs) return fuse_reject(__LINE__);
-        op.ntap = (l.mode == CONV_UPT) ? 2 : l.ks;
-        op.nslot = (l.mode == CONV_UPT) ? 4 : l.ks;
-        op.nc16 = l.cin_pad / 16;
-        red4 = std::max(red4, (size_t)(8 / T) * l.L_out * ((l.cout + 4) / 4));
         a.nops++;
     }
+    if (pending_res >= 0) return fuse_reject(__LINE__);
     if (with_final) {
         const Layer& lf = u->layers[i1 - 1];
         FusedOp& op = a.ops[a.nops++];
         memset(&op, 0, sizeof(op));
-        op.kind = FOP_FINAL;
+        op.kind = FOP_FINAL; op.shape = -1;
         op.src = bufmap[(long)(lf.dst + 8) * 4096 + lf.L_out];
         touch(op.src, a.nops - 1, false);
         op.L_in = lf.L_out;
@@ -682,23 +699,19 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
             off4 = std::max(off4, cand + buf_size4[bi]);
         }
     }
-    a.red_off4 = (int)off4;
-    off4 += red4;
-    a.lds_float4 = (int)off4;   // cleared at kernel start (activation buffers + partials); parameters follow
+    a.stat_off = (int)off4 * 4;     // GroupNorm exchange: 8 tiles x 4 rows x (mean, M2)
+    off4 += 16;
     a.par_off4 = (int)off4;
-    int poff = 0;
+    int poff = 0, nconv = 0;
     for (int k = 0; k < a.nops; ++k)
-        if (a.ops[k].kind != FOP_FINAL) { a.ops[k].p_off = poff; poff += 4 * a.ops[k].cout; }
+        if (a.ops[k].kind != FOP_FINAL) {
+            if (k != nconv) return fuse_reject(__LINE__);   // conv ops come first (FINAL last): parameter run r belongs to op r / 5
+            a.ops[k].p_off = poff; poff += 5 * a.ops[k].cout; ++nconv;
+        }
     a.par_floats = poff;
-    {   // parameter runs are indexed by lane = channel: at most 64 output channels per op; conv ops come first (FINAL last)
-        int nconv = 0;
-        for (int k = 0; k < a.nops; ++k)
-            if (a.ops[k].kind != FOP_FINAL) {
-                if (a.ops[k].cout > 64 || k != nconv) return fuse_reject(__LINE__);
-                ++nconv;
-            }
-        if (nconv * 4 > 56) return fuse_reject(__LINE__);
-        a.n_runs = nconv * 4;
+    a.n_runs = nconv * 5;
+    if (a.n_runs > 80) return fuse_reject(__LINE__);
+    {
         const int c4n = (a.gc1 + a.gc2 + 3) / 4;
         int l4 = 0;
         while ((1 << l4) < c4n) ++l4;
@@ -706,38 +719,12 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         if ((size_t)a.L0 * c4n > 4 * 512) return fuse_reject(__LINE__);   // prologue holds the input window in 4 float4 per thread
     }
     off4 += (size_t)(poff + 3) / 4;
-    // LDS weight window: as large as the remaining LDS allows (<= the largest op), in 1-KiB blocks; an op that
-    // does not fit runs in input-channel chunks, which need at least one 16-channel slab of every (m16, slot)
-    size_t need_blocks = 0, min_blocks = 0;
-    for (int k = 0; k < a.nops; ++k) {
-        const FusedOp& op = a.ops[k];
-        if (op.kind == FOP_FINAL) continue;
-        const size_t per_c16 = (size_t)(op.cout / 16) * (op.mode == CONV_UPT ? 4 : op.ks);
-        need_blocks = std::max(need_blocks, per_c16 * (op.cin_pad / 16));
-        min_blocks = std::max(min_blocks, per_c16);
-    }
-    const size_t budget_bytes = 158 * 1024;
-    if (off4 * 16 + min_blocks * 1024 > budget_bytes) return fuse_reject(__LINE__);
-    const size_t cap = std::min(need_blocks, (budget_bytes - off4 * 16) / 1024);
-    a.w_off4 = (int)off4;
-    a.w_cap_blocks = (int)cap;
-    off4 += cap * 64;
-    for (int k = 0; k < a.nops; ++k) {  // input-channel chunk (in 16-channel units) each op streams through the window
-        FusedOp& op = a.ops[k];
-        if (op.kind == FOP_FINAL) continue;
-        const int per_c16 = (op.cout / 16) * op.nslot;
-        int fit = (int)(cap / per_c16);
-        if (fit >= op.nc16) fit = op.nc16;
-        else if ((8 >> op.lg_T) == 2) fit &= ~1;  // K is split in two over 16-channel chunks: keep chunks even
-        if (fit < 1) return fuse_reject(__LINE__);
-        op.cchunk = fit;
-    }
     f.lds_bytes = off4 * 16;
     if (f.lds_bytes > 160 * 1024) return fuse_reject(__LINE__);
     u->fused.push_back(f);
     if (getenv("MPDX_DEBUG_FUSE"))
-        fprintf(stderr, "[mpdx] fused segment %zu: layers [%d,%d) %s..%s  %d ops  %d buffers  LDS %zu B (window %d KiB)\n", u->fused.size() - 1, i0, i1,
-                u->layers[i0].name.c_str(), u->layers[i1 - 1].name.c_str(), a.nops, a.nbufs, f.lds_bytes, a.w_cap_blocks);
+        fprintf(stderr, "[mpdx] fused segment %zu: layers [%d,%d) %s..%s  %d ops  %d buffers  LDS %zu B\n", u->fused.size() - 1, i0, i1,
+                u->layers[i0].name.c_str(), u->layers[i1 - 1].name.c_str(), a.nops, a.nbufs, f.lds_bytes);
     return true;
 }
 

@@ -21,10 +21,11 @@ for seg in range(4):
     _lib.check(lib.mpdx_fused_trace(hdl, packed.data_ptr(), tab.data_ptr(), x.data_ptr(), seg, B, ws.data_ptr(), st, stamps, 256, C.byref(n), C.byref(nops)))
     v = [stamps[i] for i in range(256) if stamps[i]]
     d = [b - a for a, b in zip(v, v[1:])]
-    print(f"segment {seg}: {nops.value} ops, total {v[-1]-v[0]} cycles; prologue: input loads issued {d[0]}, parameter loads issued {d[1]}, weight DMA issued {d[2]}, halo zeros {d[3]}, loads landed + barrier {d[4]}")
-    k = 5
+    print(f"segment {seg}: {nops.value} ops, total {v[-1]-v[0]} cycles; prologue: ring + input loads issued {d[0]}, parameter loads issued {d[1]}, "
+          f"halo zeros {d[2]}, loads landed + barrier {d[3]}")
+    k = 4
     for oi in range(nops.value):
-        if k + 3 < len(d) + 1 and oi < nops.value:
-            print(f"   op{oi}: mfma {d[k]:6d}  barrier {d[k+1]:6d}  epilogue {d[k+2]:6d}  barrier {d[k+3] if k+3 < len(d) else -1:6d}")
+        if k + 3 < len(d) + 1:
+            print(f"   op{oi}: k-loop {d[k]:6d}  stats+barrier {d[k+1]:6d}  epilogue {d[k+2]:6d}  barrier {d[k+3] if k+3 < len(d) else -1:6d}")
             k += 4
     print(f"   remaining stamps after the last printed op: {d[k:]}")

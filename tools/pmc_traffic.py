@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""HBM-side bytes per launch, per kernel, from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass:
+MI355X_MICROARCH.md, TCC counter budget).  Units and the gfx950 correction as that guide's HBM section prescribes:
+FETCH_SIZE / WRITE_SIZE are reported in KiB... (rocprofv3 derives them as TCC_EA0_RDREQ x 64 B / 1024); on gfx950 wide coalesced
+reads are 128-B requests counted as one 64-B request, hence fetch bytes = FETCH_SIZE x 1024 x 2.
+
+usage: pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <batch B> > profiles/rNN_pmc_traffic.json"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(d, counter):
+    acc, cnt = collections.defaultdict(float), collections.defaultdict(set)
+    for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            acc[r["Kernel_Name"]] += float(r["Counter_Value"])
+            cnt[r["Kernel_Name"]].add(r["Dispatch_Id"])
+    return {k: (acc[k] / len(cnt[k]), len(cnt[k])) for k in acc}
+
+
+fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+out = {"source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate passes) -- python bench.py --steps 1 "
+                 "--warmup 1 --no-cpu-baseline --no-roofline --no-extras ; MI355X",
+       "batch": int(sys.argv[3]) if len(sys.argv) > 3 else None, "fetch_correction": 2.0,
+       "note": "traffic = FETCH_SIZE[KiB] x 1024 x 2 + WRITE_SIZE[KiB] x 1024 per launch; counts requests the L2 sends to the fabric "
+               "(Infinity-Cache hits included): at B=100 everything is MALL-resident, so this is L2-miss traffic, an upper bound on HBM bytes",
+       "kernels": {}}
+for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, (0, 0))[0] * fetch.get(k, (0, 1))[1])):
+    fk, nf = fetch.get(k, (0.0, 0))
+    wk, nw = write.get(k, (0.0, 0))
+    out["kernels"][k[:160]] = {"launches": max(nf, nw), "FETCH_SIZE_KiB_raw_per_launch": round(fk, 2), "WRITE_SIZE_KiB_per_launch": round(wk, 2),
+                              "traffic_bytes_per_launch": int(fk * 1024 * 2 + wk * 1024)}
+print(json.dumps(out, indent=1))

@@ -1,0 +1,8 @@
+#!/bin/bash
+# GPU run 2: the new fused level kernel - parity tests first, then timing
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r02b; mkdir -p $O
+MPDX_DEBUG_FUSE=1 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | grep -v "^$" | tail -25 | tee $O/pytest_parity.txt
+timeout 300 python tools/fused_trace.py 100 2>&1 | grep -v amdgpu > $O/fused_trace.txt; cat $O/fused_trace.txt
+MPDX_BENCH_TABLE=1 timeout 900 python bench.py --no-cpu-baseline --no-extras > $O/bench_cfg2.json 2> $O/bench_cfg2.err; tail -1 $O/bench_cfg2.json | cut -c1-300; grep "^#" $O/bench_cfg2.err
+timeout 1500 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_guide.py tests/test_gpu_entry.py -x -q -s 2>&1 | grep -v "^$" | tail -30 | tee $O/pytest_rest.txt
