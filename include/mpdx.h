@@ -218,7 +218,7 @@ int mpdx_unet_profile(mpdx_unet* u, const float* packed_dev, const float* timeta
 /* dev tool: per-phase s_memtime stamps (7 each) of the first and the last workgroup of one launch of layer `layer` */
 int mpdx_layer_trace(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, const float* x, int layer, int B, float* ws,
                      void* stream, long long* stamps32);
-/* dev tool: per-phase s_memtime stamps (workgroup 0, wave 0) of one launch of fused segment `seg` */
+/* dev tool: per-phase s_memtime stamps (workgroup 0; 8 waves x 128 slots) of one launch of fused segment `seg` */
 int mpdx_fused_trace(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, const float* x, int seg, int B,
                      float* ws, void* stream, long long* stamps_out, int cap, int* n_out, int* nops_out);
 /* in-situ timing of launch units [unit_first, unit_last] inside `reps` real U-Net passes (one event pair per pass around the

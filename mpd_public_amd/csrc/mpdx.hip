@@ -345,6 +345,7 @@ struct mpdx_unet {
     int final_slot = 0;       // slot holding final_conv[0]'s output
     int n_done = 0;
     // launch units: fused whole-trajectory segments (fused_level.hpp) or single layers
+    struct CopyJob { size_t src, dst; int n0, ss0, ds0, n1, ss1, ds1, n_inner; };   // strided copy inside `packed` (float units)
     struct Fused {
         int first = 0, count = 0;       // layer range [first, first+count)
         bool has_final = false;         // final_conv[1] + DDPM step folded in
@@ -352,8 +353,11 @@ struct mpdx_unet {
         int gout_slot[3] = {-1, -1, -1};
         size_t lds_bytes = 0;
         mpdx::FusedArgs tmpl;
+        std::vector<CopyJob> jobs;      // assemble the stream-ordered weight copies + the contiguous parameter block
     };
     std::vector<Fused> fused;
+    const float* streams_for = nullptr; // `packed` buffer the fused streams were last assembled in
+    int pack_version = 0, streams_version = -1;
     struct Unit { int fused; int layer; bool pair; };   // fused >= 0: fused[fused]; else layers[layer] (pair: + layers[layer+1] in one launch)
     std::vector<int> owner;                  // layer -> fused segment (-1: per-layer launch)
 };
@@ -536,6 +540,8 @@ static bool fuse_reject(int line) {
     return false;
 }
 
+struct HostBuf { int off4 = -1, rs4 = 0, rows = 0; size_t size4 = 0; int def = 1 << 30, last = -1; };
+
 static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
     mpdx_unet::Fused f;
     f.first = i0; f.count = i1 - i0; f.has_final = with_final;
@@ -544,25 +550,21 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
     const Layer& l0 = u->layers[i0];
     f.in1 = l0.src1; f.in2 = l0.src2;
     a.gc1 = l0.c1; a.gc2 = l0.c2; a.L0 = l0.L_in;
-    int nbuf = 0;
-    size_t off4 = 0;
+    std::vector<HostBuf> bufs;
     std::unordered_map<long, int> bufmap;  // (slot, L) -> LDS buffer
     // LDS activation buffers are placed AFTER the op list is known, by live range [first write, last read] in op indices
     // (-1 = staged by the prologue): buffers whose ranges do not intersect share addresses.
-    size_t buf_size4[kMaxFusedBufs];
-    int buf_def[kMaxFusedBufs], buf_last[kMaxFusedBufs];
     auto new_buf = [&](int cpad, int L) {
-        if (nbuf >= kMaxFusedBufs) return -1;
+        HostBuf hb;
         const int rs = pick_row_stride(cpad, CONV_S1, L, L, L + 4);
-        a.bufs[nbuf].off4 = -1; a.bufs[nbuf].rs4 = rs / 4; a.bufs[nbuf].rows = L + 4; a.bufs[nbuf].clear_all = 0;
-        buf_size4[nbuf] = (size_t)(L + 4) * (rs / 4);
-        buf_def[nbuf] = 1 << 30; buf_last[nbuf] = -1;
-        return nbuf++;
+        hb.rs4 = rs / 4; hb.rows = L + 4; hb.size4 = (size_t)(L + 4) * (rs / 4);
+        bufs.push_back(hb);
+        return (int)bufs.size() - 1;
     };
     auto touch = [&](int id, int opi, bool write) {
         if (id < 0) return;
-        if (write) buf_def[id] = std::min(buf_def[id], opi);
-        buf_last[id] = std::max(buf_last[id], opi);
+        if (write) bufs[id].def = std::min(bufs[id].def, opi);
+        bufs[id].last = std::max(bufs[id].last, opi);
     };
     auto buf_for = [&](int slot, int L, int cpad) {
         const long key = (long)(slot + 8) * 4096 + L;
@@ -572,18 +574,18 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         bufmap[key] = id;
         return id;
     };
-    auto lg2 = [](int v) { int k = 0; while ((1 << k) < v) ++k; return k; };
-    a.in_buf = new_buf(l0.cin_pad, l0.L_in);
-    if (a.in_buf < 0) return fuse_reject(__LINE__);
-    a.bufs[a.in_buf].clear_all = (l0.cin_pad != l0.c1 + l0.c2) ? 1 : 0;  // channel padding of the staged input
-    touch(a.in_buf, -1, true);
-    bufmap[(long)(l0.src1 + 8) * 4096 + l0.L_in] = a.in_buf;
+    const int in_buf = new_buf(l0.cin_pad, l0.L_in);
+    a.in_clear = (l0.cin_pad != l0.c1 + l0.c2) ? 1 : 0;  // channel padding of the staged input
+    touch(in_buf, -1, true);
+    bufmap[(long)(l0.src1 + 8) * 4096 + l0.L_in] = in_buf;
     auto src_buf = [&](const Layer& l, int i) -> int {   // LDS buffer a layer reads (-1: not available inside the segment)
-        if (i == i0 || (l.src1 == l0.src1 && l.src2 == l0.src2 && l.L_in == l0.L_in)) return a.in_buf;
+        if (i == i0 || (l.src1 == l0.src1 && l.src2 == l0.src2 && l.L_in == l0.L_in)) return in_buf;
         if (l.src2 != SRC_NONE) return -1;
         const long key = (long)(l.src1 + 8) * 4096 + l.L_in;
         return bufmap.count(key) ? bufmap[key] : -1;
     };
+    struct HostOp { int src = -1, rsrc = -1, res = -1, dst = -1; const Layer* l = nullptr; const Layer* r = nullptr; int nblk = 0, ncr = 0, tot = 0, nstream = 0; };
+    std::vector<HostOp> hops;
     int ng = 0;
     int pending_res = -1;   // index of a residual 1x1 conv waiting to be folded into the block's blocks[1]
     for (int i = i0; i < i1; ++i) {
@@ -597,38 +599,34 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         if (a.nops >= kMaxFusedOps - (with_final ? 1 : 0)) return fuse_reject(__LINE__);
         FusedOp& op = a.ops[a.nops];
         memset(&op, 0, sizeof(op));
-        op.kind = (l.epi == EPI_GN_MISH) ? FOP_CONV_GN : FOP_CONV_BIAS;
-        op.mode = l.mode; op.ks = l.ks; op.nc16 = l.cin_pad / 16;
-        const int MSn = l.cout / 16, NSn = (l.mode == CONV_UPT) ? (l.L_in / 16) * 2 : l.L_out / 16;
-        const int T = MSn * NSn;
-        if (l.cout % 16 || l.L_out % 16 || (T != 4 && T != 8) || (l.mode == CONV_UPT && l.L_in % 16)) return fuse_reject(__LINE__);
-        if ((1 << lg2(MSn)) != MSn || l.cout > 64) return fuse_reject(__LINE__);   // parameter staging: lane = channel
-        op.lg_MSn = lg2(MSn); op.T = T; op.NSn = NSn; op.gs = l.gs;
-        if (op.kind == FOP_CONV_GN) {
-            // a GroupNorm group = RB DPP rows (4 channels each) of NSn tiles: 64 elements per part, 2 or 4 parts
-            if (l.gs != 4 && l.gs != 8 && l.gs != 16) return fuse_reject(__LINE__);
-            op.lg_RB = lg2(l.gs / 4);
-            const int parts = NSn << op.lg_RB;
-            if (parts != 2 && parts != 4) return fuse_reject(__LINE__);
-            if (l.mode != CONV_S1) return fuse_reject(__LINE__);
-        }
-        op.src = src_buf(l, i);
-        if (op.src < 0) return fuse_reject(__LINE__);
-        op.res = -1; op.rsrc = -1;
+        HostOp ho;
+        ho.l = &l;
+        const int gn = l.epi == EPI_GN_MISH ? 1 : 0;
+        if (gn && (l.gs * 8 != l.cout || l.mode != CONV_S1)) return fuse_reject(__LINE__);   // the shapes assume GroupNorm(8 groups)
+        ho.src = src_buf(l, i);
+        if (ho.src < 0) return fuse_reject(__LINE__);
         if (pending_res >= 0) {
-            const Layer& r = u->layers[pending_res];
-            op.rsrc = src_buf(r, pending_res);
-            if (op.rsrc < 0) return fuse_reject(__LINE__);
-            op.rnc16 = r.cin_pad / 16;
-            op.rw_off = (int)u->params[r.w].off; op.rb_off = (int)u->params[r.b].off;
+            ho.r = &u->layers[pending_res];
+            ho.rsrc = src_buf(*ho.r, pending_res);
+            if (ho.rsrc < 0) return fuse_reject(__LINE__);
             pending_res = -1;
         } else if (l.res != SRC_NONE) {
             const long key = (long)(l.res + 8) * 4096 + l.L_out;
             if (!bufmap.count(key)) return fuse_reject(__LINE__);
-            op.res = bufmap[key];
+            ho.res = bufmap[key];
         }
-        op.shape = fused_shape_id(l.mode, l.ks, op.nc16, op.rsrc >= 0 ? op.rnc16 : 0);
+        const int nc16 = l.cin_pad / 16, rnc16 = ho.r ? ho.r->cin_pad / 16 : 0;
+        op.shape = fused_shape_id(l.mode, l.ks, nc16, rnc16, l.cout, l.L_out, gn);
         if (op.shape < 0) return fuse_reject(__LINE__);
+        ho.nblk = nc16 * (l.mode == CONV_UPT ? 2 : l.ks); ho.ncr = rnc16; ho.tot = ho.nblk + ho.ncr;
+        ho.nstream = (l.cout / 16) * (l.mode == CONV_UPT ? 2 : 1);
+        {
+            int lgM = 0;
+            while ((1 << lgM) < l.cout / 16) ++lgM;
+            const int T = (l.cout / 16) * (l.L_out / 16);
+            a.geo[a.nops] = lgM | (T << 4) | ((l.mode == CONV_UPT ? 1 : 0) << 8);
+            a.sstride[a.nops] = ho.tot * 256;
+        }
         // destination: LDS if a later layer of the segment (or the final op) reads it; global if someone outside does
         bool read_inside = with_final && i == i1 - 1;
         for (int k = i + 1; k < i1; ++k) {
@@ -646,71 +644,109 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
             if (n.dst == l.dst) break;
         }
         if (i == i1 - 1 && !with_final) read_outside = true;
-        op.dst = read_inside ? buf_for(l.dst, l.L_out, l.cout) : -1;
-        if (read_inside && op.dst < 0) return fuse_reject(__LINE__);
-        if (op.dst >= 0 && (op.dst == op.src || op.dst == op.res || op.dst == op.rsrc)) return fuse_reject(__LINE__);
+        ho.dst = read_inside ? buf_for(l.dst, l.L_out, l.cout) : -1;
+        if (ho.dst >= 0 && (ho.dst == ho.src || ho.dst == ho.res || ho.dst == ho.rsrc)) return fuse_reject(__LINE__);
         op.gdst = -1;
         if (read_outside) {
             if (ng >= 3) return fuse_reject(__LINE__);
             f.gout_slot[ng] = l.dst;
             op.gdst = ng++;
         }
-        touch(op.src, a.nops, false); touch(op.res, a.nops, false); touch(op.rsrc, a.nops, false); touch(op.dst, a.nops, true);
-        op.cout = l.cout; op.L_in = l.L_in; op.L_out = l.L_out;
-        op.w_off = (int)u->params[l.w].off; op.b_off = (int)u->params[l.b].off;
-        op.ga_off = l.gamma >= 0 ? (int)u->params[l.gamma].off : 0;
-        op.be_off = l.beta >= 0 ? (int)u->params[l.beta].off : 0;
-        op.tb_off = l.tb_off;
+        touch(ho.src, a.nops, false); touch(ho.res, a.nops, false); touch(ho.rsrc, a.nops, false); touch(ho.dst, a.nops, true);
+        hops.push_back(ho);
         a.nops++;
     }
     if (pending_res >= 0) return fuse_reject(__LINE__);
+    int final_src = -1;
     if (with_final) {
         const Layer& lf = u->layers[i1 - 1];
         FusedOp& op = a.ops[a.nops++];
         memset(&op, 0, sizeof(op));
-        op.kind = FOP_FINAL; op.shape = -1;
-        op.src = bufmap[(long)(lf.dst + 8) * 4096 + lf.L_out];
-        touch(op.src, a.nops - 1, false);
-        op.L_in = lf.L_out;
+        op.shape = kFusedShapeFinal;
+        final_src = bufmap[(long)(lf.dst + 8) * 4096 + lf.L_out];
+        touch(final_src, a.nops - 1, false);
+        a.H = lf.L_out;
         a.Cf = u->cfg.unet_input_dim; a.D = u->cfg.state_dim;
         a.fw_off = (int)u->params[u->pidx.at("final_conv.1.weight")].off;
         a.fb_off = (int)u->params[u->pidx.at("final_conv.1.bias")].off;
     }
-    a.nbufs = nbuf;
+    size_t off4 = 0;
     {   // first-fit placement in order of definition; two buffers may share addresses iff one is dead strictly before the
         // op that first writes the other
+        const int nbuf = (int)bufs.size();
         std::vector<int> order(nbuf);
         for (int i = 0; i < nbuf; ++i) order[i] = i;
-        std::sort(order.begin(), order.end(), [&](int x, int y) { return buf_def[x] < buf_def[y]; });
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return bufs[x].def < bufs[y].def; });
         for (int oi = 0; oi < nbuf; ++oi) {
-            const int bi = order[oi];
-            if (buf_last[bi] < buf_def[bi]) buf_last[bi] = buf_def[bi];
+            HostBuf& bi = bufs[order[oi]];
+            if (bi.last < bi.def) bi.last = bi.def;
             size_t cand = 0;
             for (bool moved = true; moved;) {
                 moved = false;
                 for (int oj = 0; oj < oi; ++oj) {
-                    const int bj = order[oj];
-                    const bool live_overlap = !(buf_last[bj] < buf_def[bi] || buf_last[bi] < buf_def[bj]);
-                    const size_t lo = (size_t)a.bufs[bj].off4, hi = lo + buf_size4[bj];
-                    if (live_overlap && cand < hi && lo < cand + buf_size4[bi]) { cand = hi; moved = true; }
+                    const HostBuf& bj = bufs[order[oj]];
+                    const bool live_overlap = !(bj.last < bi.def || bi.last < bj.def);
+                    const size_t lo = (size_t)bj.off4, hi = lo + bj.size4;
+                    if (live_overlap && cand < hi && lo < cand + bi.size4) { cand = hi; moved = true; }
                 }
             }
-            a.bufs[bi].off4 = (int)cand;
-            off4 = std::max(off4, cand + buf_size4[bi]);
+            bi.off4 = (int)cand;
+            off4 = std::max(off4, cand + bi.size4);
         }
+    }
+    a.in_off4 = bufs[in_buf].off4; a.in_rs4 = bufs[in_buf].rs4; a.in_rows = bufs[in_buf].rows;
+    // weight streams + parameter block of the segment: a dedicated area at the end of `packed`
+    size_t area = u->packed_floats;
+    int poff = 0, tt_lo = 1 << 30, tt_hi = 0;
+    for (size_t k = 0; k < hops.size(); ++k) {
+        const HostOp& ho = hops[k];
+        const Layer& l = *ho.l;
+        FusedOp& op = a.ops[k];
+        op.src_off4 = bufs[ho.src].off4; op.src_rs4 = bufs[ho.src].rs4;
+        op.rsrc_off4 = ho.rsrc >= 0 ? bufs[ho.rsrc].off4 : 0; op.rsrc_rs4 = ho.rsrc >= 0 ? bufs[ho.rsrc].rs4 : 0;
+        op.res_off4 = ho.res >= 0 ? bufs[ho.res].off4 : -1; op.res_rs4 = ho.res >= 0 ? bufs[ho.res].rs4 : 0;
+        op.dst_off4 = ho.dst >= 0 ? bufs[ho.dst].off4 : -1; op.dst_rs4 = ho.dst >= 0 ? bufs[ho.dst].rs4 : 0;
+        op.sbase = (int)area;
+        const int MSn = l.cout / 16, nc16 = l.cin_pad / 16;
+        const size_t woff = u->params[l.w].off;
+        if (l.mode == CONV_UPT) {   // streams (ms, parity): slots {2 par, 2 par + 1} of every 16-channel chunk
+            for (int par = 0; par < 2; ++par)
+                f.jobs.push_back({woff + (size_t)par * 2 * 256, area + (size_t)par * ho.tot * 256, MSn, nc16 * 4 * 256, 2 * ho.tot * 256, nc16, 4 * 256, 2 * 256, 512});
+        } else {
+            f.jobs.push_back({woff, area, MSn, ho.nblk * 256, ho.tot * 256, 1, 0, 0, ho.nblk * 256});
+            if (ho.r) f.jobs.push_back({u->params[ho.r->w].off, area + (size_t)ho.nblk * 256, MSn, ho.ncr * 256, ho.tot * 256, 1, 0, 0, ho.ncr * 256});
+        }
+        area += (size_t)ho.nstream * ho.tot * 256;
+        op.p_off = poff;
+        poff += 4 * l.cout;
+        op.tb_off = l.tb_off;   // made relative to the staged slice below
+        if (l.tb_off >= 0) { tt_lo = std::min(tt_lo, l.tb_off); tt_hi = std::max(tt_hi, l.tb_off + l.cout); }
+    }
+    if (with_final) { a.ops[a.nops - 1].src_off4 = bufs[final_src].off4; a.ops[a.nops - 1].src_rs4 = bufs[final_src].rs4; }
+    area += (size_t)kFusedRing * 256;   // the ring request of the last stream may read up to 16 blocks past its end
+    a.gpar_off = (int)area; a.par_floats = poff;
+    for (size_t k = 0; k < hops.size(); ++k) {
+        const HostOp& ho = hops[k];
+        const Layer& l = *ho.l;
+        const size_t pb = area + a.ops[k].p_off;
+        f.jobs.push_back({u->params[l.b].off, pb, 1, 0, 0, 1, 0, 0, l.cout});
+        if (l.gamma >= 0) f.jobs.push_back({u->params[l.gamma].off, pb + l.cout, 1, 0, 0, 1, 0, 0, l.cout});
+        if (l.beta >= 0) f.jobs.push_back({u->params[l.beta].off, pb + 2 * (size_t)l.cout, 1, 0, 0, 1, 0, 0, l.cout});
+        if (ho.r) f.jobs.push_back({u->params[ho.r->b].off, pb + 3 * (size_t)l.cout, 1, 0, 0, 1, 0, 0, l.cout});
+    }
+    area += poff;
+    if (tt_hi > 0) {
+        a.tt_lo = tt_lo; a.tt_n = (tt_hi - tt_lo + 3) / 4 * 4;
+        for (int k = 0; k < (int)hops.size(); ++k)
+            if (a.ops[k].tb_off >= 0) a.ops[k].tb_off -= tt_lo;
     }
     a.stat_off = (int)off4 * 4;     // GroupNorm exchange: 8 tiles x 4 rows x (mean, M2)
     off4 += 16;
-    a.par_off4 = (int)off4;
-    int poff = 0, nconv = 0;
-    for (int k = 0; k < a.nops; ++k)
-        if (a.ops[k].kind != FOP_FINAL) {
-            if (k != nconv) return fuse_reject(__LINE__);   // conv ops come first (FINAL last): parameter run r belongs to op r / 5
-            a.ops[k].p_off = poff; poff += 5 * a.ops[k].cout; ++nconv;
-        }
-    a.par_floats = poff;
-    a.n_runs = nconv * 5;
-    if (a.n_runs > 80) return fuse_reject(__LINE__);
+    a.par_off = (int)off4 * 4;
+    off4 += (size_t)(poff + 3) / 4;
+    a.tt_off = (int)off4 * 4;
+    off4 += (size_t)a.tt_n / 4;
+    if ((size_t)(poff / 4 + a.tt_n / 4) > 4 * 512) return fuse_reject(__LINE__);   // prologue: 4 float4 of parameters per thread
     {
         const int c4n = (a.gc1 + a.gc2 + 3) / 4;
         int l4 = 0;
@@ -718,13 +754,13 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         a.lg_c4n = ((1 << l4) == c4n) ? l4 : -1;
         if ((size_t)a.L0 * c4n > 4 * 512) return fuse_reject(__LINE__);   // prologue holds the input window in 4 float4 per thread
     }
-    off4 += (size_t)(poff + 3) / 4;
     f.lds_bytes = off4 * 16;
     if (f.lds_bytes > 160 * 1024) return fuse_reject(__LINE__);
+    u->packed_floats = area;
     u->fused.push_back(f);
     if (getenv("MPDX_DEBUG_FUSE"))
-        fprintf(stderr, "[mpdx] fused segment %zu: layers [%d,%d) %s..%s  %d ops  %d buffers  LDS %zu B\n", u->fused.size() - 1, i0, i1,
-                u->layers[i0].name.c_str(), u->layers[i1 - 1].name.c_str(), a.nops, a.nbufs, f.lds_bytes);
+        fprintf(stderr, "[mpdx] fused segment %zu: layers [%d,%d) %s..%s  %d ops  %zu buffers  LDS %zu B  streams+params %zu floats\n", u->fused.size() - 1,
+                i0, i1, u->layers[i0].name.c_str(), u->layers[i1 - 1].name.c_str(), a.nops, bufs.size(), f.lds_bytes, area - (size_t)a.ops[0].sbase);
     return true;
 }
 
@@ -995,10 +1031,37 @@ static int run_final(mpdx_unet* u, const float* packed, FinalArgs& fa, int B, fl
 
 static long long* g_fused_trace = nullptr;  // dev tool (mpdx_fused_trace)
 
+// strided copy inside `packed`: dst[i0*ds0 + i1*ds1 + k] = src[i0*ss0 + i1*ss1 + k]
+__global__ void restream_kernel(float* __restrict__ packed, size_t src, size_t dst, int n0, int ss0, int ds0, int n1, int ss1, int ds1, int n_inner) {
+    const size_t total = (size_t)n0 * n1 * n_inner;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % n_inner);
+        const size_t r = i / n_inner;
+        const int i1 = (int)(r % n1), i0 = (int)(r / n1);
+        packed[dst + (size_t)i0 * ds0 + (size_t)i1 * ds1 + k] = packed[src + (size_t)i0 * ss0 + (size_t)i1 * ss1 + k];
+    }
+}
+
+// The fused segments read stream-ordered copies of their weights and one contiguous parameter block (fused_level.hpp);
+// (re)assemble them in `packed` after the state dict was (re)packed.  Enqueues copies on `st`; no synchronisation.
+static int ensure_fused_streams(mpdx_unet* u, const float* packed, hipStream_t st) {
+    if (u->streams_for == packed && u->streams_version == u->pack_version) return 0;
+    for (const auto& f : u->fused)
+        for (const auto& j : f.jobs) {
+            const size_t total = (size_t)j.n0 * j.n1 * j.n_inner;
+            hipLaunchKernelGGL(restream_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1024)), dim3(256), 0, st, const_cast<float*>(packed),
+                               j.src, j.dst, j.n0, j.ss0, j.ds0, j.n1, j.ss1, j.ds1, j.n_inner);
+        }
+    HIP_TRY(hipGetLastError());
+    u->streams_for = packed; u->streams_version = u->pack_version;
+    return 0;
+}
+
 static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packed, const float* tt_row, const float* x, float* ws,
                      int B, const FinalArgs* fa, hipStream_t st) {
     const size_t slot = u->slot_floats * (size_t)B;
     auto src = [&](int s) -> const float* { return s == SRC_X ? x : (s == SRC_NONE ? nullptr : ws + slot * s); };
+    if (int rc = ensure_fused_streams(u, packed, st)) return rc;
     FusedArgs a = f.tmpl;
     a.packed = packed; a.tt_row = tt_row;
     a.gsrc1 = src(f.in1); a.gsrc2 = src(f.in2);
@@ -1115,6 +1178,7 @@ int mpdx_unet_create(const mpdx_unet_cfg* cfg, mpdx_unet** out) {
         }
     if ((int)u->tt_w.size() > 40) { delete u; return fail(MPDX_E_INVALID, "too many residual blocks"); }
     build_units(u);
+    u->packed_floats += 64;   // tail padding
     *out = u;
     return 0;
 }
@@ -1151,6 +1215,7 @@ int mpdx_unet_pack_param(mpdx_unet* u, const char* name, const float* src, size_
     }
     HIP_TRY(hipGetLastError());
     if (!p.done) { p.done = true; u->n_done++; }
+    u->pack_version++;   // the stream-ordered copies of the fused segments are stale now
     return 0;
 }
 
@@ -1441,8 +1506,8 @@ int mpdx_fused_trace(mpdx_unet* u, const float* packed, const float* timetab, co
     if (int rc = check_ready(u)) return rc;
     hipStream_t st = (hipStream_t)stream;
     long long* dev = nullptr;
-    HIP_TRY(hipMalloc(&dev, 256 * sizeof(long long)));
-    HIP_TRY(hipMemsetAsync(dev, 0, 256 * sizeof(long long), st));
+    HIP_TRY(hipMalloc(&dev, 1024 * sizeof(long long)));
+    HIP_TRY(hipMemsetAsync(dev, 0, 1024 * sizeof(long long), st));
     static float* scratch = nullptr;
     if (!scratch) HIP_TRY(hipMalloc(&scratch, (size_t)1 << 24));
     FinalArgs fa;
@@ -1452,7 +1517,7 @@ int mpdx_fused_trace(mpdx_unet* u, const float* packed, const float* timetab, co
     int rc = run_fused(u, u->fused[seg], packed, timetab, x, ws, B, &fa, st);
     g_fused_trace = nullptr;
     HIP_TRY(hipStreamSynchronize(st));
-    const int n = std::min(cap, 256);
+    const int n = std::min(cap, 1024);   // 8 waves x 128 slots
     HIP_TRY(hipMemcpy(stamps_out, dev, n * sizeof(long long), hipMemcpyDeviceToHost));
     (void)hipFree(dev);
     if (n_out) *n_out = n;

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-phase cycle stamps of the fused level kernels (dev tool, needs a GPU)."""
+"""Per-phase cycle stamps of the fused level kernels, all 8 waves of workgroup 0 (dev tool, needs a GPU).
+Per op four stamps: k-loop issued | statistics exchanged (barrier A) | epilogue done | end-of-op barrier (B)."""
 import ctypes as C, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -15,17 +16,17 @@ x = torch.randn(B, 64, 4, device="cuda")
 dm.model(x, torch.full((B,), 50, device="cuda", dtype=torch.long))
 st = torch.cuda.current_stream().cuda_stream
 for seg in range(4):
-    stamps = (C.c_longlong * 256)(); n = C.c_int(); nops = C.c_int()
-    if lib.mpdx_fused_trace(hdl, packed.data_ptr(), tab.data_ptr(), x.data_ptr(), seg, B, ws.data_ptr(), st, stamps, 256, C.byref(n), C.byref(nops)):
+    stamps = (C.c_longlong * 1024)(); n = C.c_int(); nops = C.c_int()
+    if lib.mpdx_fused_trace(hdl, packed.data_ptr(), tab.data_ptr(), x.data_ptr(), seg, B, ws.data_ptr(), st, stamps, 1024, C.byref(n), C.byref(nops)):
         break   # no such segment
-    _lib.check(lib.mpdx_fused_trace(hdl, packed.data_ptr(), tab.data_ptr(), x.data_ptr(), seg, B, ws.data_ptr(), st, stamps, 256, C.byref(n), C.byref(nops)))
-    v = [stamps[i] for i in range(256) if stamps[i]]
-    d = [b - a for a, b in zip(v, v[1:])]
-    print(f"segment {seg}: {nops.value} ops, total {v[-1]-v[0]} cycles; prologue: ring + input loads issued {d[0]}, parameter loads issued {d[1]}, "
-          f"halo zeros {d[2]}, loads landed + barrier {d[3]}")
-    k = 4
+    _lib.check(lib.mpdx_fused_trace(hdl, packed.data_ptr(), tab.data_ptr(), x.data_ptr(), seg, B, ws.data_ptr(), st, stamps, 1024, C.byref(n), C.byref(nops)))
+    W = [[stamps[w * 128 + i] for i in range(128) if stamps[w * 128 + i]] for w in range(8)]
+    t0 = min(w[0] for w in W if w)
+    print(f"segment {seg}: {nops.value} ops; wave 0 total {W[0][-1] - W[0][0]} ticks; stamps relative to the first wave's entry, per wave")
+    names = ["entry", "loads issued", "zeros", "prologue barrier"]
     for oi in range(nops.value):
-        if k + 3 < len(d) + 1:
-            print(f"   op{oi}: k-loop {d[k]:6d}  stats+barrier {d[k+1]:6d}  epilogue {d[k+2]:6d}  barrier {d[k+3] if k+3 < len(d) else -1:6d}")
-            k += 4
-    print(f"   remaining stamps after the last printed op: {d[k:]}")
+        names += [f"op{oi} k-loop", f"op{oi} barrier A", f"op{oi} epilogue", f"op{oi} barrier B"]
+    nst = max(len(w) for w in W)
+    for i in range(nst):
+        row = [(w[i] - t0) if i < len(w) else -1 for w in W]
+        print(f"  {names[i] if i < len(names) else 'final':>20s}: " + " ".join(f"{v:7d}" for v in row))
