@@ -18,17 +18,20 @@
 //   * STATIC OP SHAPES.  An op's whole geometry (mode, taps, C_in, folded residual C_in, C_out, L_out, GroupNorm or bias) is
 //     a compile-time shape picked by ONE switch per op; tile decode, LDS strides of the exchange, the k-loop and the epilogue
 //     are specialised per shape.  The runtime descriptor is 13 dwords (buffer offsets, stream base, parameter offsets).
-//   * TILE OWNERSHIP: wave w owns tile w for the whole K range (ops with 4 tiles run on waves 0-3).  Accumulators never leave
-//     registers: no K-partials through LDS.
+//   * TILE OWNERSHIP, FOUR WAVES: a workgroup is 4 waves (one per SIMD); a wave owns one tile (4-tile ops) or two tiles that
+//     share their 16 output channels (8-tile ops: one A fragment feeds both) for the whole K range.  Accumulators never
+//     leave registers: no K-partials through LDS.  (Measured with 8 waves x 1 tile: every wave streamed its own copy of A
+//     through the CU's 64 B/clk vector-memory path - 128 KB of requests per op, as long as the op's MFMAs.)
 //   * GroupNorm statistics straight from the accumulators: per 16-lane DPP row (= 4 channels x 16 positions) a local
 //     two-pass (mean, M2), exchanged as 8 bytes per row through LDS and combined with Chan's formula (all parts have 64
 //     elements) - one barrier; normalise + Mish + time bias + residual in registers; ONE 16-byte LDS store per lane.
 //   * WEIGHT STREAMS.  At load time every fused op gets a stream-ordered copy of its weights: per tile-stream (16 output
 //     channels [x parity for ConvTranspose]) the 1-KiB A-fragment blocks in exactly the order the k-loop consumes them, a
-//     folded residual conv's blocks appended.  A wave streams its blocks through a 16-slot register ring (64 VGPRs): the
-//     k-loop refills each slot as it is consumed, and the first 16 blocks of the NEXT op are requested before the current
-//     op's epilogue, so L2/MALL latency hides under the epilogue and the barriers.  No LDS weight window; barriers are
-//     LDS-only (s_waitcnt lgkmcnt(0) + s_barrier) and do not drain the ring.
+//     folded residual conv's blocks appended.  A wave streams its blocks through a 16-slot register ring (64 VGPRs) that
+//     runs CONTINUOUSLY ACROSS OPS: every consumed slot is refilled at once - with the block 16 further down the op's
+//     stream or, in the op's last 16 steps, with the NEXT op's first blocks - so exactly one 1-KiB request per consumed
+//     block is in the memory pipe (no request bursts at op boundaries) and L2/MALL latency hides under 16 blocks of MFMAs plus
+//     the epilogue.  No LDS weight window; barriers are LDS-only (s_waitcnt lgkmcnt(0) + s_barrier): they do not drain the ring.
 //   * hipcc's scheduler would sink every ring refill next to its use and issue each ds_read right before its MFMAs: the
 //     k-loop's order is pinned block by block with sched_barrier(0) (B fragments two blocks ahead, refill after use); the
 //     s_waitcnt counts remain the compiler's (steady state: vmcnt(15), lgkmcnt(1)).
@@ -54,6 +57,9 @@ inline int fused_shape_id(int mode, int ks, int nc16, int rnc16, int cout, int L
     return -1;
 }
 
+constexpr int kFusedWaves = 4;   // waves per workgroup (one per SIMD)
+constexpr int kFusedThreads = 64 * kFusedWaves;
+
 template <int MODE_, int KS_, int NC16_, int NCR_, int COUT_, int LOUT_, int GN_>
 struct FusedShape {
     static constexpr int MODE = MODE_, KS = KS_, NC16 = NC16_, NCR = NCR_, COUT = COUT_, LOUT = LOUT_, GN = GN_;
@@ -61,13 +67,23 @@ struct FusedShape {
     static constexpr int NBLK = NC16 * NTAP;          // blocks of a tile-stream from the conv itself
     static constexpr int TOT = NBLK + NCR;            // + the folded residual conv's
     static constexpr int MSn = COUT / 16;
-    static constexpr int NSn = LOUT / 16;             // (ConvTranspose: parity sub-tiles included, L_out = 2 L_in)
-    static constexpr int T = MSn * NSn;               // tiles = owning waves (4 or 8)
-    static constexpr int NSTREAM = (MODE == CONV_UPT) ? MSn * 2 : MSn;
+    static constexpr int NSn = LOUT / 16;             // tiles along positions (ConvTranspose: parity sub-tiles included)
+    static constexpr int T = MSn * NSn;               // 16x16 tiles: 4 or 8
+    static constexpr int NTW = T / kFusedWaves;       // tiles per wave
+    // Conv / strided conv: the wave's tiles share the output channels -> ONE stream, the tiles advance together (NJ tiles per
+    // block).  ConvTranspose: the wave's two tiles are the two output parities, which use different weight slots -> the
+    // stream is [parity 0 | parity 1] and the tiles run one after the other (NSEQ = 2).
+    static constexpr int NSEQ = (MODE == CONV_UPT) ? NTW : 1;
+    static constexpr int NJ = (MODE == CONV_UPT) ? 1 : NTW;
+    static constexpr int SLEN = NSEQ * TOT;           // blocks of a wave's stream for this op
+    static constexpr int NWS = kFusedWaves / MSn;     // waves that share one stream (1 or 2)
     static constexpr int GS = COUT / 8;               // GroupNorm(8 groups): channels per group
     static constexpr int RB = GS / 4;                 // DPP rows (4 channels) per group
     static constexpr int NPARTS = NSn * RB;           // 64-element parts per group: 2 or 4
     static_assert(T == 4 || T == 8, "4 or 8 tiles");
+    static_assert(MSn == 2 || MSn == 4, "2 or 4 tile rows");
+    static_assert(MODE != CONV_UPT || NTW == 2, "ConvTranspose: a wave owns both parities of its tile");
+    static_assert(MODE != CONV_UPT || NCR == 0, "no folded residual on resampling ops");
     static_assert(!GN || NPARTS == 2 || NPARTS == 4, "GroupNorm region of 128 or 256 elements");
 };
 
@@ -102,8 +118,9 @@ struct FusedArgs {
     int tt_lo, tt_n;
     int lg_c4n;          // log2(float4 per staged input row) or -1 (generic division path)
     FusedOp ops[kMaxFusedOps];
-    int geo[kMaxFusedOps];       // per op: lg(MSn) | T << 4 | upt << 8   (runtime copy: needed one op ahead for the ring request)
-    int sstride[kMaxFusedOps];   // per op: floats per tile-stream (TOT * 256)
+    // runtime copies of what the ring needs ONE OP AHEAD: wave w streams ops[i].sbase + (w & msmask[i]) * slen[i] * 256
+    int msmask[kMaxFusedOps];    // (C_out / 16) - 1
+    int slen[kMaxFusedOps];      // blocks per wave-stream (FusedShape::SLEN)
     // final 1x1 conv + DDPM step, as FinalArgs of mpdx.hip
     const float* x_in; const float* noise; const float* hs; const float* hg;
     float* out; float* chain; uint32_t* absmax;
@@ -115,17 +132,10 @@ struct FusedArgs {
 // LDS-only workgroup barrier: waits for this wave's LDS traffic, NOT for its global loads (the weight ring stays in flight).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Request blocks 0..15 of this wave's tile-stream of an op (runtime geometry: issued one op ahead).  Streams shorter than
-// the ring read on into the next stream / the padding behind the last one (valid memory, unused data).
-__device__ __forceinline__ void fused_ring_request(f32x4 (&ring)[kFusedRing], const float* __restrict__ packed, int sbase, int sstride, int geo,
-                                                   int wave, int lane) {
-    const int lgM = geo & 15, T = (geo >> 4) & 15, upt = (geo >> 8) & 1;
-    const int sub = wave & (T - 1);              // waves >= T alias a valid stream (harmless loads, unused data)
-    const int ms = sub & ((1 << lgM) - 1), ns = sub >> lgM;
-    const int sidx = upt ? ms * 2 + (ns & 1) : ms;
-    const float* base = packed + sbase + (size_t)sidx * sstride + lane * 4;
+// Request blocks 0..15 of a wave-stream (prologue only; streams shorter than the ring re-request their last block).
+__device__ __forceinline__ void fused_ring_request(f32x4 (&ring)[kFusedRing], const float* __restrict__ wbase, int slen) {
 #pragma unroll
-    for (int p = 0; p < kFusedRing; ++p) ring[p] = *(const f32x4*)(base + p * 256);
+    for (int p = 0; p < kFusedRing; ++p) ring[p] = *(const f32x4*)(wbase + (size_t)(p < slen ? p : slen - 1) * 256);
     __builtin_amdgcn_sched_barrier(0);   // the requests go out HERE
 }
 
@@ -138,89 +148,114 @@ __device__ __forceinline__ float row_sum16(float v) {
     return v;
 }
 
-// One conv op of static shape S: k-loop of this wave's tile, request of the next op's ring, epilogue.
-//   nsbase/nsstride/ngeo: the NEXT conv op's stream (nsstride == 0: nothing to request)
+// One conv op of static shape S: k-loop over this wave's tile(s) with the ring running on into the next op's stream, epilogue.
+//   nbase: the NEXT conv op's wave-stream (+ lane*4), nmax: its last block index (the ring's cross-over requests are clamped
+//   to it; after the last conv op both describe any valid block)
 template <class S>
 __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp& op, f32x4 (&ring)[kFusedRing], float* smem, int wave, int lane, int b,
-                                              int nsbase, int nsstride, int ngeo, long long* tr_base, int& tr) {
-    constexpr int P = kFusedRing, DB = 2;
+                                              const float* __restrict__ nbase, int nmax, long long* tr_base, int& tr) {
+    constexpr int P = kFusedRing, DB = 2, NTW = S::NTW, NJ = S::NJ;
     f32x4* const sm4 = (f32x4*)smem;
     const int j = lane & 15, q = lane >> 4;
-    const bool owner = wave < S::T;
-    const int sub = wave & (S::T - 1);
-    const int ms = sub & (S::MSn - 1), ns = sub / S::MSn;
-    const int par = ns & 1;
-    const int npos = (S::MODE == CONV_UPT) ? 2 * ((ns >> 1) * 16 + j) + par : ns * 16 + j;   // output position of this lane's column
+    const int ms = wave & (S::MSn - 1);
+    const int nsg = wave / S::MSn;     // which group of position tiles this wave owns
 #define FOP_STAMP() do { if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter(); ++tr; } while (0)
-
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, racc0 = {0.f, 0.f, 0.f, 0.f}, racc1 = {0.f, 0.f, 0.f, 0.f};
-    if (owner) {
-        // lane's B row in the source buffer (float4 units); taps are row offsets in the zero-haloed buffer
+    // tile t of this wave: position-tile index and output position of this lane's column
+    int ns[NTW], npos[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        ns[t] = nsg * NTW + t;                                   // ConvTranspose: (input tile nsg, parity t)
+        npos[t] = (S::MODE == CONV_UPT) ? 2 * (nsg * 16 + j) + t : ns[t] * 16 + j;
+    }
+    // lane's B rows in the source buffer (float4 units); taps are row offsets in the zero-haloed buffer
+    const f32x4* brow[NJ];
+    const f32x4* rrow[NJ];
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) {
         int boff;
-        if (S::MODE == CONV_UPT) boff = op.src_off4 + ((ns >> 1) * 16 + j + 2) * op.src_rs4 + q;
+        if (S::MODE == CONV_UPT) boff = op.src_off4 + (nsg * 16 + j + 2) * op.src_rs4 + q;
         else {
             constexpr int pad = (S::MODE == CONV_S1) ? S::KS / 2 : 1;
-            const int l = ns * 16 + j;
+            const int l = ns[t] * 16 + j;
             boff = op.src_off4 + ((S::MODE == CONV_DOWN ? 2 * l : l) + 2 - pad) * op.src_rs4 + q;
         }
-        const f32x4* brow = sm4 + boff;
-        const f32x4* rrow = sm4 + (S::NCR > 0 ? op.rsrc_off4 + (ns * 16 + j + 2) * op.rsrc_rs4 + q : 0);
-        const int rs4 = op.src_rs4;
-        const int sidx = (S::MODE == CONV_UPT) ? ms * 2 + par : ms;
-        const float* sbase = a.packed + op.sbase + (size_t)sidx * (S::TOT * 256) + lane * 4;
-        auto read_b = [&](int r) -> f32x4 {
-            if (r < S::NBLK) {
-                const int c16 = r / S::NTAP, ts = r % S::NTAP;
-                const int roff = (S::MODE == CONV_UPT) ? ((ts == 0) ? 0 : (par == 0 ? -1 : 1)) : ts;
-                return brow[roff * rs4 + c16 * 4];
-            }
-            return rrow[(r - S::NBLK) * 4];
-        };
-        f32x4 bq[DB + 1];
-#pragma unroll
-        for (int r = 0; r < DB && r < S::TOT; ++r) bq[r] = read_b(r);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < S::TOT; ++r) {
-            if (r + DB < S::TOT) bq[(r + DB) % (DB + 1)] = read_b(r + DB);
-            const f32x4 af = ring[r % P];
-            const f32x4 bf = bq[r % (DB + 1)];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {   // two independent accumulator chains (even / odd k)
-                if (r >= S::NBLK) {
-                    if (e & 1) racc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], racc1, 0, 0, 0);
-                    else racc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], racc0, 0, 0, 0);
-                } else {
-                    if (e & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc1, 0, 0, 0);
-                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc0, 0, 0, 0);
-                }
-            }
-            if (r + P < S::TOT) ring[r % P] = *(const f32x4*)(sbase + (r + P) * 256);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        brow[t] = sm4 + boff;
+        rrow[t] = sm4 + (S::NCR > 0 ? op.rsrc_off4 + (ns[t] * 16 + j + 2) * op.rsrc_rs4 + q : 0);
     }
-    f32x4 acc = acc0 + acc1;
+    const int rs4 = op.src_rs4;
+    const float* sbase = a.packed + op.sbase + (size_t)ms * (S::SLEN * 256) + lane * 4;
+    // B fragment of stream block r for joint tile t
+    auto read_b = [&](int r, int t) -> f32x4 {
+        const int rr = r % S::TOT, par = r / S::TOT;    // (ConvTranspose: second half of the stream = odd outputs)
+        if (rr < S::NBLK) {
+            const int c16 = rr / S::NTAP, ts = rr % S::NTAP;
+            const int roff = (S::MODE == CONV_UPT) ? ((ts == 0) ? 0 : (par == 0 ? -1 : 1)) : ts;
+            return brow[t][roff * rs4 + c16 * 4];
+        }
+        return rrow[t][(rr - S::NBLK) * 4];
+    };
+    f32x4 acc[NTW][2], racc[NTW][2];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t][0] = acc[t][1] = racc[t][0] = racc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 bq[DB + 1][NJ];
+#pragma unroll
+    for (int r = 0; r < DB && r < S::SLEN; ++r)
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) bq[r][t] = read_b(r, t);
+    // hipcc's scheduler would sink every ring refill next to its use and issue each ds_read right before its MFMAs: the order is
+    // PINNED block by block with sched_barrier(0); the s_waitcnt counts are still the compiler's (straight-line code).
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < S::SLEN; ++r) {
+        if (r + DB < S::SLEN) {
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) bq[(r + DB) % (DB + 1)][t] = read_b(r + DB, t);
+        }
+        const f32x4 af = ring[r % P];
+        const bool is_res = (r % S::TOT) >= S::NBLK;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)   // two independent accumulator chains per tile (even / odd k)
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) {
+                const int tt = (S::MODE == CONV_UPT) ? r / S::TOT : t;
+                f32x4& d = is_res ? racc[tt][e & 1] : acc[tt][e & 1];
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bq[r % (DB + 1)][t][e], d, 0, 0, 0);
+            }
+        // refill slot r % P: the block P further down this op's stream, or (no such block) the next op's block of that slot
+        if (r + P < S::SLEN) ring[r % P] = *(const f32x4*)(sbase + (r + P) * 256);
+        else { const int k = r % P; ring[k] = *(const f32x4*)(nbase + (size_t)(k < nmax ? k : nmax) * 256); }
+        if (S::SLEN < P) {   // slots this op never used belong to the next op from the start
+#pragma unroll
+            for (int k = S::SLEN; k < P; ++k)
+                if ((k - S::SLEN) % S::SLEN == r) ring[k] = *(const f32x4*)(nbase + (size_t)(k < nmax ? k : nmax) * 256);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     FOP_STAMP();   // k-loop issued
-    if (nsstride > 0) fused_ring_request(ring, a.packed, nsbase, nsstride, ngeo, wave, lane);
 
     // ------------------------------------------------------------------ epilogue (registers -> destination buffer)
     const float* par_op = smem + a.par_off + op.p_off;   // [bias | gamma | beta | rbias] x COUT
     const int c0 = ms * 16 + q * 4;                      // this lane's 4 output channels
-    f32x4 y;
+    f32x4 y[NTW];
     if (S::GN) {
         const f32x4 bi = *(const f32x4*)(par_op + c0);
         const f32x4 ga = *(const f32x4*)(par_op + S::COUT + c0), be = *(const f32x4*)(par_op + 2 * S::COUT + c0);
-        f32x4 add = {0.f, 0.f, 0.f, 0.f};
-        if (op.tb_off >= 0) add = *(const f32x4*)(smem + a.tt_off + op.tb_off + c0);
-        if (S::NCR > 0) add += (racc0 + racc1) + *(const f32x4*)(par_op + 3 * S::COUT + c0);
-        else if (op.res_off4 >= 0) add += sm4[op.res_off4 + (npos + 2) * op.res_rs4 + (c0 >> 2)];
-        acc += bi;
-        // local two-pass statistics of this DPP row (4 channels x 16 positions = 64 elements)
-        const float m_loc = row_sum16((acc[0] + acc[1]) + (acc[2] + acc[3])) * (1.0f / 64.0f);
-        const f32x4 dl = acc - m_loc;
-        const float m2_loc = row_sum16((dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]));
+        f32x4 tb = {0.f, 0.f, 0.f, 0.f};
+        if (op.tb_off >= 0) tb = *(const f32x4*)(smem + a.tt_off + op.tb_off + c0);
+        f32x4 v[NTW], add[NTW];
         float* stat = smem + a.stat_off;
-        if (owner && j == 0) *(f32x2*)(stat + ((ms * S::NSn + ns) * 4 + q) * 2) = (f32x2){m_loc, m2_loc};
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            add[t] = tb;
+            if (S::NCR > 0) add[t] += (racc[t][0] + racc[t][1]) + *(const f32x4*)(par_op + 3 * S::COUT + c0);
+            else if (op.res_off4 >= 0) add[t] += sm4[op.res_off4 + (npos[t] + 2) * op.res_rs4 + (c0 >> 2)];
+            v[t] = (acc[t][0] + acc[t][1]) + bi;
+            // local two-pass statistics of this DPP row (4 channels x 16 positions = 64 elements)
+            const float m_loc = row_sum16((v[t][0] + v[t][1]) + (v[t][2] + v[t][3])) * (1.0f / 64.0f);
+            const f32x4 dl = v[t] - m_loc;
+            const float m2_loc = row_sum16((dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]));
+            if (j == 0) *(f32x2*)(stat + ((ms * S::NSn + ns[t]) * 4 + q) * 2) = (f32x2){m_loc, m2_loc};
+        }
         lds_barrier();
         FOP_STAMP();   // statistics exchanged
         // combine the parts of this lane's group: rows q0 .. q0+RB-1 of the tiles (ms, 0..NSn-1); equal counts (64 each)
@@ -229,8 +264,8 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
 #pragma unroll
         for (int k = 0; k < S::NPARTS; ++k) {
             const int ns_k = k / S::RB, q_k = q0 + (k % S::RB);
-            const f32x2 v = *(const f32x2*)(stat + ((ms * S::NSn + ns_k) * 4 + q_k) * 2);
-            pm[k] = v[0]; pM2[k] = v[1];
+            const f32x2 pv = *(const f32x2*)(stat + ((ms * S::NSn + ns_k) * 4 + q_k) * 2);
+            pm[k] = pv[0]; pM2[k] = pv[1];
         }
         float mean, M2;
         if (S::NPARTS == 4) {
@@ -245,15 +280,21 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
         const float var = M2 * (1.0f / (64.0f * S::NPARTS));
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = mish((acc[e] - mean) * rstd * ga[e] + be[e]);
-        y += add;
+        for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[t][e] = mish((v[t][e] - mean) * rstd * ga[e] + be[e]);
+            y[t] += add[t];
+        }
     } else {  // bias only: Downsample1d / Upsample1d
-        y = acc + *(const f32x4*)(par_op + c0);
+        const f32x4 bi = *(const f32x4*)(par_op + c0);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) y[t] = (acc[t][0] + acc[t][1]) + bi;
         FOP_STAMP();   // (keeps four stamps per op)
     }
-    if (owner) {
-        if (op.dst_off4 >= 0) sm4[op.dst_off4 + (npos + 2) * op.dst_rs4 + (c0 >> 2)] = y;
-        if (op.gdst >= 0) *(f32x4*)(a.gout[op.gdst] + ((size_t)b * S::LOUT + npos) * S::COUT + c0) = y;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        if (op.dst_off4 >= 0) sm4[op.dst_off4 + (npos[t] + 2) * op.dst_rs4 + (c0 >> 2)] = y[t];
+        if (op.gdst >= 0) *(f32x4*)(a.gout[op.gdst] + ((size_t)b * S::LOUT + npos[t]) * S::COUT + c0) = y[t];
     }
     if (op.dst_off4 >= 0) {   // halo rows of the buffer this op defines (2 above, 2 below its L_out interior rows)
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -269,7 +310,7 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
 #undef FOP_STAMP
 }
 
-__global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(kFusedThreads) void fused_level_kernel(const FusedArgs a) {
 #ifndef MPDX_NO_WARM_KERNARG   // dev A/B switch
     warm_kernarg<(int)sizeof(FusedArgs)>();
 #endif
@@ -286,12 +327,13 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
     // ---- prologue: every global load is issued first (weight ring of op 0, input window, parameters), the halo / padding
     //      zeros are written while they fly, and ONE barrier closes it.
     f32x4 ring[kFusedRing];
-    fused_ring_request(ring, a.packed, a.ops[0].sbase, a.sstride[0], a.geo[0], wave, lane);
+    fused_ring_request(ring, a.packed + a.ops[0].sbase + (size_t)(wave & a.msmask[0]) * a.slen[0] * 256 + lane * 4, a.slen[0]);
 
     const int cin = a.gc1 + a.gc2;
     const int c4n = (cin + 3) >> 2;
     const int n_in = a.L0 * c4n;
-    constexpr int IK = 4;   // input float4 per thread (<= 2048 float4 per trajectory window)
+    constexpr int NT_ = kFusedThreads;
+    constexpr int IK = 2048 / NT_;   // input float4 per thread (<= 2048 float4 per trajectory window)
     f32x4 iv[IK];
     int idst[IK], ck[IK];
     const bool vec_ok = ((a.gc1 & 3) == 0) && ((a.gc2 & 3) == 0);
@@ -302,7 +344,7 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
         bool vk[IK];
 #pragma unroll
         for (int k = 0; k < IK; ++k) {
-            const int idx = tid + k * 512;
+            const int idx = tid + k * NT_;
             vk[k] = idx < n_in;
             const int idc = vk[k] ? idx : 0;
             lk[k] = a.lg_c4n >= 0 ? (idc >> a.lg_c4n) : (idc / c4n);
@@ -331,12 +373,12 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
     }
     // parameters of every op ([bias | gamma | beta | rbias] blocks, contiguous in `packed` behind the weight streams) and the
     // slice of this timestep's conditioning row the segment's blocks use: two straight copies
-    constexpr int PK = 4;   // float4 per thread (<= 2048 float4 = 32 KB of parameters)
+    constexpr int PK = 2048 / NT_;   // float4 per thread (<= 2048 float4 = 32 KB of parameters)
     f32x4 pv[PK];
     const int npar4 = a.par_floats >> 2, ntt4 = a.tt_n >> 2;
 #pragma unroll
     for (int k = 0; k < PK; ++k) {
-        const int idx = tid + k * 512;
+        const int idx = tid + k * NT_;
         const float* src = idx < npar4 ? a.packed + a.gpar_off + (size_t)idx * 4 : a.tt_row + a.tt_lo + (size_t)(idx - npar4 < ntt4 ? idx - npar4 : 0) * 4;
         pv[k] = *(const f32x4*)src;
     }
@@ -345,13 +387,13 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
     // staging writes below).  Every other buffer gets its halo rows zeroed by the op that writes it.
     {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < 2 * a.in_rs4; i += 512) {
+        for (int i = tid; i < 2 * a.in_rs4; i += NT_) {
             sm4[a.in_off4 + i] = z;
             sm4[a.in_off4 + (a.in_rows - 2) * a.in_rs4 + i] = z;
         }
         if (a.in_clear) {
             const int padw = a.in_rs4 - c4n;   // float4 columns beyond the staged channels
-            for (int i = tid; i < a.L0 * padw; i += 512) {
+            for (int i = tid; i < a.L0 * padw; i += NT_) {
                 const int l = i / padw, cc = i - l * padw;
                 sm4[a.in_off4 + (l + 2) * a.in_rs4 + c4n + cc] = z;
             }
@@ -368,7 +410,7 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < PK; ++k) {
-        const int idx = tid + k * 512;
+        const int idx = tid + k * NT_;
         if (idx < npar4) sm4[(a.par_off >> 2) + idx] = pv[k];
         else if (idx - npar4 < ntt4) sm4[(a.tt_off >> 2) + idx - npar4] = pv[k];
     }
@@ -381,7 +423,7 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
             // ---- final_conv[1] (1x1, Cf -> D) + DDPM posterior step + hard conditioning (see final_step_kernel)
             float vmax = 0.f;
             const int H = a.H;
-            for (int idx = tid; idx < H * a.D; idx += 512) {
+            for (int idx = tid; idx < H * a.D; idx += NT_) {
                 const int p = idx / a.D, d = idx - p * a.D;
                 float s = a.packed[a.fb_off + d];
                 const float* wrow = a.packed + a.fw_off + d * a.Cf;
@@ -429,14 +471,16 @@ __global__ __launch_bounds__(512) void fused_level_kernel(const FusedArgs a) {
             FUSED_STAMP();
             continue;
         }
-        // the next conv op's stream (requested by this op right after its k-loop)
-        int nsbase = 0, nsstride = 0, ngeo = 0;
+        // the next conv op's wave-stream: this op's ring runs on into it (after the last conv op: any valid block, unused)
+        const float* nbase = a.packed + op.sbase + lane * 4;
+        int nmax = 0;
         if (oi + 1 < a.nops && a.ops[oi + 1].shape != kFusedShapeFinal) {
-            nsbase = a.ops[oi + 1].sbase; nsstride = a.sstride[oi + 1]; ngeo = a.geo[oi + 1];
+            nbase = a.packed + a.ops[oi + 1].sbase + (size_t)(wave & a.msmask[oi + 1]) * a.slen[oi + 1] * 256 + lane * 4;
+            nmax = a.slen[oi + 1] - 1;
         }
         switch (op.shape) {
 #define X(id, M, K, N, R, CO, LO, G) \
-    case id: fused_conv_op<FusedShape<M, K, N, R, CO, LO, G>>(a, op, ring, smem, wave, lane, b, nsbase, nsstride, ngeo, tr_base, tr); break;
+    case id: fused_conv_op<FusedShape<M, K, N, R, CO, LO, G>>(a, op, ring, smem, wave, lane, b, nbase, nmax, tr_base, tr); break;
             MPDX_FUSED_SHAPES(X)
 #undef X
             default: break;

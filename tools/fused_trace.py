@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-phase cycle stamps of the fused level kernels, all 8 waves of workgroup 0 (dev tool, needs a GPU).
+"""Per-phase cycle stamps of the fused level kernels, all 4 waves of workgroup 0 (dev tool, needs a GPU).
 Per op four stamps: k-loop issued | statistics exchanged (barrier A) | epilogue done | end-of-op barrier (B)."""
 import ctypes as C, sys
 from pathlib import Path
@@ -20,7 +20,7 @@ for seg in range(4):
     if lib.mpdx_fused_trace(hdl, packed.data_ptr(), tab.data_ptr(), x.data_ptr(), seg, B, ws.data_ptr(), st, stamps, 1024, C.byref(n), C.byref(nops)):
         break   # no such segment
     _lib.check(lib.mpdx_fused_trace(hdl, packed.data_ptr(), tab.data_ptr(), x.data_ptr(), seg, B, ws.data_ptr(), st, stamps, 1024, C.byref(n), C.byref(nops)))
-    W = [[stamps[w * 128 + i] for i in range(128) if stamps[w * 128 + i]] for w in range(8)]
+    W = [[stamps[w * 128 + i] for i in range(128) if stamps[w * 128 + i]] for w in range(4)]
     t0 = min(w[0] for w in W if w)
     print(f"segment {seg}: {nops.value} ops; wave 0 total {W[0][-1] - W[0][0]} ticks; stamps relative to the first wave's entry, per wave")
     names = ["entry", "loads issued", "zeros", "prologue barrier"]

@@ -24,9 +24,9 @@ int main() {
     long long* d; float* sink;
     hipMalloc(&d, 4096 * sizeof(long long)); hipMalloc(&sink, 64);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int iters : {100, 1000, 20000})
     for (int grid : {1, 100, 256}) {
         for (int rep = 0; rep < 3; ++rep) {
-            const int iters = 20000;   // 16 MFMAs per iteration per wave, 2 waves per SIMD
             hipEventRecord(e0, 0);
             hipLaunchKernelGGL(spin_mfma, dim3(grid), dim3(512), 0, 0, d, iters, sink);
             hipEventRecord(e1, 0);
@@ -34,8 +34,8 @@ int main() {
             float ms; hipEventElapsedTime(&ms, e0, e1);
             long long h[2]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
             const double mfma_per_simd = (double)iters * 16 * 2;   // 2 waves per SIMD
-            printf("grid %3d: wall %8.1f us  s_memtime delta %10lld (%.1f ticks/us)  clock64 delta %10lld (%.1f /us)  -> %.1f cycles per MFMA at 2.4 GHz nominal, implied clock if 32 cyc/MFMA: %.2f GHz\n",
-                   grid, ms * 1e3, h[0], h[0] / (ms * 1e3), h[1], h[1] / (ms * 1e3), ms * 1e-3 * 2.4e9 / mfma_per_simd, mfma_per_simd * 32 / (ms * 1e-3) / 1e9);
+            printf("iters %5d grid %3d: wall %8.1f us  s_memtime delta %10lld (%.1f ticks/us)  clock64 delta %10lld (%.1f /us)  -> %.1f cycles per MFMA at 2.4 GHz nominal, implied clock if 32 cyc/MFMA: %.2f GHz\n",
+                   iters, grid, ms * 1e3, h[0], h[0] / (ms * 1e3), h[1], h[1] / (ms * 1e3), ms * 1e-3 * 2.4e9 / mfma_per_simd, mfma_per_simd * 32 / (ms * 1e-3) / 1e9);
         }
     }
     return 0;
