@@ -152,8 +152,13 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
     // ring so that the ~1-2 us load latency is paid once per kernel, under the staging phase, not once per iteration.
     constexpr int NCLS = (MODE == CONV_UPT) ? 2 : 1;
     constexpr int PF = 2;   // ring depth in k-groups.  Measured (cfg2 / cfg5 plan, ms): PF 1: 27.90 / 739, 2: 27.70 / 745, 3: 27.95 / 760,
-                            // 4: 28.22 / 797, 6: 28.65 / 856 - a deeper ring only adds unrolled code and registers, the loads are
-                            // L2 hits that two k-groups of MFMAs (1-2 k cycles) already cover
+                            // 4: 28.22 / 797, 6: 28.65 / 856 - a deeper ring only adds unrolled code and registers.  Re-measured in
+                            // round 2 with the order PINNED by sched_barrier(0) and B fragments read one k-group ahead (so that the
+                            // depth is real, not re-serialised by the scheduler): 4 / 8 / 16 / 32 blocks per wave -> cfg2 26.36 /
+                            // 27.32 / 30.09 / 35.85 ms, cfg5 738 / - / 1012 / 1383 ms (unpinned depth 4: 25.95 / 733).  Deeper is
+                            // monotonically WORSE: the 8 waves' up-front requests queue in the CU's 64 B/clk vector-memory path ahead
+                            // of the activation staging loads (in-order return), and the clamped refills at the tail re-request the
+                            // last k-group.  The mid-level launches are not bound by weight latency.
     const int nc16 = a.cin_pad >> 4;
     const int ngroups = nc16 * NTAP;
     const float* wbase = a.wp + (size_t)(mt * MS) * nc16 * NSLOT * 256 + lane * 4;
