@@ -94,14 +94,19 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // Mish(x) = x*tanh(softplus(x)) (torch: softplus threshold 20).  tanh(log1p(e^x)) == n/(n+2), n = e^x(e^x+2).
-// v_exp_f32 / v_rcp_f32 based (both ~1 ulp): the result is within a few ulp of the libm form, far inside the 2e-5
-// tolerance the U-Net parity tests state, and ~4x fewer instructions in the GroupNorm epilogues.
+// Branch-free on the hardware transcendentals (v_exp_f32, v_rcp_f32: ~1 ulp each): the result is within a few ulp of the libm
+// form, far inside the 2e-5 tolerance the U-Net parity tests state.  (Round 1 used __frcp_rn - a correctly rounded reciprocal,
+// 11 dependent instructions - and an `if (x > 20) return x` that compiled to one exec-masked branch PER ELEMENT: the four
+// elements of a lane ran as four serial dependent chains.  ~2 k cycles per fused-level epilogue went there.)
 __device__ __forceinline__ float mish(float x) {
-    if (x > 20.0f) return x;
-    const float e = __expf(x);
+    const float e = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
     const float n = e * (e + 2.0f);
-    return x * (n * __frcp_rn(n + 2.0f));
+    const float r = x * (n * __builtin_amdgcn_rcpf(n + 2.0f));
+    return x > 20.0f ? x : r;   // (x > 44: n overflows, r is NaN, the select takes x)
 }
+
+// 1/sqrt(var + eps) of GroupNorm on v_rsq_f32 (~1 ulp) instead of the IEEE sqrt + divide sequences (~40 dependent instructions)
+__device__ __forceinline__ float gn_rstd(float var) { return __builtin_amdgcn_rsqf(var + 1e-5f); }
 
 template <int MODE, int KS>
 struct ConvGeom {
@@ -368,7 +373,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                 const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * inv_re;
                 const f32x4 d = v - mean;
                 const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * inv_re;
-                const float rstd = 1.0f / sqrtf(var + 1e-5f);
+                const float rstd = gn_rstd(var);
                 f32x4 y;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = mish(d[e] * rstd * ga[e] + be[e]);
@@ -392,7 +397,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                 const float mean = wave_sum(v[0] + v[1]) * inv_re;
                 const f32x2 d = v - mean;
                 const float var = wave_sum(d[0] * d[0] + d[1] * d[1]) * inv_re;
-                const float rstd = 1.0f / sqrtf(var + 1e-5f);
+                const float rstd = gn_rstd(var);
                 f32x2 y;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) y[e] = mish(d[e] * rstd * ga[e] + be[e]);

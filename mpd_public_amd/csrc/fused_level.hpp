@@ -132,10 +132,13 @@ struct FusedArgs {
 // LDS-only workgroup barrier: waits for this wave's LDS traffic, NOT for its global loads (the weight ring stays in flight).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Request blocks 0..15 of a wave-stream (prologue only; streams shorter than the ring re-request their last block).
+// Request the first min(16, slen) blocks of a wave-stream (prologue only).  Slots beyond a short stream stay unset: the first
+// op's k-loop fills them with the next op's blocks.  (wave-uniform guards: no request is issued for a block nobody reads -
+// every request costs the CU's 64 B/clk vector-memory path 16 cycles.)
 __device__ __forceinline__ void fused_ring_request(f32x4 (&ring)[kFusedRing], const float* __restrict__ wbase, int slen) {
 #pragma unroll
-    for (int p = 0; p < kFusedRing; ++p) ring[p] = *(const f32x4*)(wbase + (size_t)(p < slen ? p : slen - 1) * 256);
+    for (int p = 0; p < kFusedRing; ++p)   // (no zero-init: a load into a pre-initialised register makes hipcc drain vmcnt first)
+        if (p < slen) ring[p] = *(const f32x4*)(wbase + (size_t)p * 256);
     __builtin_amdgcn_sched_barrier(0);   // the requests go out HERE
 }
 
@@ -278,7 +281,7 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
             M2 = (pM2[0] + pM2[1]) + 64.0f * (d0 * d0 + d1 * d1);
         }
         const float var = M2 * (1.0f / (64.0f * S::NPARTS));
-        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        const float rstd = gn_rstd(var);
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
 #pragma unroll
@@ -351,9 +354,11 @@ __global__ __launch_bounds__(kFusedThreads) void fused_level_kernel(const FusedA
             ck[k] = (idc - lk[k] * c4n) << 2;
             idst[k] = vk[k] ? a.in_off4 + (lk[k] + 2) * a.in_rs4 + (ck[k] >> 2) : -1;
         }
+        // (pass k is skipped as a whole - wave-uniform - when the window has fewer than k*256 float4: D=4 needs one pass of eight)
         if (vec_ok) {
 #pragma unroll
             for (int k = 0; k < IK; ++k) {
+                if (k * NT_ >= n_in) continue;   // iv[k] stays unset and is never stored (idst[k] < 0)
                 const size_t pos = (size_t)b * a.L0 + lk[k];
                 const float* src = (ck[k] < a.gc1) ? a.gsrc1 + pos * a.gc1 + ck[k] : a.gsrc2 + pos * a.gc2 + (ck[k] - a.gc1);
                 iv[k] = *(const f32x4*)src;
@@ -361,6 +366,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_level_kernel(const FusedA
         } else {
 #pragma unroll
             for (int k = 0; k < IK; ++k) {   // channel padding (ce >= cin) is masked to zero at the LDS store below
+                if (k * NT_ >= n_in) continue;
                 const size_t pos = (size_t)b * a.L0 + lk[k];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -379,6 +385,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_level_kernel(const FusedA
 #pragma unroll
     for (int k = 0; k < PK; ++k) {
         const int idx = tid + k * NT_;
+        if (k * NT_ >= npar4 + ntt4) continue;   // wave-uniform: no pass beyond the data (pv[k] stays unset, never stored)
         const float* src = idx < npar4 ? a.packed + a.gpar_off + (size_t)idx * 4 : a.tt_row + a.tt_lo + (size_t)(idx - npar4 < ntt4 ? idx - npar4 : 0) * 4;
         pv[k] = *(const f32x4*)src;
     }
