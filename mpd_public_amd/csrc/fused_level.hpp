@@ -200,6 +200,7 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
     f32x4 acc[NTW][2], racc[NTW][2];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[t][0] = acc[t][1] = racc[t][0] = racc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    FOP_STAMP();   // op entered: descriptor decoded, addresses set up
     f32x4 bq[DB + 1][NJ];
 #pragma unroll
     for (int r = 0; r < DB && r < S::SLEN; ++r)

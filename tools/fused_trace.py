@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase cycle stamps of the fused level kernels, all 4 waves of workgroup 0 (dev tool, needs a GPU).
-Per op four stamps: k-loop issued | statistics exchanged (barrier A) | epilogue done | end-of-op barrier (B)."""
+Per op five stamps: op entered (descriptor decoded) | k-loop issued | statistics exchanged (barrier A) | epilogue done | end-of-op barrier (B)."""
 import ctypes as C, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -25,7 +25,7 @@ for seg in range(4):
     print(f"segment {seg}: {nops.value} ops; wave 0 total {W[0][-1] - W[0][0]} ticks; stamps relative to the first wave's entry, per wave")
     names = ["entry", "loads issued", "zeros", "prologue barrier"]
     for oi in range(nops.value):
-        names += [f"op{oi} k-loop", f"op{oi} barrier A", f"op{oi} epilogue", f"op{oi} barrier B"]
+        names += [f"op{oi} entered", f"op{oi} k-loop", f"op{oi} barrier A", f"op{oi} epilogue", f"op{oi} barrier B"]
     nst = max(len(w) for w in W)
     for i in range(nst):
         row = [(w[i] - t0) if i < len(w) else -1 for w in W]
