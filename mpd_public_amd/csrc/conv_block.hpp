@@ -156,7 +156,10 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
     // Each wave owns k-groups wk, wk+WK, ...; their A fragments are streamed from L2/HBM through a PF-deep register
     // ring so that the ~1-2 us load latency is paid once per kernel, under the staging phase, not once per iteration.
     constexpr int NCLS = (MODE == CONV_UPT) ? 2 : 1;
-    constexpr int PF = 2;   // ring depth in k-groups.  Measured (cfg2 / cfg5 plan, ms): PF 1: 27.90 / 739, 2: 27.70 / 745, 3: 27.95 / 760,
+#ifndef MPDX_PF
+#define MPDX_PF 2
+#endif
+    constexpr int PF = MPDX_PF;   // ring depth in k-groups.  Measured (cfg2 / cfg5 plan, ms): PF 1: 27.90 / 739, 2: 27.70 / 745, 3: 27.95 / 760,
                             // 4: 28.22 / 797, 6: 28.65 / 856 - a deeper ring only adds unrolled code and registers.  Re-measured in
                             // round 2 with the order PINNED by sched_barrier(0) and B fragments read one k-group ahead (so that the
                             // depth is real, not re-serialised by the scheduler): 4 / 8 / 16 / 32 blocks per wave -> cfg2 26.36 /
@@ -182,8 +185,16 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
     // ring loads are UNCONDITIONAL (index clamped to a valid k-group) so that the compiler can count them:
     // the wait in front of ring slot u is then a counted vmcnt((PF-1)*MS*NCLS), never vmcnt(0).
     auto ring_g = [&](int it) { const int g = wk + it * WK; return g < ngroups ? g : ngroups - 1; };
+    // The first ring fill is issued AFTER the first pass of staging loads (loads return in order: the activation window is needed
+    // first - the workgroup barrier waits for it - and the weights stream in behind it).  A/B on MI355X (cfg2 / cfg5 plan):
+    // ring first 25.22 / 738 ms, staging first 24.99 / 730 ms; with staging first, depth 3 / 4 / 6 k-groups: 25.30 / 25.52 / 25.99.
+    auto ring_init = [&]() {
 #pragma unroll
-    for (int u = 0; u < PF; ++u) load_a(ring_g(u), af[u]);
+        for (int u = 0; u < PF; ++u) load_a(ring_g(u), af[u]);
+    };
+#ifdef MPDX_RING_FIRST
+    ring_init();
+#endif
 
     // ------------------------------------------------------------------ stage the horizon windows (+halo) into LDS
     if (!(a.dbg & 1)) {
@@ -199,8 +210,9 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
         // weight ring before it issues its own loads.
         // The vector and the scalar variant are separate code paths with their own registers: sharing them makes the wait
         // counts of one path include the (never issued) loads of the other.
-        auto stage_pass = [&](int base, auto vec) {
+        auto stage_pass = [&](int base, auto vec, auto first) {
             constexpr bool VEC = decltype(vec)::value;
+            constexpr bool FIRST = decltype(first)::value;
             f32x4 v[SB];
             int dsto[SB], cc[SB];
             bool ok[SB];
@@ -232,6 +244,9 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                     }
                 }
             }
+#ifndef MPDX_RING_FIRST
+            if constexpr (FIRST) ring_init();
+#endif
 #pragma unroll
             for (int u = 0; u < SB; ++u) {
                 if constexpr (!VEC) {
@@ -242,11 +257,11 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
             }
         };
         if (vec_ok) {
-            stage_pass(tid, std::true_type{});
-            for (int base = tid + NTHR * SB; base < total; base += NTHR * SB) stage_pass(base, std::true_type{});
+            stage_pass(tid, std::true_type{}, std::true_type{});
+            for (int base = tid + NTHR * SB; base < total; base += NTHR * SB) stage_pass(base, std::true_type{}, std::false_type{});
         } else {
-            stage_pass(tid, std::false_type{});
-            for (int base = tid + NTHR * SB; base < total; base += NTHR * SB) stage_pass(base, std::false_type{});
+            stage_pass(tid, std::false_type{}, std::true_type{});
+            for (int base = tid + NTHR * SB; base < total; base += NTHR * SB) stage_pass(base, std::false_type{}, std::false_type{});
         }
         // zero halo rows (conv padding): 2*PAD rows per trajectory
         if (PAD > 0) {
@@ -260,6 +275,9 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
             }
         }
     }
+#ifndef MPDX_RING_FIRST
+    if (a.dbg & 1) ring_init();
+#endif
     CB_STAMP();  // 1: own staging loads issued/written
     __syncthreads();
     CB_STAMP();  // 2: window staged (all waves)
