@@ -193,7 +193,11 @@ int mpdx_traj_metrics(const mpdx_guide_params* gp, const float* x_unnormalised, 
  * `t_single < t_start_guide`, sample_functions.py:28-29,39) depend only on the integer loop index.
  *   coefs  : host array [T], entry t = the scalars of timestep t (see mpdx_step_coefs)
  *   x      : [B,H,D]; in: x_T ~ N(0,I) (hard conditioning is applied here, :165-166); out: the final trajectories
- *   noise  : [T + n_without_noise, B,H,D] the randn_like draw of each loop iteration, in loop order
+ *   noise  : [T + n_without_noise, B,H,D] the randn_like draw of each loop iteration, in loop order; or NULL: every iteration
+ *            draws its noise in place from the Philox stream (rng_seed, rng_offset) - iteration k takes elements
+ *            [(k+1) n, (k+2) n), n = B*H*D, of the stream whose first n elements are x_T as written by
+ *            mpdx_randn(x, n, rng_seed, rng_offset): bit-identical to passing the pre-generated tensor, without its
+ *            (T + n_without_noise) * n * 4 bytes (2.4 GB for a 6400-trajectory Panda shard)
  *   chain  : NULL or [T + n_without_noise + 1, B,H,D] <- x after every iteration, index 0 = conditioned x_T
  *            (the 'diffsteps b h d' layout run_inference returns, :310)
  *   guide  : NULL (planner_alg 'diffusion_prior') or the cost guide; applied n_guide_steps times on the posterior
@@ -204,7 +208,7 @@ int mpdx_traj_metrics(const mpdx_guide_params* gp, const float* x_unnormalised, 
 int mpdx_plan(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, int T, const mpdx_step_coefs* coefs,
               int n_without_noise, float* x, const float* noise, const float* hard_start, const float* hard_goal,
               float* chain, int B, float* ws, const mpdx_guide_params* guide, int n_guide_steps, int t_start_guide,
-              uint32_t* guide_flags, int n_per_ctx, void* stream);
+              uint32_t* guide_flags, int n_per_ctx, uint64_t rng_seed, uint64_t rng_offset, void* stream);
 
 /* ---- measurement helpers (bench.py's roofline leg; not used by the planning path) ----
  * One U-Net pass with a hipEvent pair around every kernel launch, on `stream`.  This call DOES synchronise the

@@ -68,7 +68,7 @@ SIGNATURES = {
     "mpdx_q_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mpdx_weighted_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "mpdx_plan": (_i, [_vp, _vp, _vp, _i, C.POINTER(StepCoefs), _i, _vp, _vp, _vp, _vp, _vp, _i, _vp,
-                        C.POINTER(GuideParams), _i, _i, _vp, _i, _vp]),
+                        C.POINTER(GuideParams), _i, _i, _vp, _i, C.c_uint64, C.c_uint64, _vp]),
     "mpdx_guide_step": (_i, [C.POINTER(GuideParams), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mpdx_guide_step_scaled": (_i, [C.POINTER(GuideParams), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mpdx_traj_metrics": (_i, [C.POINTER(GuideParams), _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -108,6 +108,45 @@ __device__ __forceinline__ float mish(float x) {
 // 1/sqrt(var + eps) of GroupNorm on v_rsq_f32 (~1 ulp) instead of the IEEE sqrt + divide sequences (~40 dependent instructions)
 __device__ __forceinline__ float gn_rstd(float var) { return __builtin_amdgcn_rsqf(var + 1e-5f); }
 
+// ---- Philox4x32-10 counter-based generator + Box-Muller (4 normals per 128-bit counter).  ONE definition serves the stand-alone
+// generator (mpdx_randn) and the kernels that draw their noise in place (mpdx_plan with noise == NULL): element i of a stream that
+// starts at counter `offset` is component i & 3 of counter offset + (i >> 2), so both routes produce the same bits.
+struct NoiseRng {        // in-kernel noise source of one reverse step
+    unsigned long long seed;
+    unsigned long long offset;   // counter (quad) offset of the plan's stream
+    unsigned long long elem0;    // element index of this step's first value in the stream
+    int on;                      // 0: read the noise pointer instead
+};
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t ctr, float (&z)[4]) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = ((float)(c3 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    float s0, cs0, s1, cs1;
+    sincosf(6.28318530717958647692f * u1, &s0, &cs0);
+    sincosf(6.28318530717958647692f * u3, &s1, &cs1);
+    z[0] = r0 * cs0; z[1] = r0 * s0; z[2] = r1 * cs1; z[3] = r1 * s1;
+}
+// the value mpdx_randn(out, n, seed, offset) writes to out[i]
+__device__ __forceinline__ float philox_normal_at(uint64_t seed, uint64_t offset, uint64_t i) {
+    float z[4];
+    philox_normal4(seed, offset + (i >> 2), z);
+    const int c = (int)(i & 3);
+    return c == 0 ? z[0] : c == 1 ? z[1] : c == 2 ? z[2] : z[3];
+}
+
 template <int MODE, int KS>
 struct ConvGeom {
     static constexpr int PAD = (MODE == CONV_S1) ? KS / 2 : 1;

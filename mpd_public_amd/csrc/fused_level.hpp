@@ -126,6 +126,7 @@ struct FusedArgs {
     float* out; float* chain; uint32_t* absmax;
     int D, Cf, fmode, n_per_ctx, fw_off, fb_off, H;
     mpdx_step_coefs k;
+    NoiseRng rng;        // rng.on: the step's noise is drawn in place
     long long* trace;    // dev tool: s_memtime stamps of workgroup 0, 128 slots per wave (null in production)
 };
 
@@ -461,7 +462,8 @@ __global__ __launch_bounds__(kFusedThreads) void fused_level_kernel(const FusedA
                         if (a.k.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
                         r = __fadd_rn(__fmul_rn(a.k.posterior_mean_coef1, x0), __fmul_rn(a.k.posterior_mean_coef2, xv));
                         if (a.fmode == 1) {
-                            if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, a.noise[o]), a.k.noise_std_extra));
+                            if (a.rng.on) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, philox_normal_at(a.rng.seed, a.rng.offset, a.rng.elem0 + o)), a.k.noise_std_extra));
+                            else if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, a.noise[o]), a.k.noise_std_extra));
                             if (a.hs && p == 0) r = a.hs[(size_t)b * a.D + d];
                             if (a.hg && p == H - 1) r = a.hg[(size_t)b * a.D + d];
                         }

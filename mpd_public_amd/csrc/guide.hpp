@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "../../include/mpdx.h"
+#include "conv_block.hpp"
 
 namespace mpdx {
 
@@ -53,6 +54,7 @@ struct GuideArgs {
     float noise_scale, noise_extra;
     float guide_scale;      // factor on the increment (1, or model_var when scale_grad_by_std: sample_functions.py:77-78)
     float* chain;           // optional second destination
+    NoiseRng rng;           // rng.on: the step's noise is drawn in place (noise pointer ignored)
     long long* trace;       // dev tool: cycle stamps, 16 slots per wave of workgroup 0 (null in production)
 };
 
@@ -380,7 +382,8 @@ __device__ __forceinline__ void guide_gp_apply(const GuideArgs& a, int b, int ct
                 a.grad_out[base + d] = inc;
             } else {
                 float r = __fadd_rn(xn[d], inc);
-                if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.noise_scale, a.noise[base + d]), a.noise_extra));
+                if (a.rng.on) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.noise_scale, philox_normal_at(a.rng.seed, a.rng.offset, a.rng.elem0 + base + d)), a.noise_extra));
+                else if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.noise_scale, a.noise[base + d]), a.noise_extra));
                 if (a.hs && lane == 0) r = a.hs[(size_t)b * D + d];
                 if (a.hg && lane == H - 1) r = a.hg[(size_t)b * D + d];
                 a.x[base + d] = r;

@@ -127,6 +127,7 @@ struct FinalArgs {
     int mode;            // 0: eps only; 1: full step; 2: posterior mean only (guide insertion point); 3: DDIM update
     int n_per_ctx;
     mpdx_step_coefs k;
+    NoiseRng rng;        // rng.on: the step's noise is drawn in place (noise pointer ignored)
 };
 
 __global__ __launch_bounds__(256) void final_step_kernel(const FinalArgs a) {
@@ -172,7 +173,8 @@ __global__ __launch_bounds__(256) void final_step_kernel(const FinalArgs a) {
                     if (a.k.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
                     r = __fadd_rn(__fmul_rn(a.k.posterior_mean_coef1, x0), __fmul_rn(a.k.posterior_mean_coef2, xv));
                     if (a.mode == 1) {
-                        if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, a.noise[o]), a.k.noise_std_extra));
+                        if (a.rng.on) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, philox_normal_at(a.rng.seed, a.rng.offset, a.rng.elem0 + o)), a.k.noise_std_extra));
+                        else if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, a.noise[o]), a.k.noise_std_extra));
                         if (a.hs && l == 0) r = a.hs[(size_t)b * a.D + d];
                         if (a.hg && l == a.H - 1) r = a.hg[(size_t)b * a.D + d];
                     }
@@ -267,31 +269,12 @@ __global__ __launch_bounds__(1024) void weighted_loss_kernel(const float* pred, 
     }
 }
 
-// Philox4x32-10 counter-based generator + Box-Muller: 4 normals per counter.
-__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-}
+// standard-normal generator (Philox4x32-10 + Box-Muller, conv_block.hpp): 4 normals per counter.
 __global__ __launch_bounds__(256) void randn_kernel(float* out, size_t n, uint64_t seed, uint64_t offset) {
     const size_t nquad = (n + 3) / 4;
     for (size_t qd = (size_t)blockIdx.x * blockDim.x + threadIdx.x; qd < nquad; qd += (size_t)gridDim.x * blockDim.x) {
-        const uint64_t ctr = qd + offset;
-        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
-        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            philox_round(c0, c1, c2, c3, k0, k1);
-            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-        }
-        const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = ((float)(c3 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
-        float s0, cs0, s1, cs1;
-        sincosf(6.28318530717958647692f * u1, &s0, &cs0);
-        sincosf(6.28318530717958647692f * u3, &s1, &cs1);
-        const float z[4] = {r0 * cs0, r0 * s0, r1 * cs1, r1 * s1};
+        float z[4];
+        philox_normal4(seed, qd + offset, z);
         const size_t base = qd * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -1068,6 +1051,7 @@ static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packe
         if (!fa) return fail(MPDX_E_STATE, "fused final segment needs the step arguments");
         a.x_in = fa->x_in; a.noise = fa->noise; a.hs = fa->hs; a.hg = fa->hg; a.out = fa->out; a.chain = fa->chain;
         a.absmax = fa->absmax; a.fmode = fa->mode; a.n_per_ctx = fa->n_per_ctx > 0 ? fa->n_per_ctx : B; a.k = fa->k;
+        a.rng = fa->rng;
     }
     if (int rc = raise_lds_limit((const void*)fused_level_kernel)) return rc;
     hipLaunchKernelGGL(fused_level_kernel, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
@@ -1112,7 +1096,7 @@ static int run_unet_and_final(mpdx_unet* u, const float* packed, const float* ti
 static int launch_guide(const mpdx_guide_params* gp, float* x, float* grad_out, const float* hs, const float* hg,
                         const uint32_t* amax_in, uint32_t* amax_out, int n_per_ctx, int B, int H, int D, hipStream_t st,
                         const float* noise = nullptr, float noise_scale = 0.f, float noise_extra = 0.f, float* chain = nullptr,
-                        float guide_scale = 1.0f) {
+                        float guide_scale = 1.0f, const NoiseRng* rng = nullptr) {
     if (!gp || !x || !amax_in) return fail(MPDX_E_INVALID, "null argument");
     if (H > 64 || H < 2) return fail(MPDX_E_INVALID, "guide kernel maps one support point per lane: H=%d unsupported (max 64)", H);
     if (D != 2 * gp->q_dim || D > 16) return fail(MPDX_E_INVALID, "state dim %d != 2*q_dim (%d)", D, gp->q_dim);
@@ -1124,6 +1108,8 @@ static int launch_guide(const mpdx_guide_params* gp, float* x, float* grad_out, 
     a.B = B; a.H = H; a.D = D; a.n_per_ctx = n_per_ctx > 0 ? n_per_ctx : B;
     a.noise = noise; a.noise_scale = noise_scale; a.noise_extra = noise_extra; a.chain = chain;
     a.guide_scale = guide_scale;
+    memset(&a.rng, 0, sizeof(a.rng));
+    if (rng) a.rng = *rng;
     if (gp->clip_grad && gp->clip_rule != 0 && gp->clip_rule != 1) return fail(MPDX_E_INVALID, "clip_rule %d (0 = 'norm', 1 = 'value')", gp->clip_rule);
     a.trace = g_guide_trace;
     const size_t lds = guide_lds_bytes(*gp, H, D);
@@ -1366,8 +1352,8 @@ int mpdx_absmax(const float* x, uint32_t* absmax_out, int n_per_ctx, int B, int 
 int mpdx_plan(mpdx_unet* u, const float* packed, const float* timetab, int T, const mpdx_step_coefs* coefs, int n_without_noise,
               float* x, const float* noise, const float* hard_start, const float* hard_goal, float* chain, int B, float* ws,
               const mpdx_guide_params* guide, int n_guide_steps, int t_start_guide, uint32_t* guide_flags, int n_per_ctx,
-              void* stream) {
-    if (!u || !packed || !timetab || !coefs || !x || !noise || !ws || T <= 0 || n_without_noise < 0 || B <= 0)
+              uint64_t rng_seed, uint64_t rng_offset, void* stream) {
+    if (!u || !packed || !timetab || !coefs || !x || !ws || T <= 0 || n_without_noise < 0 || B <= 0)
         return fail(MPDX_E_INVALID, "bad argument");
     if (int rc = check_ready(u)) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -1391,13 +1377,19 @@ int mpdx_plan(mpdx_unet* u, const float* packed, const float* timetab, int T, co
     for (int i = T - 1; i >= -n_without_noise; --i, ++k) {
         const int t = i < 0 ? 0 : i;
         const bool guided = guide && i < t_start_guide;  // sample_functions.py:39 compares the un-clamped index
-        const float* nz = (t == 0) ? nullptr : noise + (size_t)k * n;  // noise[t == 0] = 0  (sample_functions.py:52)
+        const float* nz = (t == 0 || !noise) ? nullptr : noise + (size_t)k * n;  // noise[t == 0] = 0  (sample_functions.py:52)
+        // noise == NULL: the step's draw is generated in place; iteration k uses elements [(k+1) n, (k+2) n) of the stream whose
+        // first n elements are x_T (what mpdx_randn(x, n, seed, offset) wrote): the same bits a pre-generated tensor would hold
+        NoiseRng rng;
+        memset(&rng, 0, sizeof(rng));
+        if (!noise && t != 0) { rng.on = 1; rng.seed = rng_seed; rng.offset = rng_offset; rng.elem0 = (unsigned long long)(k + 1) * n; }
         float* ch = chain ? chain + (size_t)(k + 1) * n : nullptr;
         FinalArgs fa;
         memset(&fa, 0, sizeof(fa));
         fa.x_in = x; fa.out = x;
         fa.k = coefs[t];
         fa.n_per_ctx = npc;
+        if (!guided) fa.rng = rng;
         if (!guided) {
             fa.noise = nz; fa.hs = hard_start; fa.hg = hard_goal; fa.chain = ch; fa.mode = 1;
             if (int rc = run_unet_and_final(u, packed, timetab, T, x, t, B, ws, fa, st)) return rc;
@@ -1409,7 +1401,7 @@ int mpdx_plan(mpdx_unet* u, const float* packed, const float* timetab, int T, co
                 const bool last = j == n_guide_steps - 1;  // the last iteration also adds the noise term and appends to the chain
                 if (int rc = launch_guide(guide, x, nullptr, hard_start, hard_goal, fl + (size_t)j * n_ctx, fl + (size_t)(j + 1) * n_ctx, npc, B, H,
                                           D, st, last ? nz : nullptr, coefs[t].noise_scale, coefs[t].noise_std_extra, last ? ch : nullptr,
-                                          coefs[t].guide_scale))
+                                          coefs[t].guide_scale, last ? &rng : nullptr))
                     return rc;
             }
         }

@@ -303,3 +303,32 @@ def test_weighted_loss_kernel_vs_formula():
         e = (p2 - targ).double()
         want = ((e.abs() if l1 else e * e) * w.double()).mean()
         assert abs(float(out) - float(want)) <= 1e-6 * float(want), (l1, float(out), float(want))
+
+
+@pytest.mark.parametrize("B,guided", [(6, False), (6, True), (520, False)])   # fused level programs / + guide kernels / per-layer path
+def test_in_kernel_noise_equals_pregenerated_stream(B, guided):
+    """mpdx_plan with noise == NULL draws every step's noise inside the step kernels from the Philox stream (seed, offset).
+    Element i of that stream is what mpdx_randn writes at flat index i of one [steps+1, B, H, D] tensor, so a plan with the
+    pre-generated tensor injected must give the SAME BITS (and the 2.4 GB tensor of a 6400-trajectory shard is not needed)."""
+    import mpd_public_amd as m
+    from helpers import product_guide
+    from math import ceil
+    T, n0, D = 25, 5, 4
+    ds = m.TrajectoryDataset("EnvDense2D", "RobotPointMass", tensor_args={"device": "cuda", "dtype": torch.float32})
+    dm = _gpu_model(D, 0, T)
+    hc = {0: t("rng_hc0", (D,), "uniform", 0.6).cuda(), 63: t("rng_hc1", (D,), "uniform", 0.6).cuda()}
+    kw = dict(n_diffusion_steps_without_noise=n0, noise_std_extra_schedule_fn=lambda tt: 0.5)
+    if guided:
+        kw.update(guide=product_guide(ds).cuda(), n_guide_steps=5, t_start_guide=ceil(0.25 * T))
+    dm.in_kernel_noise_min_bytes = 0        # force the in-kernel route (small plans pre-generate by default: same bits)
+    dm.manual_seed(1234)
+    dm._rng_offset = 77                     # a stream that does not start at counter 0
+    xa, ca = dm.plan(hc, B, 64, **kw)       # noise=None: generated in the kernels
+    off_after = dm._rng_offset
+    dm.manual_seed(1234)
+    dm._rng_offset = 77
+    noise = dm.fill_randn(torch.empty((T + n0 + 1, B, 64, D), device="cuda"))
+    assert dm._rng_offset == off_after      # both routes consume the same stretch of the stream
+    xb, cb = dm.plan(hc, B, 64, noise=noise, **kw)
+    assert torch.equal(ca, cb) and torch.equal(xa, xb)
+    assert float(ca[1].std()) > 0.1 and not torch.equal(ca[1], ca[2])
