@@ -143,6 +143,10 @@ __device__ __forceinline__ void fused_ring_request(f32x4 (&ring)[kFusedRing], co
     __builtin_amdgcn_sched_barrier(0);   // the requests go out HERE
 }
 
+// (Tried and rejected, A/B on MI355X: warming the XCD's L2 with the weight stream of the op after next - LDS-DMA loads into a
+//  scratch slot, each workgroup of an XCD a 1/12 slice - 25.56 vs 25.20 ms per cfg2 plan: the long k-loops did not speed up (they
+//  already run at ~83 % of their MFMA rate: 154 cycles per 128-cycle block), the extra requests only delayed the prologue.)
+
 // sum over the 16 lanes of a DPP row (every lane of the row gets the sum)
 __device__ __forceinline__ float row_sum16(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]

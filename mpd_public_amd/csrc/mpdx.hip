@@ -724,6 +724,7 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
     off4 += (size_t)(poff + 3) / 4;
     a.tt_off = (int)off4 * 4;
     off4 += (size_t)a.tt_n / 4;
+
     if ((size_t)(poff / 4 + a.tt_n / 4) > 2048) return fuse_reject(__LINE__);   // prologue: 2048 float4 of parameters per workgroup
     {
         const int c4n = (a.gc1 + a.gc2 + 3) / 4;
@@ -958,17 +959,17 @@ static int check_ready(const mpdx_unet* u) {
     return 0;
 }
 
-// bit k enables fused segment k.  Default: all segments for small batches, none for large ones - a fused kernel streams
-// the segment's weights once per TRAJECTORY, the per-layer kernels once per 32-64 positions x all trajectories of a tile,
-// so beyond a few hundred trajectories weight reuse wins (measured crossover on MI355X between B=400 and B=800,
-// tools/sweep_fused_vs_layer.py).  MPDX_FUSED=0/1 forces none/all, MPDX_FUSED_MASK=<bits> selects segments.
+// bit k enables fused segment k.  Default: all segments up to 4096 trajectories, none above - a fused kernel streams
+// the segment's weights once per TRAJECTORY, the per-layer kernels once per 32-64 positions x all trajectories of a tile.
+// Measured on MI355X with the round-2 fused kernel (U-Net pass, D=14): B=800 1.305 vs 1.337 ms (fused vs per-layer), 1600: 2.04 vs
+// 2.16, 3200: 3.52 vs 3.57, 6400: equal (731 vs 733 ms per cfg5 plan).  (The round-1 kernel crossed over between 400 and 800.)  MPDX_FUSED=0/1 forces none/all, MPDX_FUSED_MASK=<bits> selects segments.
 static unsigned fused_mask(int B) {
     static const int forced = getenv("MPDX_FUSED") ? atoi(getenv("MPDX_FUSED")) : -1;
     static const long mask_env = getenv("MPDX_FUSED_MASK") ? (long)strtoul(getenv("MPDX_FUSED_MASK"), nullptr, 0) : -1;
     if (forced == 0) return 0u;
     if (mask_env >= 0) return (unsigned)mask_env;
     if (forced > 0) return ~0u;
-    return B <= 512 ? ~0u : 0u;
+    return B <= 4096 ? ~0u : 0u;
 }
 // launch units for batch B
 static std::vector<mpdx_unet::Unit> current_units(const mpdx_unet* u, int B, bool* final_in_fused) {
