@@ -283,6 +283,26 @@ def serving_leg(dm, D, T, n0, n_ctx=16, n=100, plans=3):
             "ms_per_context": round(dt * 1e3 / n_ctx, 2), "context_denoising_steps_per_s": round((T + n0) * n_ctx / dt, 1)}
 
 
+def planner_baseline_leg(n=100, opt_iters=500):
+    """the reference's baseline planner pipeline (generate_trajectories.py: RRT-Connect initialisation + GPMP-objective
+    optimisation) for ONE context of n trajectories, on this GPU, next to the diffusion sampler's plan time for the same n."""
+    import torch
+    from mpd_public_amd.generate_trajectories import generate_collision_free_trajectories as gen
+    out = {}
+    for env_id, robot in (("EnvNarrowPassageDense2D", "RobotPointMass"), ("EnvSpheres3D", "RobotPanda")):
+        gen(env_id, robot, n, None, gpmp_opt_iters=opt_iters, seed=1)   # warm-up (allocator, kernels)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_coll, n_free = gen(env_id, robot, n, None, gpmp_opt_iters=opt_iters, seed=2)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        last = gen.last
+        out[f"{env_id}-{robot}"] = {"n_trajectories": n, "wall_ms": round(dt * 1e3, 1), "rrt_connect_ms": round(last["times"]["rrt_connect_s"] * 1e3, 1),
+                                    "gpmp_ms": round(last["times"]["gpmp_s"] * 1e3, 1), "gpmp_iters": opt_iters, "rrt_solved": last["rrt_solved"],
+                                    "fraction_free": round(last["fraction_free"], 3), "collision_intensity": round(last["collision_intensity"], 4)}
+    return out
+
+
 def _respawn(args):
     """`python bench.py --gpus N` without a torch.distributed.run environment: start the N ranks ourselves."""
     with socket.socket() as s:
@@ -411,6 +431,10 @@ def main():
                 out["serving"] = serving_leg(dm, D, T, n0)
             except Exception as e:
                 out["serving"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                out["planner_baseline"] = planner_baseline_leg()
+            except Exception as e:
+                out["planner_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_leg(sd, D, T, B, n0)
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)

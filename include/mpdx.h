@@ -162,6 +162,8 @@ typedef struct mpdx_guide_params {
     int32_t clip_rule;                  /* 0: clip_grad_rule 'norm' (guides.py:224-230); 1: 'value' (guides.py:232-236) */
     float   max_grad_value;             /* 0.1 (guides.py:151) */
     int32_t gp_half_factor;             /* 0: cost_GP = sum e^T Qinv e (default);  1: 1/2 sum e^T Qinv e (GPMP2's convention) */
+    int32_t identity_normalizer;        /* 1: x is ALREADY in robot units (no LimitsNormalizer, no range test): the trajectory optimiser of
+                                         * generate_trajectories (scripts/generate_data/generate_trajectories.py:94-117) works on raw trajectories */
 } mpdx_guide_params;
 
 /* one guide iteration on x[B,H,D] (normalised).  grad_out == NULL: x <- hard_cond(x + guide(x)) in place and

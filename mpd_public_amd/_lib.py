@@ -45,7 +45,8 @@ class GuideParams(C.Structure):
                 ("mins", C.c_float * 16), ("maxs", C.c_float * 16), ("cutoff_margin", C.c_float), ("link_margin", C.c_float),
                 ("n_fields", C.c_int32), ("fields", Field * MAX_FIELDS), ("use_gp", C.c_int32), ("gp_weight", C.c_float),
                 ("dt", C.c_float), ("sigma_gp", C.c_float), ("prims", C.c_void_p), ("n_prim_floats", C.c_int32),
-                ("clip_rule", C.c_int32), ("max_grad_value", C.c_float), ("gp_half_factor", C.c_int32)]
+                ("clip_rule", C.c_int32), ("max_grad_value", C.c_float), ("gp_half_factor", C.c_int32),
+                ("identity_normalizer", C.c_int32)]
 
 
 # every symbol include/mpdx.h declares: name -> (restype, argtypes)

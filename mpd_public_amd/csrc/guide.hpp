@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
         xn[d] = live ? a.x[base + d] : 0.f;
         const float c = clipall ? fminf(fmaxf(xn[d], -1.f), 1.f) : xn[d];
         const float u01 = __fadd_rn(c, 1.0f) * 0.5f;
-        xu[d] = __fadd_rn(__fmul_rn(u01, __fsub_rn(gp.maxs[d], gp.mins[d])), gp.mins[d]);
+        xu[d] = gp.identity_normalizer ? xn[d] : __fadd_rn(__fmul_rn(u01, __fsub_rn(gp.maxs[d], gp.mins[d])), gp.mins[d]);
         if (live && wv == 0) sx[lane * D + d] = xu[d];
     }
     __syncthreads();
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(512) void guide_step_panda_kernel(const GuideArgs a
         xn[d] = live ? a.x[base + d] : 0.f;
         const float c = clipall ? fminf(fmaxf(xn[d], -1.f), 1.f) : xn[d];
         const float u01 = __fadd_rn(c, 1.0f) * 0.5f;
-        xu[d] = __fadd_rn(__fmul_rn(u01, __fsub_rn(gp.maxs[d], gp.mins[d])), gp.mins[d]);
+        xu[d] = gp.identity_normalizer ? xn[d] : __fadd_rn(__fmul_rn(u01, __fsub_rn(gp.maxs[d], gp.mins[d])), gp.mins[d]);
         if (live && wv == 0) sx[lane * D + d] = xu[d];
     }
     __syncthreads();

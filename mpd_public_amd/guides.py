@@ -18,7 +18,7 @@ from .planning import CostCollision, CostComposite, CostGPTrajectory
 
 
 def build_device_params(robot, ws_dim, cutoff_margin, mins, maxs, cost_l, weight_l, interpolate, n_interp, clip_grad, max_grad_norm, device,
-                        clip_grad_rule="norm", max_grad_value=0.1):
+                        clip_grad_rule="norm", max_grad_value=0.1, identity_normalizer=False):
     """Compile cost descriptors into the `mpdx_guide_params` block the HIP kernels take.  Returns (params, primitive
     table tensor) - the caller keeps the tensor alive (params holds its raw device pointer)."""
     gp = _lib.GuideParams()
@@ -28,6 +28,7 @@ def build_device_params(robot, ws_dim, cutoff_margin, mins, maxs, cost_l, weight
     if clip_grad_rule not in ("norm", "value"):
         raise NotImplementedError(f"clip_grad_rule={clip_grad_rule!r}")   # as guides.py:219-220
     gp.clip_rule, gp.max_grad_value = (1 if clip_grad_rule == "value" else 0), float(max_grad_value)
+    gp.identity_normalizer = int(bool(identity_normalizer))
     D = 2 * robot.q_dim
     if mins is not None:
         mins, maxs = torch.as_tensor(mins).cpu().numpy(), torch.as_tensor(maxs).cpu().numpy()

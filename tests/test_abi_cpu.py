@@ -151,3 +151,20 @@ def test_product_never_imports_the_oracle():
     hits = [m.start() for m in re.finditer(r"^\s*(from|import)\s+oracle\b", bench, flags=re.M)]
     lo = bench.index("def cpu_baseline_leg"); hi = bench.index("def main")
     assert hits and all(lo < h < hi for h in hits), "bench.py may import oracle only inside cpu_baseline_leg"
+
+
+def test_resample_path_uniform_arclength_and_zero_end_velocities():
+    """Host logic of the dataset-generation entry (no GPU): a polyline resampled to H support points is uniform in arc length,
+    keeps its end points exactly and carries zero velocity at both ends."""
+    import torch
+    from mpd_public_amd.generate_trajectories import resample_path
+    path = torch.tensor([[0.0, 0.0], [0.3, 0.0], [0.3, 0.4], [1.0, 0.4]])
+    tr = resample_path(path, 64, 5.0 / 64)
+    assert tr.shape == (64, 4)
+    assert torch.equal(tr[0, :2], path[0]) and torch.equal(tr[-1, :2], path[-1])
+    assert not tr[0, 2:].any() and not tr[-1, 2:].any()
+    seg = torch.linalg.norm(tr[1:, :2] - tr[:-1, :2], dim=-1)
+    assert float(seg.sum()) <= 1.4 + 1e-5 and float(seg.sum()) > 1.35          # chords of a 1.4-long polyline
+    assert float(seg.max() - seg.min()) < 0.01                                   # (shorter only where a corner is cut)
+    vel = tr[1:-1, 2:]
+    assert torch.allclose(vel, (tr[2:, :2] - tr[:-2, :2]) / (2 * 5.0 / 64), atol=1e-6)
