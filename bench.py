@@ -84,7 +84,7 @@ def _unit_classes(lib, hdl, B, names, flops, n):
             else:
                 out.append((f"{kind}[{tile}] {flops[i]:.3e} flop", "conv_block_kernel"))
         elif nm.startswith("fused"):
-            out.append(("fused_level_kernel (whole-trajectory level programs)", "fused_level_kernel"))
+            out.append(("fused level programs (fused_program_kernel<...>: whole-trajectory U-Net levels)", "fused_program_kernel"))
         else:
             out.append((nm, "final_step_kernel"))
     return out
@@ -151,7 +151,8 @@ def roofline_leg(dm, B, T, reps=30):
             continue
         if rec.get("batch") != B:
             continue
-        hit = [v for k, v in rec.get("kernels", {}).items() if dom["kernel"].split(" ")[0] in k]
+        pats = ("fused_program_kernel", "fused_level_kernel") if dom["kernel"].startswith("fused") else (dom["kernel"].split(" ")[0],)
+        hit = [v for k, v in rec.get("kernels", {}).items() if any(p in k for p in pats)]
         if hit:
             nl = sum(v["launches"] for v in hit)
             traffic = int(sum(v["traffic_bytes_per_launch"] * v["launches"] for v in hit) / nl)

@@ -100,7 +100,13 @@ struct FusedOp {          // runtime part of an op: 13 dwords
 };
 
 constexpr int kMaxFusedOps = 16;
-constexpr int kFusedRing = 16;   // ring depth in 1-KiB A-fragment blocks (4 VGPRs each)
+#ifndef MPDX_FUSED_RING
+#define MPDX_FUSED_RING 16
+#endif
+#ifndef MPDX_FUSED_DB
+#define MPDX_FUSED_DB 2
+#endif
+constexpr int kFusedRing = MPDX_FUSED_RING;   // ring depth in 1-KiB A-fragment blocks (4 VGPRs each)
 
 struct FusedArgs {
     const float* packed;
@@ -162,7 +168,7 @@ __device__ __forceinline__ float row_sum16(float v) {
 template <class S>
 __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp& op, f32x4 (&ring)[kFusedRing], float* smem, int wave, int lane, int b,
                                               const float* __restrict__ nbase, int nmax, long long* tr_base, int& tr) {
-    constexpr int P = kFusedRing, DB = 2, NTW = S::NTW, NJ = S::NJ;
+    constexpr int P = kFusedRing, DB = MPDX_FUSED_DB, NTW = S::NTW, NJ = S::NJ;
     f32x4* const sm4 = (f32x4*)smem;
     const int j = lane & 15, q = lane >> 4;
     const int ms = wave & (S::MSn - 1);
@@ -319,23 +325,13 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
 #undef FOP_STAMP
 }
 
-__global__ __launch_bounds__(kFusedThreads) void fused_level_kernel(const FusedArgs a) {
-#ifndef MPDX_NO_WARM_KERNARG   // dev A/B switch
-    warm_kernarg<(int)sizeof(FusedArgs)>();
-#endif
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// ---- prologue of a fused program (shared by the generic and the static kernels)
+__device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, f32x4 (&ring)[kFusedRing], int tid, int lane, int wave, int b,
+                                               long long* tr_base, int& tr) {
     f32x4* const sm4 = (f32x4*)smem;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
-    int tr = 0;
-    long long* const tr_base = (a.trace && b == 0 && lane == 0) ? a.trace + wave * 128 : nullptr;   // 128 slots per wave
 #define FUSED_STAMP() do { if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter(); ++tr; } while (0)
-    FUSED_STAMP();
-
     // ---- prologue: every global load is issued first (weight ring of op 0, input window, parameters), the halo / padding
     //      zeros are written while they fly, and ONE barrier closes it.
-    f32x4 ring[kFusedRing];
     fused_ring_request(ring, a.packed + a.ops[0].sbase + (size_t)(wave & a.msmask[0]) * a.slen[0] * 256 + lane * 4, a.slen[0]);
 
     const int cin = a.gc1 + a.gc2;
@@ -430,59 +426,85 @@ __global__ __launch_bounds__(kFusedThreads) void fused_level_kernel(const FusedA
     lds_barrier();
     FUSED_STAMP();
 
+#undef FUSED_STAMP
+}
+
+// ---- final_conv[1] (1x1, Cf -> D) + DDPM posterior step + hard conditioning of a fused program (see final_step_kernel)
+__device__ __forceinline__ void fused_final_op(const FusedArgs& a, const FusedOp& op, float* smem, int tid, int lane, int b) {
+    f32x4* const sm4 = (f32x4*)smem;
+    constexpr int NT_ = kFusedThreads;
+    // ---- final_conv[1] (1x1, Cf -> D) + DDPM posterior step + hard conditioning (see final_step_kernel)
+    float vmax = 0.f;
+    const int H = a.H;
+    for (int idx = tid; idx < H * a.D; idx += NT_) {
+        const int p = idx / a.D, d = idx - p * a.D;
+        float s = a.packed[a.fb_off + d];
+        const float* wrow = a.packed + a.fw_off + d * a.Cf;
+        for (int c = 0; c < a.Cf; c += 4) {
+            const f32x4 hv = sm4[op.src_off4 + (p + 2) * op.src_rs4 + (c >> 2)];
+            const f32x4 wv = *(const f32x4*)(wrow + c);
+            s = fmaf(hv[0], wv[0], s); s = fmaf(hv[1], wv[1], s);
+            s = fmaf(hv[2], wv[2], s); s = fmaf(hv[3], wv[3], s);
+        }
+        const size_t o = ((size_t)b * H + p) * a.D + d;
+        float r;
+        if (a.fmode == 0) {
+            r = s;
+        } else {
+            const float xv = a.x_in[o];
+            float x0 = a.k.predict_epsilon
+                           ? __fsub_rn(__fmul_rn(a.k.sqrt_recip_alphas_cumprod, xv), __fmul_rn(a.k.sqrt_recipm1_alphas_cumprod, s))
+                           : s;
+            if (a.fmode == 3) {  // ddim_sample (diffusion_model_base.py:216-237): x_start is not clamped there
+                const float pn = a.k.predict_epsilon
+                                     ? s
+                                     : __fdiv_rn(__fsub_rn(__fmul_rn(a.k.sqrt_recip_alphas_cumprod, xv), s), a.k.sqrt_recipm1_alphas_cumprod);
+                r = __fadd_rn(__fmul_rn(x0, a.k.ddim_k1), __fmul_rn(a.k.ddim_k2, pn));
+                if (a.hs && p == 0) r = a.hs[(size_t)b * a.D + d];
+                if (a.hg && p == H - 1) r = a.hg[(size_t)b * a.D + d];
+            } else {
+                if (a.k.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+                r = __fadd_rn(__fmul_rn(a.k.posterior_mean_coef1, x0), __fmul_rn(a.k.posterior_mean_coef2, xv));
+                if (a.fmode == 1) {
+                    if (a.rng.on) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, philox_normal_at(a.rng.seed, a.rng.offset, a.rng.elem0 + o)), a.k.noise_std_extra));
+                    else if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, a.noise[o]), a.k.noise_std_extra));
+                    if (a.hs && p == 0) r = a.hs[(size_t)b * a.D + d];
+                    if (a.hg && p == H - 1) r = a.hg[(size_t)b * a.D + d];
+                }
+            }
+        }
+        a.out[o] = r;
+        if (a.chain) a.chain[o] = r;
+        vmax = fmaxf(vmax, fabsf(r));
+    }
+    if (a.absmax) {
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, s, 64));
+        if (lane == 0) atomicMax(a.absmax + b / a.n_per_ctx, __float_as_uint(vmax));
+    }
+}
+
+// Generic kernel: walks a runtime op list (any sequence of the shapes above).
+__global__ __launch_bounds__(kFusedThreads) void fused_level_kernel(const FusedArgs a) {
+#ifndef MPDX_NO_WARM_KERNARG   // dev A/B switch
+    warm_kernarg<(int)sizeof(FusedArgs)>();
+#endif
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    int tr = 0;
+    long long* const tr_base = (a.trace && b == 0 && lane == 0) ? a.trace + wave * 128 : nullptr;   // 128 slots per wave
+    if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter();
+    ++tr;
+    f32x4 ring[kFusedRing];
+    fused_prologue(a, smem, ring, tid, lane, wave, b, tr_base, tr);
     for (int oi = 0; oi < a.nops; ++oi) {
         const FusedOp op = a.ops[oi];
         if (op.shape == kFusedShapeFinal) {
-            // ---- final_conv[1] (1x1, Cf -> D) + DDPM posterior step + hard conditioning (see final_step_kernel)
-            float vmax = 0.f;
-            const int H = a.H;
-            for (int idx = tid; idx < H * a.D; idx += NT_) {
-                const int p = idx / a.D, d = idx - p * a.D;
-                float s = a.packed[a.fb_off + d];
-                const float* wrow = a.packed + a.fw_off + d * a.Cf;
-                for (int c = 0; c < a.Cf; c += 4) {
-                    const f32x4 hv = sm4[op.src_off4 + (p + 2) * op.src_rs4 + (c >> 2)];
-                    const f32x4 wv = *(const f32x4*)(wrow + c);
-                    s = fmaf(hv[0], wv[0], s); s = fmaf(hv[1], wv[1], s);
-                    s = fmaf(hv[2], wv[2], s); s = fmaf(hv[3], wv[3], s);
-                }
-                const size_t o = ((size_t)b * H + p) * a.D + d;
-                float r;
-                if (a.fmode == 0) {
-                    r = s;
-                } else {
-                    const float xv = a.x_in[o];
-                    float x0 = a.k.predict_epsilon
-                                   ? __fsub_rn(__fmul_rn(a.k.sqrt_recip_alphas_cumprod, xv), __fmul_rn(a.k.sqrt_recipm1_alphas_cumprod, s))
-                                   : s;
-                    if (a.fmode == 3) {  // ddim_sample (diffusion_model_base.py:216-237): x_start is not clamped there
-                        const float pn = a.k.predict_epsilon
-                                             ? s
-                                             : __fdiv_rn(__fsub_rn(__fmul_rn(a.k.sqrt_recip_alphas_cumprod, xv), s), a.k.sqrt_recipm1_alphas_cumprod);
-                        r = __fadd_rn(__fmul_rn(x0, a.k.ddim_k1), __fmul_rn(a.k.ddim_k2, pn));
-                        if (a.hs && p == 0) r = a.hs[(size_t)b * a.D + d];
-                        if (a.hg && p == H - 1) r = a.hg[(size_t)b * a.D + d];
-                    } else {
-                        if (a.k.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-                        r = __fadd_rn(__fmul_rn(a.k.posterior_mean_coef1, x0), __fmul_rn(a.k.posterior_mean_coef2, xv));
-                        if (a.fmode == 1) {
-                            if (a.rng.on) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, philox_normal_at(a.rng.seed, a.rng.offset, a.rng.elem0 + o)), a.k.noise_std_extra));
-                            else if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, a.noise[o]), a.k.noise_std_extra));
-                            if (a.hs && p == 0) r = a.hs[(size_t)b * a.D + d];
-                            if (a.hg && p == H - 1) r = a.hg[(size_t)b * a.D + d];
-                        }
-                    }
-                }
-                a.out[o] = r;
-                if (a.chain) a.chain[o] = r;
-                vmax = fmaxf(vmax, fabsf(r));
-            }
-            if (a.absmax) {
-#pragma unroll
-                for (int s = 32; s >= 1; s >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, s, 64));
-                if (lane == 0) atomicMax(a.absmax + b / a.n_per_ctx, __float_as_uint(vmax));
-            }
-            FUSED_STAMP();
+            fused_final_op(a, op, smem, tid, lane, b);
+            if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter();
+            ++tr;
             continue;
         }
         // the next conv op's wave-stream: this op's ring runs on into it (after the last conv op: any valid block, unused)
@@ -501,6 +523,70 @@ __global__ __launch_bounds__(kFusedThreads) void fused_level_kernel(const FusedA
         }
     }
 }
-#undef FUSED_STAMP
+
+// ---- STATIC programs.  The op sequences of the standard networks (dim_mults (1,2,4,8) and (1,2,4), unet_input_dim 32, H 64) are
+// compile-time lists of shape ids: the op loop, the shape switch and every descriptor index disappear (descriptor fields are read
+// at immediate offsets of the argument block; no per-op dispatch), and per-op address arithmetic is no longer hoisted out of a
+// 16-way switch into long-lived registers.  Any other network runs the generic kernel above.
+template <int ID> struct FusedShapeOf;
+#define X(id, M, K, N, R, CO, LO, G) template <> struct FusedShapeOf<id> { using type = FusedShape<M, K, N, R, CO, LO, G>; };
+MPDX_FUSED_SHAPES(X)
+#undef X
+
+template <int SH, int I, int NEXT_SH>
+__device__ __forceinline__ void fused_static_op(const FusedArgs& a, f32x4 (&ring)[kFusedRing], float* smem, int tid, int wave, int lane, int b,
+                                                long long* tr_base, int& tr) {
+    if constexpr (SH == kFusedShapeFinal) {
+        fused_final_op(a, a.ops[I], smem, tid, lane, b);
+        if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter();
+        ++tr;
+    } else {
+        const float* nbase = a.packed + a.ops[I].sbase + lane * 4;
+        int nmax = 0;
+        if constexpr (NEXT_SH >= 0 && NEXT_SH != kFusedShapeFinal) {
+            using N = typename FusedShapeOf<NEXT_SH>::type;
+            nbase = a.packed + a.ops[I + 1].sbase + (size_t)(wave & (N::MSn < kFusedWaves ? N::MSn - 1 : kFusedWaves - 1)) * (N::SLEN * 256) + lane * 4;
+            nmax = N::SLEN - 1;
+        }
+        fused_conv_op<typename FusedShapeOf<SH>::type>(a, a.ops[I], ring, smem, wave, lane, b, nbase, nmax, tr_base, tr);
+    }
+}
+
+template <int... SH>
+struct FusedSeq {
+    static constexpr int N = sizeof...(SH);
+    static constexpr int ids[sizeof...(SH)] = {SH...};
+    template <int I>
+    __device__ static __forceinline__ void run_from(const FusedArgs& a, f32x4 (&ring)[kFusedRing], float* smem, int tid, int wave, int lane, int b,
+                                                    long long* tr_base, int& tr) {
+        if constexpr (I < N) {
+            fused_static_op<ids[I], I, (I + 1 < N ? ids[I + 1 < N ? I + 1 : I] : -1)>(a, ring, smem, tid, wave, lane, b, tr_base, tr);
+            run_from<I + 1>(a, ring, smem, tid, wave, lane, b, tr_base, tr);
+        }
+    }
+};
+
+template <class SEQ>
+__global__ __launch_bounds__(kFusedThreads) void fused_program_kernel(const FusedArgs a) {
+#ifndef MPDX_NO_WARM_KERNARG
+    warm_kernarg<(int)sizeof(FusedArgs)>();
+#endif
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    int tr = 0;
+    long long* const tr_base = (a.trace && b == 0 && lane == 0) ? a.trace + wave * 128 : nullptr;
+    if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter();
+    ++tr;
+    f32x4 ring[kFusedRing];
+    fused_prologue(a, smem, ring, tid, lane, wave, b, tr_base, tr);
+    SEQ::template run_from<0>(a, ring, smem, tid, wave, lane, b, tr_base, tr);
+}
+
+// the programs of the standard networks
+using FusedSeqDown = FusedSeq<0, 1, 2, 2, 3, 4, 5, 6, 6, 7>;                       // downs.0 + downs.1
+using FusedSeqUpA = FusedSeq<8, 9, 10, 10, 11>;                                    // the up level at L = 16 (cat 256 -> 64)
+using FusedSeqUpB = FusedSeq<12, 13, 14, 14, 15, 2, kFusedShapeFinal>;             // the up level at L = 32 + final_conv + DDPM step
 
 }  // namespace mpdx

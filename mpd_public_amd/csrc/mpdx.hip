@@ -336,6 +336,7 @@ struct mpdx_unet {
         int gout_slot[3] = {-1, -1, -1};
         size_t lds_bytes = 0;
         mpdx::FusedArgs tmpl;
+        int program = -1;               // index of the matching static program (fused_program_kernel), -1: generic op-list kernel
         std::vector<CopyJob> jobs;      // assemble the stream-ordered weight copies + the contiguous parameter block
     };
     std::vector<Fused> fused;
@@ -736,10 +737,24 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
     f.lds_bytes = off4 * 16;
     if (f.lds_bytes > 160 * 1024) return fuse_reject(__LINE__);
     u->packed_floats = area;
+    {   // a known op sequence runs as a static program
+        auto matches = [&](const int* ids, int n) {
+            if (n != a.nops) return false;
+            for (int k = 0; k < n; ++k) if (a.ops[k].shape != ids[k]) return false;
+            return true;
+        };
+        static const bool off = getenv("MPDX_STATIC_PROGRAMS") && atoi(getenv("MPDX_STATIC_PROGRAMS")) == 0;
+        if (!off) {
+            if (matches(FusedSeqDown::ids, FusedSeqDown::N)) f.program = 0;
+            else if (matches(FusedSeqUpA::ids, FusedSeqUpA::N)) f.program = 1;
+            else if (matches(FusedSeqUpB::ids, FusedSeqUpB::N)) f.program = 2;
+        }
+    }
     u->fused.push_back(f);
     if (getenv("MPDX_DEBUG_FUSE"))
-        fprintf(stderr, "[mpdx] fused segment %zu: layers [%d,%d) %s..%s  %d ops  %zu buffers  LDS %zu B  streams+params %zu floats\n", u->fused.size() - 1,
-                i0, i1, u->layers[i0].name.c_str(), u->layers[i1 - 1].name.c_str(), a.nops, bufs.size(), f.lds_bytes, area - (size_t)a.ops[0].sbase);
+        fprintf(stderr, "[mpdx] fused segment %zu: layers [%d,%d) %s..%s  %d ops  %zu buffers  LDS %zu B  streams+params %zu floats  program %d\n",
+                u->fused.size() - 1, i0, i1, u->layers[i0].name.c_str(), u->layers[i1 - 1].name.c_str(), a.nops, bufs.size(), f.lds_bytes,
+                area - (size_t)a.ops[0].sbase, u->fused.back().program);
     return true;
 }
 
@@ -1054,8 +1069,23 @@ static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packe
         a.absmax = fa->absmax; a.fmode = fa->mode; a.n_per_ctx = fa->n_per_ctx > 0 ? fa->n_per_ctx : B; a.k = fa->k;
         a.rng = fa->rng;
     }
-    if (int rc = raise_lds_limit((const void*)fused_level_kernel)) return rc;
-    hipLaunchKernelGGL(fused_level_kernel, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
+    switch (f.program) {
+        case 0:
+            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqDown>)) return rc;
+            hipLaunchKernelGGL(fused_program_kernel<FusedSeqDown>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
+            break;
+        case 1:
+            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqUpA>)) return rc;
+            hipLaunchKernelGGL(fused_program_kernel<FusedSeqUpA>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
+            break;
+        case 2:
+            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqUpB>)) return rc;
+            hipLaunchKernelGGL(fused_program_kernel<FusedSeqUpB>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
+            break;
+        default:
+            if (int rc = raise_lds_limit((const void*)fused_level_kernel)) return rc;
+            hipLaunchKernelGGL(fused_level_kernel, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
+    }
     return 0;
 }
 
