@@ -974,17 +974,20 @@ static int check_ready(const mpdx_unet* u) {
     return 0;
 }
 
-// bit k enables fused segment k.  Default: all segments up to 4096 trajectories, none above - a fused kernel streams
-// the segment's weights once per TRAJECTORY, the per-layer kernels once per 32-64 positions x all trajectories of a tile.
-// Measured on MI355X with the round-2 fused kernel (U-Net pass, D=14): B=800 1.305 vs 1.337 ms (fused vs per-layer), 1600: 2.04 vs
-// 2.16, 3200: 3.52 vs 3.57, 6400: equal (731 vs 733 ms per cfg5 plan).  (The round-1 kernel crossed over between 400 and 800.)  MPDX_FUSED=0/1 forces none/all, MPDX_FUSED_MASK=<bits> selects segments.
+// bit k enables fused segment k.  Default: all segments at every batch size.  A fused program streams the segment's weights once
+// per TRAJECTORY (from the L2, warm within a launch) where the per-layer kernels stream them once per tile of 4-8 trajectories and
+// round-trip every activation through HBM; with the static programs (136-170 VGPRs: two workgroups per CU) the fused path wins
+// everywhere.  Measured on MI355X: U-Net pass D=14, round-2 generic kernel: B=800 1.305 vs 1.337 ms (fused vs per-layer), 1600: 2.04 vs
+// 2.16, 3200: 3.52 vs 3.57, 6400 equal; static programs at B=6400 (cfg5 plan): 644 vs 726 ms.  (Round 1's kernel crossed over at
+// B~600.)  MPDX_FUSED=0/1 forces none/all, MPDX_FUSED_MASK=<bits> selects segments.
 static unsigned fused_mask(int B) {
-    static const int forced = getenv("MPDX_FUSED") ? atoi(getenv("MPDX_FUSED")) : -1;
-    static const long mask_env = getenv("MPDX_FUSED_MASK") ? (long)strtoul(getenv("MPDX_FUSED_MASK"), nullptr, 0) : -1;
-    if (forced == 0) return 0u;
-    if (mask_env >= 0) return (unsigned)mask_env;
-    if (forced > 0) return ~0u;
-    return B <= 4096 ? ~0u : 0u;
+    (void)B;
+    // read on every call (two getenv per pass): tests and A/B runs switch the path inside one process
+    const char* f = getenv("MPDX_FUSED");
+    const char* m = getenv("MPDX_FUSED_MASK");
+    if (f && atoi(f) == 0) return 0u;
+    if (m) return (unsigned)strtoul(m, nullptr, 0);
+    return ~0u;
 }
 // launch units for batch B
 static std::vector<mpdx_unet::Unit> current_units(const mpdx_unet* u, int B, bool* final_in_fused) {

@@ -144,3 +144,22 @@ def oracle_plan_metrics(dataset, xu, n_check=256):
             per_point = torch.stack([term(xi[:, i:i + 1]) for i in range(xi.shape[1])], 1)
             hit |= per_point > 0
     return hit.sum(1), plen, smooth
+
+
+import contextlib
+import os
+
+
+@contextlib.contextmanager
+def kernel_path(fused: bool):
+    """Run the enclosed product calls on the fused level programs (default) or on the per-layer conv kernels everywhere
+    (MPDX_FUSED=0; libmpdx reads the variable on every pass)."""
+    old = os.environ.get("MPDX_FUSED")
+    os.environ["MPDX_FUSED"] = "1" if fused else "0"
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop("MPDX_FUSED", None)
+        else:
+            os.environ["MPDX_FUSED"] = old

@@ -41,15 +41,18 @@ def test_unet_forward_vs_reference_golden(golden_dir, D, opt):
         np.testing.assert_allclose(y, ref, rtol=0, atol=2e-5, err_msg=f"t={tt}")
 
 
-@pytest.mark.parametrize("B", [1, 3, 7, 100, 600])  # <= 512: fused level kernels; 600: per-layer launches
-def test_unet_forward_ragged_batches_vs_oracle(B):
+@pytest.mark.parametrize("B", [1, 3, 7, 100, 600])
+@pytest.mark.parametrize("fused", [True, False])   # fused level programs (the default at every B) / per-layer conv kernels everywhere
+def test_unet_forward_ragged_batches_vs_oracle(B, fused):
     from oracle.unet import unet_forward
+    from helpers import kernel_path
     D, opt = 4, 1
     sd = synth_sd(D, opt)
     net = _gpu_model(D, opt)
     x = t(f"ragged_x_{B}", (B, 64, D))
     ref = unet_forward(sd, x, torch.full((B,), 37, dtype=torch.long)).numpy()
-    y = net(x.cuda(), torch.full((B,), 37, dtype=torch.long, device="cuda"), None).cpu().numpy()
+    with kernel_path(fused):
+        y = net(x.cuda(), torch.full((B,), 37, dtype=torch.long, device="cuda"), None).cpu().numpy()
     np.testing.assert_allclose(y, ref, rtol=0, atol=2e-5)
 
 
@@ -305,8 +308,8 @@ def test_weighted_loss_kernel_vs_formula():
         assert abs(float(out) - float(want)) <= 1e-6 * float(want), (l1, float(out), float(want))
 
 
-@pytest.mark.parametrize("B,guided", [(6, False), (6, True), (520, False)])   # fused level programs / + guide kernels / per-layer path
-def test_in_kernel_noise_equals_pregenerated_stream(B, guided):
+@pytest.mark.parametrize("B,guided,fused", [(6, False, True), (6, True, True), (70, False, False)])   # fused final op / guide kernel / final_step_kernel
+def test_in_kernel_noise_equals_pregenerated_stream(B, guided, fused):
     """mpdx_plan with noise == NULL draws every step's noise inside the step kernels from the Philox stream (seed, offset).
     Element i of that stream is what mpdx_randn writes at flat index i of one [steps+1, B, H, D] tensor, so a plan with the
     pre-generated tensor injected must give the SAME BITS (and the 2.4 GB tensor of a 6400-trajectory shard is not needed)."""
@@ -320,15 +323,18 @@ def test_in_kernel_noise_equals_pregenerated_stream(B, guided):
     kw = dict(n_diffusion_steps_without_noise=n0, noise_std_extra_schedule_fn=lambda tt: 0.5)
     if guided:
         kw.update(guide=product_guide(ds).cuda(), n_guide_steps=5, t_start_guide=ceil(0.25 * T))
+    from helpers import kernel_path
     dm.in_kernel_noise_min_bytes = 0        # force the in-kernel route (small plans pre-generate by default: same bits)
     dm.manual_seed(1234)
     dm._rng_offset = 77                     # a stream that does not start at counter 0
-    xa, ca = dm.plan(hc, B, 64, **kw)       # noise=None: generated in the kernels
+    with kernel_path(fused):
+        xa, ca = dm.plan(hc, B, 64, **kw)   # noise=None: generated in the kernels
     off_after = dm._rng_offset
     dm.manual_seed(1234)
     dm._rng_offset = 77
     noise = dm.fill_randn(torch.empty((T + n0 + 1, B, 64, D), device="cuda"))
     assert dm._rng_offset == off_after      # both routes consume the same stretch of the stream
-    xb, cb = dm.plan(hc, B, 64, noise=noise, **kw)
+    with kernel_path(fused):
+        xb, cb = dm.plan(hc, B, 64, noise=noise, **kw)
     assert torch.equal(ca, cb) and torch.equal(xa, xb)
     assert float(ca[1].std()) > 0.1 and not torch.equal(ca[1], ca[2])
