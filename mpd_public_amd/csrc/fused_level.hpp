@@ -116,6 +116,11 @@ struct FusedArgs {
     float* gout[3];      // global outputs, channel-last [B][L][C]
     int gc1, gc2, L0;
     int in_off4, in_rs4, in_rows, in_clear;   // staged input buffer
+    // a SECOND staged input: the skip tensor [B][L3][c3] that a later op of the program concatenates behind an LDS-resident
+    // tensor (torch.cat((x, h.pop()), dim=1) of the second up level, temporal_unet.py:159): written by the prologue into columns
+    // [col3, col3 + c3/4) of that op's (wider) source buffer, whose first columns the producing Upsample1d fills later
+    const float* gsrc3;
+    int c3, L3, s3_off4, s3_rs4, s3_col4;     // c3 == 0: none
     int B, nops;
     int stat_off;        // GroupNorm exchange area (floats): [tile 0..7][row 0..3][mean, M2]
     int par_off;         // LDS parameter area (floats): copy of packed[gpar_off .. +par_floats)
@@ -379,6 +384,16 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, 
             }
         }
     }
+    // second staged input (skip tensor of a later concat): <= 4 float4 per thread
+    constexpr int SK = 1024 / NT_;
+    f32x4 sv[SK];
+    const int s3c4 = a.c3 >> 2, n_s3 = a.L3 * s3c4;
+#pragma unroll
+    for (int k = 0; k < SK; ++k) {
+        const int idx = tid + k * NT_;
+        if (k * NT_ >= n_s3) continue;   // wave-uniform (sv[k] stays unset, never stored)
+        sv[k] = *(const f32x4*)(a.gsrc3 + ((size_t)b * n_s3 + (idx < n_s3 ? idx : 0)) * 4);
+    }
     // parameters of every op ([bias | gamma | beta | rbias] blocks, contiguous in `packed` behind the weight streams) and the
     // slice of this timestep's conditioning row the segment's blocks use: two straight copies
     constexpr int PK = 2048 / NT_;   // float4 per thread (<= 2048 float4 = 32 KB of parameters)
@@ -416,6 +431,14 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, 
             for (int e = 0; e < 4; ++e) iv[k][e] = (ck[k] + e < cin) ? iv[k][e] : 0.f;
         }
         if (idst[k] >= 0) sm4[idst[k]] = iv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < SK; ++k) {
+        const int idx = tid + k * NT_;
+        if (idx < n_s3) {
+            const int l = idx / s3c4, c = idx - l * s3c4;
+            sm4[a.s3_off4 + (l + 2) * a.s3_rs4 + a.s3_col4 + c] = sv[k];
+        }
     }
 #pragma unroll
     for (int k = 0; k < PK; ++k) {
@@ -588,5 +611,6 @@ __global__ __launch_bounds__(kFusedThreads) void fused_program_kernel(const Fuse
 using FusedSeqDown = FusedSeq<0, 1, 2, 2, 3, 4, 5, 6, 6, 7>;                       // downs.0 + downs.1
 using FusedSeqUpA = FusedSeq<8, 9, 10, 10, 11>;                                    // the up level at L = 16 (cat 256 -> 64)
 using FusedSeqUpB = FusedSeq<12, 13, 14, 14, 15, 2, kFusedShapeFinal>;             // the up level at L = 32 + final_conv + DDPM step
+using FusedSeqUpAB = FusedSeq<8, 9, 10, 10, 11, 12, 13, 14, 14, 15, 2, kFusedShapeFinal>;   // both up levels in one launch
 
 }  // namespace mpdx

@@ -333,6 +333,7 @@ struct mpdx_unet {
         int first = 0, count = 0;       // layer range [first, first+count)
         bool has_final = false;         // final_conv[1] + DDPM step folded in
         int in1 = 0, in2 = 0;           // input slots (SRC_X / SRC_NONE allowed)
+        int in3 = mpdx::SRC_NONE;       // slot of a skip tensor concatenated INSIDE the program (FusedArgs::gsrc3)
         int gout_slot[3] = {-1, -1, -1};
         size_t lds_bytes = 0;
         mpdx::FusedArgs tmpl;
@@ -562,11 +563,24 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
     a.in_clear = (l0.cin_pad != l0.c1 + l0.c2) ? 1 : 0;  // channel padding of the staged input
     touch(in_buf, -1, true);
     bufmap[(long)(l0.src1 + 8) * 4096 + l0.L_in] = in_buf;
+    int cat_buf = -1;    // buffer whose tail columns hold a skip tensor staged by the prologue (concat inside the program)
     auto src_buf = [&](const Layer& l, int i) -> int {   // LDS buffer a layer reads (-1: not available inside the segment)
         if (i == i0 || (l.src1 == l0.src1 && l.src2 == l0.src2 && l.L_in == l0.L_in)) return in_buf;
-        if (l.src2 != SRC_NONE) return -1;
         const long key = (long)(l.src1 + 8) * 4096 + l.L_in;
-        return bufmap.count(key) ? bufmap[key] : -1;
+        if (!bufmap.count(key)) return -1;
+        if (l.src2 != SRC_NONE) {   // cat(x produced in LDS, skip from global): the producer's buffer was made wide enough (below)
+            if (bufmap[key] != cat_buf || f.in3 != l.src2) return -1;
+        }
+        return bufmap[key];
+    };
+    // a layer of the segment (not the first) that concatenates a global skip tensor behind a tensor produced inside
+    auto cat_consumer = [&](int from, int slot, int L) -> const Layer* {
+        for (int k = from; k < i1; ++k) {
+            const Layer& n = u->layers[k];
+            if (n.src1 == slot && n.L_in == L && n.src2 != SRC_NONE && !(n.src1 == l0.src1 && n.src2 == l0.src2)) return &n;
+            if (n.dst == slot) break;   // overwritten: later readers see another tensor
+        }
+        return nullptr;
     };
     struct HostOp { int src = -1, rsrc = -1, res = -1, dst = -1; const Layer* l = nullptr; const Layer* r = nullptr; int nblk = 0, ncr = 0, tot = 0, nstream = 0; };
     std::vector<HostOp> hops;
@@ -623,7 +637,20 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
             if (n.dst == l.dst) break;
         }
         if (i == i1 - 1 && !with_final) read_outside = true;
-        ho.dst = read_inside ? buf_for(l.dst, l.L_out, l.cout) : -1;
+        if (read_inside) {
+            const Layer* cc = cat_consumer(i + 1, l.dst, l.L_out);
+            if (cc) {   // this op's output is the head of a concat: make the buffer wide enough for the skip tensor behind it
+                if (cat_buf >= 0 || cc->c1 != l.cout || (cc->c2 & 3) || (l.cout & 3) || (size_t)cc->L_in * (cc->c2 / 4) > 1024) {
+                    if (getenv("MPDX_DEBUG_FUSE")) fprintf(stderr, "[mpdx] cat: layer %s -> %s cat_buf %d c1 %d c2 %d cout %d L %d\n", l.name.c_str(), cc->name.c_str(), cat_buf, cc->c1, cc->c2, l.cout, cc->L_in);
+                    return fuse_reject(__LINE__);
+                }
+                ho.dst = buf_for(l.dst, l.L_out, cc->c1 + cc->c2);
+                cat_buf = ho.dst;
+                f.in3 = cc->src2;
+                a.c3 = cc->c2; a.L3 = cc->L_in; a.s3_col4 = cc->c1 / 4;
+                touch(cat_buf, -1, true);   // its skip columns are written by the prologue: live from the start
+            } else ho.dst = buf_for(l.dst, l.L_out, l.cout);
+        } else ho.dst = -1;
         if (ho.dst >= 0 && (ho.dst == ho.src || ho.dst == ho.res || ho.dst == ho.rsrc)) return fuse_reject(__LINE__);
         op.gdst = -1;
         if (read_outside) {
@@ -674,6 +701,7 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         }
     }
     a.in_off4 = bufs[in_buf].off4; a.in_rs4 = bufs[in_buf].rs4; a.in_rows = bufs[in_buf].rows;
+    if (cat_buf >= 0) { a.s3_off4 = bufs[cat_buf].off4; a.s3_rs4 = bufs[cat_buf].rs4; }
     // weight streams + parameter block of the segment: a dedicated area at the end of `packed`
     size_t area = u->packed_floats;
     int poff = 0, tt_lo = 1 << 30, tt_hi = 0;
@@ -748,6 +776,7 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
             if (matches(FusedSeqDown::ids, FusedSeqDown::N)) f.program = 0;
             else if (matches(FusedSeqUpA::ids, FusedSeqUpA::N)) f.program = 1;
             else if (matches(FusedSeqUpB::ids, FusedSeqUpB::N)) f.program = 2;
+            else if (matches(FusedSeqUpAB::ids, FusedSeqUpAB::N)) f.program = 3;
         }
     }
     u->fused.push_back(f);
@@ -792,8 +821,20 @@ static void build_units(mpdx_unet* u) {
         try_seg("downs.0.", false);
         if (nl >= 3) try_seg("downs.1.", false);
     }
-    if (nl >= 3) try_seg("ups." + std::to_string(nl - 3) + ".", false);
-    try_seg("ups." + std::to_string(nl - 2) + ".", true);
+    // the two outer up levels + final_conv + DDPM step as ONE program (the second level's skip tensor is staged by the prologue)
+    bool merged_up = false;
+    if (nl >= 3 && !getenv("MPDX_NO_MERGE_UP")) {
+        int a0, a1, b0, b1;
+        if (range_of("ups." + std::to_string(nl - 3) + ".", a0, a1) && range_of("ups." + std::to_string(nl - 2) + ".", b0, b1) && a1 == b0 &&
+            b1 == n - 1 && u->layers[n - 1].name.compare(0, 12, "final_conv.0") == 0 && build_fused_segment(u, a0, n, true)) {
+            for (int i = a0; i < n; ++i) owner[i] = (int)u->fused.size() - 1;
+            merged_up = true;
+        }
+    }
+    if (!merged_up) {
+        if (nl >= 3) try_seg("ups." + std::to_string(nl - 3) + ".", false);
+        try_seg("ups." + std::to_string(nl - 2) + ".", true);
+    }
     u->owner = owner;
 }
 
@@ -1063,6 +1104,7 @@ static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packe
     FusedArgs a = f.tmpl;
     a.packed = packed; a.tt_row = tt_row;
     a.gsrc1 = src(f.in1); a.gsrc2 = src(f.in2);
+    a.gsrc3 = f.in3 != SRC_NONE ? src(f.in3) : a.gsrc1;
     for (int k = 0; k < 3; ++k) a.gout[k] = f.gout_slot[k] >= 0 ? ws + slot * f.gout_slot[k] : nullptr;
     a.B = B;
     a.trace = (g_fused_trace && (g_fused_trace_seg < 0 || g_fused_trace_seg == (int)(&f - &u->fused[0]))) ? g_fused_trace : nullptr;
@@ -1084,6 +1126,10 @@ static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packe
         case 2:
             if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqUpB>)) return rc;
             hipLaunchKernelGGL(fused_program_kernel<FusedSeqUpB>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
+            break;
+        case 3:
+            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqUpAB>)) return rc;
+            hipLaunchKernelGGL(fused_program_kernel<FusedSeqUpAB>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
             break;
         default:
             if (int rc = raise_lds_limit((const void*)fused_level_kernel)) return rc;
