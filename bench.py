@@ -304,6 +304,75 @@ def planner_baseline_leg(n=100, opt_iters=500):
     return out
 
 
+def training_leg(steps=40, B=32, T=25, D=4, opt=1):
+    """training iterations per second at the reference's training configuration (train.py: batch 32, T = 25, dim_mults
+    option 1, Adam 1e-4, clip_grad_norm 1.0, EMA every 10 steps) - the native step (HIP forward + backward + Adam + EMA) next to
+    the same iteration written with torch autograd over the functional U-Net (ATen / MIOpen kernels) on the same GPU, which is
+    how the reference trains."""
+    import copy
+    import torch
+    import mpd_public_amd as m
+    from mpd_public_amd import synthetic as syn
+    from mpd_public_amd.trainer import TrainStep, EMA
+    from oracle import unet as ounet   # baseline leg only
+    from oracle import train as otrain, diffusion as odiff, schedules as osched
+    net = m.TemporalUnet(n_support_points=64, state_dim=D, unet_input_dim=32, dim_mults=m.UNET_DIM_MULTS[opt])
+    sd = syn.synth_state_dict(ounet.unet_param_shapes(D, 32, m.UNET_DIM_MULTS[opt]))
+    net.load_state_dict(sd, strict=True)
+    dm = m.GaussianDiffusionModel(model=net, n_diffusion_steps=T, predict_epsilon=True).cuda()
+    ema_model = copy.deepcopy(dm)
+    x0 = torch.from_numpy(syn.synth_tensor("train_x0", (B, 64, D), "uniform", 0.8)).cuda()
+    hc = {0: x0[:, 0, :].contiguous(), 63: x0[:, -1, :].contiguous()}
+    ts, ema = TrainStep(dm), EMA(0.995)
+
+    def native(k):
+        ts.loss_backward(x0, hc)
+        ts.adam_step(1e-4, max_norm=1.0)
+        if k % 10 == 0:
+            ema.update_model_average(ema_model, dm)
+    for k in range(5):
+        native(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        native(k)
+    torch.cuda.synchronize()
+    dt_native = (time.perf_counter() - t0) / steps
+    # the reference's way: autograd over ATen kernels + torch.optim.Adam, same GPU
+    params = {k: v.clone().cuda().requires_grad_(True) for k, v in sd.items()}
+    opt_t = torch.optim.Adam(list(params.values()), lr=1e-4)
+    buf = {k: v.cuda() for k, v in osched.make_buffers(T, "exponential").items()}
+    ema_t = {k: v.detach().clone() for k, v in params.items()}
+
+    def eager(k):
+        t = torch.randint(0, T, (B,), device="cuda")
+        noise = torch.randn_like(x0)
+        x_noisy = odiff.apply_hard_conditioning(odiff.q_sample(buf, x0, t, noise), hc)
+        x_recon = odiff.apply_hard_conditioning(ounet.unet_forward(params, x_noisy, t), hc)
+        loss = torch.nn.functional.mse_loss(x_recon, noise)
+        opt_t.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+        opt_t.step()
+        if k % 10 == 0:
+            with torch.no_grad():
+                for kk in ema_t:
+                    ema_t[kk].mul_(0.995).add_(params[kk].detach(), alpha=0.005)
+    for k in range(5):
+        eager(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        eager(k)
+    torch.cuda.synchronize()
+    dt_eager = (time.perf_counter() - t0) / steps
+    return {"workload": f"p_losses + backward + clip_grad_norm_ + Adam + EMA/10, batch {B} x H=64 x D={D}, T={T}, dim_mults option {opt}, fp32",
+            "train_steps_per_s": round(1.0 / dt_native, 1), "ms_per_train_step": round(dt_native * 1e3, 3),
+            "torch_autograd_same_gpu": {"train_steps_per_s": round(1.0 / dt_eager, 1), "ms_per_train_step": round(dt_eager * 1e3, 3),
+                                        "what": "the same iteration as torch autograd over ATen/MIOpen kernels + torch.optim.Adam (how the reference trains)"},
+            "speedup": round(dt_eager / dt_native, 2)}
+
+
 def _respawn(args):
     """`python bench.py --gpus N` without a torch.distributed.run environment: start the N ranks ourselves."""
     with socket.socket() as s:
@@ -436,6 +505,10 @@ def main():
                 out["planner_baseline"] = planner_baseline_leg()
             except Exception as e:
                 out["planner_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                out["training"] = training_leg()
+            except Exception as e:
+                out["training"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_leg(sd, D, T, B, n0)
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)

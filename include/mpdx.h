@@ -116,6 +116,36 @@ int mpdx_q_sample(const float* x_start, const float* noise, const long long* t_d
 int mpdx_weighted_loss(const float* pred, const float* targ, const float* weights_hd, const float* hard_start, const float* hard_goal,
                        int l1, float* out1, int B, int H, int D, void* stream);
 
+/* ---- training step: replaces  loss = model.loss(x, context, hard_conds); loss.backward();
+ * clip_grad_norm_; optimizer.step(); EMA.update_model_average   of mpd/trainer/trainer.py:186-283 with
+ * GaussianDiffusionModel.p_losses (diffusion_model_base.py:331-352) and WeightedL1/L2 (helpers.py:71-99).
+ * Parameters, gradients, Adam moments and the EMA copy are FLAT fp32 vectors in reference (state-dict) layout: parameter idx
+ * (mpdx_unet_param_info order) lives at [off, off + n) with (off, n) from mpdx_train_param_offset, gaps are zero.  A host
+ * framework can alias its parameter tensors onto the vector (mpd_public_amd/trainer.py does, so torch optimisers keep working). */
+size_t mpdx_train_flat_floats(mpdx_unet* u);
+size_t mpdx_train_dgrad_pack_floats(mpdx_unet* u);              /* transposed / tap-flipped packs for the input-gradient convolutions */
+size_t mpdx_train_workspace_floats(mpdx_unet* u, int B);     /* every activation of a batch of B + gradient buffers */
+int    mpdx_train_param_offset(mpdx_unet* u, int idx, size_t* off, size_t* n);
+/* flat parameters -> forward pack (what mpdx_unet_pack_param builds, all parameters, one launch) and, if packedT != NULL,
+ * the dgrad pack.  Call after every optimiser step. */
+int    mpdx_train_pack(mpdx_unet* u, const float* flat, float* packed, float* packedT, void* stream);
+/* one p_losses evaluation and its gradient wrt every parameter:
+ *   x_start, noise [B,H,D]; t_dev [B] int64 timesteps; sqrt_alphas_cumprod / sqrt_one_minus_alphas_cumprod [T] device tables;
+ *   freqs16 the SinusoidalPosEmb frequencies (as mpdx_unet_build_timetab); hard_start / hard_goal [B,D] or NULL;
+ *   weights_hd [H,D] loss weights or NULL; l1: 1 = WeightedL1, 0 = WeightedL2; loss_scale multiplies the gradient;
+ *   loss_out: one device float <- the loss; grads_flat <- d(loss_scale * loss)/d(parameters), every parameter entry written. */
+int    mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packed, const float* packedT, float* grads_flat,
+                                const float* x_start, const float* noise, const long long* t_dev, const float* sqrt_alphas_cumprod_dev,
+                                const float* sqrt_one_minus_alphas_cumprod_dev, const float* freqs16, const float* hard_start,
+                                const float* hard_goal, const float* weights_hd, int T, int B, int predict_epsilon, int l1, float loss_scale,
+                                float* loss_out, float* ws, void* stream);
+/* torch.nn.utils.clip_grad_norm_(max_norm) if max_norm > 0, then torch.optim.Adam.step() (no weight decay, no amsgrad);
+ * step counts from 1; scratch: >= 1032 floats (scratch[0] <- the gradient norm before clipping, scratch[1] <- the clip factor) */
+int    mpdx_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
+                      float eps, int step, float max_norm, float* scratch, void* stream);
+/* EMA.update_model_average (trainer.py:67-85): ema = beta * ema + (1 - beta) * params */
+int    mpdx_ema_update(float* ema, const float* params, size_t n, float beta, void* stream);
+
 /* standard-normal generator for the production path (Philox4x32-10 + Box-Muller); replaces torch.randn /
  * torch.randn_like (diffusion_model_base.py:165, sample_functions.py:51).  Parity runs inject noise instead. */
 int mpdx_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);

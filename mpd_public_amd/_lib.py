@@ -85,6 +85,14 @@ SIGNATURES = {
     "mpdx_bench_layer": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, C.POINTER(C.c_float)]),
     "mpdx_unet_layer_tile": (_i, [_vp, _i, _i, C.c_char_p, _sz]),
     "mpdx_randn": (_i, [_vp, _sz, C.c_uint64, C.c_uint64, _vp]),
+    "mpdx_train_flat_floats": (_sz, [_vp]),
+    "mpdx_train_dgrad_pack_floats": (_sz, [_vp]),
+    "mpdx_train_workspace_floats": (_sz, [_vp, _i]),
+    "mpdx_train_param_offset": (_i, [_vp, _i, C.POINTER(_sz), C.POINTER(_sz)]),
+    "mpdx_train_pack": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "mpdx_train_loss_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "mpdx_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _f, _vp, _vp]),
+    "mpdx_ema_update": (_i, [_vp, _vp, _sz, _f, _vp]),
 }
 
 

@@ -56,6 +56,10 @@ struct ConvArgs {
     int dbg;             // ablation mask for mpdx_bench_layer: 1 skip staging, 2 skip MFMA loop, 4 skip epilogue; only in builds with
                          // -DMPDX_LOOP_ABLATION: 8 no weight-ring refills in the loop, 32 no B-fragment LDS reads
     long long* trace;    // dev tool: s_memtime stamps of workgroups 0 and last / wave 0 (null in production)
+    // training (train.hpp): per-trajectory time-bias rows (tbias + b * tb_stride; 0 on the planning path: one row for the batch)
+    // and an optional second destination for the GroupNorm INPUT (conv + bias), which the backward pass differentiates through
+    int tb_stride;
+    float* pre;          // [B][L_out][C_out] or null
 };
 
 // wave64 all-reduce (sum) with DPP row operations + 4 readlanes instead of a 6-step ds_bpermute butterfly:
@@ -420,13 +424,14 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                 const f32x4 bi = *(const f32x4*)(a.bias + co);
                 const f32x4 ga = *(const f32x4*)(a.gamma + co), be = *(const f32x4*)(a.beta + co);
                 f32x4 tb = {0.f, 0.f, 0.f, 0.f}, rs4 = {0.f, 0.f, 0.f, 0.f};
-                if (a.tbias) tb = *(const f32x4*)(a.tbias + co);
+                if (a.tbias) tb = *(const f32x4*)(a.tbias + (size_t)(b < a.B ? b : 0) * a.tb_stride + co);
                 if (a.res) rs4 = *(const f32x4*)(a.res + o);
                 const int ri = n * MTP4 + (c >> 2);  // gs % 4 == 0 -> c % 4 == 0
                 f32x4 v = smem4[ri];
 #pragma unroll
                 for (int k = 1; k < WK; ++k) v += smem4[ri + k * NT * MTP4];
                 v += bi;
+                if (a.pre && b < a.B) *(f32x4*)(a.pre + o) = v;
                 const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * inv_re;
                 const f32x4 d = v - mean;
                 const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * inv_re;
@@ -445,12 +450,13 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                 const f32x2 bi = *(const f32x2*)(a.bias + co);
                 const f32x2 ga = *(const f32x2*)(a.gamma + co), be = *(const f32x2*)(a.beta + co);
                 f32x2 tb = {0.f, 0.f}, rs2 = {0.f, 0.f};
-                if (a.tbias) tb = *(const f32x2*)(a.tbias + co);
+                if (a.tbias) tb = *(const f32x2*)(a.tbias + (size_t)(b < a.B ? b : 0) * a.tb_stride + co);
                 if (a.res) rs2 = *(const f32x2*)(a.res + o);
                 f32x2 v = *(const f32x2*)(red + (size_t)n * MTP + c);
 #pragma unroll
                 for (int k = 1; k < WK; ++k) v += *(const f32x2*)(red + ((size_t)(k * NT + n)) * MTP + c);
                 v += bi;
+                if (a.pre && b < a.B) *(f32x2*)(a.pre + o) = v;
                 const float mean = wave_sum(v[0] + v[1]) * inv_re;
                 const f32x2 d = v - mean;
                 const float var = wave_sum(d[0] * d[0] + d[1] * d[1]) * inv_re;

@@ -120,6 +120,7 @@ struct FusedArgs {
     // tensor (torch.cat((x, h.pop()), dim=1) of the second up level, temporal_unet.py:159): written by the prologue into columns
     // [col3, col3 + c3/4) of that op's (wider) source buffer, whose first columns the producing Upsample1d fills later
     const float* gsrc3;
+    int fpar_off;                             // final_conv[1] weights [D][Cf + 4] + bias [D] inside the staged parameter block (floats)
     int c3, L3, s3_off4, s3_rs4, s3_col4;     // c3 == 0: none
     int B, nops;
     int stat_off;        // GroupNorm exchange area (floats): [tile 0..7][row 0..3][mean, M2]
@@ -453,28 +454,60 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, 
 }
 
 // ---- final_conv[1] (1x1, Cf -> D) + DDPM posterior step + hard conditioning of a fused program (see final_step_kernel)
-__device__ __forceinline__ void fused_final_op(const FusedArgs& a, const FusedOp& op, float* smem, int tid, int lane, int b) {
+// Inputs of the DDPM step that do not depend on the network: requested one conv op EARLY (before the k-loop of the last
+// Conv1dBlock), so their first-touch latency (~1.4 us from a cold L2) is hidden instead of heading the final op.
+constexpr int kFinalPre = 4;   // elements per thread: H * D <= 1024
+struct FinalPre { float xv[kFinalPre], nz[kFinalPre], hc[kFinalPre]; };
+
+__device__ __forceinline__ void fused_final_prefetch(const FusedArgs& a, FinalPre& fp, int tid, int b) {
+    if (a.fmode == 0) return;
+    const int H = a.H, n = H * a.D;
+#pragma unroll
+    for (int k = 0; k < kFinalPre; ++k) {
+        const int idx = tid + k * kFusedThreads;
+        if (k * kFusedThreads >= n) continue;   // wave-uniform; the registers stay unset and unused
+        const int ic = idx < n ? idx : 0;
+        const int p = ic / a.D, d = ic - p * a.D;
+        const size_t o = (size_t)b * n + ic;
+        fp.xv[k] = a.x_in[o];
+        if (a.fmode == 1 && !a.rng.on && a.noise) fp.nz[k] = a.noise[o];
+        if (a.hs && p == 0) fp.hc[k] = a.hs[(size_t)b * a.D + d];
+        if (a.hg && p == H - 1) fp.hc[k] = a.hg[(size_t)b * a.D + d];
+    }
+}
+
+// CF: the channel count of final_conv[0] when the program fixes it (static programs: the dot product unrolls, its 2 * CF / 4 LDS
+// reads are issued together), 0 = read it from the argument block.
+template <int CF = 0>
+__device__ __forceinline__ void fused_final_op(const FusedArgs& a, const FusedOp& op, const FinalPre& fp, float* smem, int tid, int lane, int b) {
     f32x4* const sm4 = (f32x4*)smem;
     constexpr int NT_ = kFusedThreads;
     // ---- final_conv[1] (1x1, Cf -> D) + DDPM posterior step + hard conditioning (see final_step_kernel)
     float vmax = 0.f;
-    const int H = a.H;
-    for (int idx = tid; idx < H * a.D; idx += NT_) {
+    const int H = a.H, n = H * a.D;
+    const int Cf = CF ? CF : a.Cf;
+    const int wrs = Cf + 4;   // LDS row stride of the staged weights: rows d and d + 1 start 4 banks apart
+    const float* const fw = smem + a.par_off + a.fpar_off;
+#pragma unroll
+    for (int k = 0; k < kFinalPre; ++k) {
+        const int idx = tid + k * NT_;
+        if (idx >= n) continue;
         const int p = idx / a.D, d = idx - p * a.D;
-        float s = a.packed[a.fb_off + d];
-        const float* wrow = a.packed + a.fw_off + d * a.Cf;
-        for (int c = 0; c < a.Cf; c += 4) {
+        float s = fw[a.D * wrs + d];
+        const float* wrow = fw + d * wrs;
+#pragma unroll
+        for (int c = 0; c < Cf; c += 4) {
             const f32x4 hv = sm4[op.src_off4 + (p + 2) * op.src_rs4 + (c >> 2)];
             const f32x4 wv = *(const f32x4*)(wrow + c);
             s = fmaf(hv[0], wv[0], s); s = fmaf(hv[1], wv[1], s);
             s = fmaf(hv[2], wv[2], s); s = fmaf(hv[3], wv[3], s);
         }
-        const size_t o = ((size_t)b * H + p) * a.D + d;
+        const size_t o = (size_t)b * n + idx;
         float r;
         if (a.fmode == 0) {
             r = s;
         } else {
-            const float xv = a.x_in[o];
+            const float xv = fp.xv[k];
             float x0 = a.k.predict_epsilon
                            ? __fsub_rn(__fmul_rn(a.k.sqrt_recip_alphas_cumprod, xv), __fmul_rn(a.k.sqrt_recipm1_alphas_cumprod, s))
                            : s;
@@ -483,16 +516,16 @@ __device__ __forceinline__ void fused_final_op(const FusedArgs& a, const FusedOp
                                      ? s
                                      : __fdiv_rn(__fsub_rn(__fmul_rn(a.k.sqrt_recip_alphas_cumprod, xv), s), a.k.sqrt_recipm1_alphas_cumprod);
                 r = __fadd_rn(__fmul_rn(x0, a.k.ddim_k1), __fmul_rn(a.k.ddim_k2, pn));
-                if (a.hs && p == 0) r = a.hs[(size_t)b * a.D + d];
-                if (a.hg && p == H - 1) r = a.hg[(size_t)b * a.D + d];
+                if (a.hs && p == 0) r = fp.hc[k];
+                if (a.hg && p == H - 1) r = fp.hc[k];
             } else {
                 if (a.k.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
                 r = __fadd_rn(__fmul_rn(a.k.posterior_mean_coef1, x0), __fmul_rn(a.k.posterior_mean_coef2, xv));
                 if (a.fmode == 1) {
                     if (a.rng.on) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, philox_normal_at(a.rng.seed, a.rng.offset, a.rng.elem0 + o)), a.k.noise_std_extra));
-                    else if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, a.noise[o]), a.k.noise_std_extra));
-                    if (a.hs && p == 0) r = a.hs[(size_t)b * a.D + d];
-                    if (a.hg && p == H - 1) r = a.hg[(size_t)b * a.D + d];
+                    else if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.k.noise_scale, fp.nz[k]), a.k.noise_std_extra));
+                    if (a.hs && p == 0) r = fp.hc[k];
+                    if (a.hg && p == H - 1) r = fp.hc[k];
                 }
             }
         }
@@ -521,11 +554,13 @@ __global__ __launch_bounds__(kFusedThreads) void fused_level_kernel(const FusedA
     if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter();
     ++tr;
     f32x4 ring[kFusedRing];
+    FinalPre fp;
     fused_prologue(a, smem, ring, tid, lane, wave, b, tr_base, tr);
     for (int oi = 0; oi < a.nops; ++oi) {
         const FusedOp op = a.ops[oi];
+        if (oi + 1 < a.nops && a.ops[oi + 1].shape == kFusedShapeFinal) fused_final_prefetch(a, fp, tid, b);
         if (op.shape == kFusedShapeFinal) {
-            fused_final_op(a, op, smem, tid, lane, b);
+            fused_final_op(a, op, fp, smem, tid, lane, b);
             if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter();
             ++tr;
             continue;
@@ -556,11 +591,12 @@ template <int ID> struct FusedShapeOf;
 MPDX_FUSED_SHAPES(X)
 #undef X
 
-template <int SH, int I, int NEXT_SH>
-__device__ __forceinline__ void fused_static_op(const FusedArgs& a, f32x4 (&ring)[kFusedRing], float* smem, int tid, int wave, int lane, int b,
-                                                long long* tr_base, int& tr) {
+template <int SH, int I, int NEXT_SH, int PREV_COUT>
+__device__ __forceinline__ void fused_static_op(const FusedArgs& a, f32x4 (&ring)[kFusedRing], FinalPre& fp, float* smem, int tid, int wave, int lane,
+                                                int b, long long* tr_base, int& tr) {
+    if constexpr (NEXT_SH == kFusedShapeFinal) fused_final_prefetch(a, fp, tid, b);
     if constexpr (SH == kFusedShapeFinal) {
-        fused_final_op(a, a.ops[I], smem, tid, lane, b);
+        fused_final_op<PREV_COUT>(a, a.ops[I], fp, smem, tid, lane, b);
         if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter();
         ++tr;
     } else {
@@ -580,11 +616,16 @@ struct FusedSeq {
     static constexpr int N = sizeof...(SH);
     static constexpr int ids[sizeof...(SH)] = {SH...};
     template <int I>
-    __device__ static __forceinline__ void run_from(const FusedArgs& a, f32x4 (&ring)[kFusedRing], float* smem, int tid, int wave, int lane, int b,
-                                                    long long* tr_base, int& tr) {
+    static constexpr int prev_cout() {   // C_out of the op before op I (what the final op reads); 0 if there is none
+        if constexpr (I > 0 && ids[I > 0 ? I - 1 : 0] != kFusedShapeFinal) return FusedShapeOf<ids[I > 0 ? I - 1 : 0]>::type::COUT;
+        else return 0;
+    }
+    template <int I>
+    __device__ static __forceinline__ void run_from(const FusedArgs& a, f32x4 (&ring)[kFusedRing], FinalPre& fp, float* smem, int tid, int wave, int lane,
+                                                    int b, long long* tr_base, int& tr) {
         if constexpr (I < N) {
-            fused_static_op<ids[I], I, (I + 1 < N ? ids[I + 1 < N ? I + 1 : I] : -1)>(a, ring, smem, tid, wave, lane, b, tr_base, tr);
-            run_from<I + 1>(a, ring, smem, tid, wave, lane, b, tr_base, tr);
+            fused_static_op<ids[I], I, (I + 1 < N ? ids[I + 1 < N ? I + 1 : I] : -1), prev_cout<I>()>(a, ring, fp, smem, tid, wave, lane, b, tr_base, tr);
+            run_from<I + 1>(a, ring, fp, smem, tid, wave, lane, b, tr_base, tr);
         }
     }
 };
@@ -603,8 +644,9 @@ __global__ __launch_bounds__(kFusedThreads) void fused_program_kernel(const Fuse
     if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter();
     ++tr;
     f32x4 ring[kFusedRing];
+    FinalPre fp;
     fused_prologue(a, smem, ring, tid, lane, wave, b, tr_base, tr);
-    SEQ::template run_from<0>(a, ring, smem, tid, wave, lane, b, tr_base, tr);
+    SEQ::template run_from<0>(a, ring, fp, smem, tid, wave, lane, b, tr_base, tr);
 }
 
 // the programs of the standard networks

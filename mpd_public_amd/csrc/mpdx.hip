@@ -18,6 +18,7 @@
 #include "../../include/mpdx.h"
 #include "conv_block.hpp"
 #include "fused_level.hpp"
+#include "train.hpp"
 #include "guide.hpp"
 
 namespace mpdx {
@@ -295,6 +296,7 @@ struct Param {
     int32_t ndim = 0;
     size_t n = 0;       // floats in the reference tensor
     size_t off = 0;     // offset (floats) in the packed buffer
+    size_t foff = 0;    // offset (floats) in the flat reference-layout parameter vector (training, train_host.hpp)
     size_t pn = 0;      // floats in the packed buffer
     int kind = PK_VEC;
     int cout = 0, cin = 0, ksz = 0, cin_pad = 0, nslot = 0;
@@ -345,6 +347,18 @@ struct mpdx_unet {
     int pack_version = 0, streams_version = -1;
     struct Unit { int fused; int layer; bool pair; };   // fused >= 0: fused[fused]; else layers[layer] (pair: + layers[layer+1] in one launch)
     std::vector<int> owner;                  // layer -> fused segment (-1: per-layer launch)
+    // training (train_host.hpp)
+    struct TrainLayer {
+        int src1_l = -2, src2_l = -2, res_l = -2;   // layer that produced the tensor (-1: the network input, -2: none)
+        bool need_dgrad = false;
+        size_t dgrad_woff = 0;                      // offset of the dgrad weights in packedT
+        mpdx::Layer dg;                             // the stride-1 convolution that computes the input gradient
+    };
+    bool train_ready = false;
+    size_t flat_floats = 0, packedT_floats = 0;
+    std::vector<TrainLayer> tl;
+    std::vector<mpdx::PackDesc> pack_descs_host;
+    void* pack_descs_dev = nullptr;
 };
 
 namespace mpdx {
@@ -731,6 +745,11 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
     }
     if (with_final) { a.ops[a.nops - 1].src_off4 = bufs[final_src].off4; a.ops[a.nops - 1].src_rs4 = bufs[final_src].rs4; }
     area += (size_t)kFusedRing * 256;   // the ring request of the last stream may read up to 16 blocks past its end
+    if (with_final) {   // final_conv[1]: rows padded to Cf + 4 floats (bank spread), the bias behind them
+        if (a.H * a.D > kFinalPre * kFusedThreads || (a.Cf & 3)) return fuse_reject(__LINE__);
+        a.fpar_off = poff;
+        poff += (a.D * (a.Cf + 4) + a.D + 3) / 4 * 4;
+    }
     a.gpar_off = (int)area; a.par_floats = poff;
     for (size_t k = 0; k < hops.size(); ++k) {
         const HostOp& ho = hops[k];
@@ -740,6 +759,10 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         if (l.gamma >= 0) f.jobs.push_back({u->params[l.gamma].off, pb + l.cout, 1, 0, 0, 1, 0, 0, l.cout});
         if (l.beta >= 0) f.jobs.push_back({u->params[l.beta].off, pb + 2 * (size_t)l.cout, 1, 0, 0, 1, 0, 0, l.cout});
         if (ho.r) f.jobs.push_back({u->params[ho.r->b].off, pb + 3 * (size_t)l.cout, 1, 0, 0, 1, 0, 0, l.cout});
+    }
+    if (with_final) {
+        f.jobs.push_back({(size_t)a.fw_off, area + a.fpar_off, a.D, a.Cf, a.Cf + 4, 1, 0, 0, a.Cf});
+        f.jobs.push_back({(size_t)a.fb_off, area + a.fpar_off + (size_t)a.D * (a.Cf + 4), 1, 0, 0, 1, 0, 0, a.D});
     }
     area += poff;
     if (tt_hi > 0) {
@@ -1245,7 +1268,10 @@ int mpdx_unet_create(const mpdx_unet_cfg* cfg, mpdx_unet** out) {
     return 0;
 }
 
-void mpdx_unet_destroy(mpdx_unet* u) { delete u; }
+void mpdx_unet_destroy(mpdx_unet* u) {
+    if (u && u->pack_descs_dev) (void)hipFree(u->pack_descs_dev);
+    delete u;
+}
 
 int mpdx_unet_num_params(const mpdx_unet* u) { return u ? (int)u->params.size() : 0; }
 
@@ -1720,3 +1746,5 @@ int mpdx_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* strea
 }
 
 }  // extern "C"
+
+#include "train_host.hpp"

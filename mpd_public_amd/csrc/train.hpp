@@ -1,0 +1,524 @@
+// train.hpp - device code of the TRAINING step: the backward pass of the TemporalUnet, the loss
+// gradient, Adam and the EMA of the reference's trainer.
+//
+//   reference:  GaussianDiffusionModel.p_losses   mpd/models/diffusion_models/diffusion_model_base.py:331-352
+//               WeightedL1 / WeightedL2           mpd/models/diffusion_models/helpers.py:71-99
+//               train() / EMA                     mpd/trainer/trainer.py:67-85, 174-300  (torch.optim.Adam, clip_grad_norm_, EMA)
+//               the modules differentiated        mpd/models/layers/layers.py:229-355, temporal_unet.py:118-171
+//
+// The reference gets its gradients from torch autograd over ATen/MIOpen kernels.  Here the backward pass is written out:
+//
+//   * Conv1d input gradients ("dgrad") are convolutions again, so they run on the forward MFMA kernels (conv_block.hpp) with
+//     the weights packed transposed and tap-flipped (pack_train_kernel):
+//        Conv1d(k, stride 1, pad k/2)          dX = conv_S1(dU;  Wt[ci][co][k'] = W[co][ci][k-1-k'])
+//        Conv1d(3, stride 2, pad 1)            dX = conv_S1_k3(zero-stuffed dU; same transposition)       (Downsample1d)
+//        ConvTranspose1d(4, stride 2, pad 1)   dX[m] = f[2m],  f = conv_S1_k5(dY; Wt[ci][co][k'] = k' ? W[ci][co][k'-1] : 0)   (Upsample1d)
+//   * weight gradients ("wgrad") are GEMMs with the reduction over batch x horizon: wgrad_kernel (fp32 MFMA 16x16x4, operands
+//     staged per trajectory in LDS, all taps of a 16x16 weight tile accumulated from one staged window), split over the batch into
+//     partial sums that a second kernel adds in a fixed order (deterministic, no float atomics);
+//   * GroupNorm + Mish backward, with the per-channel sums (d gamma, d beta, d bias) and the time-embedding gradient of the block
+//     taken from the same registers: gn_mish_bwd_kernel, one wave per GroupNorm region exactly like the forward epilogue;
+//   * the time MLP (SinusoidalPosEmb -> Linear -> Mish -> Linear; per block Mish -> Linear) forward with saved activations and
+//     backward: time_train_fwd_kernel / time_bwd_* (tiny GEMMs: plain FMA);
+//   * Adam (torch.optim.Adam defaults, optional global-norm clipping as torch.nn.utils.clip_grad_norm_) and the EMA in one pass
+//     over the flat parameter vector.
+//
+// Layouts: activations channel-last [B][L][C] (as everywhere); parameters and gradients in ONE flat fp32 vector in reference
+// (state-dict) layout, so torch Parameters can alias it.
+#pragma once
+#include "conv_block.hpp"
+
+namespace mpdx {
+
+// d/dv [ v * tanh(softplus(v)) ]
+__device__ __forceinline__ float mish_grad(float v) {
+    const float e = __expf(fminf(v, 20.0f));
+    const float n = (1.0f + e) * (1.0f + e);
+    const float th = (n - 1.0f) / (n + 1.0f);          // tanh(softplus(v))
+    const float sg = e / (1.0f + e);                   // sigmoid(v)
+    return th + v * (1.0f - th * th) * sg;
+}
+__device__ __forceinline__ float mish_ref(float v) {   // same formula as the forward kernels' mish()
+    return mish(v);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// GroupNorm(8 groups) + Mish backward for one Conv1dBlock (layers.py:276-293):   y = mish(GN(u)),  u = conv(x) + bias
+//   in : gy [B][L][C] (gradient wrt the block output; the +time-bias / +residual of the ResidualTemporalBlock pass it through
+//        unchanged), pre = u [B][L][C]
+//   out: du [B][L][C];  per-trajectory channel sums pg/pb/pbias [B][C] of (g * vhat), (g), (du)  -> summed over B by colsum_kernel
+//        (deterministic);  dT[b][c] = sum_l gy[b][l][c]  when the block adds a time bias (the gradient wrt cond_mlp's output)
+// One wave per GroupNorm region (trajectory x group): gs * L = 64 * EPL elements, EPL consecutive channels per lane.
+struct GnBwdArgs {
+    const float* gy;
+    const float* pre;
+    const float* gamma;
+    const float* beta;
+    float* du;
+    float* pg;
+    float* pb;
+    float* pbias;
+    float* dT;        // or null
+    int dT_stride;
+    int B, L, C, gs, lg_gs, n_groups;
+};
+
+template <int EPL>
+__global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnBwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int region = blockIdx.x * 4 + wave;
+    if (region >= a.B * a.n_groups) return;
+    const int b = region / a.n_groups, g = region - b * a.n_groups;
+    const int e0 = lane * EPL;
+    const int l = e0 >> a.lg_gs, c = g * a.gs + (e0 & (a.gs - 1));
+    const size_t o = ((size_t)b * a.L + l) * a.C + c;
+    float u[EPL], gy[EPL], ga[EPL], be[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { u[e] = a.pre[o + e]; gy[e] = a.gy[o + e]; ga[e] = a.gamma[c + e]; be[e] = a.beta[c + e]; }
+    const float inv_n = 1.0f / (float)(64 * EPL);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) s += u[e];
+    const float mean = wave_sum(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { u[e] -= mean; q += u[e] * u[e]; }
+    const float var = wave_sum(q) * inv_n;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    float vh[EPL], gm[EPL], dvh[EPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        vh[e] = u[e] * rstd;
+        gm[e] = gy[e] * mish_grad(vh[e] * ga[e] + be[e]);   // gradient wrt the GroupNorm output
+        dvh[e] = gm[e] * ga[e];
+        s1 += dvh[e];
+        s2 += dvh[e] * vh[e];
+    }
+    s1 = wave_sum(s1) * inv_n;
+    s2 = wave_sum(s2) * inv_n;
+    float du[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        du[e] = rstd * (dvh[e] - s1 - vh[e] * s2);
+        a.du[o + e] = du[e];
+    }
+    // per-channel sums over the horizon: lanes with the same channel offset differ in the bits >= log2(gs / EPL)
+    float r[4 * EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { r[e] = gm[e] * vh[e]; r[EPL + e] = gm[e]; r[2 * EPL + e] = du[e]; r[3 * EPL + e] = gy[e]; }
+    for (int off = a.gs / EPL; off < 64; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 4 * EPL; ++k) r[k] += __shfl_xor(r[k], off, 64);
+    }
+    if (l == 0) {
+        const size_t po = (size_t)b * a.C + c;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            a.pg[po + e] = r[e];
+            a.pb[po + e] = r[EPL + e];
+            a.pbias[po + e] = r[2 * EPL + e];
+            if (a.dT) a.dT[(size_t)b * a.dT_stride + c + e] = r[3 * EPL + e];
+        }
+    }
+}
+
+// out_k[c] = sum_b part_k[b][c]   for up to 4 arrays (k = blockIdx.y); fixed summation order
+struct ColsumArgs { const float* part[4]; float* out[4]; int B, C; };
+__global__ __launch_bounds__(64) void colsum_kernel(const ColsumArgs a) {
+    const int c = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
+    if (c >= a.C || !a.part[k]) return;
+    float s = 0.f;
+    for (int b = 0; b < a.B; ++b) s += a.part[k][(size_t)b * a.C + c];
+    a.out[k][c] = s;
+}
+
+// channel sums of a dense [n_rows][C] tensor (bias gradient of the convolutions without GroupNorm): two passes through `part`
+__global__ __launch_bounds__(256) void rowsum_part_kernel(const float* __restrict__ x, float* __restrict__ part, int n_rows, int C, int rows_per_block) {
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(n_rows, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int r = r0; r < r1; ++r) s += x[(size_t)r * C + c];
+        part[(size_t)blockIdx.x * C + c] = s;
+    }
+}
+
+// dst[b][l][c] += src[b][l * step][c_off + c]      dst dense [B][L][Cd];  src [B][Ls][Cs]
+__global__ __launch_bounds__(256) void acc_slice_kernel(float* __restrict__ dst, const float* __restrict__ src, int B, int L, int Cd, int Ls, int Cs,
+                                                        int c_off, int step) {
+    const size_t total = (size_t)B * L * Cd;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % Cd);
+        const size_t r = i / Cd;
+        const int l = (int)(r % L), b = (int)(r / L);
+        dst[i] += src[((size_t)b * Ls + (size_t)l * step) * Cs + c_off + c];
+    }
+}
+
+// z[b][2j][c] = x[b][j][c], z[b][2j+1][c] = 0   (input gradient of a stride-2 convolution = stride-1 convolution of this)
+__global__ __launch_bounds__(256) void zero_stuff_kernel(const float* __restrict__ x, float* __restrict__ z, int B, int L, int C) {
+    const size_t total = (size_t)B * 2 * L * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const size_t r = i / C;
+        const int l2 = (int)(r % (2 * L)), b = (int)(r / (2 * L));
+        z[i] = (l2 & 1) ? 0.f : x[((size_t)b * L + (l2 >> 1)) * C + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a 1-D convolution:   G[m][n][k] = sum_{b, t < LA}  A[b][t][m] * Bm[b][sb * t + k + ob][n]     (zero outside [0, LB))
+//   Conv1d(k5 / k1, stride 1):   A = dU (m = c_out), Bm = x (n = c_in), sb = 1, ob = -pad           -> G = dW[c_out][c_in][k]
+//   Conv1d(3, stride 2, pad 1):  A = dU,             Bm = x,            sb = 2, ob = -1
+//   ConvTranspose1d(4, 2, 1):    A = x (m = c_in),   Bm = dY (n = c_out), sb = 2, ob = -1             -> G = dW[c_in][c_out][k]
+// Workgroup = 4 waves = a 32 x 32 tile of (m, n), every tap; per trajectory the two operand windows are staged in LDS and each wave
+// runs  LA / 4 * KS  v_mfma_f32_16x16x4_f32 on its 16 x 16 sub-tile.  gridDim.z splits the batch; partial sums go to
+// part[z][m][n][k] and are added in order by wgrad_reduce_kernel.
+struct WgradArgs {
+    const float* A;
+    const float* Bm;
+    float* part;
+    int LA, lda, a_off, M;   // A row stride (floats), first channel, channels
+    int LB, ldb, b_off, N;
+    int sb, ob;
+    int B, b_per_split;
+};
+
+constexpr int kWgRS = 48;   // LDS row stride: 4 consecutive rows start 16 banks apart
+
+template <int KS>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                               // [LA][48]
+    float* Bs = smem + (size_t)a.LA * kWgRS;        // [LB + 4][48], row r holds position r - 2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int b0 = blockIdx.z * a.b_per_split, b1 = min(a.B, b0 + a.b_per_split);
+    const int mi = (wave & 1) * 16, ni = (wave >> 1) * 16;
+    const int i16 = lane & 15, kq = lane >> 4;
+    f32x4 acc[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // halo rows of Bs stay zero
+    for (int i = tid; i < 4 * kWgRS; i += 256) {
+        const int r = i / kWgRS, c = i - r * kWgRS;
+        Bs[(size_t)(r < 2 ? r : a.LB + r) * kWgRS + c] = 0.f;
+    }
+    const int col = tid & 31, row0 = tid >> 5;   // 8 rows per pass
+    for (int b = b0; b < b1; ++b) {
+        __syncthreads();   // the previous trajectory's fragments are read
+        for (int r = row0; r < a.LA; r += 8)
+            As[(size_t)r * kWgRS + col] = (m0 + col < a.M) ? a.A[((size_t)b * a.LA + r) * a.lda + a.a_off + m0 + col] : 0.f;
+        for (int r = row0; r < a.LB; r += 8)
+            Bs[(size_t)(r + 2) * kWgRS + col] = (n0 + col < a.N) ? a.Bm[((size_t)b * a.LB + r) * a.ldb + a.b_off + n0 + col] : 0.f;
+        __syncthreads();
+        for (int t0 = 0; t0 < a.LA; t0 += 4) {
+            const float av = As[(size_t)(t0 + kq) * kWgRS + mi + i16];
+            const int pr = a.sb * (t0 + kq) + a.ob + 2;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                const float bv = Bs[(size_t)(pr + k) * kWgRS + ni + i16];
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[k], 0, 0, 0);
+            }
+        }
+    }
+    // D fragment: lane holds rows 4 * kq + r (r = 0..3), column i16
+    const int n = n0 + ni + i16;
+    if (n < a.N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + mi + 4 * kq + r;
+            if (m >= a.M) continue;
+            float* dst = a.part + (((size_t)blockIdx.z * a.M + m) * a.N + n) * KS;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) dst[k] = acc[k][r];
+        }
+    }
+}
+
+// g[(m * n_tot + n_off + n) * KS + k] = sum_s part[s][m][n][k]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ g, int S, int M, int N, int KS, int n_tot,
+                                                           int n_off) {
+    const size_t per = (size_t)M * N * KS;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int z = 0; z < S; ++z) s += part[(size_t)z * per + i];
+        const int k = (int)(i % KS);
+        const size_t mn = i / KS;
+        const int n = (int)(mn % N), m = (int)(mn / N);
+        g[((size_t)m * n_tot + n_off + n) * KS + k] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Packing for a training step, ONE launch for every parameter (blockIdx.y = parameter): flat reference layout ->
+//   packed  : the forward layout of conv_block.hpp (pack_conv_weights_kernel) / plain copies for vectors
+//   packedT : the dgrad layout (see the file header); only for convolutions whose input gradient is needed
+struct PackDesc {
+    unsigned long long src, dst, dstT;   // float offsets (dstT == ~0: no dgrad copy)
+    unsigned long long n, pn, pnT;       // floats: reference tensor, forward pack, dgrad pack
+    int kind;                            // PK_VEC / PK_CONV / PK_CONVT
+    int cout, cin, ks, cin_pad, nslot;   // forward geometry
+    int t_cout, t_cin, t_ks, t_cin_pad;  // dgrad geometry (a CONV_S1 convolution t_cin -> t_cout with t_ks taps)
+    int t_mode;                          // 0: transpose + flip (Conv1d), 1: ConvTranspose1d k4 -> 5 taps
+};
+
+__global__ __launch_bounds__(256) void pack_train_kernel(const PackDesc* __restrict__ descs, const float* __restrict__ flat, float* __restrict__ packed,
+                                                         float* __restrict__ packedT) {
+    const PackDesc d = descs[blockIdx.y];
+    const float* src = flat + d.src;
+    const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (d.kind == 0) {   // PK_VEC
+        for (size_t i = i0; i < d.pn; i += stride) packed[d.dst + i] = i < d.n ? src[i] : 0.f;
+        return;
+    }
+    const int nc16 = d.cin_pad >> 4;
+    for (size_t i = i0; i < d.pn; i += stride) {   // forward layout [m16][c16][slot][lane][4]
+        const int e = i & 3, lane = (i >> 2) & 63;
+        size_t r = i >> 8;
+        const int slot = r % d.nslot; r /= d.nslot;
+        const int c16 = r % nc16; const int m16 = (int)(r / nc16);
+        const int co = m16 * 16 + (lane & 15);
+        const int ci = c16 * 16 + (lane >> 4) * 4 + e;
+        float v = 0.f;
+        if (ci < d.cin) {
+            if (d.kind == 2) v = src[((size_t)ci * d.cout + co) * d.ks + upt_slot_to_k(slot)];
+            else v = src[((size_t)co * d.cin + ci) * d.ks + slot];
+        }
+        packed[d.dst + i] = v;
+    }
+    if (d.dstT == ~0ull || !packedT) return;
+    const int tnc16 = d.t_cin_pad >> 4;
+    for (size_t i = i0; i < d.pnT; i += stride) {   // dgrad layout: a CONV_S1 weight [t_cout][t_cin][t_ks]
+        const int e = i & 3, lane = (i >> 2) & 63;
+        size_t r = i >> 8;
+        const int slot = r % d.t_ks; r /= d.t_ks;
+        const int c16 = r % tnc16; const int m16 = (int)(r / tnc16);
+        const int o = m16 * 16 + (lane & 15);            // output channel of the dgrad conv = input channel of the layer
+        const int ii = c16 * 16 + (lane >> 4) * 4 + e;   // input channel of the dgrad conv = output channel of the layer
+        float v = 0.f;
+        if (ii < d.t_cin && o < d.t_cout) {
+            if (d.t_mode == 0) v = src[((size_t)ii * d.cin + o) * d.ks + (d.ks - 1 - slot)];      // W[co = ii][ci = o][k - 1 - k']
+            else if (slot > 0) v = src[((size_t)o * d.cout + ii) * d.ks + (slot - 1)];            // W[ci = o][co = ii][k' - 1]
+        }
+        packedT[d.dstT + i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Time conditioning for per-sample timesteps, with everything the backward pass needs (layers.py:229-255, 336-340):
+//   emb[b] = [sin(t f) | cos(t f)] (32)   h1 = W1 emb + b1 (128)   temb = W3 mish(h1) + b3 (32)   tb[b][row] = Wj mish(temb) + bj
+struct TimeTrainArgs {
+    const float* flat;          // parameters, reference layout
+    const long long* t;         // [B]
+    const float* freqs;         // [16]
+    float* emb;                 // [B][32]
+    float* h1;                  // [B][128]  (pre-Mish)
+    float* temb;                // [B][32]   (pre-Mish)
+    float* tb;                  // [B][row]
+    unsigned long long w1, b1, w3, b3;
+    int row, nblk;
+    unsigned long long woff[40], boff[40];
+    int cout[40], toff[40];
+};
+
+__global__ __launch_bounds__(128) void time_train_fwd_kernel(const TimeTrainArgs a) {
+    __shared__ float emb[32], h1m[128], tm[32];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < 16) {
+        const float arg = (float)a.t[b] * a.freqs[tid];
+        emb[tid] = sinf(arg);
+        emb[tid + 16] = cosf(arg);
+        a.emb[(size_t)b * 32 + tid] = emb[tid];
+        a.emb[(size_t)b * 32 + tid + 16] = emb[tid + 16];
+    }
+    __syncthreads();
+    {
+        const float* w = a.flat + a.w1 + tid * 32;
+        float s = a.flat[a.b1 + tid];
+        for (int k = 0; k < 32; ++k) s = fmaf(w[k], emb[k], s);
+        a.h1[(size_t)b * 128 + tid] = s;
+        h1m[tid] = mish(s);
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const float* w = a.flat + a.w3 + tid * 128;
+        float s = a.flat[a.b3 + tid];
+        for (int k = 0; k < 128; ++k) s = fmaf(w[k], h1m[k], s);
+        a.temb[(size_t)b * 32 + tid] = s;
+        tm[tid] = mish(s);
+    }
+    __syncthreads();
+    for (int blk = 0; blk < a.nblk; ++blk)
+        for (int c = tid; c < a.cout[blk]; c += 128) {
+            const float* w = a.flat + a.woff[blk] + c * 32;
+            float s = a.flat[a.boff[blk] + c];
+            for (int k = 0; k < 32; ++k) s = fmaf(w[k], tm[k], s);
+            a.tb[(size_t)b * a.row + a.toff[blk] + c] = s;
+        }
+}
+
+// cond_mlp weight / bias gradients: for row index c (a channel of some block):  dW[c][e] = sum_b dT[b][c] * mish(temb[b][e]),
+// db[c] = sum_b dT[b][c].  One thread per (c, e).
+struct TimeBwdArgs {
+    const float* flat;
+    float* grad;                // flat gradient vector
+    const float* dT;            // [B][row]
+    const float* emb;
+    const float* h1;
+    const float* temb;
+    float* dtm;                 // [B][32]  gradient wrt mish(temb), then wrt temb
+    float* dh1;                 // [B][128] gradient wrt h1
+    unsigned long long w1, b1, w3, b3;
+    int B, row, nblk;
+    unsigned long long woff[40], boff[40];
+    int cout[40], toff[40];
+};
+
+__global__ __launch_bounds__(256) void time_bwd_cond_kernel(const TimeBwdArgs a) {
+    // blockIdx.x: 8 rows of the table per block; thread = (row in block, e)
+    const int rr = blockIdx.x * 8 + (threadIdx.x >> 5), e = threadIdx.x & 31;
+    if (rr >= a.row) return;
+    int blk = 0;
+    while (blk + 1 < a.nblk && rr >= a.toff[blk + 1]) ++blk;   // toff ascending
+    const int c = rr - a.toff[blk];
+    float sw = 0.f, sb = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+        const float d = a.dT[(size_t)b * a.row + rr];
+        sw = fmaf(d, mish(a.temb[(size_t)b * 32 + e]), sw);
+        sb += d;
+    }
+    a.grad[a.woff[blk] + (size_t)c * 32 + e] = sw;
+    if (e == 0) a.grad[a.boff[blk] + c] = sb;
+}
+
+// gradient wrt temb:  dtm[b][e] = mish'(temb[b][e]) * sum_rows dT[b][row] * W_row[e]        one block per sample
+__global__ __launch_bounds__(256) void time_bwd_temb_kernel(const TimeBwdArgs a) {
+    __shared__ float red[8][32];
+    const int b = blockIdx.x, e = threadIdx.x & 31, part = threadIdx.x >> 5;
+    float s = 0.f;
+    for (int blk = 0; blk < a.nblk; ++blk)
+        for (int c = part; c < a.cout[blk]; c += 8)
+            s = fmaf(a.dT[(size_t)b * a.row + a.toff[blk] + c], a.flat[a.woff[blk] + (size_t)c * 32 + e], s);
+    red[part][e] = s;
+    __syncthreads();
+    if (part == 0) {
+        float t = 0.f;
+        for (int p = 0; p < 8; ++p) t += red[p][e];
+        a.dtm[(size_t)b * 32 + e] = t * mish_grad(a.temb[(size_t)b * 32 + e]);
+    }
+}
+
+// time_mlp.encoder.3 (Linear 128 -> 32): dW3[e][k] = sum_b dtemb[b][e] mish(h1[b][k]); db3; dh1[b][k] = mish'(h1) sum_e dtemb[b][e] W3[e][k]
+// grid: 32 blocks (e) x 128 threads (k) for the weight gradient, then B blocks for dh1 (blockIdx.x >= 32)
+__global__ __launch_bounds__(128) void time_bwd_l3_kernel(const TimeBwdArgs a) {
+    const int k = threadIdx.x;
+    if (blockIdx.x < 32) {
+        const int e = blockIdx.x;
+        float sw = 0.f, sb = 0.f;
+        for (int b = 0; b < a.B; ++b) {
+            const float d = a.dtm[(size_t)b * 32 + e];
+            sw = fmaf(d, mish(a.h1[(size_t)b * 128 + k]), sw);
+            sb += d;
+        }
+        a.grad[a.w3 + (size_t)e * 128 + k] = sw;
+        if (k == 0) a.grad[a.b3 + e] = sb;
+    } else {
+        const int b = blockIdx.x - 32;
+        float s = 0.f;
+        for (int e = 0; e < 32; ++e) s = fmaf(a.dtm[(size_t)b * 32 + e], a.flat[a.w3 + (size_t)e * 128 + k], s);
+        a.dh1[(size_t)b * 128 + k] = s * mish_grad(a.h1[(size_t)b * 128 + k]);
+    }
+}
+
+// time_mlp.encoder.1 (Linear 32 -> 128): dW1[k][j] = sum_b dh1[b][k] emb[b][j]; db1[k] = sum_b dh1[b][k].   128 blocks x 32 threads
+__global__ __launch_bounds__(32) void time_bwd_l1_kernel(const TimeBwdArgs a) {
+    const int k = blockIdx.x, j = threadIdx.x;
+    float sw = 0.f, sb = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+        const float d = a.dh1[(size_t)b * 128 + k];
+        sw = fmaf(d, a.emb[(size_t)b * 32 + j], sw);
+        sb += d;
+    }
+    a.grad[a.w1 + (size_t)k * 32 + j] = sw;
+    if (j == 0) a.grad[a.b1 + k] = sb;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Loss gradient (helpers.py:71-99; mean over B*H*D of |e| or e^2 [* weights]):  dE = s * w * d|e|^p / de / (B H D), zero where
+// apply_hard_conditioning overwrote the prediction with a constant (diffusion_model_base.py:343).
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ pred, const float* __restrict__ targ, const float* __restrict__ weights_hd,
+                                                        int has_hs, int has_hg, int l1, float scale, float* __restrict__ dE, int B, int H, int D) {
+    const size_t total = (size_t)B * H * D;
+    const float inv = scale / (float)total;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int hd = (int)(i % ((size_t)H * D)), h = hd / D;
+        float g = 0.f;
+        if (!((has_hs && h == 0) || (has_hg && h == H - 1))) {
+            const float e = pred[i] - targ[i];
+            g = l1 ? (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) : 2.0f * e;
+            if (weights_hd) g *= weights_hd[hd];
+            g *= inv;
+        }
+        dE[i] = g;
+    }
+}
+
+// final_conv[1] (Conv1d 1x1, C -> D) input gradient:  gH[b][l][c] = sum_d dE[b][l][d] W[d][c]
+__global__ __launch_bounds__(256) void final_dgrad_kernel(const float* __restrict__ dE, const float* __restrict__ w, float* __restrict__ gH, size_t n_rows, int D,
+                                                          int C) {
+    const size_t total = n_rows * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const size_t r = i / C;
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) s = fmaf(dE[r * D + d], w[(size_t)d * C + c], s);
+        gH[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Optimiser.  sumsq_kernel + adam_kernel = torch.nn.utils.clip_grad_norm_(params, max_norm) (trainer.py:268-272) followed by
+// torch.optim.Adam.step() with the defaults the reference uses (betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad):
+//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s = fmaf(g[i], g[i], s);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// norm[0] = sqrt(sum part), norm[1] = clip coefficient min(1, max_norm / (norm + 1e-6))   (one block)
+__global__ __launch_bounds__(256) void norm_finish_kernel(const float* __restrict__ part, int n_part, float max_norm, float* __restrict__ norm) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_part; i += 256) s += part[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float nrm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        norm[0] = nrm;
+        norm[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (nrm + 1e-6f)) : 1.0f;
+    }
+}
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                   float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, const float* __restrict__ clip) {
+    const float coef = clip ? clip[1] : 1.0f;
+    const float step = lr / bc1;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i] * coef;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+// EMA.update_model_average (trainer.py:67-85): ema = beta * ema + (1 - beta) * p
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, size_t n, float beta) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) ema[i] = ema[i] * beta + (1.0f - beta) * p[i];
+}
+
+}  // namespace mpdx

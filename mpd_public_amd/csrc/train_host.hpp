@@ -1,0 +1,424 @@
+// train_host.hpp - host side of the training step (included at the end of mpdx.hip; kernels in train.hpp).
+// Entry points: mpdx_train_* (include/mpdx.h).  Everything is enqueued on the caller's stream; no synchronisation.
+#pragma once
+
+namespace mpdx {
+
+// one-off: the flat (reference-layout) offsets of every parameter, the dgrad convolution of every layer whose input needs a
+// gradient, and the producer of every tensor a layer reads (the forward engine recycles 4 + n_levels slots; training keeps
+// every layer's output)
+static void build_train_plan(mpdx_unet* u) {
+    if (u->train_ready) return;
+    size_t fo = 0;
+    for (auto& p : u->params) { p.foff = fo; fo += (p.n + 3) / 4 * 4; }
+    u->flat_floats = fo;
+    const int n = (int)u->layers.size();
+    u->tl.assign(n, {});
+    std::unordered_map<int, int> owner;   // slot -> layer that wrote it last
+    size_t pt = 0;
+    for (int i = 0; i < n; ++i) {
+        const Layer& l = u->layers[i];
+        auto& t = u->tl[i];
+        auto prod = [&](int s) { return s == SRC_X ? -1 : (s == SRC_NONE ? -2 : owner.at(s)); };
+        t.src1_l = prod(l.src1); t.src2_l = prod(l.src2); t.res_l = prod(l.res);
+        owner[l.dst] = i;
+        t.need_dgrad = (t.src1_l >= 0) || (t.src2_l >= 0);
+        t.dgrad_woff = ~(size_t)0;
+        if (t.need_dgrad) {
+            Layer d;
+            d.name = "dgrad(" + l.name + ")";
+            d.mode = CONV_S1; d.epi = EPI_BIAS;
+            d.ks = l.mode == CONV_S1 ? l.ks : (l.mode == CONV_DOWN ? 3 : 5);
+            d.c1 = l.cout; d.c2 = 0; d.cout = l.c1 + l.c2;
+            d.L_in = d.L_out = l.mode == CONV_UPT ? l.L_out : l.L_in;
+            d.cin_pad = (d.c1 + 15) / 16 * 16;
+            d.rs = pick_row_stride(d.cin_pad, CONV_S1, d.L_in, d.L_out, d.L_in + 2 * (d.ks / 2));
+            t.dg = d;
+            t.dgrad_woff = pt;
+            pt += (size_t)(d.cout / 16) * (d.cin_pad / 16) * d.ks * 256;
+        }
+    }
+    u->packedT_floats = pt;
+    // packing table
+    std::vector<PackDesc> descs;
+    for (size_t k = 0; k < u->params.size(); ++k) {
+        const Param& p = u->params[k];
+        PackDesc d;
+        memset(&d, 0, sizeof(d));
+        d.src = p.foff; d.dst = p.off; d.dstT = ~0ull;
+        d.n = p.n; d.pn = p.pn; d.kind = p.kind;
+        d.cout = p.cout; d.cin = p.cin; d.ks = p.ksz; d.cin_pad = p.cin_pad; d.nslot = p.nslot;
+        for (int i = 0; i < n; ++i)
+            if (u->layers[i].w == (int)k && u->tl[i].need_dgrad) {
+                const Layer& g = u->tl[i].dg;
+                d.dstT = u->tl[i].dgrad_woff;
+                d.t_cout = g.cout; d.t_cin = g.c1; d.t_ks = g.ks; d.t_cin_pad = g.cin_pad;
+                d.t_mode = u->layers[i].mode == CONV_UPT ? 1 : 0;
+                d.pnT = (size_t)(g.cout / 16) * (g.cin_pad / 16) * g.ks * 256;
+            }
+        descs.push_back(d);
+    }
+    u->pack_descs_host = descs;
+    u->train_ready = true;
+}
+
+static int ensure_pack_descs(mpdx_unet* u) {
+    if (u->pack_descs_dev) return 0;
+    HIP_TRY(hipMalloc(&u->pack_descs_dev, u->pack_descs_host.size() * sizeof(PackDesc)));
+    HIP_TRY(hipMemcpy(u->pack_descs_dev, u->pack_descs_host.data(), u->pack_descs_host.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// workspace layout for a batch of B (float offsets)
+struct TrainWs {
+    size_t xn, eps, dE, out0, pre0, grad0, tmpX, dU, zst, pvec, wpart, rpart, emb, h1, temb, tb, dT, dtm, dh1, zeros, norm, total;
+    size_t slotB;          // floats of one activation slot for the batch
+    size_t wpart_floats;
+};
+static size_t wgrad_splits(int M, int N, int B) {
+    const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
+    int S = (512 + tiles - 1) / tiles;
+    S = std::max(1, std::min(S, B));
+    const int per = (B + S - 1) / S;
+    return (size_t)((B + per - 1) / per);
+}
+static TrainWs train_ws(const mpdx_unet* u, int B) {
+    TrainWs w;
+    const size_t n = u->layers.size();
+    const int H = u->cfg.n_support_points, D = u->cfg.state_dim;
+    w.slotB = u->slot_floats * (size_t)B;
+    const size_t xs = ((size_t)B * H * D + 3) / 4 * 4;
+    size_t o = 0;
+    auto take = [&](size_t k) { const size_t r = o; o += (k + 3) / 4 * 4; return r; };
+    w.xn = take(xs); w.eps = take(xs); w.dE = take(xs);
+    w.out0 = take(n * w.slotB);
+    w.pre0 = take(n * w.slotB);
+    w.grad0 = take(n * w.slotB);
+    w.tmpX = take(2 * w.slotB);
+    w.dU = take(w.slotB);
+    w.zst = take(2 * w.slotB);
+    w.pvec = take((size_t)4 * B * 512);
+    size_t wp = 0;
+    for (const Layer& l : u->layers) {
+        const int M = l.mode == CONV_UPT ? l.c1 + l.c2 : l.cout, N = l.mode == CONV_UPT ? l.cout : std::max(l.c1, l.c2);
+        wp = std::max(wp, wgrad_splits(M, N, B) * M * N * (size_t)l.ks);
+    }
+    wp = std::max(wp, wgrad_splits(D, u->cfg.unet_input_dim, B) * D * (size_t)u->cfg.unet_input_dim);
+    w.wpart_floats = wp;
+    w.wpart = take(wp);
+    w.rpart = take((size_t)256 * 512);
+    w.emb = take((size_t)B * 32); w.h1 = take((size_t)B * 128); w.temb = take((size_t)B * 32);
+    w.tb = take((size_t)B * u->tt_row); w.dT = take((size_t)B * u->tt_row);
+    w.dtm = take((size_t)B * 32); w.dh1 = take((size_t)B * 128);
+    w.zeros = take(1024);
+    w.norm = take(1024 + 8);
+    w.total = o;
+    return w;
+}
+
+static int launch_layer(const Layer& l, ConvArgs& a, int B, hipStream_t st) {
+    if (l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH) return dispatch_tile<CONV_S1, 5, EPI_GN_MISH>(l, a, B, st);
+    if (l.mode == CONV_S1 && l.ks == 1 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 1, EPI_BIAS>(l, a, B, st);
+    if (l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 5, EPI_BIAS>(l, a, B, st);
+    if (l.mode == CONV_S1 && l.ks == 3 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 3, EPI_BIAS>(l, a, B, st);
+    if (l.mode == CONV_DOWN && l.ks == 3) return dispatch_tile_ksplit_only<CONV_DOWN, 3, EPI_BIAS>(l, a, B, st);
+    if (l.mode == CONV_UPT && l.ks == 4) return dispatch_tile_ksplit_only<CONV_UPT, 4, EPI_BIAS>(l, a, B, st);
+    return fail(MPDX_E_INVALID, "layer %s: unsupported conv (mode %d k %d epi %d)", l.name.c_str(), l.mode, l.ks, l.epi);
+}
+
+static int fill_geom(const Layer& l, int B, ConvArgs& a) {
+    a.c1 = l.c1; a.c2 = l.c2;
+    a.B = B; a.L_in = l.L_in; a.L_out = l.L_out; a.C_out = l.cout;
+    a.cin_pad = l.cin_pad; a.rs = l.rs; a.gs = l.gs;
+    auto lg2 = [](int v) { int k = 0; while ((1 << k) < v) ++k; return k; };
+    a.lg_c4n = lg2(l.cin_pad / 4); a.lg_Lin = lg2(l.L_in); a.lg_Lout = lg2(l.L_out); a.lg_gs = l.gs > 0 ? lg2(l.gs) : 0;
+    if ((1 << a.lg_c4n) != l.cin_pad / 4 || (1 << a.lg_Lin) != l.L_in || (1 << a.lg_Lout) != l.L_out || (l.gs > 0 && (1 << a.lg_gs) != l.gs))
+        return fail(MPDX_E_INVALID, "layer %s: channel/length/group sizes must be powers of two", l.name.c_str());
+    return 0;
+}
+
+static int launch_wgrad(const float* A, int LA, int lda, int a_off, int M, const float* Bm, int LB, int ldb, int b_off, int N, int sb, int ob, int KS,
+                        int B, float* part, float* g, int n_tot, int n_off, hipStream_t st) {
+    WgradArgs a;
+    a.A = A; a.Bm = Bm; a.part = part;
+    a.LA = LA; a.lda = lda; a.a_off = a_off; a.M = M;
+    a.LB = LB; a.ldb = ldb; a.b_off = b_off; a.N = N;
+    a.sb = sb; a.ob = ob; a.B = B;
+    const int S = (int)wgrad_splits(M, N, B);
+    a.b_per_split = (B + S - 1) / S;
+    if (LA % 4) return fail(MPDX_E_INVALID, "wgrad: horizon %d is not a multiple of 4", LA);
+    const size_t lds = (size_t)(LA + LB + 4) * kWgRS * sizeof(float);
+    const dim3 grid((N + 31) / 32, (M + 31) / 32, S);
+    switch (KS) {
+        case 1: hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), lds, st, a); break;
+        case 3: hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(256), lds, st, a); break;
+        case 4: hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(256), lds, st, a); break;
+        case 5: hipLaunchKernelGGL(wgrad_kernel<5>, grid, dim3(256), lds, st, a); break;
+        default: return fail(MPDX_E_INVALID, "wgrad: %d taps", KS);
+    }
+    const size_t per = (size_t)M * N * KS;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((per + 255) / 256, 1024)), dim3(256), 0, st, part, g, S, M, N, KS, n_tot, n_off);
+    return 0;
+}
+
+// channel sums of a dense [rows][C] tensor -> out[C]
+static void launch_rowsum(const float* x, size_t rows, int C, float* part, float* out, hipStream_t st) {
+    const int nb = (int)std::min<size_t>(256, rows);
+    const int rpb = (int)((rows + nb - 1) / nb);
+    const int nblk = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(rowsum_part_kernel, dim3(nblk), dim3(256), 0, st, x, part, (int)rows, C, rpb);
+    ColsumArgs c;
+    memset(&c, 0, sizeof(c));
+    c.part[0] = part; c.out[0] = out; c.B = nblk; c.C = C;
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, 1), dim3(64), 0, st, c);
+}
+
+static void launch_acc(float* dst, const float* src, int B, int L, int Cd, int Ls, int Cs, int c_off, int step, hipStream_t st) {
+    const size_t total = (size_t)B * L * Cd;
+    hipLaunchKernelGGL(acc_slice_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, dst, src, B, L, Cd, Ls, Cs, c_off, step);
+}
+
+}  // namespace mpdx
+
+using namespace mpdx;
+
+extern "C" {
+
+size_t mpdx_train_flat_floats(mpdx_unet* u) {
+    if (!u) return 0;
+    build_train_plan(u);
+    return u->flat_floats;
+}
+size_t mpdx_train_dgrad_pack_floats(mpdx_unet* u) {
+    if (!u) return 0;
+    build_train_plan(u);
+    return std::max<size_t>(u->packedT_floats, 4);
+}
+size_t mpdx_train_workspace_floats(mpdx_unet* u, int B) {
+    if (!u || B <= 0) return 0;
+    build_train_plan(u);
+    return train_ws(u, B).total;
+}
+int mpdx_train_param_offset(mpdx_unet* u, int idx, size_t* off, size_t* n) {
+    if (!u || idx < 0 || idx >= (int)u->params.size() || !off || !n) return fail(MPDX_E_INVALID, "bad argument");
+    build_train_plan(u);
+    *off = u->params[idx].foff; *n = u->params[idx].n;
+    return 0;
+}
+
+/* flat parameter vector (reference layout) -> forward pack (+ the dgrad pack when packedT is given): one launch */
+int mpdx_train_pack(mpdx_unet* u, const float* flat, float* packed, float* packedT, void* stream) {
+    if (!u || !flat || !packed) return fail(MPDX_E_INVALID, "null argument");
+    build_train_plan(u);
+    if (int rc = ensure_pack_descs(u)) return rc;
+    hipLaunchKernelGGL(pack_train_kernel, dim3(64, (unsigned)u->params.size()), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)u->pack_descs_dev, flat,
+                       packed, packedT);
+    HIP_TRY(hipGetLastError());
+    for (auto& p : u->params) if (!p.done) { p.done = true; u->n_done++; }
+    u->pack_version++;
+    return 0;
+}
+
+/* One p_losses evaluation WITH its gradient (diffusion_model_base.py:331-352 + loss.backward()):
+ *   x_noisy = q_sample(x_start, t, noise) with hard conditions; x_recon = unet(x_noisy, t) with hard conditions;
+ *   loss = mean(|x_recon - target|^p [* weights]);  grads_flat = d loss * loss_scale / d parameters  (every entry written).
+ * `flat` / `packed` / `packedT`: the parameters and their two packs (mpdx_train_pack).  loss_out: one device float. */
+int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packed, const float* packedT, float* grads_flat, const float* x_start,
+                             const float* noise, const long long* t_dev, const float* sqrt_alphas_cumprod_dev,
+                             const float* sqrt_one_minus_alphas_cumprod_dev, const float* freqs16, const float* hard_start, const float* hard_goal,
+                             const float* weights_hd, int T, int B, int predict_epsilon, int l1, float loss_scale, float* loss_out, float* ws,
+                             void* stream) {
+    if (!u || !flat || !packed || !packedT || !grads_flat || !x_start || !noise || !t_dev || !freqs16 || !loss_out || !ws || B <= 0)
+        return fail(MPDX_E_INVALID, "bad argument");
+    build_train_plan(u);
+    if (int rc = check_ready(u)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const mpdx_unet_cfg& c = u->cfg;
+    const int H = c.n_support_points, D = c.state_dim, n = (int)u->layers.size();
+    const TrainWs w = train_ws(u, B);
+    float* const xn = ws + w.xn;
+    float* const eps = ws + w.eps;
+    float* const dE = ws + w.dE;
+    auto out = [&](int i) { return ws + w.out0 + (size_t)i * w.slotB; };
+    auto pre = [&](int i) { return ws + w.pre0 + (size_t)i * w.slotB; };
+    auto grd = [&](int i) { return ws + w.grad0 + (size_t)i * w.slotB; };
+    auto tensor = [&](int li) -> const float* { return li == -1 ? xn : (li < 0 ? nullptr : out(li)); };
+    auto gflat = [&](int pidx) { return grads_flat + u->params[pidx].foff; };
+
+    // ---- forward, every layer's output (and GroupNorm input) kept
+    HIP_TRY(hipMemsetAsync(ws + w.grad0, 0, (size_t)n * w.slotB * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(ws + w.zeros, 0, 1024 * sizeof(float), st));
+    {
+        const size_t ne = (size_t)B * H * D;
+        hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)std::min<size_t>((ne + 255) / 256, 2048)), dim3(256), 0, st, x_start, noise, t_dev,
+                           sqrt_alphas_cumprod_dev, sqrt_one_minus_alphas_cumprod_dev, hard_start, hard_goal, xn, B, H, D, T);
+    }
+    TimeTrainArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    TimeBwdArgs tb;
+    memset(&tb, 0, sizeof(tb));
+    {
+        ta.flat = flat; ta.t = t_dev; ta.freqs = freqs16;
+        ta.emb = ws + w.emb; ta.h1 = ws + w.h1; ta.temb = ws + w.temb; ta.tb = ws + w.tb;
+        ta.w1 = u->params[u->pidx.at("time_mlp.encoder.1.weight")].foff; ta.b1 = u->params[u->pidx.at("time_mlp.encoder.1.bias")].foff;
+        ta.w3 = u->params[u->pidx.at("time_mlp.encoder.3.weight")].foff; ta.b3 = u->params[u->pidx.at("time_mlp.encoder.3.bias")].foff;
+        ta.row = u->tt_row; ta.nblk = (int)u->tt_w.size();
+        if (ta.nblk > 40 || c.time_emb_dim != 32) return fail(MPDX_E_INVALID, "time MLP shape unsupported by the training kernels");
+        for (int i = 0; i < ta.nblk; ++i) {
+            ta.woff[i] = u->params[u->tt_w[i]].foff; ta.boff[i] = u->params[u->tt_b[i]].foff;
+            ta.cout[i] = u->tt_cout[i]; ta.toff[i] = u->tt_off[i];
+        }
+        hipLaunchKernelGGL(time_train_fwd_kernel, dim3(B), dim3(128), 0, st, ta);
+        tb.flat = flat; tb.grad = grads_flat; tb.dT = ws + w.dT; tb.emb = ta.emb; tb.h1 = ta.h1; tb.temb = ta.temb;
+        tb.dtm = ws + w.dtm; tb.dh1 = ws + w.dh1;
+        tb.w1 = ta.w1; tb.b1 = ta.b1; tb.w3 = ta.w3; tb.b3 = ta.b3;
+        tb.B = B; tb.row = ta.row; tb.nblk = ta.nblk;
+        for (int i = 0; i < ta.nblk; ++i) { tb.woff[i] = ta.woff[i]; tb.boff[i] = ta.boff[i]; tb.cout[i] = ta.cout[i]; tb.toff[i] = ta.toff[i]; }
+    }
+    for (int i = 0; i < n; ++i) {
+        const Layer& l = u->layers[i];
+        const auto& t = u->tl[i];
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        if (int rc = fill_geom(l, B, a)) return rc;
+        a.src1 = tensor(t.src1_l); a.src2 = tensor(t.src2_l);
+        a.wp = packed + u->params[l.w].off;
+        a.bias = packed + u->params[l.b].off;
+        a.gamma = l.gamma >= 0 ? packed + u->params[l.gamma].off : nullptr;
+        a.beta = l.beta >= 0 ? packed + u->params[l.beta].off : nullptr;
+        if (l.tb_off >= 0) { a.tbias = ws + w.tb + l.tb_off; a.tb_stride = u->tt_row; }
+        a.res = tensor(t.res_l);
+        a.dst = out(i);
+        a.pre = l.epi == EPI_GN_MISH ? pre(i) : nullptr;
+        if (int rc = launch_layer(l, a, B, st)) return rc;
+    }
+    {   // final_conv[1] -> eps (the network output), hard conditions, loss value and its gradient
+        FinalArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.h = out(n - 1);
+        fa.w = packed + u->params[u->pidx.at("final_conv.1.weight")].off;
+        fa.bias = packed + u->params[u->pidx.at("final_conv.1.bias")].off;
+        fa.out = eps; fa.mode = 0; fa.n_per_ctx = 1;
+        fa.B = B; fa.H = H; fa.D = D; fa.C = c.unet_input_dim;
+        const int np = B * H;
+        hipLaunchKernelGGL(final_step_kernel, dim3((np + 255) / 256), dim3(256), (size_t)(fa.D * fa.C + fa.D) * sizeof(float), st, fa);
+        const float* target = predict_epsilon ? noise : x_start;
+        hipLaunchKernelGGL(weighted_loss_kernel, dim3(1), dim3(1024), 0, st, (const float*)eps, target, weights_hd, hard_start, hard_goal, l1, loss_out, B, H, D);
+        const size_t ne = (size_t)B * H * D;
+        hipLaunchKernelGGL(loss_grad_kernel, dim3((unsigned)std::min<size_t>((ne + 255) / 256, 1024)), dim3(256), 0, st, (const float*)eps, target, weights_hd,
+                           hard_start ? 1 : 0, hard_goal ? 1 : 0, l1, loss_scale, dE, B, H, D);
+    }
+    HIP_TRY(hipGetLastError());
+
+    // ---- backward
+    float* const part = ws + w.wpart;
+    float* const rpart = ws + w.rpart;
+    {   // final_conv[1]
+        const int C = c.unet_input_dim;
+        const int wi = u->pidx.at("final_conv.1.weight"), bi = u->pidx.at("final_conv.1.bias");
+        const size_t rows = (size_t)B * H;
+        hipLaunchKernelGGL(final_dgrad_kernel, dim3((unsigned)std::min<size_t>((rows * C + 255) / 256, 2048)), dim3(256), 0, st, (const float*)dE,
+                           flat + u->params[wi].foff, grd(n - 1), rows, D, C);
+        if (int rc = launch_wgrad(dE, H, D, 0, D, out(n - 1), H, C, 0, C, 1, 0, 1, B, part, gflat(wi), C, 0, st)) return rc;
+        launch_rowsum(dE, rows, D, rpart, gflat(bi), st);
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        const Layer& l = u->layers[i];
+        const auto& t = u->tl[i];
+        const int Cin = l.c1 + l.c2;
+        float* gy = grd(i);
+        const float* dy = gy;   // gradient wrt the convolution output (after the GroupNorm/Mish backward for Conv1dBlocks)
+        if (l.epi == EPI_GN_MISH) {
+            if (t.res_l >= 0) launch_acc(grd(t.res_l), gy, B, l.L_out, l.cout, l.L_out, l.cout, 0, 1, st);
+            GnBwdArgs g;
+            memset(&g, 0, sizeof(g));
+            g.gy = gy; g.pre = pre(i); g.gamma = flat + u->params[l.gamma].foff; g.beta = flat + u->params[l.beta].foff;
+            g.du = ws + w.dU;
+            g.pg = ws + w.pvec; g.pb = g.pg + (size_t)B * 512; g.pbias = g.pb + (size_t)B * 512;
+            if (l.tb_off >= 0) { g.dT = ws + w.dT + l.tb_off; g.dT_stride = u->tt_row; }
+            g.B = B; g.L = l.L_out; g.C = l.cout; g.gs = l.gs; g.n_groups = l.cout / l.gs;
+            { int k = 0; while ((1 << k) < l.gs) ++k; g.lg_gs = k; }
+            if (l.cout > 512) return fail(MPDX_E_INVALID, "layer %s: more than 512 channels", l.name.c_str());
+            const int re = l.gs * l.L_out, regions = B * g.n_groups;
+            if (re == 256) hipLaunchKernelGGL(gn_mish_bwd_kernel<4>, dim3((regions + 3) / 4), dim3(256), 0, st, g);
+            else if (re == 128) hipLaunchKernelGGL(gn_mish_bwd_kernel<2>, dim3((regions + 3) / 4), dim3(256), 0, st, g);
+            else return fail(MPDX_E_INVALID, "layer %s: GroupNorm region of %d elements", l.name.c_str(), re);
+            ColsumArgs cs;
+            memset(&cs, 0, sizeof(cs));
+            cs.part[0] = g.pg; cs.out[0] = gflat(l.gamma);
+            cs.part[1] = g.pb; cs.out[1] = gflat(l.beta);
+            cs.part[2] = g.pbias; cs.out[2] = gflat(l.b);
+            cs.B = B; cs.C = l.cout;
+            hipLaunchKernelGGL(colsum_kernel, dim3((l.cout + 63) / 64, 3), dim3(64), 0, st, cs);
+            dy = g.du;
+        } else {
+            launch_rowsum(gy, (size_t)B * l.L_out, l.cout, rpart, gflat(l.b), st);
+        }
+        // weight gradient
+        float* gw = gflat(l.w);
+        if (l.mode == CONV_UPT) {
+            if (int rc = launch_wgrad(tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, dy, l.L_out, l.cout, 0, l.cout, 2, -1, 4, B, part, gw, l.cout, 0, st)) return rc;
+        } else {
+            const int sb = l.mode == CONV_DOWN ? 2 : 1, ob = l.mode == CONV_DOWN ? -1 : -(l.ks / 2);
+            if (int rc = launch_wgrad(dy, l.L_out, l.cout, 0, l.cout, tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, sb, ob, l.ks, B, part, gw, Cin, 0, st)) return rc;
+            if (l.c2 > 0)
+                if (int rc = launch_wgrad(dy, l.L_out, l.cout, 0, l.cout, tensor(t.src2_l), l.L_in, l.c2, 0, l.c2, sb, ob, l.ks, B, part, gw, Cin, l.c1, st)) return rc;
+        }
+        // input gradient
+        if (t.need_dgrad) {
+            const Layer& dgl = t.dg;
+            const float* din = dy;
+            if (l.mode == CONV_DOWN) {
+                const size_t tot = (size_t)B * 2 * l.L_out * l.cout;
+                hipLaunchKernelGGL(zero_stuff_kernel, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, st, dy, ws + w.zst, B, l.L_out, l.cout);
+                din = ws + w.zst;
+            }
+            ConvArgs a;
+            memset(&a, 0, sizeof(a));
+            if (int rc = fill_geom(dgl, B, a)) return rc;
+            a.src1 = din;
+            a.wp = packedT + t.dgrad_woff;
+            a.bias = ws + w.zeros;
+            a.dst = ws + w.tmpX;
+            if (int rc = launch_layer(dgl, a, B, st)) return rc;
+            const int step = l.mode == CONV_UPT ? 2 : 1;
+            if (t.src1_l >= 0) launch_acc(grd(t.src1_l), ws + w.tmpX, B, l.L_in, l.c1, dgl.L_out, Cin, 0, step, st);
+            if (t.src2_l >= 0) launch_acc(grd(t.src2_l), ws + w.tmpX, B, l.L_in, l.c2, dgl.L_out, Cin, l.c1, step, st);
+        }
+    }
+    // time MLP
+    hipLaunchKernelGGL(time_bwd_cond_kernel, dim3((tb.row + 7) / 8), dim3(256), 0, st, tb);
+    hipLaunchKernelGGL(time_bwd_temb_kernel, dim3(B), dim3(256), 0, st, tb);
+    hipLaunchKernelGGL(time_bwd_l3_kernel, dim3(32 + B), dim3(128), 0, st, tb);
+    hipLaunchKernelGGL(time_bwd_l1_kernel, dim3(128), dim3(32), 0, st, tb);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* clip_grad_norm_ (max_norm > 0) + Adam step on flat vectors; scratch: >= 1032 floats; step: 1-based step count */
+int mpdx_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2, float eps,
+                   int step, float max_norm, float* scratch, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch || n == 0 || step < 1) return fail(MPDX_E_INVALID, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const float* clip = nullptr;
+    if (max_norm > 0.f) {
+        const int nb = (int)std::min<size_t>((n + 255) / 256, 1024);
+        hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, grads, n, scratch + 8);
+        hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)(scratch + 8), nb, max_norm, scratch);
+        clip = scratch;
+    }
+    const float bc1 = 1.0f - (float)pow((double)beta1, step), bc2 = 1.0f - (float)pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, lr,
+                       beta1, beta2, eps, bc1, sqrtf(bc2), clip);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mpdx_ema_update(float* ema, const float* params, size_t n, float beta, void* stream) {
+    if (!ema || !params || n == 0) return fail(MPDX_E_INVALID, "bad argument");
+    hipLaunchKernelGGL(ema_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, ema, params, n, beta);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

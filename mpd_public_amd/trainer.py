@@ -1,0 +1,302 @@
+"""Training step on the GPU - host mirror of mpd/trainer/trainer.py (train :120-320, EMA :67-85, get_num_epochs :16-17,
+save_models_to_disk :20-37) and mpd/losses/gaussian_diffusion_loss.py (GaussianDiffusionLoss :6-28) for the one model family the
+reference trains: GaussianDiffusionModel over a TemporalUnet without context.
+
+What the reference does per step with torch autograd + torch.optim.Adam,
+
+    loss = model.loss(traj_normalized, context, hard_conds);  loss.backward();  clip_grad_norm_;  optimizer.step();  EMA
+
+runs here as hand-written HIP kernels behind libmpdx.so (include/mpdx.h "training step"; kernels mpd_public_amd/csrc/train.hpp):
+the U-Net forward with saved activations, its whole backward pass, the loss gradient, Adam and the EMA.  PyTorch provides the
+device memory: parameters, gradients, Adam moments and the EMA copy are flat fp32 tensors, and the nn.Parameters of the
+TemporalUnet are re-pointed at views of the flat parameter / gradient tensors (FlatParams) - `p.grad` is populated after
+`loss_backward`, so `torch.optim` optimisers passed through `optimizers=` keep working exactly as in the reference.
+
+There is no CPU fallback: every entry point raises if the model is not on an AMD GPU.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import math
+import os
+from math import ceil
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def get_num_epochs(num_train_steps, batch_size, dataset_len):   # trainer.py:16-17
+    return ceil(num_train_steps * batch_size / dataset_len)
+
+
+class FlatParams:
+    """The parameters of a TemporalUnet as ONE flat fp32 tensor in the layout libmpdx differentiates (parameter i of
+    mpdx_unet_param_info at mpdx_train_param_offset(i)), with every nn.Parameter (and its .grad) a view into it."""
+
+    def __init__(self, unet):
+        self.unet = unet
+        lib, h = _lib.load(), unet._handle()
+        dev = next(unet.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("training runs on an AMD GPU only (move the model to 'cuda'); there is no CPU fallback")
+        self.n = int(lib.mpdx_train_flat_floats(h))
+        self.flat = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.slices = {}
+        named = dict(unet.named_parameters())
+        name_p, shape, ndim = C.c_char_p(), (C.c_int32 * 3)(), C.c_int32()
+        off, cnt = C.c_size_t(), C.c_size_t()
+        for i in range(lib.mpdx_unet_num_params(h)):
+            _lib.check(lib.mpdx_unet_param_info(h, i, C.byref(name_p), C.byref(shape), C.byref(ndim)), "param_info")
+            _lib.check(lib.mpdx_train_param_offset(h, i, C.byref(off), C.byref(cnt)), "param_offset")
+            name = name_p.value.decode()
+            p = named[name]
+            if p.numel() != cnt.value:
+                raise RuntimeError(f"{name}: {p.numel()} elements, libmpdx expects {cnt.value}")
+            view = self.flat[off.value:off.value + cnt.value].view(p.shape)
+            view.copy_(p.data.to(torch.float32))
+            p.data = view
+            p.grad = self.grad[off.value:off.value + cnt.value].view(p.shape)
+            self.slices[name] = (off.value, cnt.value)
+        self.packedT = torch.zeros(int(lib.mpdx_train_dgrad_pack_floats(h)), dtype=torch.float32, device=dev)
+
+    def aliased(self) -> bool:
+        base = self.flat.data_ptr()
+        named = dict(self.unet.named_parameters())
+        return all(named[k].data_ptr() == base + 4 * off for k, (off, _) in self.slices.items())
+
+
+def flat_params(unet) -> FlatParams:
+    fp = getattr(unet, "_flat_params", None)
+    if fp is None or not fp.aliased():
+        fp = FlatParams(unet)
+        unet._flat_params = fp
+    return fp
+
+
+class TrainStep:
+    """loss + gradient of GaussianDiffusionModel.loss (diffusion_model_base.py:331-357) and the optimiser step, native."""
+
+    def __init__(self, model):
+        self.model = model
+        self.unet = model.model
+        self.fp = flat_params(self.unet)
+        self.exp_avg = torch.zeros_like(self.fp.flat)
+        self.exp_avg_sq = torch.zeros_like(self.fp.flat)
+        self.scratch = torch.zeros(2048, dtype=torch.float32, device=self.fp.flat.device)
+        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.fp.flat.device)
+        self.step_count = 0
+        self._ws = None
+        self._ws_B = 0
+        half = 16
+        self._freqs = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(device=self.fp.flat.device, dtype=torch.float32)
+
+    def _packed(self):
+        lib, h = _lib.load(), self.unet._handle()
+        u = self.unet
+        if u._packed is None or u._packed.device != self.fp.flat.device:
+            u._packed = torch.zeros(lib.mpdx_unet_packed_floats(h), dtype=torch.float32, device=self.fp.flat.device)
+        return u._packed
+
+    def pack(self):
+        """flat parameters -> the two kernel layouts (after every optimiser step)."""
+        if not self.fp.aliased():
+            raise RuntimeError("the model's parameters no longer alias the flat training vector (was the model moved or re-created?) - "
+                               "build a new TrainStep")
+        lib, h = _lib.load(), self.unet._handle()
+        packed = self._packed()
+        _lib.check(lib.mpdx_train_pack(h, self.fp.flat.data_ptr(), packed.data_ptr(), self.fp.packedT.data_ptr(), _lib.current_stream()),
+                   "mpdx_train_pack")
+        # the inference engine of this TemporalUnet sees the new weights: its pack is current, its time table is not
+        self.unet._stamp = self.unet._param_stamp()
+        self.unet._timetab, self.unet._timetab_T = None, 0
+
+    def loss_backward(self, x_start, hard_conds=None, t=None, noise=None, loss_scale=1.0):
+        """(loss, info) as model.loss(x, None, hard_conds) returns them, with d loss / d parameters left in every p.grad
+        (overwritten, not accumulated - the reference zeroes the gradients before every backward, trainer.py:262-263)."""
+        m = self.model
+        if not x_start.is_cuda:
+            raise RuntimeError("training runs on the GPU (libmpdx); there is no CPU fallback")
+        if m.loss_type not in ("l1", "l2"):
+            raise NotImplementedError(m.loss_type)
+        lib, h = _lib.load(), self.unet._handle()
+        x_start = x_start.to(torch.float32).contiguous()
+        B, H, D = x_start.shape
+        dev = x_start.device
+        if t is None:
+            t = torch.randint(0, m.n_diffusion_steps, (B,), device=dev).long()   # diffusion_model_base.py:356
+        t = t.to(device=dev, dtype=torch.long).reshape(-1).contiguous()
+        if noise is None:
+            noise = m.fill_randn(torch.empty((B, H, D), device=dev, dtype=torch.float32))
+        noise = noise.to(torch.float32).contiguous()
+        hs, hg = m._hard_tables(hard_conds, B, H, D, dev)
+        if self._ws is None or self._ws_B < B:
+            self._ws = torch.empty(int(lib.mpdx_train_workspace_floats(h, B)), dtype=torch.float32, device=dev)
+            self._ws_B = B
+        self.pack()
+        _lib.check(lib.mpdx_train_loss_backward(
+            h, self.fp.flat.data_ptr(), self._packed().data_ptr(), self.fp.packedT.data_ptr(), self.fp.grad.data_ptr(), x_start.data_ptr(),
+            noise.data_ptr(), t.data_ptr(), m.sqrt_alphas_cumprod.data_ptr(), m.sqrt_one_minus_alphas_cumprod.data_ptr(),
+            self._freqs.data_ptr(), hs.data_ptr() if hs is not None else None, hg.data_ptr() if hg is not None else None, None,
+            int(m.n_diffusion_steps), B, 1 if m.predict_epsilon else 0, 1 if m.loss_type == "l1" else 0, float(loss_scale),
+            self.loss_buf.data_ptr(), self._ws.data_ptr(), _lib.current_stream()), "mpdx_train_loss_backward")
+        return self.loss_buf[0].clone(), {}
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, max_norm=None):
+        """clip_grad_norm_(max_norm) if given, then one torch.optim.Adam step (defaults as trainer.py:140); returns the
+        0-dim tensor holding the gradient norm before clipping (or None)."""
+        lib = _lib.load()
+        self.step_count += 1
+        mn = float(max_norm) if max_norm else 0.0
+        _lib.check(lib.mpdx_adam_step(self.fp.flat.data_ptr(), self.fp.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                      self.fp.n, float(lr), float(betas[0]), float(betas[1]), float(eps), self.step_count, mn,
+                                      self.scratch.data_ptr(), _lib.current_stream()), "mpdx_adam_step")
+        return self.scratch[0] if mn > 0 else None
+
+
+class EMA:
+    """trainer.py:67-85.  update_model_average takes two models like the reference; when both are flat (FlatParams) it is
+    one kernel over the flat vectors."""
+
+    def __init__(self, beta=0.995):
+        self.beta = beta
+
+    def update_model_average(self, ema_model, current_model):
+        eu, cu = getattr(ema_model, "model", ema_model), getattr(current_model, "model", current_model)
+        ef, cf = flat_params(eu), flat_params(cu)
+        _lib.check(_lib.load().mpdx_ema_update(ef.flat.data_ptr(), cf.flat.data_ptr(), ef.n, float(self.beta), _lib.current_stream()),
+                   "mpdx_ema_update")
+        eu._stamp = None   # the EMA model's inference pack is stale
+
+    def update_average(self, old, new):
+        if old is None:
+            return new
+        return old * self.beta + (1 - self.beta) * new
+
+
+class GaussianDiffusionLoss:
+    """mpd/losses/gaussian_diffusion_loss.py:6-28 - forward value (no autograd history), used for validation."""
+
+    @staticmethod
+    def loss_fn(diffusion_model, input_dict, dataset, step=None):
+        traj_normalized = input_dict[f"{dataset.field_key_traj}_normalized"]
+        hard_conds = input_dict.get("hard_conds", {})
+        loss, info = diffusion_model.loss(traj_normalized, None, hard_conds)
+        return {"diffusion_loss": loss}, info
+
+
+def save_model_to_disk(model, epoch, total_steps, checkpoints_dir=None, prefix="model_"):   # trainer.py:29-37
+    if hasattr(model, "is_frozen") and model.is_frozen:
+        return
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    torch.save(sd, os.path.join(checkpoints_dir, f"{prefix}current_state_dict.pth"))
+    torch.save(sd, os.path.join(checkpoints_dir, f"{prefix}epoch_{epoch:04d}_iter_{total_steps:06d}_state_dict.pth"))
+
+
+def save_models_to_disk(models_prefix_l, epoch, total_steps, checkpoints_dir=None):   # trainer.py:20-26
+    for model, prefix in models_prefix_l:
+        if model is not None:
+            save_model_to_disk(model, epoch, total_steps, checkpoints_dir, prefix=f"{prefix}_")
+
+
+def save_losses_to_disk(train_losses, val_losses, checkpoints_dir=None):   # trainer.py:40-42
+    np.save(os.path.join(checkpoints_dir, "train_losses.npy"), np.array(train_losses, dtype=object), allow_pickle=True)
+    np.save(os.path.join(checkpoints_dir, "val_losses.npy"), np.array(val_losses, dtype=object), allow_pickle=True)
+
+
+def train(model=None, train_dataloader=None, epochs=None, lr=None, steps_til_summary=None, model_dir=None, loss_fn=None,
+          train_subset=None, summary_fn=None, steps_til_checkpoint=None, val_dataloader=None, val_subset=None, clip_grad=False,
+          clip_grad_max_norm=1.0, val_loss_fn=None, optimizers=None, steps_per_validation=10, max_steps=None, use_ema: bool = True,
+          ema_decay: float = 0.995, step_start_ema: int = 1000, update_ema_every: int = 10, use_amp=False, early_stopper_patience=-1,
+          debug=False, tensor_args=None, **kwargs):
+    """trainer.py:120-320 with the same arguments.  Per step: loss + gradients (TrainStep.loss_backward), optional
+    clip_grad_norm_, Adam (native unless `optimizers` - torch optimisers over model.parameters() - are given), EMA every
+    `update_ema_every` steps (reset to the model before `step_start_ema`).  Differences, all outside the compute path: no wandb
+    (not installed here), no AMP (`use_amp=True` raises: the kernels are fp32 like the reference's default), checkpoints hold
+    state dicts only.  Returns (model, ema_model, train_losses)."""
+    if use_amp:
+        raise NotImplementedError("use_amp=True: the training kernels are fp32 (the reference's default is use_amp=False)")
+    if model is None or train_dataloader is None or epochs is None:
+        raise ValueError("model, train_dataloader and epochs are required")
+    field = train_subset.dataset.field_key_traj if train_subset is not None else "traj"
+    ema_model = None
+    if use_ema:
+        ema = EMA(beta=ema_decay)
+        ema_model = copy.deepcopy(model)
+    step_fn = TrainStep(model)
+    if val_dataloader is not None and val_loss_fn is None:
+        raise AssertionError("If validation set is passed, have to pass a validation loss_fn!")
+    checkpoints_dir = None
+    if model_dir is not None:
+        os.makedirs(model_dir, exist_ok=True)
+        os.makedirs(os.path.join(model_dir, "summaries"), exist_ok=True)
+        checkpoints_dir = os.path.join(model_dir, "checkpoints")
+        os.makedirs(checkpoints_dir, exist_ok=True)
+        save_models_to_disk([(model, "model"), (ema_model, "ema_model")], 0, 0, checkpoints_dir)
+    max_norm = None
+    if clip_grad:
+        max_norm = clip_grad_max_norm if isinstance(clip_grad, bool) else clip_grad
+    train_steps_current = 0
+    train_losses_l, validation_losses_l = [], []
+    dev = next(model.parameters()).device
+    stop = False
+
+    def ema_update():
+        if train_steps_current < step_start_ema:
+            flat_params(ema_model.model).flat.copy_(flat_params(model.model).flat)   # ema_model.load_state_dict(model.state_dict())
+            ema_model.model._stamp = None
+        ema.update_model_average(ema_model, model)
+
+    for epoch in range(epochs):
+        model.train()
+        for step, batch in enumerate(train_dataloader):
+            x = batch[f"{field}_normalized"].to(dev)
+            hard_conds = {k: v.to(dev) for k, v in batch.get("hard_conds", {}).items()}
+            loss, info = step_fn.loss_backward(x, hard_conds)
+            if steps_til_summary and train_steps_current % steps_til_summary == 0:
+                lv = float(loss)   # the only host synchronisation of a step, on summary steps
+                train_losses_l.append((train_steps_current, {"diffusion_loss": lv}))
+                print(f"train_steps_current: {train_steps_current}  diffusion_loss {lv:.6f}")
+                if summary_fn is not None:
+                    with torch.no_grad():
+                        summary_fn(train_steps_current, ema_model if ema_model is not None else model, batch_dict=batch, loss_info=info,
+                                   datasubset=train_subset, prefix="TRAINING ", debug=debug, tensor_args=tensor_args)
+                if val_dataloader is not None:
+                    vals = []
+                    for step_val, vb in enumerate(val_dataloader):
+                        vb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in vb.items()}
+                        if "hard_conds" in vb:
+                            vb["hard_conds"] = {k: v.to(dev) for k, v in vb["hard_conds"].items()}
+                        vl, _ = val_loss_fn(model, vb, val_subset.dataset, step=train_steps_current)
+                        vals.append(float(sum(v.mean() for v in vl.values())))
+                        if step_val == steps_per_validation:
+                            break
+                    validation_losses_l.append((train_steps_current, {"VALIDATION diffusion_loss": float(np.mean(vals))}))
+            if optimizers is None:
+                step_fn.adam_step(lr, max_norm=max_norm)
+            else:   # torch optimisers over the same (aliased) parameters, as the reference runs them
+                if max_norm is not None:
+                    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)
+                for opt in optimizers:
+                    opt.step()
+            if ema_model is not None and train_steps_current % update_ema_every == 0:
+                ema_update()
+            train_steps_current += 1
+            if checkpoints_dir is not None and steps_til_checkpoint is not None and train_steps_current % steps_til_checkpoint == 0:
+                step_fn.pack()
+                save_models_to_disk([(model, "model"), (ema_model, "ema_model")], epoch, train_steps_current, checkpoints_dir)
+                save_losses_to_disk(train_losses_l, validation_losses_l, checkpoints_dir)
+            if stop or (max_steps is not None and train_steps_current == max_steps):
+                break
+        if max_steps is not None and train_steps_current == max_steps:
+            break
+    if ema_model is not None:
+        ema_update()
+    step_fn.pack()
+    if checkpoints_dir is not None:
+        save_models_to_disk([(model, "model"), (ema_model, "ema_model")], epoch, train_steps_current, checkpoints_dir)
+        save_losses_to_disk(train_losses_l, validation_losses_l, checkpoints_dir)
+    return model, ema_model, train_losses_l

@@ -181,3 +181,46 @@ def test_scaled_and_ddim_guided_chains_match_reference(golden_dir):
     chain = diffusion.ddim_sample(sd, hc, x_T, T, guide=GuideManager(nrm, toy_cost), n_guide_steps=3, t_start_guide=13).numpy()
     ref = g["ddim_guided_chain_opt0"]
     np.testing.assert_allclose(chain, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("D,opt", [(4, 1), (14, 0)])
+def test_training_step_vs_reference_golden(golden_dir, D, opt):
+    """oracle/train.py against the REAL reference's training iteration (tests/golden/make_golden.py --only train: p_losses ->
+    backward -> clip_grad_norm_(1.0) -> Adam(1e-4), twice; trainer.py:186-283): loss, gradient of every parameter (norms; full
+    small tensors; samples of large ones), total norm, parameter change after two steps, EMA."""
+    from oracle import train as otrain
+    g = load_npz(golden_dir / "train.npz")
+    T, B = 25, 6
+    tts = [torch.tensor([3, 24, 0, 12, 12, 7]), torch.tensor([1, 5, 20, 9, 0, 17])]
+    x0, noise = t(f"loss_x0_D{D}", (B, 64, D), "uniform", 0.8), t(f"loss_noise_D{D}", (B, 64, D))
+    hc = {0: t(f"loss_hc0_D{D}", (B, D), "uniform", 0.7), 63: t(f"loss_hc1_D{D}", (B, D), "uniform", 0.7)}
+    names = [str(k) for k in g[f"D{D}_names"]]
+    sd0 = synth_sd(D, opt)
+    assert set(names) == set(sd0)
+    params = {k: v.clone() for k, v in sd0.items()}
+    state = {}
+    for it, tt in enumerate(tts):
+        loss, grads = otrain.loss_and_grads(params, x0, tt, hc, noise, T)
+        assert abs(float(loss) - float(g[f"D{D}_loss{it}"])) < 2e-6 * max(1.0, abs(float(loss)))
+        if it == 0:
+            gn = np.array([float(grads[k].norm()) for k in names])
+            np.testing.assert_allclose(gn, g[f"D{D}_grad_norms"], rtol=2e-4, atol=1e-7)
+            for k in names:
+                if f"D{D}_grad::{k}" in g:
+                    ref = g[f"D{D}_grad::{k}"]
+                    np.testing.assert_allclose(grads[k].numpy(), ref, rtol=0, atol=2e-4 * max(np.abs(ref).max(), 1e-6))
+                else:
+                    ref = g[f"D{D}_gradsample::{k}"]
+                    got = grads[k].reshape(-1)[::max(1, grads[k].numel() // 256)][:256].numpy()
+                    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4 * max(np.abs(ref).max(), 1e-6))
+        total, clipped = otrain.clip_grad_norm(grads, 1.0)
+        assert abs(float(total) - float(g[f"D{D}_total_norm{it}"])) < 2e-4 * float(total)
+        params = otrain.adam_step(params, clipped, state, 1e-4)
+    dn = np.array([float((params[k] - sd0[k]).norm()) for k in names])
+    np.testing.assert_allclose(dn, g[f"D{D}_delta_norms"], rtol=2e-3, atol=1e-7)
+    for k in names:
+        if f"D{D}_delta::{k}" in g:
+            np.testing.assert_allclose((params[k] - sd0[k]).numpy(), g[f"D{D}_delta::{k}"], rtol=0, atol=2e-6)   # steps of ~lr = 1e-4 each
+    k0 = "final_conv.1.bias"
+    ema = otrain.ema_update({k0: sd0[k0]}, {k0: params[k0]}, 0.995)[k0]
+    np.testing.assert_allclose(ema.numpy(), g[f"D{D}_ema::{k0}"], rtol=0, atol=1e-7)

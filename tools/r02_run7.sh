@@ -1,14 +1,13 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02j; mkdir -p $O
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | grep -v "^$" | tail -2
-for n in default RINGFIRST PF3 PF4 PF6; do
-  L=mpd_public_amd/libmpdx_$n.so; [ $n = default ] && L=mpd_public_amd/libmpdx.so
-  MPDX_LIB=$GRAFT_REPO_ROOT/$L MPDX_BENCH_TABLE=1 timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/bench_$n.json 2> $O/bench_$n.err
-  python -c "import json;d=json.loads(open('$O/bench_$n.json').read().strip().splitlines()[-1]);print('$n cfg2 ms/plan', d['ms_per_step'])"; grep "^#" $O/bench_$n.err | sed -n 2,4p
-done
-for n in default PF4; do
-  L=mpd_public_amd/libmpdx_$n.so; [ $n = default ] && L=mpd_public_amd/libmpdx.so
-  MPDX_LIB=$GRAFT_REPO_ROOT/$L timeout 600 python bench.py --config cfg5 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-roofline > $O/bench_cfg5_$n.json 2>/dev/null
-  python -c "import json;d=json.loads(open('$O/bench_cfg5_$n.json').read().strip().splitlines()[-1]);print('cfg5 $n ms/plan', d['ms_per_step'])"
-done
+O=gpurun_out/r02p; mkdir -p $O
+(cd tools/micro && timeout 120 ./kp_plain > ../../$O/kp_plain.txt 2>&1; timeout 120 ./kp_preload > ../../$O/kp_preload.txt 2>&1)
+echo "--- plain"; cat $O/kp_plain.txt; echo "--- preload"; cat $O/kp_preload.txt
+HIP_FORCE_DEV_KERNARG=1 timeout 120 tools/micro/kp_plain | head -4
+HIP_FORCE_DEV_KERNARG=0 timeout 120 tools/micro/kp_plain | head -4
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_guide.py -x -q 2>&1 | grep -v "^$" | tail -5 | tee $O/pytest_parity.txt
+timeout 300 python tools/fused_trace.py 100 2>&1 | grep -v amdgpu > $O/fused_trace.txt; tail -8 $O/fused_trace.txt
+MPDX_BENCH_TABLE=1 timeout 900 python bench.py --no-cpu-baseline --no-extras > $O/bench_cfg2.json 2> $O/bench_cfg2.err; tail -1 $O/bench_cfg2.json | cut -c1-200; grep "^#" $O/bench_cfg2.err | head -3
+HIP_FORCE_DEV_KERNARG=1 timeout 900 python bench.py --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | cut -c1-200
+HIP_FORCE_DEV_KERNARG=0 timeout 900 python bench.py --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | cut -c1-200
+timeout 900 python bench.py --config cfg3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | cut -c1-200
