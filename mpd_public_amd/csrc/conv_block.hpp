@@ -60,6 +60,10 @@ struct ConvArgs {
     // and an optional second destination for the GroupNorm INPUT (conv + bias), which the backward pass differentiates through
     int tb_stride;
     float* pre;          // [B][L_out][C_out] or null
+    // EPI_BIAS only (the input-gradient convolutions of train_host.hpp): channels >= c_split go to dst2 (a channel concat is split
+    // back into its two sources; either destination may be null = not needed), and with `accum` the result is ADDED to the destination
+    float* dst2;
+    int c_split, accum;
 };
 
 // wave64 all-reduce (sum) with DPP row operations + 4 readlanes instead of a 6-step ds_bpermute butterfly:
@@ -480,7 +484,17 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
 #pragma unroll
             for (int k = 1; k < WK; ++k) v += smem4[ri + k * NT * MTP4];
             v += *(const f32x4*)(a.bias + co);
-            if (b < a.B) *(f32x4*)(a.dst + ((size_t)b * L_out + l) * a.C_out + co) = v;
+            float* d = a.dst;
+            int ld = a.C_out, cc = co;
+            if (a.c_split > 0) {
+                if (co >= a.c_split) { d = a.dst2; cc = co - a.c_split; ld = a.C_out - a.c_split; }
+                else ld = a.c_split;
+            }
+            if (b < a.B && d) {
+                f32x4* q = (f32x4*)(d + ((size_t)b * L_out + l) * ld + cc);
+                if (a.accum) v += *q;
+                *q = v;
+            }
         }
     }
     CB_STAMP();  // 6: epilogue done (wave 0)

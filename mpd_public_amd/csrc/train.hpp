@@ -59,6 +59,7 @@ struct GnBwdArgs {
     float* pb;
     float* pbias;
     float* dT;        // or null
+    float* gres;      // or null: gradient buffer of the block's residual branch, += gy (the residual add passes it through)
     int dT_stride;
     int B, L, C, gs, lg_gs, n_groups;
 };
@@ -75,6 +76,10 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnBwdArgs a) {
     float u[EPL], gy[EPL], ga[EPL], be[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) { u[e] = a.pre[o + e]; gy[e] = a.gy[o + e]; ga[e] = a.gamma[c + e]; be[e] = a.beta[c + e]; }
+    if (a.gres) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) a.gres[o + e] += gy[e];
+    }
     const float inv_n = 1.0f / (float)(64 * EPL);
     float s = 0.f;
 #pragma unroll
@@ -123,14 +128,22 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnBwdArgs a) {
     }
 }
 
-// out_k[c] = sum_b part_k[b][c]   for up to 4 arrays (k = blockIdx.y); fixed summation order
+// out_k[c] = sum_b part_k[b][c]   for up to 4 arrays (k = blockIdx.y); fixed summation order (4 row phases, then ((0+1)+(2+3)))
 struct ColsumArgs { const float* part[4]; float* out[4]; int B, C; };
-__global__ __launch_bounds__(64) void colsum_kernel(const ColsumArgs a) {
-    const int c = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
-    if (c >= a.C || !a.part[k]) return;
+__global__ __launch_bounds__(256) void colsum_kernel(const ColsumArgs a) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx, k = blockIdx.y;
+    if (!a.part[k]) return;
     float s = 0.f;
-    for (int b = 0; b < a.B; ++b) s += a.part[k][(size_t)b * a.C + c];
-    a.out[k][c] = s;
+    if (c < a.C) {
+        const float* p = a.part[k] + c;
+#pragma unroll 8
+        for (int b = ry; b < a.B; b += 4) s += p[(size_t)b * a.C];
+    }
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < a.C) a.out[k][c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
 
 // channel sums of a dense [n_rows][C] tensor (bias gradient of the convolutions without GroupNorm): two passes through `part`
@@ -138,6 +151,7 @@ __global__ __launch_bounds__(256) void rowsum_part_kernel(const float* __restric
     const int r0 = blockIdx.x * rows_per_block, r1 = min(n_rows, r0 + rows_per_block);
     for (int c = threadIdx.x; c < C; c += 256) {
         float s = 0.f;
+#pragma unroll 8
         for (int r = r0; r < r1; ++r) s += x[(size_t)r * C + c];
         part[(size_t)blockIdx.x * C + c] = s;
     }
@@ -242,6 +256,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const size_t per = (size_t)M * N * KS;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
         float s = 0.f;
+#pragma unroll 8
         for (int z = 0; z < S; ++z) s += part[(size_t)z * per + i];
         const int k = (int)(i % KS);
         const size_t mn = i / KS;
@@ -393,18 +408,18 @@ __global__ __launch_bounds__(256) void time_bwd_cond_kernel(const TimeBwdArgs a)
 }
 
 // gradient wrt temb:  dtm[b][e] = mish'(temb[b][e]) * sum_rows dT[b][row] * W_row[e]        one block per sample
-__global__ __launch_bounds__(256) void time_bwd_temb_kernel(const TimeBwdArgs a) {
-    __shared__ float red[8][32];
+__global__ __launch_bounds__(1024) void time_bwd_temb_kernel(const TimeBwdArgs a) {
+    __shared__ float red[32][32];
     const int b = blockIdx.x, e = threadIdx.x & 31, part = threadIdx.x >> 5;
     float s = 0.f;
     for (int blk = 0; blk < a.nblk; ++blk)
-        for (int c = part; c < a.cout[blk]; c += 8)
+        for (int c = part; c < a.cout[blk]; c += 32)
             s = fmaf(a.dT[(size_t)b * a.row + a.toff[blk] + c], a.flat[a.woff[blk] + (size_t)c * 32 + e], s);
     red[part][e] = s;
     __syncthreads();
     if (part == 0) {
         float t = 0.f;
-        for (int p = 0; p < 8; ++p) t += red[p][e];
+        for (int p = 0; p < 32; ++p) t += red[p][e];
         a.dtm[(size_t)b * 32 + e] = t * mish_grad(a.temb[(size_t)b * 32 + e]);
     }
 }

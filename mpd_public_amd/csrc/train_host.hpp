@@ -163,14 +163,14 @@ static int launch_wgrad(const float* A, int LA, int lda, int a_off, int M, const
 
 // channel sums of a dense [rows][C] tensor -> out[C]
 static void launch_rowsum(const float* x, size_t rows, int C, float* part, float* out, hipStream_t st) {
-    const int nb = (int)std::min<size_t>(256, rows);
+    const int nb = (int)std::min<size_t>(64, rows);
     const int rpb = (int)((rows + nb - 1) / nb);
     const int nblk = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(rowsum_part_kernel, dim3(nblk), dim3(256), 0, st, x, part, (int)rows, C, rpb);
     ColsumArgs c;
     memset(&c, 0, sizeof(c));
     c.part[0] = part; c.out[0] = out; c.B = nblk; c.C = C;
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, 1), dim3(64), 0, st, c);
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, 1), dim3(256), 0, st, c);
 }
 
 static void launch_acc(float* dst, const float* src, int B, int L, int Cd, int Ls, int Cs, int c_off, int step, hipStream_t st) {
@@ -329,9 +329,9 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         float* gy = grd(i);
         const float* dy = gy;   // gradient wrt the convolution output (after the GroupNorm/Mish backward for Conv1dBlocks)
         if (l.epi == EPI_GN_MISH) {
-            if (t.res_l >= 0) launch_acc(grd(t.res_l), gy, B, l.L_out, l.cout, l.L_out, l.cout, 0, 1, st);
             GnBwdArgs g;
             memset(&g, 0, sizeof(g));
+            if (t.res_l >= 0) g.gres = grd(t.res_l);
             g.gy = gy; g.pre = pre(i); g.gamma = flat + u->params[l.gamma].foff; g.beta = flat + u->params[l.beta].foff;
             g.du = ws + w.dU;
             g.pg = ws + w.pvec; g.pb = g.pg + (size_t)B * 512; g.pbias = g.pb + (size_t)B * 512;
@@ -349,7 +349,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             cs.part[1] = g.pb; cs.out[1] = gflat(l.beta);
             cs.part[2] = g.pbias; cs.out[2] = gflat(l.b);
             cs.B = B; cs.C = l.cout;
-            hipLaunchKernelGGL(colsum_kernel, dim3((l.cout + 63) / 64, 3), dim3(64), 0, st, cs);
+            hipLaunchKernelGGL(colsum_kernel, dim3((l.cout + 63) / 64, 3), dim3(256), 0, st, cs);
             dy = g.du;
         } else {
             launch_rowsum(gy, (size_t)B * l.L_out, l.cout, rpart, gflat(l.b), st);
@@ -379,16 +379,21 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             a.src1 = din;
             a.wp = packedT + t.dgrad_woff;
             a.bias = ws + w.zeros;
-            a.dst = ws + w.tmpX;
-            if (int rc = launch_layer(dgl, a, B, st)) return rc;
-            const int step = l.mode == CONV_UPT ? 2 : 1;
-            if (t.src1_l >= 0) launch_acc(grd(t.src1_l), ws + w.tmpX, B, l.L_in, l.c1, dgl.L_out, Cin, 0, step, st);
-            if (t.src2_l >= 0) launch_acc(grd(t.src2_l), ws + w.tmpX, B, l.L_in, l.c2, dgl.L_out, Cin, l.c1, step, st);
+            if (l.mode == CONV_UPT) {   // full-resolution result, every second position is the gradient
+                a.dst = ws + w.tmpX;
+                if (int rc = launch_layer(dgl, a, B, st)) return rc;
+                if (t.src1_l >= 0) launch_acc(grd(t.src1_l), ws + w.tmpX, B, l.L_in, l.c1, dgl.L_out, Cin, 0, 2, st);
+            } else {   // added straight into the gradient buffer(s) of the layer's input(s)
+                a.accum = 1;
+                a.dst = t.src1_l >= 0 ? grd(t.src1_l) : nullptr;
+                if (l.c2 > 0) { a.c_split = l.c1; a.dst2 = t.src2_l >= 0 ? grd(t.src2_l) : nullptr; }
+                if (int rc = launch_layer(dgl, a, B, st)) return rc;
+            }
         }
     }
     // time MLP
     hipLaunchKernelGGL(time_bwd_cond_kernel, dim3((tb.row + 7) / 8), dim3(256), 0, st, tb);
-    hipLaunchKernelGGL(time_bwd_temb_kernel, dim3(B), dim3(256), 0, st, tb);
+    hipLaunchKernelGGL(time_bwd_temb_kernel, dim3(B), dim3(1024), 0, st, tb);
     hipLaunchKernelGGL(time_bwd_l3_kernel, dim3(32 + B), dim3(128), 0, st, tb);
     hipLaunchKernelGGL(time_bwd_l1_kernel, dim3(128), dim3(32), 0, st, tb);
     HIP_TRY(hipGetLastError());

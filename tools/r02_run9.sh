@@ -1,10 +1,11 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02l; mkdir -p $O
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | grep -v "^$" | tail -2
-for n in default NOPF; do
-  L=mpd_public_amd/libmpdx_$n.so; [ $n = default ] && L=mpd_public_amd/libmpdx.so
-  MPDX_LIB=$GRAFT_REPO_ROOT/$L MPDX_BENCH_TABLE=1 timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/bench_$n.json 2> $O/bench_$n.err
-  python -c "import json;d=json.loads(open('$O/bench_$n.json').read().strip().splitlines()[-1]);print('$n cfg2 ms/plan', d['ms_per_step'])"; grep "^#" $O/bench_$n.err | sed -n 1,3p
-done
-python tools/fused_trace.py 100 2>&1 | grep -v amdgpu > $O/fused_trace.txt; grep "segment\|op0 \|op1 " $O/fused_trace.txt
+O=gpurun_out/r02r; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_train -- python -c "
+import sys; sys.path.insert(0, '$GRAFT_REPO_ROOT')
+import bench
+print(bench.training_leg(steps=20))
+" > $GRAFT_REPO_ROOT/$O/prof_train.log 2>&1
+cd $GRAFT_REPO_ROOT
+f=$(find $O/prof_train -name "*kernel_stats.csv" | head -1); cp "$f" $O/train_kernel_stats.csv; head -45 $O/train_kernel_stats.csv | cut -c1-220
