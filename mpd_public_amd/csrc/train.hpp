@@ -146,6 +146,32 @@ __global__ __launch_bounds__(256) void colsum_kernel(const ColsumArgs a) {
     if (ry == 0 && c < a.C) a.out[k][c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
 
+// every column sum of a backward pass in ONE launch (blockIdx.y = entry): out[c] = sum_{r < rows} part[r][c]
+struct ColsumAllArgs {
+    const float* ws;
+    float* grad;
+    int n;
+    struct E { unsigned long long part, out; int rows, C; } e[120];
+};
+__global__ __launch_bounds__(256) void colsum_all_kernel(const ColsumAllArgs a) {
+    __shared__ float red[4][64];
+    const ColsumAllArgs::E e = a.e[blockIdx.y];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    for (int c0 = blockIdx.x * 64; c0 < e.C; c0 += gridDim.x * 64) {
+        const int c = c0 + cx;
+        float s = 0.f;
+        if (c < e.C) {
+            const float* p = a.ws + e.part + c;
+#pragma unroll 8
+            for (int b = ry; b < e.rows; b += 4) s += p[(size_t)b * e.C];
+        }
+        __syncthreads();
+        red[ry][cx] = s;
+        __syncthreads();
+        if (ry == 0 && c < e.C) a.grad[e.out + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+    }
+}
+
 // channel sums of a dense [n_rows][C] tensor (bias gradient of the convolutions without GroupNorm): two passes through `part`
 __global__ __launch_bounds__(256) void rowsum_part_kernel(const float* __restrict__ x, float* __restrict__ part, int n_rows, int C, int rows_per_block) {
     const int r0 = blockIdx.x * rows_per_block, r1 = min(n_rows, r0 + rows_per_block);
@@ -262,6 +288,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const size_t mn = i / KS;
         const int n = (int)(mn % N), m = (int)(mn / N);
         g[((size_t)m * n_tot + n_off + n) * KS + k] = s;
+    }
+}
+
+// every split-batch weight-gradient reduction of a backward pass in ONE launch (blockIdx.y = entry)
+struct ReduceAllArgs {
+    const float* ws;
+    float* grad;
+    int n;
+    struct E { unsigned long long part, g; int S, M, N, KS, n_tot, n_off; } e[96];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const ReduceAllArgs a) {
+    const ReduceAllArgs::E e = a.e[blockIdx.y];
+    const float* part = a.ws + e.part;
+    float* g = a.grad + e.g;
+    const size_t per = (size_t)e.M * e.N * e.KS;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int z = 0; z < e.S; ++z) s += part[(size_t)z * per + i];
+        const int k = (int)(i % e.KS);
+        const size_t mn = i / e.KS;
+        const int n = (int)(mn % e.N), m = (int)(mn / e.N);
+        g[((size_t)m * e.n_tot + e.n_off + n) * e.KS + k] = s;
     }
 }
 

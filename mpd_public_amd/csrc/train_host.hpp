@@ -74,6 +74,9 @@ struct TrainWs {
     size_t xn, eps, dE, out0, pre0, grad0, tmpX, dU, zst, pvec, wpart, rpart, emb, h1, temb, tb, dT, dtm, dh1, zeros, norm, total;
     size_t slotB;          // floats of one activation slot for the batch
     size_t wpart_floats;
+    // deferred reductions (one launch each at the end of the backward pass): every layer keeps its own partial sums
+    bool deferred;
+    size_t wparts, pvecs;  // areas; carved up in launch order by the backward pass
 };
 static size_t wgrad_splits(int M, int N, int B) {
     const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
@@ -106,6 +109,24 @@ static TrainWs train_ws(const mpdx_unet* u, int B) {
     wp = std::max(wp, wgrad_splits(D, u->cfg.unet_input_dim, B) * D * (size_t)u->cfg.unet_input_dim);
     w.wpart_floats = wp;
     w.wpart = take(wp);
+    {   // total partial-sum storage if no layer re-uses another's: deferred mode while it stays below 256 MB
+        size_t tot = 0, pv = 0;
+        for (const Layer& l : u->layers) {
+            const int KS = l.ks;
+            if (l.mode == CONV_UPT) tot += wgrad_splits(l.c1, l.cout, B) * l.c1 * l.cout * (size_t)KS;
+            else {
+                tot += wgrad_splits(l.cout, l.c1, B) * l.cout * l.c1 * (size_t)KS;
+                if (l.c2 > 0) tot += wgrad_splits(l.cout, l.c2, B) * l.cout * l.c2 * (size_t)KS;
+            }
+            pv += (l.epi == EPI_GN_MISH ? (size_t)3 * B : (size_t)64) * l.cout;
+        }
+        tot += wgrad_splits(D, u->cfg.unet_input_dim, B) * D * (size_t)u->cfg.unet_input_dim;
+        pv += (size_t)64 * D;
+        static const bool off = getenv("MPDX_TRAIN_DEFERRED") && atoi(getenv("MPDX_TRAIN_DEFERRED")) == 0;
+        w.deferred = !off && tot <= ((size_t)64 << 20);
+        w.wparts = take(w.deferred ? tot : 4);
+        w.pvecs = take(w.deferred ? pv : 4);
+    }
     w.rpart = take((size_t)256 * 512);
     w.emb = take((size_t)B * 32); w.h1 = take((size_t)B * 128); w.temb = take((size_t)B * 32);
     w.tb = take((size_t)B * u->tt_row); w.dT = take((size_t)B * u->tt_row);
@@ -137,8 +158,25 @@ static int fill_geom(const Layer& l, int B, ConvArgs& a) {
     return 0;
 }
 
+// deferred reductions of one backward pass
+struct Deferred {
+    bool on = false;
+    float* ws = nullptr;
+    float* grads = nullptr;
+    size_t wcur = 0, pcur = 0;   // next free float in the partial areas (offsets from ws)
+    ReduceAllArgs red;
+    ColsumAllArgs col;
+};
+
 static int launch_wgrad(const float* A, int LA, int lda, int a_off, int M, const float* Bm, int LB, int ldb, int b_off, int N, int sb, int ob, int KS,
-                        int B, float* part, float* g, int n_tot, int n_off, hipStream_t st) {
+                        int B, float* part, float* g, int n_tot, int n_off, hipStream_t st, Deferred* df = nullptr) {
+    if (df && df->on && df->red.n < 96) {   // this layer's partial sums get their own storage; reduced at the end of the pass
+        const size_t S0 = wgrad_splits(M, N, B);
+        part = df->ws + df->wcur;
+        auto& e = df->red.e[df->red.n++];
+        e.part = df->wcur; e.g = (unsigned long long)(g - df->grads); e.S = (int)S0; e.M = M; e.N = N; e.KS = KS; e.n_tot = n_tot; e.n_off = n_off;
+        df->wcur += S0 * M * N * (size_t)KS;
+    } else df = nullptr;
     WgradArgs a;
     a.A = A; a.Bm = Bm; a.part = part;
     a.LA = LA; a.lda = lda; a.a_off = a_off; a.M = M;
@@ -156,16 +194,25 @@ static int launch_wgrad(const float* A, int LA, int lda, int a_off, int M, const
         case 5: hipLaunchKernelGGL(wgrad_kernel<5>, grid, dim3(256), lds, st, a); break;
         default: return fail(MPDX_E_INVALID, "wgrad: %d taps", KS);
     }
+    if (df) return 0;
     const size_t per = (size_t)M * N * KS;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((per + 255) / 256, 1024)), dim3(256), 0, st, part, g, S, M, N, KS, n_tot, n_off);
     return 0;
 }
 
 // channel sums of a dense [rows][C] tensor -> out[C]
-static void launch_rowsum(const float* x, size_t rows, int C, float* part, float* out, hipStream_t st) {
+static void launch_rowsum(const float* x, size_t rows, int C, float* part, float* out, hipStream_t st, Deferred* df = nullptr) {
     const int nb = (int)std::min<size_t>(64, rows);
     const int rpb = (int)((rows + nb - 1) / nb);
     const int nblk = (int)((rows + rpb - 1) / rpb);
+    if (df && df->on && df->col.n < 120) {
+        part = df->ws + df->pcur;
+        auto& e = df->col.e[df->col.n++];
+        e.part = df->pcur; e.out = (unsigned long long)(out - df->grads); e.rows = nblk; e.C = C;
+        df->pcur += (size_t)64 * C;
+        hipLaunchKernelGGL(rowsum_part_kernel, dim3(nblk), dim3(256), 0, st, x, part, (int)rows, C, rpb);
+        return;
+    }
     hipLaunchKernelGGL(rowsum_part_kernel, dim3(nblk), dim3(256), 0, st, x, part, (int)rows, C, rpb);
     ColsumArgs c;
     memset(&c, 0, sizeof(c));
@@ -313,14 +360,18 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     // ---- backward
     float* const part = ws + w.wpart;
     float* const rpart = ws + w.rpart;
+    Deferred df;
+    df.on = w.deferred; df.ws = ws; df.grads = grads_flat; df.wcur = w.wparts; df.pcur = w.pvecs;
+    df.red.ws = ws; df.red.grad = grads_flat; df.red.n = 0;
+    df.col.ws = ws; df.col.grad = grads_flat; df.col.n = 0;
     {   // final_conv[1]
         const int C = c.unet_input_dim;
         const int wi = u->pidx.at("final_conv.1.weight"), bi = u->pidx.at("final_conv.1.bias");
         const size_t rows = (size_t)B * H;
         hipLaunchKernelGGL(final_dgrad_kernel, dim3((unsigned)std::min<size_t>((rows * C + 255) / 256, 2048)), dim3(256), 0, st, (const float*)dE,
                            flat + u->params[wi].foff, grd(n - 1), rows, D, C);
-        if (int rc = launch_wgrad(dE, H, D, 0, D, out(n - 1), H, C, 0, C, 1, 0, 1, B, part, gflat(wi), C, 0, st)) return rc;
-        launch_rowsum(dE, rows, D, rpart, gflat(bi), st);
+        if (int rc = launch_wgrad(dE, H, D, 0, D, out(n - 1), H, C, 0, C, 1, 0, 1, B, part, gflat(wi), C, 0, st, &df)) return rc;
+        launch_rowsum(dE, rows, D, rpart, gflat(bi), st, &df);
     }
     for (int i = n - 1; i >= 0; --i) {
         const Layer& l = u->layers[i];
@@ -335,6 +386,16 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             g.gy = gy; g.pre = pre(i); g.gamma = flat + u->params[l.gamma].foff; g.beta = flat + u->params[l.beta].foff;
             g.du = ws + w.dU;
             g.pg = ws + w.pvec; g.pb = g.pg + (size_t)B * 512; g.pbias = g.pb + (size_t)B * 512;
+            const bool dcol = df.on && df.col.n + 3 <= 120;
+            if (dcol) {
+                g.pg = ws + df.pcur; g.pb = g.pg + (size_t)B * l.cout; g.pbias = g.pb + (size_t)B * l.cout;
+                const int prm[3] = {l.gamma, l.beta, l.b};
+                for (int k = 0; k < 3; ++k) {
+                    auto& e = df.col.e[df.col.n++];
+                    e.part = df.pcur + (size_t)k * B * l.cout; e.out = u->params[prm[k]].foff; e.rows = B; e.C = l.cout;
+                }
+                df.pcur += (size_t)3 * B * l.cout;
+            }
             if (l.tb_off >= 0) { g.dT = ws + w.dT + l.tb_off; g.dT_stride = u->tt_row; }
             g.B = B; g.L = l.L_out; g.C = l.cout; g.gs = l.gs; g.n_groups = l.cout / l.gs;
             { int k = 0; while ((1 << k) < l.gs) ++k; g.lg_gs = k; }
@@ -349,20 +410,20 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             cs.part[1] = g.pb; cs.out[1] = gflat(l.beta);
             cs.part[2] = g.pbias; cs.out[2] = gflat(l.b);
             cs.B = B; cs.C = l.cout;
-            hipLaunchKernelGGL(colsum_kernel, dim3((l.cout + 63) / 64, 3), dim3(256), 0, st, cs);
+            if (!dcol) hipLaunchKernelGGL(colsum_kernel, dim3((l.cout + 63) / 64, 3), dim3(256), 0, st, cs);
             dy = g.du;
         } else {
-            launch_rowsum(gy, (size_t)B * l.L_out, l.cout, rpart, gflat(l.b), st);
+            launch_rowsum(gy, (size_t)B * l.L_out, l.cout, rpart, gflat(l.b), st, &df);
         }
         // weight gradient
         float* gw = gflat(l.w);
         if (l.mode == CONV_UPT) {
-            if (int rc = launch_wgrad(tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, dy, l.L_out, l.cout, 0, l.cout, 2, -1, 4, B, part, gw, l.cout, 0, st)) return rc;
+            if (int rc = launch_wgrad(tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, dy, l.L_out, l.cout, 0, l.cout, 2, -1, 4, B, part, gw, l.cout, 0, st, &df)) return rc;
         } else {
             const int sb = l.mode == CONV_DOWN ? 2 : 1, ob = l.mode == CONV_DOWN ? -1 : -(l.ks / 2);
-            if (int rc = launch_wgrad(dy, l.L_out, l.cout, 0, l.cout, tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, sb, ob, l.ks, B, part, gw, Cin, 0, st)) return rc;
+            if (int rc = launch_wgrad(dy, l.L_out, l.cout, 0, l.cout, tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, sb, ob, l.ks, B, part, gw, Cin, 0, st, &df)) return rc;
             if (l.c2 > 0)
-                if (int rc = launch_wgrad(dy, l.L_out, l.cout, 0, l.cout, tensor(t.src2_l), l.L_in, l.c2, 0, l.c2, sb, ob, l.ks, B, part, gw, Cin, l.c1, st)) return rc;
+                if (int rc = launch_wgrad(dy, l.L_out, l.cout, 0, l.cout, tensor(t.src2_l), l.L_in, l.c2, 0, l.c2, sb, ob, l.ks, B, part, gw, Cin, l.c1, st, &df)) return rc;
         }
         // input gradient
         if (t.need_dgrad) {
@@ -391,6 +452,8 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             }
         }
     }
+    if (df.red.n) hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(48, df.red.n), dim3(256), 0, st, df.red);
+    if (df.col.n) hipLaunchKernelGGL(colsum_all_kernel, dim3(2, df.col.n), dim3(256), 0, st, df.col);
     // time MLP
     hipLaunchKernelGGL(time_bwd_cond_kernel, dim3((tb.row + 7) / 8), dim3(256), 0, st, tb);
     hipLaunchKernelGGL(time_bwd_temb_kernel, dim3(B), dim3(1024), 0, st, tb);

@@ -1,8 +1,11 @@
 """LimitsNormalizer and the slice of TrajectoryDataset the planning loop touches.
 
 Reference: mpd/datasets/normalization.py:144-167 (LimitsNormalizer) and mpd/datasets/trajectories.py:196-237
-(unnormalize_trajectories, get_hard_conditions).  Loading the authors' `trajs-free.pt` shards (trajectories.py:45-80,
-needs the Google-Drive dataset + gitpython) is out of scope: limits are given explicitly (synthetic).
+(unnormalize_trajectories, get_hard_conditions).  Without a dataset directory the limits are given explicitly (synthetic,
+SURVEY 8d).  With `base_dir=` the `trajs-free.pt` shards under it are loaded as the reference does (trajectories.py:84-110:
+os.walk, one task id per shard, the `task` field = start/goal positions) and the limits come from the data
+(normalization.py:144-167) - this is the training set of mpd_public_amd.trainer / train.py; the shards are what
+`generate_trajectories.py` (the reference's, or mpd_public_amd.generate_trajectories) writes.
 The in-loop unnormalise runs inside the HIP guide kernel; the methods below serve the one-off calls outside the loop
 (hard conditions, un-normalising the returned chain) with plain torch ops.
 """
@@ -43,7 +46,7 @@ class TrajectoryDataset:
     field_key_traj = "traj"
 
     def __init__(self, env_id="EnvDense2D", robot_id="RobotPointMass", n_support_points=64, include_velocity=True,
-                 obstacle_cutoff_margin=0.05, use_extra_objects=True, tensor_args=None, **kw):
+                 obstacle_cutoff_margin=0.05, use_extra_objects=True, tensor_args=None, base_dir=None, **kw):
         self.tensor_args = tensor_args or {"device": "cpu", "dtype": torch.float32}
         self.env, self.robot = make_env(env_id), make_robot(robot_id)
         self.task = PlanningTask(self.env, self.robot, obstacle_cutoff_margin=obstacle_cutoff_margin,
@@ -53,6 +56,55 @@ class TrajectoryDataset:
         mins, maxs = syn.limits_for(robot_id)
         self.normalizer = LimitsNormalizer(mins[: self.state_dim], maxs[: self.state_dim]).to(self.tensor_args["device"])
         self.threshold_start_goal_pos = 1.0 if self.robot.q_dim <= 3 else 1.83  # launch_generate_trajectories.py:13-16
+        self.fields = {}
+        self.map_task_id_to_trajectories_id, self.map_trajectory_id_to_task_id = {}, {}
+        if base_dir is not None:
+            self.load_trajectories(base_dir)
+
+    # ---- the training set (trajectories.py:84-123, 150-172)
+    def load_trajectories(self, base_dir):
+        import os
+        import numpy as np
+        dev = self.tensor_args["device"]
+        shards, task_id, n = [], 0, 0
+        for current_dir, subdirs, files in sorted(os.walk(base_dir, topdown=True)):
+            if "trajs-free.pt" in files:
+                tr = torch.load(os.path.join(current_dir, "trajs-free.pt"), map_location=dev).to(torch.float32)
+                if tr.numel() == 0:
+                    continue
+                idx = n + np.arange(len(tr))
+                self.map_task_id_to_trajectories_id[task_id] = idx
+                for j in idx:
+                    self.map_trajectory_id_to_task_id[int(j)] = task_id
+                task_id += 1
+                n += len(tr)
+                shards.append(tr)
+        if not shards:
+            raise FileNotFoundError(f"no trajs-free.pt under {base_dir}")
+        trajs_free = torch.cat(shards)
+        pos = self.robot.get_position(trajs_free)
+        trajs = trajs_free if self.include_velocity else pos
+        if trajs.shape[-1] != self.state_dim:
+            raise ValueError(f"trajectories have state dim {trajs.shape[-1]}, expected {self.state_dim}")
+        self.fields["traj"] = trajs
+        self.fields["task"] = torch.cat((pos[..., 0, :], pos[..., -1, :]), dim=-1)
+        self.n_trajs, self.n_support_points = trajs.shape[0], trajs.shape[1]
+        self.trajectory_dim = (self.n_support_points, self.state_dim)
+        flat = trajs.reshape(-1, self.state_dim)
+        self.normalizer = LimitsNormalizer(flat.min(0).values, flat.max(0).values).to(dev)   # normalization.py:144-153
+        tflat = self.fields["task"]
+        self._task_normalizer = LimitsNormalizer(tflat.min(0).values, tflat.max(0).values).to(dev)
+        self.fields["traj_normalized"] = self.normalizer.normalize(trajs)
+        self.fields["task_normalized"] = self._task_normalizer.normalize(tflat)
+
+    def __len__(self):
+        return self.fields["traj"].shape[0] if "traj" in self.fields else 0
+
+    def __getitem__(self, index):
+        traj_normalized = self.fields["traj_normalized"][index]
+        data = {"traj_normalized": traj_normalized, "task_normalized": self.fields["task_normalized"][index]}
+        data["hard_conds"] = self.get_hard_conditions(traj_normalized, horizon=len(traj_normalized))
+        return data
 
     def normalize_trajectories(self, x):
         return self.normalizer.normalize(x)

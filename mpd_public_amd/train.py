@@ -1,0 +1,89 @@
+"""`experiment(...)` of scripts/train_diffusion/train.py:16-150 with the same arguments: dataset -> TemporalUnet +
+GaussianDiffusionModel -> trainer.train (native HIP training step).  Writes what inference.py reads back:
+`<results_dir>/args.yaml`, `checkpoints/{model,ema_model}_current_state_dict.pth` and `limits.yaml` (the normaliser limits of
+the training set, which the reference re-derives by re-loading the dataset at inference time).
+
+    python -m mpd_public_amd.train --dataset_subdir EnvSimple2D-RobotPointMass --data_dir data_trajectories --num_train_steps 2000
+"""
+from __future__ import annotations
+
+import argparse
+import os
+
+import torch
+import yaml
+
+from . import trainer
+from .datasets import TrajectoryDataset
+from .diffusion_model import GaussianDiffusionModel
+from .temporal_unet import TemporalUnet, UNET_DIM_MULTS
+
+
+def get_dataset(dataset_class="TrajectoryDataset", dataset_subdir=None, batch_size=2, val_set_size=0.05, results_dir=None,
+                save_indices=False, data_dir="data_trajectories", tensor_args=None, seed=0, **kwargs):
+    """mpd/trainer/train_loaders.py:77-99: full dataset, random split, two DataLoaders (batches stay on the dataset's device)."""
+    from torch.utils.data import DataLoader, random_split
+    env_id, robot_id = dataset_subdir.split("-")[0], dataset_subdir.split("-")[1]
+    full = TrajectoryDataset(env_id=env_id, robot_id=robot_id, base_dir=os.path.join(data_dir, dataset_subdir), tensor_args=tensor_args, **kwargs)
+    n_val = max(1, int(round(len(full) * val_set_size)))
+    gen = torch.Generator().manual_seed(seed)
+    train_subset, val_subset = random_split(full, [len(full) - n_val, n_val], generator=gen)
+    train_dataloader = DataLoader(train_subset, batch_size=batch_size)
+    val_dataloader = DataLoader(val_subset, batch_size=batch_size)
+    if save_indices and results_dir is not None:
+        torch.save(train_subset.indices, os.path.join(results_dir, "train_subset_indices.pt"))
+        torch.save(val_subset.indices, os.path.join(results_dir, "val_subset_indices.pt"))
+    return train_subset, train_dataloader, val_subset, val_dataloader
+
+
+def experiment(dataset_subdir: str = "EnvSimple2D-RobotPointMass", include_velocity: bool = True,
+               diffusion_model_class: str = "GaussianDiffusionModel", variance_schedule: str = "exponential", n_diffusion_steps: int = 25,
+               predict_epsilon: bool = True, unet_input_dim: int = 32, unet_dim_mults_option: int = 1,
+               loss_class: str = "GaussianDiffusionLoss", batch_size: int = 32, lr: float = 1e-4, num_train_steps: int = 500000,
+               use_ema: bool = True, use_amp: bool = False, steps_til_summary: int = 10, summary_class: str = None,
+               steps_til_ckpt: int = 50000, device: str = "cuda", debug: bool = True, seed: int = 0, results_dir: str = "logs",
+               data_dir: str = "data_trajectories", **kwargs):
+    if diffusion_model_class != "GaussianDiffusionModel" or loss_class != "GaussianDiffusionLoss":
+        raise NotImplementedError("only GaussianDiffusionModel / GaussianDiffusionLoss (the classes train.py's defaults name)")
+    torch.manual_seed(seed)
+    os.makedirs(results_dir, exist_ok=True)
+    tensor_args = {"device": device, "dtype": torch.float32}
+    train_subset, train_dataloader, val_subset, val_dataloader = get_dataset(
+        dataset_class="TrajectoryDataset", include_velocity=include_velocity, dataset_subdir=dataset_subdir, batch_size=batch_size,
+        results_dir=results_dir, save_indices=True, data_dir=data_dir, tensor_args=tensor_args, seed=seed)
+    dataset = train_subset.dataset
+    unet_configs = dict(state_dim=dataset.state_dim, n_support_points=dataset.n_support_points, unet_input_dim=unet_input_dim,
+                        dim_mults=UNET_DIM_MULTS[unet_dim_mults_option])
+    model = GaussianDiffusionModel(model=TemporalUnet(**unet_configs), variance_schedule=variance_schedule,
+                                   n_diffusion_steps=n_diffusion_steps, predict_epsilon=predict_epsilon).to(device)
+    model.manual_seed(seed)
+    args = dict(dataset_subdir=dataset_subdir, include_velocity=include_velocity, diffusion_model_class=diffusion_model_class,
+                variance_schedule=variance_schedule, n_diffusion_steps=n_diffusion_steps, predict_epsilon=predict_epsilon,
+                unet_input_dim=unet_input_dim, unet_dim_mults_option=unet_dim_mults_option, loss_class=loss_class, batch_size=batch_size,
+                lr=lr, num_train_steps=num_train_steps, use_ema=use_ema, seed=seed)
+    with open(os.path.join(results_dir, "args.yaml"), "w") as f:
+        yaml.safe_dump(args, f)
+    with open(os.path.join(results_dir, "limits.yaml"), "w") as f:
+        yaml.safe_dump({"mins": [float(v) for v in dataset.normalizer.mins.cpu()], "maxs": [float(v) for v in dataset.normalizer.maxs.cpu()]}, f)
+    loss_fn = trainer.GaussianDiffusionLoss.loss_fn
+    model, ema_model, losses = trainer.train(
+        model=model, train_dataloader=train_dataloader, train_subset=train_subset, val_dataloader=val_dataloader, val_subset=train_subset,
+        epochs=trainer.get_num_epochs(num_train_steps, batch_size, len(dataset)), model_dir=results_dir, summary_fn=None, lr=lr,
+        loss_fn=loss_fn, val_loss_fn=loss_fn, steps_til_summary=steps_til_summary, steps_til_checkpoint=steps_til_ckpt, clip_grad=True,
+        use_ema=use_ema, use_amp=use_amp, debug=debug, tensor_args=tensor_args, max_steps=num_train_steps)
+    return model, ema_model, losses
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    for name, typ, default in (("dataset_subdir", str, "EnvSimple2D-RobotPointMass"), ("data_dir", str, "data_trajectories"),
+                               ("results_dir", str, "logs"), ("n_diffusion_steps", int, 25), ("unet_dim_mults_option", int, 1),
+                               ("batch_size", int, 32), ("lr", float, 1e-4), ("num_train_steps", int, 500000), ("steps_til_summary", int, 10),
+                               ("steps_til_ckpt", int, 50000), ("seed", int, 0)):
+        ap.add_argument(f"--{name}", type=typ, default=default)
+    a = ap.parse_args(argv)
+    experiment(**vars(a))
+
+
+if __name__ == "__main__":
+    main()

@@ -178,3 +178,44 @@ def test_train_function_mirrors_the_reference_loop(tmp_path):
     hc = {0: data[0, 0].cuda(), 63: data[0, -1].cuda()}
     traj = dm.run_inference(None, hc, n_samples=4, horizon=64)
     assert traj.shape == (4, 64, D) and bool(torch.isfinite(traj).all())
+
+
+def test_generate_train_plan_end_to_end(tmp_path):
+    """The reference's three scripts in a row on this box: generate_trajectories.py (baseline planners) -> train.py (training step)
+    -> the trained EMA model plans.  Small sizes; checks the artefacts and formats that connect the stages, not plan quality."""
+    import yaml
+    from mpd_public_amd import train as train_script
+    from mpd_public_amd.generate_trajectories import generate_collision_free_trajectories as gen
+    sub = "EnvSimple2D-RobotPointMass"
+    data = tmp_path / "data_trajectories" / sub
+    n_free = 0
+    for ctx in range(3):
+        d = data / str(ctx)
+        d.mkdir(parents=True)
+        _, nf = gen("EnvSimple2D", "RobotPointMass", 24, str(d), gpmp_opt_iters=150, seed=ctx)
+        n_free += nf
+    assert n_free >= 24, n_free
+    logs = tmp_path / "logs"
+    model, ema_model, losses = train_script.experiment(dataset_subdir=sub, data_dir=str(tmp_path / "data_trajectories"), results_dir=str(logs),
+                                                      n_diffusion_steps=25, unet_dim_mults_option=0, batch_size=16, lr=3e-4,
+                                                      num_train_steps=40, steps_til_summary=10, steps_til_ckpt=20, seed=1)
+    vals = [v["diffusion_loss"] for _, v in losses]
+    assert len(vals) >= 3 and all(np.isfinite(vals)) and vals[-1] < vals[0]
+    args = yaml.safe_load(open(logs / "args.yaml"))
+    lim = yaml.safe_load(open(logs / "limits.yaml"))
+    assert args["dataset_subdir"] == sub and len(lim["mins"]) == 4 and all(a < b for a, b in zip(lim["mins"], lim["maxs"]))
+    for f in ("model_current_state_dict.pth", "ema_model_current_state_dict.pth"):
+        assert (logs / "checkpoints" / f).exists()
+    assert (logs / "train_subset_indices.pt").exists()
+    # the EMA model (what inference.py loads, inference.py:145-148) plans between a start and a goal of the training set
+    ds = model.model  # noqa: F841
+    sd = torch.load(logs / "checkpoints" / "ema_model_current_state_dict.pth")
+    import mpd_public_amd as m
+    net = m.TemporalUnet(n_support_points=64, state_dim=4, unet_input_dim=32, dim_mults=m.UNET_DIM_MULTS[0])
+    dm = m.GaussianDiffusionModel(model=net, n_diffusion_steps=25, predict_epsilon=True)
+    dm.load_state_dict(sd, strict=True)
+    dm = dm.cuda().eval()
+    hc = {0: torch.tensor([-0.5, -0.5, 0.0, 0.0]).cuda(), 63: torch.tensor([0.5, 0.5, 0.0, 0.0]).cuda()}
+    traj = dm.run_inference(None, hc, n_samples=8, horizon=64)
+    assert traj.shape == (8, 64, 4) and bool(torch.isfinite(traj).all())
+    assert torch.equal(traj[:, 0], hc[0].expand(8, 4)) and torch.equal(traj[:, 63], hc[63].expand(8, 4))
