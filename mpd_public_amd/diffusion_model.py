@@ -2,9 +2,9 @@
 (diffusion_model_base.py:46-316): same constructor, same registered buffers (state-dict compatible), same
 ``run_inference / conditional_sample / p_sample_loop / p_mean_variance / warmup`` protocol.
 
-The sampling half (DDPM and DDIM) runs on libmpdx.so.  Of the training half (:320-357) the FORWARD value is provided:
-q_sample / p_losses / loss return the loss the reference's validation pass computes under no_grad (per-sample timesteps,
-hard conditioning, WeightedL1/L2); there is no backward pass - the returned loss carries no autograd history.
+The sampling half (DDPM and DDIM) runs on libmpdx.so.  The training half (:320-357): q_sample / p_losses return the forward
+value (per-sample timesteps, hard conditioning, WeightedL1/L2) without autograd history; `loss()` - what the reference's trainer
+calls - returns a loss whose backward() is the native backward pass (mpd_public_amd/trainer.py, csrc/train.hpp).
 """
 from __future__ import annotations
 
@@ -374,6 +374,13 @@ class GaussianDiffusionModel(nn.Module):
         return out[0], {}
 
     def loss(self, x, context, *args):
-        """diffusion_model_base.py:354-357: uniform random timestep per sample, then p_losses."""
+        """diffusion_model_base.py:354-357: uniform random timestep per sample, then p_losses.  With gradients enabled and a
+        trainable U-Net the returned loss carries autograd history (trainer.loss_with_grad: the native forward + backward pass of
+        csrc/train.hpp), so `loss.backward()` fills p.grad as in the reference's training loop; under torch.no_grad() (validation)
+        it is the forward value only."""
         t = torch.randint(0, self.n_diffusion_steps, (x.shape[0],), device=x.device).long()
+        if torch.is_grad_enabled() and context is None and any(p.requires_grad for p in self.model.parameters()):
+            from .trainer import loss_with_grad
+            hard_conds = args[0] if args else None
+            return loss_with_grad(self, x, hard_conds, t=t), {}
         return self.p_losses(x, context, t, *args)

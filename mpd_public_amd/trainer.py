@@ -46,6 +46,7 @@ class FlatParams:
         self.flat = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.slices = {}
+        self.order = []
         named = dict(unet.named_parameters())
         name_p, shape, ndim = C.c_char_p(), (C.c_int32 * 3)(), C.c_int32()
         off, cnt = C.c_size_t(), C.c_size_t()
@@ -61,6 +62,7 @@ class FlatParams:
             p.data = view
             p.grad = self.grad[off.value:off.value + cnt.value].view(p.shape)
             self.slices[name] = (off.value, cnt.value)
+            self.order.append(name)
         self.packedT = torch.zeros(int(lib.mpdx_train_dgrad_pack_floats(h)), dtype=torch.float32, device=dev)
 
     def aliased(self) -> bool:
@@ -155,6 +157,45 @@ class TrainStep:
                                       self.fp.n, float(lr), float(betas[0]), float(betas[1]), float(eps), self.step_count, mn,
                                       self.scratch.data_ptr(), _lib.current_stream()), "mpdx_adam_step")
         return self.scratch[0] if mn > 0 else None
+
+
+class _PLossesFn(torch.autograd.Function):
+    """autograd bridge: forward = TrainStep.loss_backward (loss AND gradients in one native pass), backward hands each parameter its
+    slice of the flat gradient times the incoming gradient - so the reference's own loop body
+    `loss, info = model.loss(x, context, hard_conds); loss.backward(); optimizer.step()` runs unchanged."""
+
+    @staticmethod
+    def forward(ctx, step, x_start, hard_conds, t, noise, *params):
+        loss, _ = step.loss_backward(x_start, hard_conds, t=t, noise=noise)
+        ctx.step = step
+        ctx.n_params = len(params)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        fp = ctx.step.fp
+        named = dict(fp.unet.named_parameters())
+        grads = []
+        for name in fp.order:
+            off, cnt = fp.slices[name]
+            grads.append((fp.grad[off:off + cnt].view(named[name].shape) * grad_out).clone())
+        return (None, None, None, None, None) + tuple(grads)
+
+
+def loss_with_grad(model, x_start, hard_conds=None, t=None, noise=None):
+    """model.loss(x, None, hard_conds) as a 0-dim tensor WITH autograd history (its backward() fills / accumulates p.grad of every
+    TemporalUnet parameter, as torch autograd would).  GaussianDiffusionModel.loss returns this when gradients are enabled."""
+    step = getattr(model, "_train_step", None)
+    if step is None or not step.fp.aliased():
+        step = TrainStep(model)
+        model._train_step = step
+    named = dict(step.unet.named_parameters())
+    params = [named[k] for k in step.fp.order]
+    # p.grad aliases the flat gradient that the native pass overwrites: autograd must accumulate into its own tensors
+    for p in params:
+        if p.grad is not None and p.grad.data_ptr() >= step.fp.grad.data_ptr() and p.grad.data_ptr() < step.fp.grad.data_ptr() + 4 * step.fp.n:
+            p.grad = None
+    return _PLossesFn.apply(step, x_start, hard_conds, t, noise, *params)
 
 
 class EMA:

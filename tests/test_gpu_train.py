@@ -219,3 +219,39 @@ def test_generate_train_plan_end_to_end(tmp_path):
     traj = dm.run_inference(None, hc, n_samples=8, horizon=64)
     assert traj.shape == (8, 64, 4) and bool(torch.isfinite(traj).all())
     assert torch.equal(traj[:, 0], hc[0].expand(8, 4)) and torch.equal(traj[:, 63], hc[63].expand(8, 4))
+
+
+def test_reference_loop_body_runs_unchanged_through_autograd():
+    """The literal body of trainer.py:186-283 - loss = model.loss(...); optimizer.zero_grad(); loss.backward(); clip_grad_norm_;
+    optimizer.step() - with torch.optim.Adam over model.parameters(): gradients and updated parameters equal the native step's."""
+    from mpd_public_amd.trainer import TrainStep
+    D, opt = 4, 0
+    dm_a, dm_b = _model(D, opt), _model(D, opt)
+    x0, noise, hc = _batch(D)
+    x0, hc = x0.cuda(), {k: v.cuda() for k, v in hc.items()}
+    # a: the reference's code
+    dm_a.train()
+    optim = torch.optim.Adam(lr=1e-4, params=dm_a.parameters())
+    torch.manual_seed(5); dm_a.manual_seed(5)
+    loss, info = dm_a.loss(x0, None, hc)
+    assert loss.requires_grad and loss.dim() == 0
+    optim.zero_grad()
+    (2.0 * loss).backward()          # a scaled loss: the incoming gradient must be honoured
+    ga = {k: p.grad.detach().clone() for k, p in dm_a.model.named_parameters()}
+    torch.nn.utils.clip_grad_norm_(dm_a.parameters(), max_norm=1.0)
+    optim.step()
+    # b: the native step with the same draws
+    ts = TrainStep(dm_b)
+    torch.manual_seed(5); dm_b.manual_seed(5)
+    t = torch.randint(0, dm_b.n_diffusion_steps, (x0.shape[0],), device=x0.device).long()
+    lb, _ = ts.loss_backward(x0, hc, t=t, loss_scale=2.0)
+    assert float(loss) == float(lb)
+    for k, p in dm_b.model.named_parameters():
+        assert torch.equal(ga[k], p.grad), k
+    ts.adam_step(1e-4, max_norm=1.0)
+    for (k, pa), (_, pb) in zip(dm_a.model.named_parameters(), dm_b.model.named_parameters()):
+        assert float((pa.detach() - pb.detach()).abs().max()) < 2e-7, k
+    # validation path: no autograd history under no_grad (trainer.py:226-235)
+    with torch.no_grad():
+        lv, _ = dm_a.loss(x0, None, hc)
+    assert not lv.requires_grad and bool(torch.isfinite(lv))

@@ -12,7 +12,20 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GR
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_write -- $BENCH1 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_sq -- $BENCH1 > /dev/null 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_default -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/$O/default_bench_under_rocprof.json 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_cfg5 -- python $GRAFT_REPO_ROOT/bench.py --config cfg5 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_train -- python -c "
+import sys; sys.path.insert(0, '$GRAFT_REPO_ROOT')
+import bench
+print(bench.training_leg(steps=40, baseline=False))
+" > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
+cp $(find $O/prof_cfg5 -name "*kernel_stats.csv" | head -1) $O/cfg5_kernel_stats.csv
+cp $(find $O/prof_train -name "*kernel_stats.csv" | head -1) $O/train_kernel_stats.csv
+rm -rf $O/prof_cfg5 $O/prof_train
+timeout 900 python -c "
+import json, bench
+print(json.dumps({'batch32_D4': bench.training_leg(), 'batch128_D14': bench.training_leg(B=128, D=14)}, indent=1))
+" 2>/dev/null > $O/training.json
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/cfg2_kernel_stats.csv
 cp $(find $O/prof_default -name "*kernel_stats.csv" | head -1) $O/default_cmd_kernel_stats.csv
 python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write 100 > $O/pmc_traffic.json
