@@ -47,7 +47,8 @@ namespace mpdx {
     X(0, CONV_S1, 5, 1, 0, 32, 64, 1) X(1, CONV_S1, 5, 2, 1, 32, 64, 1) X(2, CONV_S1, 5, 2, 0, 32, 64, 1) X(3, CONV_DOWN, 3, 2, 0, 32, 32, 0)     \
     X(4, CONV_S1, 5, 2, 0, 64, 32, 1) X(5, CONV_S1, 5, 4, 2, 64, 32, 1) X(6, CONV_S1, 5, 4, 0, 64, 32, 1) X(7, CONV_DOWN, 3, 4, 0, 64, 16, 0)     \
     X(8, CONV_S1, 5, 16, 0, 64, 16, 1) X(9, CONV_S1, 5, 4, 16, 64, 16, 1) X(10, CONV_S1, 5, 4, 0, 64, 16, 1) X(11, CONV_UPT, 4, 4, 0, 64, 32, 0)  \
-    X(12, CONV_S1, 5, 8, 0, 32, 32, 1) X(13, CONV_S1, 5, 2, 8, 32, 32, 1) X(14, CONV_S1, 5, 2, 0, 32, 32, 1) X(15, CONV_UPT, 4, 2, 0, 32, 64, 0)
+    X(12, CONV_S1, 5, 8, 0, 32, 32, 1) X(13, CONV_S1, 5, 2, 8, 32, 32, 1) X(14, CONV_S1, 5, 2, 0, 32, 32, 1) X(15, CONV_UPT, 4, 2, 0, 32, 64, 0) \
+    X(16, CONV_S1, 5, 4, 0, 128, 16, 1) X(17, CONV_S1, 5, 8, 4, 128, 16, 1) X(18, CONV_S1, 5, 8, 0, 128, 16, 1) X(19, CONV_DOWN, 3, 8, 0, 128, 8, 0)
 constexpr int kFusedShapeFinal = 63;
 
 inline int fused_shape_id(int mode, int ks, int nc16, int rnc16, int cout, int L_out, int gn) {
@@ -67,24 +68,28 @@ struct FusedShape {
     static constexpr int NBLK = NC16 * NTAP;          // blocks of a tile-stream from the conv itself
     static constexpr int TOT = NBLK + NCR;            // + the folded residual conv's
     static constexpr int MSn = COUT / 16;
-    static constexpr int NSn = LOUT / 16;             // tiles along positions (ConvTranspose: parity sub-tiles included)
+    static constexpr int MSW = MSn < kFusedWaves ? MSn : kFusedWaves;   // tile rows worked on at the same time (one per wave)
+    static constexpr int MP = MSn / MSW;              // M-PASSES: with 8 tile rows a wave runs rows ms and ms + 4 one after the other
+    static constexpr int NSn = LOUT >= 16 ? LOUT / 16 : 1;   // tiles along positions (ConvTranspose: parity sub-tiles included; L_out = 8: a half-used tile)
     static constexpr int T = MSn * NSn;               // 16x16 tiles: 4 or 8
     static constexpr int NTW = T / kFusedWaves;       // tiles per wave
     // Conv / strided conv: the wave's tiles share the output channels -> ONE stream, the tiles advance together (NJ tiles per
     // block).  ConvTranspose: the wave's two tiles are the two output parities, which use different weight slots -> the
-    // stream is [parity 0 | parity 1] and the tiles run one after the other (NSEQ = 2).
-    static constexpr int NSEQ = (MODE == CONV_UPT) ? NTW : 1;
-    static constexpr int NJ = (MODE == CONV_UPT) ? 1 : NTW;
+    // stream is [parity 0 | parity 1] and the tiles run one after the other (NSEQ = 2).  M-passes: the wave's two tiles are two
+    // tile ROWS (different weights, same B fragments) -> the stream is [row ms | row ms + 4], again one after the other.
+    static constexpr int NSEQ = (MODE == CONV_UPT) ? NTW : MP;
+    static constexpr int NJ = (MODE == CONV_UPT) ? 1 : NTW / MP;
     static constexpr int SLEN = NSEQ * TOT;           // blocks of a wave's stream for this op
-    static constexpr int NWS = kFusedWaves / MSn;     // waves that share one stream (1 or 2)
     static constexpr int GS = COUT / 8;               // GroupNorm(8 groups): channels per group
     static constexpr int RB = GS / 4;                 // DPP rows (4 channels) per group
     static constexpr int NPARTS = NSn * RB;           // 64-element parts per group: 2 or 4
     static_assert(T == 4 || T == 8, "4 or 8 tiles");
-    static_assert(MSn == 2 || MSn == 4, "2 or 4 tile rows");
+    static_assert(MSn == 2 || MSn == 4 || MSn == 8, "2, 4 or 8 tile rows");
+    static_assert(MP == 1 || (MODE != CONV_UPT && NSn == 1), "M-passes: one position tile");
     static_assert(MODE != CONV_UPT || NTW == 2, "ConvTranspose: a wave owns both parities of its tile");
     static_assert(MODE != CONV_UPT || NCR == 0, "no folded residual on resampling ops");
     static_assert(!GN || NPARTS == 2 || NPARTS == 4, "GroupNorm region of 128 or 256 elements");
+    static_assert(LOUT >= 16 || !GN, "half-used tiles: resampling ops only");
 };
 
 struct FusedOp {          // runtime part of an op: 13 dwords
@@ -177,16 +182,17 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
     constexpr int P = kFusedRing, DB = MPDX_FUSED_DB, NTW = S::NTW, NJ = S::NJ;
     f32x4* const sm4 = (f32x4*)smem;
     const int j = lane & 15, q = lane >> 4;
-    const int ms = wave & (S::MSn - 1);
-    const int nsg = wave / S::MSn;     // which group of position tiles this wave owns
+    const int ms = wave & (S::MSW - 1);   // this wave's tile row (first of S::MP rows: ms, ms + 4)
+    const int nsg = wave / S::MSW;     // which group of position tiles this wave owns
 #define FOP_STAMP() do { if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter(); ++tr; } while (0)
     // tile t of this wave: position-tile index and output position of this lane's column
     int ns[NTW], npos[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-        ns[t] = nsg * NTW + t;                                   // ConvTranspose: (input tile nsg, parity t)
+        ns[t] = (S::MP > 1) ? 0 : nsg * NTW + t;                 // ConvTranspose: (input tile nsg, parity t); M-passes: tile row t of position tile 0
         npos[t] = (S::MODE == CONV_UPT) ? 2 * (nsg * 16 + j) + t : ns[t] * 16 + j;
     }
+    const bool col_ok = S::LOUT >= 16 || j < S::LOUT;           // half-used tile: columns beyond L_out are computed on clamped rows, never stored
     // lane's B rows in the source buffer (float4 units); taps are row offsets in the zero-haloed buffer
     const f32x4* brow[NJ];
     const f32x4* rrow[NJ];
@@ -196,7 +202,8 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
         if (S::MODE == CONV_UPT) boff = op.src_off4 + (nsg * 16 + j + 2) * op.src_rs4 + q;
         else {
             constexpr int pad = (S::MODE == CONV_S1) ? S::KS / 2 : 1;
-            const int l = ns[t] * 16 + j;
+            int l = ns[t] * 16 + j;
+            if (S::LOUT < 16) l = l < S::LOUT ? l : S::LOUT - 1;
             boff = op.src_off4 + ((S::MODE == CONV_DOWN ? 2 * l : l) + 2 - pad) * op.src_rs4 + q;
         }
         brow[t] = sm4 + boff;
@@ -238,7 +245,7 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
         for (int e = 0; e < 4; ++e)   // two independent accumulator chains per tile (even / odd k)
 #pragma unroll
             for (int t = 0; t < NJ; ++t) {
-                const int tt = (S::MODE == CONV_UPT) ? r / S::TOT : t;
+                const int tt = (S::NSEQ > 1) ? r / S::TOT : t;
                 f32x4& d = is_res ? racc[tt][e & 1] : acc[tt][e & 1];
                 d = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bq[r % (DB + 1)][t][e], d, 0, 0, 0);
             }
@@ -256,17 +263,21 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
 
     // ------------------------------------------------------------------ epilogue (registers -> destination buffer)
     const float* par_op = smem + a.par_off + op.p_off;   // [bias | gamma | beta | rbias] x COUT
-    const int c0 = ms * 16 + q * 4;                      // this lane's 4 output channels
+    // this lane's 4 output channels in tile t (M-passes: tile t is tile row ms + 4 t)
+    int c0t[NTW], mst[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) { mst[t] = (S::MP > 1) ? ms + t * S::MSW : ms; c0t[t] = mst[t] * 16 + q * 4; }
     f32x4 y[NTW];
     if (S::GN) {
-        const f32x4 bi = *(const f32x4*)(par_op + c0);
-        const f32x4 ga = *(const f32x4*)(par_op + S::COUT + c0), be = *(const f32x4*)(par_op + 2 * S::COUT + c0);
-        f32x4 tb = {0.f, 0.f, 0.f, 0.f};
-        if (op.tb_off >= 0) tb = *(const f32x4*)(smem + a.tt_off + op.tb_off + c0);
-        f32x4 v[NTW], add[NTW];
+        f32x4 v[NTW], add[NTW], gat[NTW], bet[NTW];
         float* stat = smem + a.stat_off;
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
+            const int c0 = c0t[t];
+            const f32x4 bi = *(const f32x4*)(par_op + c0);
+            gat[t] = *(const f32x4*)(par_op + S::COUT + c0); bet[t] = *(const f32x4*)(par_op + 2 * S::COUT + c0);
+            f32x4 tb = {0.f, 0.f, 0.f, 0.f};
+            if (op.tb_off >= 0) tb = *(const f32x4*)(smem + a.tt_off + op.tb_off + c0);
             add[t] = tb;
             if (S::NCR > 0) add[t] += (racc[t][0] + racc[t][1]) + *(const f32x4*)(par_op + 3 * S::COUT + c0);
             else if (op.res_off4 >= 0) add[t] += sm4[op.res_off4 + (npos[t] + 2) * op.res_rs4 + (c0 >> 2)];
@@ -275,47 +286,53 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
             const float m_loc = row_sum16((v[t][0] + v[t][1]) + (v[t][2] + v[t][3])) * (1.0f / 64.0f);
             const f32x4 dl = v[t] - m_loc;
             const float m2_loc = row_sum16((dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]));
-            if (j == 0) *(f32x2*)(stat + ((ms * S::NSn + ns[t]) * 4 + q) * 2) = (f32x2){m_loc, m2_loc};
+            if (j == 0) *(f32x2*)(stat + ((mst[t] * S::NSn + ns[t]) * 4 + q) * 2) = (f32x2){m_loc, m2_loc};
         }
         lds_barrier();
         FOP_STAMP();   // statistics exchanged
-        // combine the parts of this lane's group: rows q0 .. q0+RB-1 of the tiles (ms, 0..NSn-1); equal counts (64 each)
+        // combine the parts of this lane's group: rows q0 .. q0+RB-1 of the tiles (row, 0..NSn-1); equal counts (64 each).
+        // Tiles that share their tile row (NJ > 1) share the group: one combination; M-pass tiles are different rows: one each.
         const int q0 = q & ~(S::RB - 1);
-        float pm[S::NPARTS], pM2[S::NPARTS];
+        float mean_t[NTW], rstd_t[NTW];
 #pragma unroll
-        for (int k = 0; k < S::NPARTS; ++k) {
-            const int ns_k = k / S::RB, q_k = q0 + (k % S::RB);
-            const f32x2 pv = *(const f32x2*)(stat + ((ms * S::NSn + ns_k) * 4 + q_k) * 2);
-            pm[k] = pv[0]; pM2[k] = pv[1];
+        for (int t = 0; t < NTW; ++t) {
+            if (S::MP == 1 && t > 0) { mean_t[t] = mean_t[0]; rstd_t[t] = rstd_t[0]; continue; }
+            float pm[S::NPARTS], pM2[S::NPARTS];
+#pragma unroll
+            for (int k = 0; k < S::NPARTS; ++k) {
+                const int ns_k = k / S::RB, q_k = q0 + (k % S::RB);
+                const f32x2 pv = *(const f32x2*)(stat + ((mst[t] * S::NSn + ns_k) * 4 + q_k) * 2);
+                pm[k] = pv[0]; pM2[k] = pv[1];
+            }
+            float mean, M2;
+            if constexpr (S::NPARTS == 4) {
+                mean = ((pm[0] + pm[1]) + (pm[2] + pm[3])) * 0.25f;
+                const float d0 = pm[0] - mean, d1 = pm[1] - mean, d2 = pm[2] - mean, d3 = pm[3] - mean;
+                M2 = ((pM2[0] + pM2[1]) + (pM2[2] + pM2[3])) + 64.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+            } else {
+                mean = (pm[0] + pm[1]) * 0.5f;
+                const float d0 = pm[0] - mean, d1 = pm[1] - mean;
+                M2 = (pM2[0] + pM2[1]) + 64.0f * (d0 * d0 + d1 * d1);
+            }
+            mean_t[t] = mean;
+            rstd_t[t] = gn_rstd(M2 * (1.0f / (64.0f * S::NPARTS)));
         }
-        float mean, M2;
-        if (S::NPARTS == 4) {
-            mean = ((pm[0] + pm[1]) + (pm[2] + pm[3])) * 0.25f;
-            const float d0 = pm[0] - mean, d1 = pm[1] - mean, d2 = pm[2] - mean, d3 = pm[3] - mean;
-            M2 = ((pM2[0] + pM2[1]) + (pM2[2] + pM2[3])) + 64.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
-        } else {
-            mean = (pm[0] + pm[1]) * 0.5f;
-            const float d0 = pm[0] - mean, d1 = pm[1] - mean;
-            M2 = (pM2[0] + pM2[1]) + 64.0f * (d0 * d0 + d1 * d1);
-        }
-        const float var = M2 * (1.0f / (64.0f * S::NPARTS));
-        const float rstd = gn_rstd(var);
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[t][e] = mish((v[t][e] - mean) * rstd * ga[e] + be[e]);
+            for (int e = 0; e < 4; ++e) y[t][e] = mish((v[t][e] - mean_t[t]) * rstd_t[t] * gat[t][e] + bet[t][e]);
             y[t] += add[t];
         }
     } else {  // bias only: Downsample1d / Upsample1d
-        const f32x4 bi = *(const f32x4*)(par_op + c0);
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) y[t] = (acc[t][0] + acc[t][1]) + bi;
+        for (int t = 0; t < NTW; ++t) y[t] = (acc[t][0] + acc[t][1]) + *(const f32x4*)(par_op + c0t[t]);
         FOP_STAMP();   // (keeps four stamps per op)
     }
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-        if (op.dst_off4 >= 0) sm4[op.dst_off4 + (npos[t] + 2) * op.dst_rs4 + (c0 >> 2)] = y[t];
-        if (op.gdst >= 0) *(f32x4*)(a.gout[op.gdst] + ((size_t)b * S::LOUT + npos[t]) * S::COUT + c0) = y[t];
+        if (!col_ok) continue;
+        if (op.dst_off4 >= 0) sm4[op.dst_off4 + (npos[t] + 2) * op.dst_rs4 + (c0t[t] >> 2)] = y[t];
+        if (op.gdst >= 0) *(f32x4*)(a.gout[op.gdst] + ((size_t)b * S::LOUT + npos[t]) * S::COUT + c0t[t]) = y[t];
     }
     if (op.dst_off4 >= 0) {   // halo rows of the buffer this op defines (2 above, 2 below its L_out interior rows)
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -654,5 +671,6 @@ using FusedSeqDown = FusedSeq<0, 1, 2, 2, 3, 4, 5, 6, 6, 7>;                    
 using FusedSeqUpA = FusedSeq<8, 9, 10, 10, 11>;                                    // the up level at L = 16 (cat 256 -> 64)
 using FusedSeqUpB = FusedSeq<12, 13, 14, 14, 15, 2, kFusedShapeFinal>;             // the up level at L = 32 + final_conv + DDPM step
 using FusedSeqUpAB = FusedSeq<8, 9, 10, 10, 11, 12, 13, 14, 14, 15, 2, kFusedShapeFinal>;   // both up levels in one launch
+using FusedSeqMid2 = FusedSeq<16, 17, 18, 18, 19>;                                 // downs.2 (C = 128, L = 16): two tile rows per wave
 
 }  // namespace mpdx

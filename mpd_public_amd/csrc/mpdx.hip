@@ -632,8 +632,9 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         if (op.shape < 0) return fuse_reject(__LINE__);
         ho.nblk = nc16 * (l.mode == CONV_UPT ? 2 : l.ks); ho.ncr = rnc16; ho.tot = ho.nblk + ho.ncr;
         ho.nstream = (l.cout / 16) * (l.mode == CONV_UPT ? 2 : 1);
-        a.msmask[a.nops] = l.cout / 16 - 1;
-        a.slen[a.nops] = ho.tot * (l.mode == CONV_UPT ? 2 : 1);
+        const int msn = l.cout / 16, msw = std::min(msn, kFusedWaves), mp = msn / msw;   // tile rows, rows in flight, M-passes (FusedShape)
+        a.msmask[a.nops] = msw - 1;
+        a.slen[a.nops] = ho.tot * (l.mode == CONV_UPT ? 2 : mp);
         // destination: LDS if a later layer of the segment (or the final op) reads it; global if someone outside does
         bool read_inside = with_final && i == i1 - 1;
         for (int k = i + 1; k < i1; ++k) {
@@ -733,6 +734,12 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         if (l.mode == CONV_UPT) {   // streams (ms, parity): slots {2 par, 2 par + 1} of every 16-channel chunk
             for (int par = 0; par < 2; ++par)
                 f.jobs.push_back({woff + (size_t)par * 2 * 256, area + (size_t)par * ho.tot * 256, MSn, nc16 * 4 * 256, 2 * ho.tot * 256, nc16, 4 * 256, 2 * 256, 512});
+        } else if (MSn > kFusedWaves) {   // M-passes: wave-stream s = [tile row s | tile row s + 4], each [conv blocks | folded residual blocks]
+            const int mp = MSn / kFusedWaves;
+            f.jobs.push_back({woff, area, mp, kFusedWaves * ho.nblk * 256, ho.tot * 256, kFusedWaves, ho.nblk * 256, mp * ho.tot * 256, ho.nblk * 256});
+            if (ho.r)
+                f.jobs.push_back({u->params[ho.r->w].off, area + (size_t)ho.nblk * 256, mp, kFusedWaves * ho.ncr * 256, ho.tot * 256, kFusedWaves, ho.ncr * 256,
+                                  mp * ho.tot * 256, ho.ncr * 256});
         } else {
             f.jobs.push_back({woff, area, MSn, ho.nblk * 256, ho.tot * 256, 1, 0, 0, ho.nblk * 256});
             if (ho.r) f.jobs.push_back({u->params[ho.r->w].off, area + (size_t)ho.nblk * 256, MSn, ho.ncr * 256, ho.tot * 256, 1, 0, 0, ho.ncr * 256});
@@ -800,6 +807,7 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
             else if (matches(FusedSeqUpA::ids, FusedSeqUpA::N)) f.program = 1;
             else if (matches(FusedSeqUpB::ids, FusedSeqUpB::N)) f.program = 2;
             else if (matches(FusedSeqUpAB::ids, FusedSeqUpAB::N)) f.program = 3;
+            else if (matches(FusedSeqMid2::ids, FusedSeqMid2::N)) f.program = 4;
         }
     }
     u->fused.push_back(f);
@@ -844,6 +852,8 @@ static void build_units(mpdx_unet* u) {
         try_seg("downs.0.", false);
         if (nl >= 3) try_seg("downs.1.", false);
     }
+    // the third down level (C = 128, L = 16: two tile rows per wave) as its own program
+    if (nl >= 4 && !getenv("MPDX_NO_MID2")) try_seg("downs.2.", false);
     // the two outer up levels + final_conv + DDPM step as ONE program (the second level's skip tensor is staged by the prologue)
     bool merged_up = false;
     if (nl >= 3 && !getenv("MPDX_NO_MERGE_UP")) {
@@ -1153,6 +1163,10 @@ static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packe
         case 3:
             if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqUpAB>)) return rc;
             hipLaunchKernelGGL(fused_program_kernel<FusedSeqUpAB>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
+            break;
+        case 4:
+            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqMid2>)) return rc;
+            hipLaunchKernelGGL(fused_program_kernel<FusedSeqMid2>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
             break;
         default:
             if (int rc = raise_lds_limit((const void*)fused_level_kernel)) return rc;

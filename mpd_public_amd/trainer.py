@@ -311,7 +311,8 @@ def train(model=None, train_dataloader=None, epochs=None, lr=None, steps_til_sum
                         vb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in vb.items()}
                         if "hard_conds" in vb:
                             vb["hard_conds"] = {k: v.to(dev) for k, v in vb["hard_conds"].items()}
-                        vl, _ = val_loss_fn(model, vb, val_subset.dataset, step=train_steps_current)
+                        with torch.no_grad():   # forward value only (the reference runs validation without stepping the optimiser)
+                            vl, _ = val_loss_fn(model, vb, val_subset.dataset, step=train_steps_current)
                         vals.append(float(sum(v.mean() for v in vl.values())))
                         if step_val == steps_per_validation:
                             break
