@@ -671,6 +671,7 @@ using FusedSeqDown = FusedSeq<0, 1, 2, 2, 3, 4, 5, 6, 6, 7>;                    
 using FusedSeqUpA = FusedSeq<8, 9, 10, 10, 11>;                                    // the up level at L = 16 (cat 256 -> 64)
 using FusedSeqUpB = FusedSeq<12, 13, 14, 14, 15, 2, kFusedShapeFinal>;             // the up level at L = 32 + final_conv + DDPM step
 using FusedSeqUpAB = FusedSeq<8, 9, 10, 10, 11, 12, 13, 14, 14, 15, 2, kFusedShapeFinal>;   // both up levels in one launch
+using FusedSeqDown3 = FusedSeq<0, 1, 2, 2, 3, 4, 5, 6, 6, 7, 16, 17, 18, 18, 19>;   // downs.0 + downs.1 + downs.2 in one launch
 using FusedSeqMid2 = FusedSeq<16, 17, 18, 18, 19>;                                 // downs.2 (C = 128, L = 16): two tile rows per wave
 
 }  // namespace mpdx

@@ -808,6 +808,7 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
             else if (matches(FusedSeqUpB::ids, FusedSeqUpB::N)) f.program = 2;
             else if (matches(FusedSeqUpAB::ids, FusedSeqUpAB::N)) f.program = 3;
             else if (matches(FusedSeqMid2::ids, FusedSeqMid2::N)) f.program = 4;
+            else if (matches(FusedSeqDown3::ids, FusedSeqDown3::N)) f.program = 5;
         }
     }
     u->fused.push_back(f);
@@ -839,9 +840,19 @@ static void build_units(mpdx_unet* u) {
         if (build_fused_segment(u, i0, i1, with_final))
             for (int i = i0; i < i1; ++i) owner[i] = (int)u->fused.size() - 1;
     };
-    // the two outer down levels as ONE program if it fits (one launch boundary and one prologue less per step)
+    // the outer down levels as ONE program if it fits (every launch boundary + prologue removed is ~5 us per step): with four
+    // levels downs.0 + downs.1 + downs.2 (15 ops; measured cfg 2 23.10 -> 22.47 ms, cfg 5 shard 624 -> 617 ms against two programs;
+    // MPDX_MERGE_DOWN3=0 keeps them apart), else downs.0 + downs.1
     bool merged_down = false;
-    if (nl >= 3 && !getenv("MPDX_NO_MERGE")) {
+    if (nl >= 4 && !(getenv("MPDX_MERGE_DOWN3") && atoi(getenv("MPDX_MERGE_DOWN3")) == 0)) {
+        int a0, a1, b0, b1, c0, c1;
+        if (range_of("downs.0.", a0, a1) && range_of("downs.1.", b0, b1) && range_of("downs.2.", c0, c1) && a1 == b0 && b1 == c0 &&
+            build_fused_segment(u, a0, c1, false)) {
+            for (int i = a0; i < c1; ++i) owner[i] = (int)u->fused.size() - 1;
+            merged_down = true;
+        }
+    }
+    if (!merged_down && nl >= 3 && !getenv("MPDX_NO_MERGE")) {
         int a0, a1, b0, b1;
         if (range_of("downs.0.", a0, a1) && range_of("downs.1.", b0, b1) && a1 == b0 && build_fused_segment(u, a0, b1, false)) {
             for (int i = a0; i < b1; ++i) owner[i] = (int)u->fused.size() - 1;
@@ -1167,6 +1178,10 @@ static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packe
         case 4:
             if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqMid2>)) return rc;
             hipLaunchKernelGGL(fused_program_kernel<FusedSeqMid2>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
+            break;
+        case 5:
+            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqDown3>)) return rc;
+            hipLaunchKernelGGL(fused_program_kernel<FusedSeqDown3>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
             break;
         default:
             if (int rc = raise_lds_limit((const void*)fused_level_kernel)) return rc;

@@ -285,7 +285,7 @@ def test_forward_loss_vs_reference_golden(golden_dir, D, opt):
             want = float(g[f"D{D}_eps{int(pe)}_{lt}"])
             assert abs(float(loss) - want) <= 2e-5 * abs(want), (pe, lt, float(loss), want)
     l2, _ = dm.loss(x0, None, hc)   # random timesteps + device noise: finite, positive
-    assert bool(torch.isfinite(l2)) and float(l2) > 0
+    assert bool(torch.isfinite(l2)) and float(l2.detach()) > 0
 
 
 def test_weighted_loss_kernel_vs_formula():

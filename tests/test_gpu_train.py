@@ -101,6 +101,32 @@ def test_two_training_steps_vs_reference_golden(golden_dir, D, opt):
     assert float((y - yr).abs().max()) < 5e-5
 
 
+@pytest.mark.parametrize("B", [1, 33])
+def test_ragged_batches_gradients_vs_oracle(B):
+    """Batch sizes that fill no tile (1) and straddle the batch splits of the weight-gradient kernel (33), opt-0 network."""
+    from mpd_public_amd.trainer import TrainStep
+    from oracle import train as otrain
+    D, opt, T = 4, 0, 25
+    x0, noise = t(f"train_rag_x0_{B}", (B, 64, D), "uniform", 0.8), t(f"train_rag_noise_{B}", (B, 64, D))
+    hc = {0: t(f"train_rag_hc0_{B}", (B, D), "uniform", 0.7), 63: t(f"train_rag_hc1_{B}", (B, D), "uniform", 0.7)}
+    tt = torch.from_numpy(np.random.default_rng(B).integers(0, T, B))
+    dm = _model(D, opt, T=T)
+    ts = TrainStep(dm)
+    loss, _ = ts.loss_backward(x0.cuda(), {k: v.cuda() for k, v in hc.items()}, t=tt.cuda(), noise=noise.cuda())
+    ref_loss, ref = otrain.loss_and_grads(synth_sd(D, opt), x0, tt, hc, noise, T, dtype=torch.float64)
+    assert abs(float(loss) - float(ref_loss)) < 5e-6 * max(1.0, abs(float(ref_loss)))
+    for name, p in dm.model.named_parameters():
+        r = ref[name]
+        assert float((p.grad.cpu().double() - r).abs().max()) <= 2e-4 * max(float(r.abs().max()), 1e-7), name
+    # a second, smaller batch through the same TrainStep (workspace sized for the larger one)
+    if B > 1:
+        loss2, _ = ts.loss_backward(x0[:5].cuda(), {k: v[:5].cuda() for k, v in hc.items()}, t=tt[:5].cuda(), noise=noise[:5].cuda())
+        ref2, g2 = otrain.loss_and_grads(synth_sd(D, opt), x0[:5], tt[:5], {k: v[:5] for k, v in hc.items()}, noise[:5], T, dtype=torch.float64)
+        assert abs(float(loss2) - float(ref2)) < 5e-6
+        k = "downs.0.0.blocks.0.block.0.weight"
+        assert float((dict(dm.model.named_parameters())[k].grad.cpu().double() - g2[k]).abs().max()) <= 2e-4 * float(g2[k].abs().max())
+
+
 def test_batch_128_gradients_and_torch_optimizer_path():
     """Reference-scale batch (train.py: batch_size 32; here 128, Panda state dim): gradients against the fp32 oracle, and the
     `optimizers=` path - torch.optim.Adam over the aliased parameters - lands on the native Adam's result."""
