@@ -144,7 +144,11 @@ def roofline_leg(dm, B, T, reps=30):
     # collected by tools/r02_evidence.sh (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, gfx950 x2 fetch
     # correction, MI355X_MICROARCH.md section HBM) on this same command and committed under profiles/.
     traffic, traffic_src = None, None
-    for f in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
+    def _round_key(f):   # r02_ (a round's final evidence) after r02a_, r02b_ (mid-round states), rounds ascending
+        import re
+        m = re.match(r"r(\d+)([a-z]?)_", f.name)
+        return (int(m.group(1)), m.group(2) or "~") if m else (-1, "")
+    for f in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"), key=_round_key, reverse=True):
         try:
             rec = json.loads(f.read_text())
         except Exception:
