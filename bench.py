@@ -170,6 +170,12 @@ def roofline_leg(dm, B, T, reps=30):
             "unet_pass_us": round(whole.value * 1e3, 1), "unet_pass_us_sum_of_classes": round(tot_us, 1),
             "unet_pass_tflops": round(sum(fl[k] for k in range(n)) / (whole.value * 1e-3) / 1e12, 3),
             "classes": classes}
+    if dom["kernel"].startswith("fused"):
+        # one workgroup = one trajectory: a batch of B trajectories occupies min(B, 256) of the 256 CUs, so the fp32 MFMA rate these
+        # programs can reach is that fraction of the chip peak (`frac` above stays achieved / CHIP peak)
+        cus = min(B, 256)
+        roof["occupancy"] = {"workgroups": B, "cus_in_use": cus, "peak_at_occupancy_tflops": round(FP32_PEAK_TFLOPS * cus / 256, 1),
+                             "frac_of_peak_at_occupancy": round(dom["tflops"] / (FP32_PEAK_TFLOPS * cus / 256), 4)}
     return roof, sum(fl[k] for k in range(n))
 
 
