@@ -65,15 +65,18 @@ class FlatParams:
             self.order.append(name)
         self.packedT = torch.zeros(int(lib.mpdx_train_dgrad_pack_floats(h)), dtype=torch.float32, device=dev)
 
-    def aliased(self) -> bool:
+    def aliased(self, full: bool = False) -> bool:
+        """Do the module's parameters still live in the flat vector?  (`.to()` / `.cuda()` / re-creating parameters breaks the
+        aliasing.)  The per-step check looks at three parameters; `full` at all of them."""
         base = self.flat.data_ptr()
         named = dict(self.unet.named_parameters())
-        return all(named[k].data_ptr() == base + 4 * off for k, (off, _) in self.slices.items())
+        keys = self.order if full else (self.order[0], self.order[len(self.order) // 2], self.order[-1])
+        return all(k in named and named[k].data_ptr() == base + 4 * self.slices[k][0] for k in keys)
 
 
 def flat_params(unet) -> FlatParams:
     fp = getattr(unet, "_flat_params", None)
-    if fp is None or not fp.aliased():
+    if fp is None or not fp.aliased(full=True):
         fp = FlatParams(unet)
         unet._flat_params = fp
     return fp
@@ -103,8 +106,10 @@ class TrainStep:
             u._packed = torch.zeros(lib.mpdx_unet_packed_floats(h), dtype=torch.float32, device=self.fp.flat.device)
         return u._packed
 
-    def pack(self):
-        """flat parameters -> the two kernel layouts (after every optimiser step)."""
+    def pack(self, sync_engine: bool = True):
+        """flat parameters -> the two kernel layouts (after every optimiser step).  `sync_engine`: also tell the TemporalUnet's
+        inference engine that its pack is current (a walk over the parameters; the per-step call inside loss_backward skips it and
+        leaves the engine marked stale instead)."""
         if not self.fp.aliased():
             raise RuntimeError("the model's parameters no longer alias the flat training vector (was the model moved or re-created?) - "
                                "build a new TrainStep")
@@ -113,7 +118,7 @@ class TrainStep:
         _lib.check(lib.mpdx_train_pack(h, self.fp.flat.data_ptr(), packed.data_ptr(), self.fp.packedT.data_ptr(), _lib.current_stream()),
                    "mpdx_train_pack")
         # the inference engine of this TemporalUnet sees the new weights: its pack is current, its time table is not
-        self.unet._stamp = self.unet._param_stamp()
+        self.unet._stamp = self.unet._param_stamp() if sync_engine else None
         self.unet._timetab, self.unet._timetab_T = None, 0
 
     def loss_backward(self, x_start, hard_conds=None, t=None, noise=None, loss_scale=1.0):
@@ -138,7 +143,7 @@ class TrainStep:
         if self._ws is None or self._ws_B < B:
             self._ws = torch.empty(int(lib.mpdx_train_workspace_floats(h, B)), dtype=torch.float32, device=dev)
             self._ws_B = B
-        self.pack()
+        self.pack(sync_engine=False)
         _lib.check(lib.mpdx_train_loss_backward(
             h, self.fp.flat.data_ptr(), self._packed().data_ptr(), self.fp.packedT.data_ptr(), self.fp.grad.data_ptr(), x_start.data_ptr(),
             noise.data_ptr(), t.data_ptr(), m.sqrt_alphas_cumprod.data_ptr(), m.sqrt_one_minus_alphas_cumprod.data_ptr(),
@@ -156,6 +161,7 @@ class TrainStep:
         _lib.check(lib.mpdx_adam_step(self.fp.flat.data_ptr(), self.fp.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                       self.fp.n, float(lr), float(betas[0]), float(betas[1]), float(eps), self.step_count, mn,
                                       self.scratch.data_ptr(), _lib.current_stream()), "mpdx_adam_step")
+        self.unet._stamp = None   # the inference engine's pack of these weights is stale until the next pack()
         return self.scratch[0] if mn > 0 else None
 
 

@@ -271,7 +271,7 @@ def test_reference_loop_body_runs_unchanged_through_autograd():
     torch.manual_seed(5); dm_b.manual_seed(5)
     t = torch.randint(0, dm_b.n_diffusion_steps, (x0.shape[0],), device=x0.device).long()
     lb, _ = ts.loss_backward(x0, hc, t=t, loss_scale=2.0)
-    assert float(loss) == float(lb)
+    assert float(loss.detach()) == float(lb)
     for k, p in dm_b.model.named_parameters():
         assert torch.equal(ga[k], p.grad), k
     ts.adam_step(1e-4, max_norm=1.0)
