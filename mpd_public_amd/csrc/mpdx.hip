@@ -844,7 +844,7 @@ static void build_units(mpdx_unet* u) {
     // levels downs.0 + downs.1 + downs.2 (15 ops; measured cfg 2 23.10 -> 22.47 ms, cfg 5 shard 624 -> 617 ms against two programs;
     // MPDX_MERGE_DOWN3=0 keeps them apart), else downs.0 + downs.1
     bool merged_down = false;
-    if (nl >= 4 && !(getenv("MPDX_MERGE_DOWN3") && atoi(getenv("MPDX_MERGE_DOWN3")) == 0)) {
+    if (nl >= 4 && !getenv("MPDX_NO_MERGE") && !(getenv("MPDX_MERGE_DOWN3") && atoi(getenv("MPDX_MERGE_DOWN3")) == 0)) {
         int a0, a1, b0, b1, c0, c1;
         if (range_of("downs.0.", a0, a1) && range_of("downs.1.", b0, b1) && range_of("downs.2.", c0, c1) && a1 == b0 && b1 == c0 &&
             build_fused_segment(u, a0, c1, false)) {
@@ -867,7 +867,7 @@ static void build_units(mpdx_unet* u) {
     if (nl >= 4 && !getenv("MPDX_NO_MID2")) try_seg("downs.2.", false);
     // the two outer up levels + final_conv + DDPM step as ONE program (the second level's skip tensor is staged by the prologue)
     bool merged_up = false;
-    if (nl >= 3 && !getenv("MPDX_NO_MERGE_UP")) {
+    if (nl >= 3 && !getenv("MPDX_NO_MERGE_UP") && !getenv("MPDX_NO_MERGE")) {
         int a0, a1, b0, b1;
         if (range_of("ups." + std::to_string(nl - 3) + ".", a0, a1) && range_of("ups." + std::to_string(nl - 2) + ".", b0, b1) && a1 == b0 &&
             b1 == n - 1 && u->layers[n - 1].name.compare(0, 12, "final_conv.0") == 0 && build_fused_segment(u, a0, n, true)) {

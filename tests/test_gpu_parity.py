@@ -224,20 +224,22 @@ np.savez(sys.argv[2], **out)
 
 def test_fused_program_variants_agree(tmp_path):
     """The launch-structure switches are read once per process, so each variant runs in its own interpreter:
-    default (the two outer down levels merged into one fused program), MPDX_NO_MERGE=1 (one program per level) and
-    MPDX_FUSED=0 (one launch per layer).  Merged vs unmerged: same ops in the same order -> bit-identical.
-    Fused vs per-layer: different K split -> the eps tolerance of the golden test."""
+    default (static programs: all down levels in one launch, both up levels + final op in another), MPDX_NO_MERGE=1 (one program
+    per level), MPDX_STATIC_PROGRAMS=0 (the generic op-list kernel walks the same op lists) and MPDX_FUSED=0 (one launch per
+    layer).  Merged vs unmerged vs generic: same ops in the same order -> bit-identical.  Fused vs per-layer: different K split
+    -> the eps tolerance of the golden test."""
     import os, subprocess, sys
     from pathlib import Path
     root = str(Path(__file__).resolve().parent.parent)
     res = {}
-    for name, env in (("merged", {}), ("unmerged", {"MPDX_NO_MERGE": "1"}), ("per_layer", {"MPDX_FUSED": "0"})):
+    for name, env in (("merged", {}), ("unmerged", {"MPDX_NO_MERGE": "1"}), ("generic", {"MPDX_STATIC_PROGRAMS": "0"}), ("per_layer", {"MPDX_FUSED": "0"})):
         f = tmp_path / f"{name}.npz"
         e = dict(os.environ); e.update(env)
         subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT, root, str(f)], check=True, env=e, timeout=600)
         res[name] = load_npz(f)
     for k in ("D4", "D14"):
         assert np.array_equal(res["merged"][k], res["unmerged"][k]), k
+        assert np.array_equal(res["merged"][k], res["generic"][k]), k
         np.testing.assert_allclose(res["merged"][k], res["per_layer"][k], rtol=0, atol=2e-5, err_msg=k)
 
 
