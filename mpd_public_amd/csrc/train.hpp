@@ -227,13 +227,13 @@ struct WgradArgs {
 constexpr int kWgRS = 48;   // LDS row stride: 4 consecutive rows start 16 banks apart
 
 template <int KS>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                               // [LA][48]
     float* Bs = smem + (size_t)a.LA * kWgRS;        // [LB + 4][48], row r holds position r - 2
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
-    const int b0 = blockIdx.z * a.b_per_split, b1 = min(a.B, b0 + a.b_per_split);
+    const int n0 = bx * 32, m0 = by * 32;
+    const int b0 = bz * a.b_per_split, b1 = min(a.B, b0 + a.b_per_split);
     const int mi = (wave & 1) * 16, ni = (wave >> 1) * 16;
     const int i16 = lane & 15, kq = lane >> 4;
     f32x4 acc[KS];
@@ -269,10 +269,47 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + mi + 4 * kq + r;
             if (m >= a.M) continue;
-            float* dst = a.part + (((size_t)blockIdx.z * a.M + m) * a.N + n) * KS;
+            float* dst = a.part + (((size_t)bz * a.M + m) * a.N + n) * KS;
 #pragma unroll
             for (int k = 0; k < KS; ++k) dst[k] = acc[k][r];
         }
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+    wgrad_body<KS>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// One launch for everything that depends only on a layer's dU: the input-gradient convolution (blocks [0, n_dgrad): the forward
+// kernel's body on the dgrad pack, 512 threads) and the weight-gradient GEMM(s) against the layer's one or two sources (the blocks
+// behind them: 4 of the 8 waves work, the others leave at once - a finished wave does not take part in the workgroup's barriers).
+struct BwdPairArgs {
+    ConvArgs cd;
+    WgradArgs w[2];
+    int n_dgrad;
+    int nw[2];           // blocks of each weight-gradient GEMM (nw[1] == 0: one source)
+    int gx[2], gy[2];    // their grids: x = N tiles, y = M tiles, z = batch splits
+    int ks_w;            // taps of the weight gradient (1, 3, 4 or 5)
+};
+template <int KS_D, int MT, int NT>
+__global__ __launch_bounds__(512) void bwd_pair_kernel(const BwdPairArgs a) {
+    if ((int)blockIdx.x < a.n_dgrad) {
+        conv_block_body<CONV_S1, KS_D, EPI_BIAS, MT, NT, 1, 8>(a.cd, blockIdx.x);
+        return;
+    }
+    if (threadIdx.x >= 256) return;
+    int idx = (int)blockIdx.x - a.n_dgrad;
+    const int which = idx >= a.nw[0] ? 1 : 0;
+    if (which) idx -= a.nw[0];
+    const WgradArgs& w = a.w[which];
+    const int bx = idx % a.gx[which], r = idx / a.gx[which];
+    const int by = r % a.gy[which], bz = r / a.gy[which];
+    switch (a.ks_w) {
+        case 1: wgrad_body<1>(w, bx, by, bz); break;
+        case 3: wgrad_body<3>(w, bx, by, bz); break;
+        case 4: wgrad_body<4>(w, bx, by, bz); break;
+        default: wgrad_body<5>(w, bx, by, bz); break;
     }
 }
 

@@ -80,7 +80,7 @@ struct TrainWs {
 };
 static size_t wgrad_splits(int M, int N, int B) {
     const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
-    int S = (512 + tiles - 1) / tiles;
+    int S = (256 + tiles - 1) / tiles;   // about one workgroup per CU
     S = std::max(1, std::min(S, B));
     const int per = (B + S - 1) / S;
     return (size_t)((B + per - 1) / per);
@@ -123,7 +123,7 @@ static TrainWs train_ws(const mpdx_unet* u, int B) {
         tot += wgrad_splits(D, u->cfg.unet_input_dim, B) * D * (size_t)u->cfg.unet_input_dim;
         pv += (size_t)64 * D;
         static const bool off = getenv("MPDX_TRAIN_DEFERRED") && atoi(getenv("MPDX_TRAIN_DEFERRED")) == 0;
-        w.deferred = !off && tot <= ((size_t)64 << 20);
+        w.deferred = !off && tot <= ((size_t)96 << 20);   // floats
         w.wparts = take(w.deferred ? tot : 4);
         w.pvecs = take(w.deferred ? pv : 4);
     }
@@ -168,8 +168,11 @@ struct Deferred {
     ColsumAllArgs col;
 };
 
-static int launch_wgrad(const float* A, int LA, int lda, int a_off, int M, const float* Bm, int LB, int ldb, int b_off, int N, int sb, int ob, int KS,
-                        int B, float* part, float* g, int n_tot, int n_off, hipStream_t st, Deferred* df = nullptr) {
+// a weight-gradient GEMM ready to launch (alone, or inside bwd_pair_kernel)
+struct WgradJob { WgradArgs a; dim3 grid; size_t lds; int KS; bool deferred; float* g; int n_tot, n_off, S; };
+
+static int make_wgrad(const float* A, int LA, int lda, int a_off, int M, const float* Bm, int LB, int ldb, int b_off, int N, int sb, int ob, int KS,
+                      int B, float* part, float* g, int n_tot, int n_off, Deferred* df, WgradJob& j) {
     if (df && df->on && df->red.n < 96) {   // this layer's partial sums get their own storage; reduced at the end of the pass
         const size_t S0 = wgrad_splits(M, N, B);
         part = df->ws + df->wcur;
@@ -177,7 +180,7 @@ static int launch_wgrad(const float* A, int LA, int lda, int a_off, int M, const
         e.part = df->wcur; e.g = (unsigned long long)(g - df->grads); e.S = (int)S0; e.M = M; e.N = N; e.KS = KS; e.n_tot = n_tot; e.n_off = n_off;
         df->wcur += S0 * M * N * (size_t)KS;
     } else df = nullptr;
-    WgradArgs a;
+    WgradArgs& a = j.a;
     a.A = A; a.Bm = Bm; a.part = part;
     a.LA = LA; a.lda = lda; a.a_off = a_off; a.M = M;
     a.LB = LB; a.ldb = ldb; a.b_off = b_off; a.N = N;
@@ -185,19 +188,72 @@ static int launch_wgrad(const float* A, int LA, int lda, int a_off, int M, const
     const int S = (int)wgrad_splits(M, N, B);
     a.b_per_split = (B + S - 1) / S;
     if (LA % 4) return fail(MPDX_E_INVALID, "wgrad: horizon %d is not a multiple of 4", LA);
-    const size_t lds = (size_t)(LA + LB + 4) * kWgRS * sizeof(float);
-    const dim3 grid((N + 31) / 32, (M + 31) / 32, S);
-    switch (KS) {
-        case 1: hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), lds, st, a); break;
-        case 3: hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(256), lds, st, a); break;
-        case 4: hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(256), lds, st, a); break;
-        case 5: hipLaunchKernelGGL(wgrad_kernel<5>, grid, dim3(256), lds, st, a); break;
-        default: return fail(MPDX_E_INVALID, "wgrad: %d taps", KS);
-    }
-    if (df) return 0;
-    const size_t per = (size_t)M * N * KS;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((per + 255) / 256, 1024)), dim3(256), 0, st, part, g, S, M, N, KS, n_tot, n_off);
+    if (KS != 1 && KS != 3 && KS != 4 && KS != 5) return fail(MPDX_E_INVALID, "wgrad: %d taps", KS);
+    j.lds = (size_t)(LA + LB + 4) * kWgRS * sizeof(float);
+    j.grid = dim3((N + 31) / 32, (M + 31) / 32, S);
+    j.KS = KS; j.deferred = df != nullptr; j.g = g; j.n_tot = n_tot; j.n_off = n_off; j.S = S;
     return 0;
+}
+// the reduction of a job whose partial sums are not deferred
+static void finish_wgrad(const WgradJob& j, hipStream_t st) {
+    if (j.deferred) return;
+    const size_t per = (size_t)j.a.M * j.a.N * j.KS;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((per + 255) / 256, 1024)), dim3(256), 0, st, (const float*)j.a.part, j.g, j.S,
+                       j.a.M, j.a.N, j.KS, j.n_tot, j.n_off);
+}
+static void run_wgrad(const WgradJob& j, hipStream_t st) {
+    switch (j.KS) {
+        case 1: hipLaunchKernelGGL(wgrad_kernel<1>, j.grid, dim3(256), j.lds, st, j.a); break;
+        case 3: hipLaunchKernelGGL(wgrad_kernel<3>, j.grid, dim3(256), j.lds, st, j.a); break;
+        case 4: hipLaunchKernelGGL(wgrad_kernel<4>, j.grid, dim3(256), j.lds, st, j.a); break;
+        default: hipLaunchKernelGGL(wgrad_kernel<5>, j.grid, dim3(256), j.lds, st, j.a); break;
+    }
+    finish_wgrad(j, st);
+}
+static int launch_wgrad(const float* A, int LA, int lda, int a_off, int M, const float* Bm, int LB, int ldb, int b_off, int N, int sb, int ob, int KS,
+                        int B, float* part, float* g, int n_tot, int n_off, hipStream_t st, Deferred* df = nullptr) {
+    WgradJob j;
+    if (int rc = make_wgrad(A, LA, lda, a_off, M, Bm, LB, ldb, b_off, N, sb, ob, KS, B, part, g, n_tot, n_off, df, j)) return rc;
+    run_wgrad(j, st);
+    return 0;
+}
+
+// dgrad convolution + the layer's weight-gradient GEMM(s) in ONE launch (bwd_pair_kernel); the jobs must use distinct partial buffers
+template <int KS_D>
+static int launch_bwd_pair(const Layer& dgl, ConvArgs& cd, int B, const WgradJob* jobs, int njobs, hipStream_t st) {
+    int MT, NT;
+    choose_tile(dgl, B, MT, NT);
+    if (dgl.cout % MT) MT = 16;
+    if (dgl.cout % MT || NT % dgl.L_out) return fail(MPDX_E_INVALID, "layer %s: no tile for C_out=%d L=%d", dgl.name.c_str(), dgl.cout, dgl.L_out);
+    cd.n_tiles_n = (int)(((long)B * dgl.L_out + NT - 1) / NT);
+    BwdPairArgs a;
+    memset(&a, 0, sizeof(a));
+    a.cd = cd;
+    a.n_dgrad = (dgl.cout / MT) * cd.n_tiles_n;
+    a.ks_w = jobs[0].KS;
+    size_t lds = 0;
+    int total = a.n_dgrad;
+    for (int k = 0; k < njobs; ++k) {
+        a.w[k] = jobs[k].a;
+        a.gx[k] = jobs[k].grid.x; a.gy[k] = jobs[k].grid.y;
+        a.nw[k] = jobs[k].grid.x * jobs[k].grid.y * jobs[k].grid.z;
+        total += a.nw[k];
+        lds = std::max(lds, jobs[k].lds);
+    }
+#define MPDX_BP_TILE(mt, nt)                                                                              \
+    if (MT == mt && NT == nt) {                                                                           \
+        lds = std::max(lds, conv_block_lds_bytes<CONV_S1, KS_D, mt, nt, 8>(cd.L_in, cd.L_out, cd.rs));      \
+        if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "backward pair needs %zu B of LDS", lds);        \
+        auto kern = bwd_pair_kernel<KS_D, mt, nt>;                                                        \
+        if (lds > 64 * 1024)                                                                              \
+            if (int rc = raise_lds_limit((const void*)kern)) return rc;                                   \
+        hipLaunchKernelGGL(kern, dim3(total), dim3(512), lds, st, a);                                     \
+        for (int k = 0; k < njobs; ++k) finish_wgrad(jobs[k], st);                                        \
+        return 0;                                                                                         \
+    }
+    MPDX_BP_TILE(32, 64) MPDX_BP_TILE(32, 32) MPDX_BP_TILE(16, 64) MPDX_BP_TILE(16, 32) MPDX_BP_TILE(32, 16) MPDX_BP_TILE(16, 16)
+#undef MPDX_BP_TILE
+    return fail(MPDX_E_INVALID, "no backward-pair instantiation for tile %dx%d", MT, NT);
 }
 
 // channel sums of a dense [rows][C] tensor -> out[C]
@@ -415,17 +471,23 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         } else {
             launch_rowsum(gy, (size_t)B * l.L_out, l.cout, rpart, gflat(l.b), st, &df);
         }
-        // weight gradient
+        // weight gradient(s) and input gradient: everything below depends only on dy
         float* gw = gflat(l.w);
+        WgradJob jobs[2];
+        int njobs = 0;
         if (l.mode == CONV_UPT) {
-            if (int rc = launch_wgrad(tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, dy, l.L_out, l.cout, 0, l.cout, 2, -1, 4, B, part, gw, l.cout, 0, st, &df)) return rc;
+            if (int rc = make_wgrad(tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, dy, l.L_out, l.cout, 0, l.cout, 2, -1, 4, B, part, gw, l.cout, 0, &df, jobs[njobs++])) return rc;
         } else {
             const int sb = l.mode == CONV_DOWN ? 2 : 1, ob = l.mode == CONV_DOWN ? -1 : -(l.ks / 2);
-            if (int rc = launch_wgrad(dy, l.L_out, l.cout, 0, l.cout, tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, sb, ob, l.ks, B, part, gw, Cin, 0, st, &df)) return rc;
+            if (int rc = make_wgrad(dy, l.L_out, l.cout, 0, l.cout, tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, sb, ob, l.ks, B, part, gw, Cin, 0, &df, jobs[njobs++])) return rc;
             if (l.c2 > 0)
-                if (int rc = launch_wgrad(dy, l.L_out, l.cout, 0, l.cout, tensor(t.src2_l), l.L_in, l.c2, 0, l.c2, sb, ob, l.ks, B, part, gw, Cin, l.c1, st, &df)) return rc;
+                if (int rc = make_wgrad(dy, l.L_out, l.cout, 0, l.cout, tensor(t.src2_l), l.L_in, l.c2, 0, l.c2, sb, ob, l.ks, B, part, gw, Cin, l.c1, &df, jobs[njobs++])) return rc;
         }
-        // input gradient
+        static const bool pair_off = getenv("MPDX_TRAIN_PAIR") && atoi(getenv("MPDX_TRAIN_PAIR")) == 0;
+        // one launch for all of them needs every job on its own partial buffer (the deferred mode)
+        const bool paired = t.need_dgrad && !pair_off && jobs[0].deferred && (njobs == 1 || jobs[1].deferred);
+        if (!paired)
+            for (int k = 0; k < njobs; ++k) run_wgrad(jobs[k], st);
         if (t.need_dgrad) {
             const Layer& dgl = t.dg;
             const float* din = dy;
@@ -440,16 +502,20 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             a.src1 = din;
             a.wp = packedT + t.dgrad_woff;
             a.bias = ws + w.zeros;
-            if (l.mode == CONV_UPT) {   // full-resolution result, every second position is the gradient
-                a.dst = ws + w.tmpX;
-                if (int rc = launch_layer(dgl, a, B, st)) return rc;
-                if (t.src1_l >= 0) launch_acc(grd(t.src1_l), ws + w.tmpX, B, l.L_in, l.c1, dgl.L_out, Cin, 0, 2, st);
-            } else {   // added straight into the gradient buffer(s) of the layer's input(s)
+            if (l.mode == CONV_UPT) a.dst = ws + w.tmpX;   // full-resolution result, every second position is the gradient
+            else {   // added straight into the gradient buffer(s) of the layer's input(s)
                 a.accum = 1;
                 a.dst = t.src1_l >= 0 ? grd(t.src1_l) : nullptr;
                 if (l.c2 > 0) { a.c_split = l.c1; a.dst2 = t.src2_l >= 0 ? grd(t.src2_l) : nullptr; }
-                if (int rc = launch_layer(dgl, a, B, st)) return rc;
             }
+            if (paired) {
+                int rc;
+                if (dgl.ks == 5) rc = launch_bwd_pair<5>(dgl, a, B, jobs, njobs, st);
+                else if (dgl.ks == 3) rc = launch_bwd_pair<3>(dgl, a, B, jobs, njobs, st);
+                else rc = launch_bwd_pair<1>(dgl, a, B, jobs, njobs, st);
+                if (rc) return rc;
+            } else if (int rc = launch_layer(dgl, a, B, st)) return rc;
+            if (l.mode == CONV_UPT && t.src1_l >= 0) launch_acc(grd(t.src1_l), ws + w.tmpX, B, l.L_in, l.c1, dgl.L_out, Cin, 0, 2, st);
         }
     }
     if (df.red.n) hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(48, df.red.n), dim3(256), 0, st, df.red);
