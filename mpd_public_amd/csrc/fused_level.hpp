@@ -102,6 +102,9 @@ struct FusedOp {          // runtime part of an op: 13 dwords
     int sbase;                 // float offset (in `packed`) of the op's weight streams: [tile-stream][TOT blocks][256]
     int p_off;                 // float offset of the op's [bias | gamma | beta | rbias] x C_out block in the LDS parameter area
     int tb_off;                // float offset of the op's time-bias row in the LDS time-table slice (-1: none)
+    // training forward (FusedArgs::save != null): float offsets in `save` of dense [B][L_out][C_out] copies of the op's output and of
+    // its GroupNorm input (conv + bias), which the backward pass differentiates through; -1: not kept
+    int save_out, save_pre;
 };
 
 constexpr int kMaxFusedOps = 16;
@@ -125,6 +128,8 @@ struct FusedArgs {
     // tensor (torch.cat((x, h.pop()), dim=1) of the second up level, temporal_unet.py:159): written by the prologue into columns
     // [col3, col3 + c3/4) of that op's (wider) source buffer, whose first columns the producing Upsample1d fills later
     const float* gsrc3;
+    float* save;                              // training: base of the kept activations (see FusedOp::save_out); null when planning
+    int tt_stride;                            // training: per-trajectory time-table rows (tt_row + b * tt_stride); 0 when planning
     int fpar_off;                             // final_conv[1] weights [D][Cf + 4] + bias [D] inside the staged parameter block (floats)
     int c3, L3, s3_off4, s3_rs4, s3_col4;     // c3 == 0: none
     int B, nops;
@@ -287,6 +292,7 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
             const f32x4 dl = v[t] - m_loc;
             const float m2_loc = row_sum16((dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]));
             if (j == 0) *(f32x2*)(stat + ((mst[t] * S::NSn + ns[t]) * 4 + q) * 2) = (f32x2){m_loc, m2_loc};
+            if (a.save && op.save_pre >= 0) *(f32x4*)(a.save + op.save_pre + ((size_t)b * S::LOUT + npos[t]) * S::COUT + c0) = v[t];
         }
         lds_barrier();
         FOP_STAMP();   // statistics exchanged
@@ -333,6 +339,7 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
         if (!col_ok) continue;
         if (op.dst_off4 >= 0) sm4[op.dst_off4 + (npos[t] + 2) * op.dst_rs4 + (c0t[t] >> 2)] = y[t];
         if (op.gdst >= 0) *(f32x4*)(a.gout[op.gdst] + ((size_t)b * S::LOUT + npos[t]) * S::COUT + c0t[t]) = y[t];
+        if (a.save && op.save_out >= 0) *(f32x4*)(a.save + op.save_out + ((size_t)b * S::LOUT + npos[t]) * S::COUT + c0t[t]) = y[t];
     }
     if (op.dst_off4 >= 0) {   // halo rows of the buffer this op defines (2 above, 2 below its L_out interior rows)
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -421,7 +428,7 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, 
     for (int k = 0; k < PK; ++k) {
         const int idx = tid + k * NT_;
         if (k * NT_ >= npar4 + ntt4) continue;   // wave-uniform: no pass beyond the data (pv[k] stays unset, never stored)
-        const float* src = idx < npar4 ? a.packed + a.gpar_off + (size_t)idx * 4 : a.tt_row + a.tt_lo + (size_t)(idx - npar4 < ntt4 ? idx - npar4 : 0) * 4;
+        const float* src = idx < npar4 ? a.packed + a.gpar_off + (size_t)idx * 4 : a.tt_row + (size_t)b * a.tt_stride + a.tt_lo + (size_t)(idx - npar4 < ntt4 ? idx - npar4 : 0) * 4;
         pv[k] = *(const f32x4*)src;
     }
     FUSED_STAMP();   // ring + input + parameter loads issued

@@ -341,8 +341,12 @@ struct mpdx_unet {
         mpdx::FusedArgs tmpl;
         int program = -1;               // index of the matching static program (fused_program_kernel), -1: generic op-list kernel
         std::vector<CopyJob> jobs;      // assemble the stream-ordered weight copies + the contiguous parameter block
+        std::vector<int> op_layer;      // conv op k computes layer op_layer[k] (a folded residual conv has no op of its own)
+        int in3_consumer = -1;          // layer whose second source is the in3 skip tensor
     };
     std::vector<Fused> fused;
+    void* jobs_dev = nullptr;           // device copy of every segment's CopyJobs (restream_all_kernel)
+    int n_jobs = 0;
     const float* streams_for = nullptr; // `packed` buffer the fused streams were last assembled in
     int pack_version = 0, streams_version = -1;
     struct Unit { int fused; int layer; bool pair; };   // fused >= 0: fused[fused]; else layers[layer] (pair: + layers[layer+1] in one launch)
@@ -662,6 +666,7 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
                 ho.dst = buf_for(l.dst, l.L_out, cc->c1 + cc->c2);
                 cat_buf = ho.dst;
                 f.in3 = cc->src2;
+                f.in3_consumer = (int)(cc - &u->layers[0]);
                 a.c3 = cc->c2; a.L3 = cc->L_in; a.s3_col4 = cc->c1 / 4;
                 touch(cat_buf, -1, true);   // its skip columns are written by the prologue: live from the start
             } else ho.dst = buf_for(l.dst, l.L_out, l.cout);
@@ -675,6 +680,7 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         }
         touch(ho.src, a.nops, false); touch(ho.res, a.nops, false); touch(ho.rsrc, a.nops, false); touch(ho.dst, a.nops, true);
         hops.push_back(ho);
+        f.op_layer.push_back(i);
         a.nops++;
     }
     if (pending_res >= 0) return fuse_reject(__LINE__);
@@ -1125,21 +1131,41 @@ __global__ void restream_kernel(float* __restrict__ packed, size_t src, size_t d
     }
 }
 
+// all strided copies of every fused segment in ONE launch (blockIdx.y = job; the table lives in device memory)
+struct CopyJobDev { unsigned long long src, dst; int n0, ss0, ds0, n1, ss1, ds1, n_inner; };
+__global__ __launch_bounds__(256) void restream_all_kernel(float* __restrict__ packed, const CopyJobDev* __restrict__ jobs) {
+    const CopyJobDev j = jobs[blockIdx.y];
+    const size_t total = (size_t)j.n0 * j.n1 * j.n_inner;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i % j.n_inner);
+        const size_t r = i / j.n_inner;
+        const int i1 = (int)(r % j.n1), i0 = (int)(r / j.n1);
+        packed[j.dst + (size_t)i0 * j.ds0 + (size_t)i1 * j.ds1 + k] = packed[j.src + (size_t)i0 * j.ss0 + (size_t)i1 * j.ss1 + k];
+    }
+}
+
 // The fused segments read stream-ordered copies of their weights and one contiguous parameter block (fused_level.hpp);
 // (re)assemble them in `packed` after the state dict was (re)packed.  Enqueues copies on `st`; no synchronisation.
 static int ensure_fused_streams(mpdx_unet* u, const float* packed, hipStream_t st) {
     if (u->streams_for == packed && u->streams_version == u->pack_version) return 0;
-    for (const auto& f : u->fused)
-        for (const auto& j : f.jobs) {
-            const size_t total = (size_t)j.n0 * j.n1 * j.n_inner;
-            hipLaunchKernelGGL(restream_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1024)), dim3(256), 0, st, const_cast<float*>(packed),
-                               j.src, j.dst, j.n0, j.ss0, j.ds0, j.n1, j.ss1, j.ds1, j.n_inner);
+    if (!u->jobs_dev) {   // the job table never changes after build_units
+        std::vector<CopyJobDev> all;
+        for (const auto& f : u->fused)
+            for (const auto& j : f.jobs) all.push_back({(unsigned long long)j.src, (unsigned long long)j.dst, j.n0, j.ss0, j.ds0, j.n1, j.ss1, j.ds1, j.n_inner});
+        u->n_jobs = (int)all.size();
+        if (u->n_jobs) {
+            HIP_TRY(hipMalloc(&u->jobs_dev, all.size() * sizeof(CopyJobDev)));
+            HIP_TRY(hipMemcpy(u->jobs_dev, all.data(), all.size() * sizeof(CopyJobDev), hipMemcpyHostToDevice));
         }
+    }
+    if (u->n_jobs)
+        hipLaunchKernelGGL(restream_all_kernel, dim3(16, (unsigned)u->n_jobs), dim3(256), 0, st, const_cast<float*>(packed), (const CopyJobDev*)u->jobs_dev);
     HIP_TRY(hipGetLastError());
     u->streams_for = packed; u->streams_version = u->pack_version;
     return 0;
 }
 
+static int launch_fused_args(const mpdx_unet::Fused& f, const FusedArgs& a, int B, hipStream_t st);
 static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packed, const float* tt_row, const float* x, float* ws,
                      int B, const FinalArgs* fa, hipStream_t st) {
     const size_t slot = u->slot_floats * (size_t)B;
@@ -1158,6 +1184,10 @@ static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packe
         a.absmax = fa->absmax; a.fmode = fa->mode; a.n_per_ctx = fa->n_per_ctx > 0 ? fa->n_per_ctx : B; a.k = fa->k;
         a.rng = fa->rng;
     }
+    return launch_fused_args(f, a, B, st);
+}
+
+static int launch_fused_args(const mpdx_unet::Fused& f, const FusedArgs& a, int B, hipStream_t st) {
     switch (f.program) {
         case 0:
             if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqDown>)) return rc;
@@ -1299,6 +1329,7 @@ int mpdx_unet_create(const mpdx_unet_cfg* cfg, mpdx_unet** out) {
 
 void mpdx_unet_destroy(mpdx_unet* u) {
     if (u && u->pack_descs_dev) (void)hipFree(u->pack_descs_dev);
+    if (u && u->jobs_dev) (void)hipFree(u->jobs_dev);
     delete u;
 }
 

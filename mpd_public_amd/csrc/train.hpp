@@ -222,6 +222,10 @@ struct WgradArgs {
     int LB, ldb, b_off, N;
     int sb, ob;
     int B, b_per_split;
+    // bias gradient of a convolution without GroupNorm = column sums of its dY, which is this GEMM's A operand (Conv1d) or B operand
+    // (ConvTranspose1d): the first tile column / row of blocks adds them up on the side -> bias_part[split][channel]
+    float* bias_part;    // or null
+    int bias_from_b;
 };
 
 constexpr int kWgRS = 48;   // LDS row stride: 4 consecutive rows start 16 banks apart
@@ -245,6 +249,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
         Bs[(size_t)(r < 2 ? r : a.LB + r) * kWgRS + c] = 0.f;
     }
     const int col = tid & 31, row0 = tid >> 5;   // 8 rows per pass
+    const bool do_bias = a.bias_part && (a.bias_from_b ? by == 0 : bx == 0);   // all 256 threads: (column, row phase of 8)
+    float bsum = 0.f;
     for (int b = b0; b < b1; ++b) {
         __syncthreads();   // the previous trajectory's fragments are read
         for (int r = row0; r < a.LA; r += 8)
@@ -252,6 +258,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
         for (int r = row0; r < a.LB; r += 8)
             Bs[(size_t)(r + 2) * kWgRS + col] = (n0 + col < a.N) ? a.Bm[((size_t)b * a.LB + r) * a.ldb + a.b_off + n0 + col] : 0.f;
         __syncthreads();
+        if (do_bias) {   // fixed order: this thread's rows ascending, trajectories ascending; the 8 row phases are combined at the end
+            if (a.bias_from_b) for (int r = row0; r < a.LB; r += 8) bsum += Bs[(size_t)(r + 2) * kWgRS + col];
+            else for (int r = row0; r < a.LA; r += 8) bsum += As[(size_t)r * kWgRS + col];
+        }
         for (int t0 = 0; t0 < a.LA; t0 += 4) {
             const float av = As[(size_t)(t0 + kq) * kWgRS + mi + i16];
             const int pr = a.sb * (t0 + kq) + a.ob + 2;
@@ -260,6 +270,18 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
                 const float bv = Bs[(size_t)(pr + k) * kWgRS + ni + i16];
                 acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[k], 0, 0, 0);
             }
+        }
+    }
+    if (do_bias) {
+        __syncthreads();   // the last trajectory's fragments are read: As is free
+        As[row0 * 32 + col] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            float t = 0.f;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) t += As[p * 32 + tid];
+            const int c = (a.bias_from_b ? n0 : m0) + tid, C = a.bias_from_b ? a.N : a.M;
+            if (c < C) a.bias_part[(size_t)bz * C + c] = t;
         }
     }
     // D fragment: lane holds rows 4 * kq + r (r = 0..3), column i16

@@ -118,10 +118,10 @@ static TrainWs train_ws(const mpdx_unet* u, int B) {
                 tot += wgrad_splits(l.cout, l.c1, B) * l.cout * l.c1 * (size_t)KS;
                 if (l.c2 > 0) tot += wgrad_splits(l.cout, l.c2, B) * l.cout * l.c2 * (size_t)KS;
             }
-            pv += (l.epi == EPI_GN_MISH ? (size_t)3 * B : (size_t)64) * l.cout;
+            pv += (l.epi == EPI_GN_MISH ? (size_t)3 * B : (size_t)256 + 64) * l.cout;
         }
         tot += wgrad_splits(D, u->cfg.unet_input_dim, B) * D * (size_t)u->cfg.unet_input_dim;
-        pv += (size_t)64 * D;
+        pv += (size_t)(256 + 64) * D;
         static const bool off = getenv("MPDX_TRAIN_DEFERRED") && atoi(getenv("MPDX_TRAIN_DEFERRED")) == 0;
         w.deferred = !off && tot <= ((size_t)96 << 20);   // floats
         w.wparts = take(w.deferred ? tot : 4);
@@ -181,6 +181,7 @@ static int make_wgrad(const float* A, int LA, int lda, int a_off, int M, const f
         df->wcur += S0 * M * N * (size_t)KS;
     } else df = nullptr;
     WgradArgs& a = j.a;
+    a.bias_part = nullptr; a.bias_from_b = 0;
     a.A = A; a.Bm = Bm; a.part = part;
     a.LA = LA; a.lda = lda; a.a_off = a_off; a.M = M;
     a.LB = LB; a.ldb = ldb; a.b_off = b_off; a.N = N;
@@ -193,6 +194,18 @@ static int make_wgrad(const float* A, int LA, int lda, int a_off, int M, const f
     j.grid = dim3((N + 31) / 32, (M + 31) / 32, S);
     j.KS = KS; j.deferred = df != nullptr; j.g = g; j.n_tot = n_tot; j.n_off = n_off; j.S = S;
     return 0;
+}
+// let a (deferred) weight-gradient job add up its convolution's bias gradient too: true if attached (else the caller runs launch_rowsum)
+static bool attach_bias(WgradJob& j, Deferred* df, float* gbias, bool from_b) {
+    static const bool off = getenv("MPDX_TRAIN_BIAS_FOLD") && atoi(getenv("MPDX_TRAIN_BIAS_FOLD")) == 0;   // dev A/B switch
+    if (off || !df || !df->on || !j.deferred || df->col.n >= 120) return false;
+    const int C = from_b ? j.a.N : j.a.M;
+    j.a.bias_part = df->ws + df->pcur;
+    j.a.bias_from_b = from_b ? 1 : 0;
+    auto& e = df->col.e[df->col.n++];
+    e.part = df->pcur; e.out = (unsigned long long)(gbias - df->grads); e.rows = j.S; e.C = C;
+    df->pcur += (size_t)j.S * C;
+    return true;
 }
 // the reduction of a job whose partial sums are not deferred
 static void finish_wgrad(const WgradJob& j, hipStream_t st) {
@@ -378,7 +391,40 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         tb.B = B; tb.row = ta.row; tb.nblk = ta.nblk;
         for (int i = 0; i < ta.nblk; ++i) { tb.woff[i] = ta.woff[i]; tb.boff[i] = ta.boff[i]; tb.cout[i] = ta.cout[i]; tb.toff[i] = ta.toff[i]; }
     }
+    // forward: the fused level programs of the planning path (they additionally keep every op's output and GroupNorm input,
+    // FusedArgs::save) for the outer levels, one launch per layer for the rest
+    static const bool fused_fwd_off = getenv("MPDX_TRAIN_FUSED_FWD") && atoi(getenv("MPDX_TRAIN_FUSED_FWD")) == 0;
+    const bool fused_fwd = !fused_fwd_off && fused_mask(B) != 0u && (w.total < ((size_t)1 << 31));
+    bool eps_done = false;
     for (int i = 0; i < n; ++i) {
+        const int seg = fused_fwd ? u->owner[i] : -1;
+        if (seg >= 0 && ((fused_mask(B) >> seg) & 1u)) {
+            const mpdx_unet::Fused& f = u->fused[seg];
+            if (i != f.first) continue;   // the segment's launch covers layers [first, first + count)
+            if (int rc = ensure_fused_streams(u, packed, st)) return rc;
+            FusedArgs a = f.tmpl;
+            a.packed = packed;
+            a.tt_row = ws + w.tb; a.tt_stride = u->tt_row;
+            const auto& t0 = u->tl[f.first];
+            a.gsrc1 = tensor(t0.src1_l); a.gsrc2 = tensor(t0.src2_l);
+            a.gsrc3 = f.in3_consumer >= 0 ? tensor(u->tl[f.in3_consumer].src2_l) : a.gsrc1;
+            a.B = B;
+            a.save = ws;
+            int k = 0;
+            for (; k < (int)f.op_layer.size(); ++k) {
+                const int li = f.op_layer[k];
+                a.ops[k].gdst = -1;   // nothing reads the planning path's slots here
+                a.ops[k].save_out = (int)(w.out0 + (size_t)li * w.slotB);
+                a.ops[k].save_pre = u->layers[li].epi == EPI_GN_MISH ? (int)(w.pre0 + (size_t)li * w.slotB) : -1;
+            }
+            for (; k < a.nops; ++k) { a.ops[k].save_out = -1; a.ops[k].save_pre = -1; }
+            if (f.has_final) {   // final_conv[1] -> eps, no DDPM step
+                a.out = eps; a.fmode = 0; a.n_per_ctx = B;
+                eps_done = true;
+            }
+            if (int rc = launch_fused_args(f, a, B, st)) return rc;
+            continue;
+        }
         const Layer& l = u->layers[i];
         const auto& t = u->tl[i];
         ConvArgs a;
@@ -404,7 +450,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         fa.out = eps; fa.mode = 0; fa.n_per_ctx = 1;
         fa.B = B; fa.H = H; fa.D = D; fa.C = c.unet_input_dim;
         const int np = B * H;
-        hipLaunchKernelGGL(final_step_kernel, dim3((np + 255) / 256), dim3(256), (size_t)(fa.D * fa.C + fa.D) * sizeof(float), st, fa);
+        if (!eps_done) hipLaunchKernelGGL(final_step_kernel, dim3((np + 255) / 256), dim3(256), (size_t)(fa.D * fa.C + fa.D) * sizeof(float), st, fa);
         const float* target = predict_epsilon ? noise : x_start;
         hipLaunchKernelGGL(weighted_loss_kernel, dim3(1), dim3(1024), 0, st, (const float*)eps, target, weights_hd, hard_start, hard_goal, l1, loss_out, B, H, D);
         const size_t ne = (size_t)B * H * D;
@@ -426,8 +472,11 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         const size_t rows = (size_t)B * H;
         hipLaunchKernelGGL(final_dgrad_kernel, dim3((unsigned)std::min<size_t>((rows * C + 255) / 256, 2048)), dim3(256), 0, st, (const float*)dE,
                            flat + u->params[wi].foff, grd(n - 1), rows, D, C);
-        if (int rc = launch_wgrad(dE, H, D, 0, D, out(n - 1), H, C, 0, C, 1, 0, 1, B, part, gflat(wi), C, 0, st, &df)) return rc;
-        launch_rowsum(dE, rows, D, rpart, gflat(bi), st, &df);
+        WgradJob fj;
+        if (int rc = make_wgrad(dE, H, D, 0, D, out(n - 1), H, C, 0, C, 1, 0, 1, B, part, gflat(wi), C, 0, &df, fj)) return rc;
+        const bool fb = attach_bias(fj, &df, gflat(bi), false);
+        run_wgrad(fj, st);
+        if (!fb) launch_rowsum(dE, rows, D, rpart, gflat(bi), st, &df);
     }
     for (int i = n - 1; i >= 0; --i) {
         const Layer& l = u->layers[i];
@@ -468,8 +517,6 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             cs.B = B; cs.C = l.cout;
             if (!dcol) hipLaunchKernelGGL(colsum_kernel, dim3((l.cout + 63) / 64, 3), dim3(256), 0, st, cs);
             dy = g.du;
-        } else {
-            launch_rowsum(gy, (size_t)B * l.L_out, l.cout, rpart, gflat(l.b), st, &df);
         }
         // weight gradient(s) and input gradient: everything below depends only on dy
         float* gw = gflat(l.w);
@@ -482,6 +529,9 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             if (int rc = make_wgrad(dy, l.L_out, l.cout, 0, l.cout, tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, sb, ob, l.ks, B, part, gw, Cin, 0, &df, jobs[njobs++])) return rc;
             if (l.c2 > 0)
                 if (int rc = make_wgrad(dy, l.L_out, l.cout, 0, l.cout, tensor(t.src2_l), l.L_in, l.c2, 0, l.c2, sb, ob, l.ks, B, part, gw, Cin, l.c1, &df, jobs[njobs++])) return rc;
+        }
+        if (l.epi != EPI_GN_MISH) {   // bias gradient = channel sums of dY: rides on the first weight-gradient job, else its own two launches
+            if (!attach_bias(jobs[0], &df, gflat(l.b), l.mode == CONV_UPT)) launch_rowsum(gy, (size_t)B * l.L_out, l.cout, rpart, gflat(l.b), st, &df);
         }
         static const bool pair_off = getenv("MPDX_TRAIN_PAIR") && atoi(getenv("MPDX_TRAIN_PAIR")) == 0;
         // one launch for all of them needs every job on its own partial buffer (the deferred mode)
