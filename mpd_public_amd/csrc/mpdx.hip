@@ -1165,7 +1165,9 @@ static int ensure_fused_streams(mpdx_unet* u, const float* packed, hipStream_t s
     return 0;
 }
 
-static int launch_fused_args(const mpdx_unet::Fused& f, const FusedArgs& a, int B, hipStream_t st);
+static int launch_fused_args(const mpdx_unet::Fused& f, const FusedArgs& a, int B, hipStream_t st, bool save = false);
+// programs that exist in the training-forward variant (the two of the standard 4-level network, and the generic op-list kernel)
+static bool fused_save_variant(const mpdx_unet::Fused& f) { return f.program == 3 || f.program == 5 || f.program < 0; }
 static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packed, const float* tt_row, const float* x, float* ws,
                      int B, const FinalArgs* fa, hipStream_t st) {
     const size_t slot = u->slot_floats * (size_t)B;
@@ -1187,7 +1189,21 @@ static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packe
     return launch_fused_args(f, a, B, st);
 }
 
-static int launch_fused_args(const mpdx_unet::Fused& f, const FusedArgs& a, int B, hipStream_t st) {
+static int launch_fused_args(const mpdx_unet::Fused& f, const FusedArgs& a, int B, hipStream_t st, bool save) {
+    if (save) {
+        if (!fused_save_variant(f)) return fail(MPDX_E_STATE, "fused program %d has no training variant", f.program);
+        if (f.program == 3) {
+            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqUpAB, true>)) return rc;
+            hipLaunchKernelGGL((fused_program_kernel<FusedSeqUpAB, true>), dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
+        } else if (f.program == 5) {
+            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqDown3, true>)) return rc;
+            hipLaunchKernelGGL((fused_program_kernel<FusedSeqDown3, true>), dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
+        } else {
+            if (int rc = raise_lds_limit((const void*)fused_level_kernel<true>)) return rc;
+            hipLaunchKernelGGL(fused_level_kernel<true>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
+        }
+        return 0;
+    }
     switch (f.program) {
         case 0:
             if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqDown>)) return rc;
@@ -1214,8 +1230,8 @@ static int launch_fused_args(const mpdx_unet::Fused& f, const FusedArgs& a, int 
             hipLaunchKernelGGL(fused_program_kernel<FusedSeqDown3>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
             break;
         default:
-            if (int rc = raise_lds_limit((const void*)fused_level_kernel)) return rc;
-            hipLaunchKernelGGL(fused_level_kernel, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
+            if (int rc = raise_lds_limit((const void*)fused_level_kernel<false>)) return rc;
+            hipLaunchKernelGGL(fused_level_kernel<false>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
     }
     return 0;
 }

@@ -398,7 +398,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     bool eps_done = false;
     for (int i = 0; i < n; ++i) {
         const int seg = fused_fwd ? u->owner[i] : -1;
-        if (seg >= 0 && ((fused_mask(B) >> seg) & 1u)) {
+        if (seg >= 0 && ((fused_mask(B) >> seg) & 1u) && fused_save_variant(u->fused[seg])) {
             const mpdx_unet::Fused& f = u->fused[seg];
             if (i != f.first) continue;   // the segment's launch covers layers [first, first + count)
             if (int rc = ensure_fused_streams(u, packed, st)) return rc;
@@ -422,7 +422,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
                 a.out = eps; a.fmode = 0; a.n_per_ctx = B;
                 eps_done = true;
             }
-            if (int rc = launch_fused_args(f, a, B, st)) return rc;
+            if (int rc = launch_fused_args(f, a, B, st, true)) return rc;
             continue;
         }
         const Layer& l = u->layers[i];

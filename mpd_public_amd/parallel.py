@@ -70,7 +70,15 @@ def gather_trajectories(local: torch.Tensor, n_contexts: int, n_samples: int, gr
     pad = local
     if local.shape[0] < mx:
         pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
-    out = local.new_empty((world * mx,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo moves host memory: stage through the CPU (the CPU tests' backend, and two ranks sharing one GPU in the GPU test;
+        # production runs one rank per GPU on the nccl = RCCL backend, device to device)
+        host = pad.contiguous().cpu()
+        out_h = host.new_empty((world * mx,) + tuple(host.shape[1:]))
+        dist.all_gather_into_tensor(out_h, host, group=group)
+        out = out_h.to(local.device)
+    else:
+        out = local.new_empty((world * mx,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
     parts = [out[r * mx: r * mx + sizes[r]] for r in range(world)]
     return torch.cat(parts, dim=0)

@@ -206,3 +206,63 @@ def test_rccl_world_of_one_runs_real_planner_under_parallel():
         assert torch.equal(full[3 * n:4 * n], x3)
     finally:
         dist.destroy_process_group()
+
+
+_TWO_RANK_SCRIPT = r"""
+import sys, os, numpy as np, torch
+from math import ceil
+sys.path[:0] = [sys.argv[1], sys.argv[1] + "/tests"]
+import torch.distributed as dist
+import mpd_public_amd as m
+from mpd_public_amd.parallel import plan_contexts, gather_trajectories, shard_range
+from helpers import synth_sd, t, product_guide, DIM_MULTS
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+T, n, C_, n0 = 25, 8, 5, 5
+ds = m.TrajectoryDataset("EnvSpheres3D", "RobotPanda", tensor_args={"device": "cuda", "dtype": torch.float32})
+D = ds.state_dim
+net = m.TemporalUnet(n_support_points=64, state_dim=D, unet_input_dim=32, dim_mults=DIM_MULTS[1])
+net.load_state_dict(synth_sd(D, 1), strict=True)
+dm = m.GaussianDiffusionModel(model=net, n_diffusion_steps=T, predict_epsilon=True).cuda().eval()
+pg = product_guide(ds, 1e-2, 1e-7).cuda()
+zeros = torch.zeros(C_, D // 2, device="cuda")
+starts = ds.normalizer.normalize(torch.cat([t("tr_s", (C_, D // 2), "uniform", 0.6).cuda(), zeros], 1))
+goals = ds.normalizer.normalize(torch.cat([t("tr_g", (C_, D // 2), "uniform", 0.6).cuda(), zeros], 1))
+g = torch.Generator(device="cuda"); g.manual_seed(77)
+noise = torch.randn((T + n0 + 1, C_ * n, 64, D), generator=g, device="cuda")
+kw = dict(n_diffusion_steps_without_noise=n0, noise_std_extra_schedule_fn=lambda tt: 0.5, guide=pg, n_guide_steps=5, t_start_guide=ceil(0.25 * T))
+lo_, hi_ = shard_range(C_, world, rank)   # injected noise is per trajectory: this rank's columns of the same global stream
+local, (lo, hi) = plan_contexts(dm, starts, goals, n, rank=rank, world_size=world, horizon=64, noise=noise[:, lo_ * n:hi_ * n].contiguous(), **kw)
+assert (lo, hi) == (lo_, hi_)
+full = gather_trajectories(local, C_, n)
+np.savez(out, full=full.cpu().numpy(), lo=lo, hi=hi)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_real_planner_one_gpu(tmp_path):
+    """World size 2 with the REAL kernels: two processes (gloo rendezvous on 127.0.0.1, both on cuda:0 - this box has one GPU)
+    each plan their contiguous share of 5 contexts through parallel.plan_contexts (model.plan, guided, Panda) and all-gather.
+    Every rank must hold the same full tensor, equal bit for bit to one process planning all 5 contexts."""
+    import os, socket, subprocess, sys
+    from pathlib import Path
+    root = str(Path(__file__).resolve().parent.parent)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    outs = [tmp_path / f"rank{r}.npz" for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, "-c", _TWO_RANK_SCRIPT, root, str(r), "2", str(port), str(outs[r])], env=dict(os.environ))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    single = tmp_path / "single.npz"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port1 = s.getsockname()[1]
+    subprocess.run([sys.executable, "-c", _TWO_RANK_SCRIPT, root, "0", "1", str(port1), str(single)], check=True, timeout=600)
+    r0, r1, one = (dict(np.load(f)) for f in (outs[0], outs[1], single))
+    assert (int(r0["lo"]), int(r0["hi"])) == (0, 3) and (int(r1["lo"]), int(r1["hi"])) == (3, 5)
+    assert r0["full"].shape == (40, 64, 14) and np.isfinite(r0["full"]).all()
+    assert np.array_equal(r0["full"], r1["full"])
+    assert np.array_equal(r0["full"], one["full"])
