@@ -438,6 +438,8 @@ struct TimeTrainArgs {
     float* emb;                 // [B][32]
     float* h1;                  // [B][128]  (pre-Mish)
     float* temb;                // [B][32]   (pre-Mish)
+    float* tm;                  // [B][32]   mish(temb): the input of every cond_mlp (kept: its backward needs it once per table row)
+    float* h1m;                 // [B][128]  mish(h1)
     float* tb;                  // [B][row]
     unsigned long long w1, b1, w3, b3;
     int row, nblk;
@@ -457,26 +459,40 @@ __global__ __launch_bounds__(128) void time_train_fwd_kernel(const TimeTrainArgs
     }
     __syncthreads();
     {
-        const float* w = a.flat + a.w1 + tid * 32;
+        const f32x4* w = (const f32x4*)(a.flat + a.w1 + tid * 32);   // parameter offsets are multiples of 4 floats
         float s = a.flat[a.b1 + tid];
-        for (int k = 0; k < 32; ++k) s = fmaf(w[k], emb[k], s);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x4 wv = w[k];
+            s = fmaf(wv[0], emb[4 * k], s); s = fmaf(wv[1], emb[4 * k + 1], s); s = fmaf(wv[2], emb[4 * k + 2], s); s = fmaf(wv[3], emb[4 * k + 3], s);
+        }
         a.h1[(size_t)b * 128 + tid] = s;
         h1m[tid] = mish(s);
+        a.h1m[(size_t)b * 128 + tid] = h1m[tid];
     }
     __syncthreads();
     if (tid < 32) {
-        const float* w = a.flat + a.w3 + tid * 128;
+        const f32x4* w = (const f32x4*)(a.flat + a.w3 + tid * 128);
         float s = a.flat[a.b3 + tid];
-        for (int k = 0; k < 128; ++k) s = fmaf(w[k], h1m[k], s);
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const f32x4 wv = w[k];
+            s = fmaf(wv[0], h1m[4 * k], s); s = fmaf(wv[1], h1m[4 * k + 1], s); s = fmaf(wv[2], h1m[4 * k + 2], s); s = fmaf(wv[3], h1m[4 * k + 3], s);
+        }
         a.temb[(size_t)b * 32 + tid] = s;
         tm[tid] = mish(s);
+        a.tm[(size_t)b * 32 + tid] = tm[tid];
     }
     __syncthreads();
     for (int blk = 0; blk < a.nblk; ++blk)
         for (int c = tid; c < a.cout[blk]; c += 128) {
-            const float* w = a.flat + a.woff[blk] + c * 32;
+            const f32x4* w = (const f32x4*)(a.flat + a.woff[blk] + c * 32);
             float s = a.flat[a.boff[blk] + c];
-            for (int k = 0; k < 32; ++k) s = fmaf(w[k], tm[k], s);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const f32x4 wv = w[k];
+                s = fmaf(wv[0], tm[4 * k], s); s = fmaf(wv[1], tm[4 * k + 1], s); s = fmaf(wv[2], tm[4 * k + 2], s); s = fmaf(wv[3], tm[4 * k + 3], s);
+            }
             a.tb[(size_t)b * a.row + a.toff[blk] + c] = s;
         }
 }
@@ -490,6 +506,8 @@ struct TimeBwdArgs {
     const float* emb;
     const float* h1;
     const float* temb;
+    const float* tm;            // mish(temb), mish(h1) as the forward kernel stored them
+    const float* h1m;
     float* dtm;                 // [B][32]  gradient wrt mish(temb), then wrt temb
     float* dh1;                 // [B][128] gradient wrt h1
     unsigned long long w1, b1, w3, b3;
@@ -508,7 +526,7 @@ __global__ __launch_bounds__(256) void time_bwd_cond_kernel(const TimeBwdArgs a)
     float sw = 0.f, sb = 0.f;
     for (int b = 0; b < a.B; ++b) {
         const float d = a.dT[(size_t)b * a.row + rr];
-        sw = fmaf(d, mish(a.temb[(size_t)b * 32 + e]), sw);
+        sw = fmaf(d, a.tm[(size_t)b * 32 + e], sw);
         sb += d;
     }
     a.grad[a.woff[blk] + (size_t)c * 32 + e] = sw;
@@ -541,7 +559,7 @@ __global__ __launch_bounds__(128) void time_bwd_l3_kernel(const TimeBwdArgs a) {
         float sw = 0.f, sb = 0.f;
         for (int b = 0; b < a.B; ++b) {
             const float d = a.dtm[(size_t)b * 32 + e];
-            sw = fmaf(d, mish(a.h1[(size_t)b * 128 + k]), sw);
+            sw = fmaf(d, a.h1m[(size_t)b * 128 + k], sw);
             sb += d;
         }
         a.grad[a.w3 + (size_t)e * 128 + k] = sw;

@@ -71,7 +71,7 @@ static int ensure_pack_descs(mpdx_unet* u) {
 
 // workspace layout for a batch of B (float offsets)
 struct TrainWs {
-    size_t xn, eps, dE, out0, pre0, grad0, tmpX, dU, zst, pvec, wpart, rpart, emb, h1, temb, tb, dT, dtm, dh1, zeros, norm, total;
+    size_t xn, eps, dE, out0, pre0, grad0, tmpX, dU, zst, pvec, wpart, rpart, emb, h1, temb, tm, h1m, tb, dT, dtm, dh1, zeros, norm, total;
     size_t slotB;          // floats of one activation slot for the batch
     size_t wpart_floats;
     // deferred reductions (one launch each at the end of the backward pass): every layer keeps its own partial sums
@@ -129,6 +129,7 @@ static TrainWs train_ws(const mpdx_unet* u, int B) {
     }
     w.rpart = take((size_t)256 * 512);
     w.emb = take((size_t)B * 32); w.h1 = take((size_t)B * 128); w.temb = take((size_t)B * 32);
+    w.tm = take((size_t)B * 32); w.h1m = take((size_t)B * 128);
     w.tb = take((size_t)B * u->tt_row); w.dT = take((size_t)B * u->tt_row);
     w.dtm = take((size_t)B * 32); w.dh1 = take((size_t)B * 128);
     w.zeros = take(1024);
@@ -376,6 +377,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     {
         ta.flat = flat; ta.t = t_dev; ta.freqs = freqs16;
         ta.emb = ws + w.emb; ta.h1 = ws + w.h1; ta.temb = ws + w.temb; ta.tb = ws + w.tb;
+        ta.tm = ws + w.tm; ta.h1m = ws + w.h1m;
         ta.w1 = u->params[u->pidx.at("time_mlp.encoder.1.weight")].foff; ta.b1 = u->params[u->pidx.at("time_mlp.encoder.1.bias")].foff;
         ta.w3 = u->params[u->pidx.at("time_mlp.encoder.3.weight")].foff; ta.b3 = u->params[u->pidx.at("time_mlp.encoder.3.bias")].foff;
         ta.row = u->tt_row; ta.nblk = (int)u->tt_w.size();
@@ -385,7 +387,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             ta.cout[i] = u->tt_cout[i]; ta.toff[i] = u->tt_off[i];
         }
         hipLaunchKernelGGL(time_train_fwd_kernel, dim3(B), dim3(128), 0, st, ta);
-        tb.flat = flat; tb.grad = grads_flat; tb.dT = ws + w.dT; tb.emb = ta.emb; tb.h1 = ta.h1; tb.temb = ta.temb;
+        tb.flat = flat; tb.grad = grads_flat; tb.dT = ws + w.dT; tb.emb = ta.emb; tb.h1 = ta.h1; tb.temb = ta.temb; tb.tm = ta.tm; tb.h1m = ta.h1m;
         tb.dtm = ws + w.dtm; tb.dh1 = ws + w.dh1;
         tb.w1 = ta.w1; tb.b1 = ta.b1; tb.w3 = ta.w3; tb.b3 = ta.b3;
         tb.B = B; tb.row = ta.row; tb.nblk = ta.nblk;
