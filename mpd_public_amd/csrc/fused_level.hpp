@@ -278,6 +278,11 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
     if (S::GN) {
         f32x4 v[NTW], add[NTW], gat[NTW], bet[NTW];
         float* stat = smem + a.stat_off;
+        // A GroupNorm group = RB DPP rows of the NSn tiles of one tile row.  With four or more tile rows every wave owns ALL position
+        // tiles of its row(s), so the group's parts sit in this wave's registers: they are combined through readlane, with the same
+        // formula and order as the LDS exchange - and without its barrier.  (C_out = 32: two waves share a tile row -> exchange.)
+        constexpr bool LOCAL = (S::MSW == kFusedWaves);
+        float rm[NTW][4], rM2[NTW][4];   // LOCAL: (mean, M2) of DPP row r of tile t, wave-uniform
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             const int c0 = c0t[t];
@@ -293,10 +298,18 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
             const float m_loc = row_sum16((v[t][0] + v[t][1]) + (v[t][2] + v[t][3])) * (1.0f / 64.0f);
             const f32x4 dl = v[t] - m_loc;
             const float m2_loc = row_sum16((dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]));
-            if (j == 0) *(f32x2*)(stat + ((mst[t] * S::NSn + ns[t]) * 4 + q) * 2) = (f32x2){m_loc, m2_loc};
+            if constexpr (LOCAL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    rm[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m_loc), 16 * r));
+                    rM2[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m2_loc), 16 * r));
+                }
+            } else {
+                if (j == 0) *(f32x2*)(stat + ((mst[t] * S::NSn + ns[t]) * 4 + q) * 2) = (f32x2){m_loc, m2_loc};
+            }
             if (SAVE && op.save_pre >= 0) *(f32x4*)(a.save + op.save_pre + ((size_t)b * S::LOUT + npos[t]) * S::COUT + c0) = v[t];
         }
-        lds_barrier();
+        if constexpr (!LOCAL) lds_barrier();
         FOP_STAMP();   // statistics exchanged
         // combine the parts of this lane's group: rows q0 .. q0+RB-1 of the tiles (row, 0..NSn-1); equal counts (64 each).
         // Tiles that share their tile row (NJ > 1) share the group: one combination; M-pass tiles are different rows: one each.
@@ -309,8 +322,14 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
 #pragma unroll
             for (int k = 0; k < S::NPARTS; ++k) {
                 const int ns_k = k / S::RB, q_k = q0 + (k % S::RB);
-                const f32x2 pv = *(const f32x2*)(stat + ((mst[t] * S::NSn + ns_k) * 4 + q_k) * 2);
-                pm[k] = pv[0]; pM2[k] = pv[1];
+                if constexpr (LOCAL) {
+                    const int tk = (S::MP > 1) ? t : ns_k;   // the wave's tile holding position tile ns_k of this row
+                    pm[k] = q_k == 0 ? rm[tk][0] : (q_k == 1 ? rm[tk][1] : (q_k == 2 ? rm[tk][2] : rm[tk][3]));
+                    pM2[k] = q_k == 0 ? rM2[tk][0] : (q_k == 1 ? rM2[tk][1] : (q_k == 2 ? rM2[tk][2] : rM2[tk][3]));
+                } else {
+                    const f32x2 pv = *(const f32x2*)(stat + ((mst[t] * S::NSn + ns_k) * 4 + q_k) * 2);
+                    pm[k] = pv[0]; pM2[k] = pv[1];
+                }
             }
             float mean, M2;
             if constexpr (S::NPARTS == 4) {
