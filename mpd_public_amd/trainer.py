@@ -263,7 +263,9 @@ def train(model=None, train_dataloader=None, epochs=None, lr=None, steps_til_sum
     clip_grad_norm_, Adam (native unless `optimizers` - torch optimisers over model.parameters() - are given), EMA every
     `update_ema_every` steps (reset to the model before `step_start_ema`).  Differences, all outside the compute path: no wandb
     (not installed here), no AMP (`use_amp=True` raises: the kernels are fp32 like the reference's default), checkpoints hold
-    state dicts only.  Returns (model, ema_model, train_losses)."""
+    state dicts only.  A `loss_fn` other than GaussianDiffusionLoss.loss_fn (the reference's hook: loss_fn(model, batch, dataset) ->
+    ({name: loss}, info)) is honoured the reference's way: its losses are summed, `.backward()` runs through the autograd bridge of
+    `model.loss` and torch optimisers step (created as torch.optim.Adam(lr) when none are passed).  Returns (model, ema_model, train_losses)."""
     if use_amp:
         raise NotImplementedError("use_amp=True: the training kernels are fp32 (the reference's default is use_amp=False)")
     if model is None or train_dataloader is None or epochs is None:
@@ -274,6 +276,9 @@ def train(model=None, train_dataloader=None, epochs=None, lr=None, steps_til_sum
         ema = EMA(beta=ema_decay)
         ema_model = copy.deepcopy(model)
     step_fn = TrainStep(model)
+    custom_loss = loss_fn is not None and loss_fn is not GaussianDiffusionLoss.loss_fn
+    if custom_loss and optimizers is None:
+        optimizers = [torch.optim.Adam(lr=lr, params=model.parameters())]   # trainer.py:140
     if val_dataloader is not None and val_loss_fn is None:
         raise AssertionError("If validation set is passed, have to pass a validation loss_fn!")
     checkpoints_dir = None
@@ -289,7 +294,6 @@ def train(model=None, train_dataloader=None, epochs=None, lr=None, steps_til_sum
     train_steps_current = 0
     train_losses_l, validation_losses_l = [], []
     dev = next(model.parameters()).device
-    stop = False
 
     def ema_update():
         if train_steps_current < step_start_ema:
@@ -300,9 +304,20 @@ def train(model=None, train_dataloader=None, epochs=None, lr=None, steps_til_sum
     for epoch in range(epochs):
         model.train()
         for step, batch in enumerate(train_dataloader):
-            x = batch[f"{field}_normalized"].to(dev)
-            hard_conds = {k: v.to(dev) for k, v in batch.get("hard_conds", {}).items()}
-            loss, info = step_fn.loss_backward(x, hard_conds)
+            if custom_loss:   # the reference's generic path (trainer.py:186-197, 262-266)
+                bd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+                if "hard_conds" in bd:
+                    bd["hard_conds"] = {k: v.to(dev) for k, v in bd["hard_conds"].items()}
+                losses, info = loss_fn(model, bd, train_subset.dataset if train_subset is not None else None)
+                loss = sum(l.mean() for l in losses.values())
+                for opt in optimizers:
+                    opt.zero_grad()
+                loss.backward()
+                loss = loss.detach()
+            else:
+                x = batch[f"{field}_normalized"].to(dev)
+                hard_conds = {k: v.to(dev) for k, v in batch.get("hard_conds", {}).items()}
+                loss, info = step_fn.loss_backward(x, hard_conds)
             if steps_til_summary and train_steps_current % steps_til_summary == 0:
                 lv = float(loss)   # the only host synchronisation of a step, on summary steps
                 train_losses_l.append((train_steps_current, {"diffusion_loss": lv}))
@@ -337,7 +352,7 @@ def train(model=None, train_dataloader=None, epochs=None, lr=None, steps_til_sum
                 step_fn.pack()
                 save_models_to_disk([(model, "model"), (ema_model, "ema_model")], epoch, train_steps_current, checkpoints_dir)
                 save_losses_to_disk(train_losses_l, validation_losses_l, checkpoints_dir)
-            if stop or (max_steps is not None and train_steps_current == max_steps):
+            if max_steps is not None and train_steps_current == max_steps:
                 break
         if max_steps is not None and train_steps_current == max_steps:
             break
