@@ -32,6 +32,28 @@ def get_num_epochs(num_train_steps, batch_size, dataset_len):   # trainer.py:16-
     return ceil(num_train_steps * batch_size / dataset_len)
 
 
+class EarlyStopper:
+    """trainer.py:45-64 (patience -1 deactivates it)."""
+
+    def __init__(self, patience=10, min_delta=0):
+        self.patience = patience
+        self.min_delta = min_delta
+        self.counter = 0
+        self.min_validation_loss = float("inf")
+
+    def early_stop(self, validation_loss):
+        if self.patience == -1:
+            return False
+        if validation_loss < self.min_validation_loss:
+            self.min_validation_loss = validation_loss
+            self.counter = 0
+        elif validation_loss > (self.min_validation_loss + self.min_delta):
+            self.counter += 1
+            if self.counter >= self.patience:
+                return True
+        return False
+
+
 class FlatParams:
     """The parameters of a TemporalUnet as ONE flat fp32 tensor in the layout libmpdx differentiates (parameter i of
     mpdx_unet_param_info at mpdx_train_param_offset(i)), with every nn.Parameter (and its .grad) a view into it."""
@@ -293,6 +315,8 @@ def train(model=None, train_dataloader=None, epochs=None, lr=None, steps_til_sum
         max_norm = clip_grad_max_norm if isinstance(clip_grad, bool) else clip_grad
     train_steps_current = 0
     train_losses_l, validation_losses_l = [], []
+    early_stopper = EarlyStopper(patience=early_stopper_patience, min_delta=0)   # trainer.py:161
+    stop_training = False
     dev = next(model.parameters()).device
 
     def ema_update():
@@ -338,6 +362,9 @@ def train(model=None, train_dataloader=None, epochs=None, lr=None, steps_til_sum
                         if step_val == steps_per_validation:
                             break
                     validation_losses_l.append((train_steps_current, {"VALIDATION diffusion_loss": float(np.mean(vals))}))
+                    if early_stopper.early_stop(float(np.sum(vals))):   # total_val_loss of trainer.py:232-255
+                        print(f"Early stopped training at {train_steps_current} steps.")
+                        stop_training = True
             if optimizers is None:
                 step_fn.adam_step(lr, max_norm=max_norm)
             else:   # torch optimisers over the same (aliased) parameters, as the reference runs them
@@ -352,9 +379,9 @@ def train(model=None, train_dataloader=None, epochs=None, lr=None, steps_til_sum
                 step_fn.pack()
                 save_models_to_disk([(model, "model"), (ema_model, "ema_model")], epoch, train_steps_current, checkpoints_dir)
                 save_losses_to_disk(train_losses_l, validation_losses_l, checkpoints_dir)
-            if max_steps is not None and train_steps_current == max_steps:
+            if stop_training or (max_steps is not None and train_steps_current == max_steps):
                 break
-        if max_steps is not None and train_steps_current == max_steps:
+        if stop_training or (max_steps is not None and train_steps_current == max_steps):
             break
     if ema_model is not None:
         ema_update()

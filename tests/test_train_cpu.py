@@ -57,3 +57,11 @@ def test_training_step_has_no_cpu_fallback():
     dm = m.GaussianDiffusionModel(model=net, n_diffusion_steps=25, predict_epsilon=True)
     with pytest.raises(RuntimeError, match="GPU"):
         TrainStep(dm)
+
+
+def test_early_stopper_mirrors_the_reference():
+    """trainer.py:45-64: stops after `patience` validations above the best; patience -1 never stops."""
+    from mpd_public_amd.trainer import EarlyStopper
+    e = EarlyStopper(patience=2)
+    assert [e.early_stop(v) for v in (1.0, 0.9, 0.95, 0.96)] == [False, False, False, True]
+    assert not any(EarlyStopper(patience=-1).early_stop(v) for v in (1.0, 2.0, 3.0, 4.0))
