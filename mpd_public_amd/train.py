@@ -14,6 +14,7 @@ import torch
 import yaml
 
 from . import trainer
+from . import summaries
 from .datasets import TrajectoryDataset
 from .diffusion_model import GaussianDiffusionModel
 from .temporal_unet import TemporalUnet, UNET_DIM_MULTS
@@ -66,9 +67,10 @@ def experiment(dataset_subdir: str = "EnvSimple2D-RobotPointMass", include_veloc
     with open(os.path.join(results_dir, "limits.yaml"), "w") as f:
         yaml.safe_dump({"mins": [float(v) for v in dataset.normalizer.mins.cpu()], "maxs": [float(v) for v in dataset.normalizer.maxs.cpu()]}, f)
     loss_fn = trainer.GaussianDiffusionLoss.loss_fn
+    summary_fn = getattr(summaries, summary_class)(seed=seed).summary_fn if summary_class else None   # train_loaders.py:102-107
     model, ema_model, losses = trainer.train(
         model=model, train_dataloader=train_dataloader, train_subset=train_subset, val_dataloader=val_dataloader, val_subset=train_subset,
-        epochs=trainer.get_num_epochs(num_train_steps, batch_size, len(dataset)), model_dir=results_dir, summary_fn=None, lr=lr,
+        epochs=trainer.get_num_epochs(num_train_steps, batch_size, len(dataset)), model_dir=results_dir, summary_fn=summary_fn, lr=lr,
         loss_fn=loss_fn, val_loss_fn=loss_fn, steps_til_summary=steps_til_summary, steps_til_checkpoint=steps_til_ckpt, clip_grad=True,
         use_ema=use_ema, use_amp=use_amp, debug=debug, tensor_args=tensor_args, max_steps=num_train_steps)
     return model, ema_model, losses

@@ -224,7 +224,8 @@ def test_generate_train_plan_end_to_end(tmp_path):
     logs = tmp_path / "logs"
     model, ema_model, losses = train_script.experiment(dataset_subdir=sub, data_dir=str(tmp_path / "data_trajectories"), results_dir=str(logs),
                                                       n_diffusion_steps=25, unet_dim_mults_option=0, batch_size=16, lr=3e-4,
-                                                      num_train_steps=40, steps_til_summary=10, steps_til_ckpt=20, seed=1)
+                                                      num_train_steps=40, steps_til_summary=10, steps_til_ckpt=20, seed=1,
+                                                      summary_class="SummaryTrajectoryGeneration")
     vals = [v["diffusion_loss"] for _, v in losses]
     assert len(vals) >= 3 and all(np.isfinite(vals)) and vals[-1] < vals[0]
     args = yaml.safe_load(open(logs / "args.yaml"))
