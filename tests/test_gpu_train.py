@@ -246,6 +246,11 @@ def test_generate_train_plan_end_to_end(tmp_path):
     traj = dm.run_inference(None, hc, n_samples=8, horizon=64)
     assert traj.shape == (8, 64, 4) and bool(torch.isfinite(traj).all())
     assert torch.equal(traj[:, 0], hc[0].expand(8, 4)) and torch.equal(traj[:, 63], hc[63].expand(8, 4))
+    # ... and the results directory IS a model directory of the inference entry (inference.py:103,145-148: args.yaml + checkpoints;
+    # limits.yaml carries the training set's normaliser)
+    from mpd_public_amd.inference import experiment as infer
+    r = infer(model_id=sub, model_dir=str(logs), n_samples=6, debug=False, results_dir=str(tmp_path / "infer"), seed=5)
+    assert r["trajs_iters"].shape[-3:] == (6, 64, 4) and bool(torch.isfinite(torch.as_tensor(r["trajs_iters"])).all())
 
 
 def test_reference_loop_body_runs_unchanged_through_autograd():
