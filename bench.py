@@ -224,17 +224,34 @@ def cpu_baseline_leg(sd, D, T, B, n0, min_seconds=10.0, max_plans=12):
             "host_cpu": cpu_model, "kind": "port",
             "sample": f"{plans} full plan(s) of {T + n0} steps, B={B}, torch-CPU fp32 oracle on {cores} threads (best of a probe over "
                       f"8..{min(host_cores, 128)} on this {host_cores}-logical-core host), {dt:.1f} s",
+            "note": f"a {cores}-thread figure, not a {host_cores}-core one: a step is ~1 400 small ATen calls (46 convolutions of <= 100 x 64 "
+                    "positions, GroupNorm, Mish) whose intra-op parallelism saturates at 8-32 threads; more threads run SLOWER (probe)",
             "plan_wall_s": round(dt / plans, 3)}
 
 
 # ------------------------------------------------------------------------------------------------------ sub-records
+def _all_ranks(dist, vals, device):
+    """[world][len(vals)] float64 table of every rank's values (host-staged on gloo)."""
+    import torch
+    if dist is None:
+        return [list(map(float, vals))]
+    gloo = dist.get_backend() == "gloo"
+    mine = torch.tensor(vals, dtype=torch.float64, device="cpu" if gloo else device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [[float(v) for v in t.cpu()] for t in out]
+
+
 def sharded_leg(rank, world, dist, device, plans=2):
     """BASELINE configs[4] per-GPU shard: 128 start/goal contexts x 50 Panda trajectories per rank (weak scaling: 128*N contexts in
-    total), guided, per-trajectory hard conditions, per-context range tests, zero exchange during the loop, ONE all-gather of the
-    planned trajectories at the end (RCCL over xGMI when N > 1)."""
+    total), guided, per-trajectory hard conditions, per-context range tests, zero exchange during the loop, ONE gather of the
+    planned trajectories at the end (RCCL over xGMI when N > 1).  Self-checking: the gathered tensor is verified block by block
+    against checksums the owning ranks publish; both gather variants (all_gather_into_tensor / one-hop grouped send+recv over the
+    direct links) are timed in the same run; per-rank plan times are reported as min / median / max, not only the max."""
+    import statistics
     import torch
     from mpd_public_amd import synthetic as syn
-    from mpd_public_amd.parallel import expand_contexts, gather_trajectories
+    from mpd_public_amd.parallel import expand_contexts, gather_trajectories, verify_gather
     env_id, robot, D, mults, T, B, n0, _, n_ctx = CONFIGS["cfg5"]
     dm, _sd = build_model(D, mults, T, device)
     dm.manual_seed(1000 + rank)
@@ -242,8 +259,9 @@ def sharded_leg(rank, world, dist, device, plans=2):
     st = torch.from_numpy(syn.synth_tensor(f"bench_ctx_s{rank}", (n_ctx, D), "uniform", 0.6)).to(device)
     gl = torch.from_numpy(syn.synth_tensor(f"bench_ctx_g{rank}", (n_ctx, D), "uniform", 0.6)).to(device)
     hs, hg = expand_contexts(st, gl, B // n_ctx)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    plan_ms, gather_ms = [], []
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    plan_ms, gather_ms, hop_ms = [], [], []
+    verified = True
     for it in range(plans + 1):
         if dist is not None:
             dist.barrier()
@@ -251,23 +269,39 @@ def sharded_leg(rank, world, dist, device, plans=2):
         ev[0].record()
         x, _ = dm.plan({0: hs, 63: hg}, B, 64, n0, None, lambda t: 0.5, return_chain=False, n_per_context=B // n_ctx, **gk)
         ev[1].record()
-        g = gather_trajectories(x, n_ctx * world, B // n_ctx, force_collective=dist is not None)
+        g = gather_trajectories(x, n_ctx * world, B // n_ctx, force_collective=dist is not None, mode="collective")
         ev[2].record()
+        g1 = gather_trajectories(x, n_ctx * world, B // n_ctx, force_collective=dist is not None, mode="one_hop")
+        ev[3].record()
         torch.cuda.synchronize()
         assert g.shape[0] == world * B and bool(torch.isfinite(g[-1]).all())
+        if it == plans:   # transport check of both variants on the last plan: every block against its owner's checksum
+            verified = verify_gather(g, x, n_ctx * world, B // n_ctx) and verify_gather(g1, x, n_ctx * world, B // n_ctx) and bool(torch.equal(g, g1))
         if it > 0:
-            plan_ms.append(ev[0].elapsed_time(ev[1])); gather_ms.append(ev[1].elapsed_time(ev[2]))
-    pm, gm = max(plan_ms), max(gather_ms)
-    if dist is not None:
-        tt = torch.tensor([pm, gm], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        pm, gm = float(tt[0]), float(tt[1])
+            plan_ms.append(ev[0].elapsed_time(ev[1])); gather_ms.append(ev[1].elapsed_time(ev[2])); hop_ms.append(ev[2].elapsed_time(ev[3]))
+    table = _all_ranks(dist, [statistics.median(plan_ms), max(plan_ms), statistics.median(gather_ms), max(gather_ms),
+                              statistics.median(hop_ms), max(hop_ms), 1.0 if verified else 0.0], device)
+    if not all(r[6] == 1.0 for r in table):
+        raise RuntimeError("gathered trajectories do not match the per-rank checksums")
+    per_rank_plan = [r[0] for r in table]
+    pm, gm, hm = max(r[1] for r in table), max(r[3] for r in table), max(r[5] for r in table)
+    best = min(gm, hm)
+    nccl_env = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_")) and k not in ("NCCL_ASYNC_ERROR_HANDLING",)}
     return {"workload": f"cfg5 shard per rank: {n_ctx} contexts x {B // n_ctx} = {B} Panda trajectories, T={T} (+{n0}), guided; {n_ctx * world} contexts in total",
             "ranks": world, "backend": (dist.get_backend() if dist is not None else None),
+            "process_group_world_size": (dist.get_world_size() if dist is not None else None),
+            "ranks_per_gpu": (max(1, world // max(1, torch.cuda.device_count())) if dist is not None else 1),
+            "nccl_env": nccl_env or None,
             "collective": "all_gather_into_tensor of the final trajectories" if dist is not None else None,
-            "plan_ms_per_rank_max": round(pm, 2), "all_gather_ms_max": round(gm, 3), "all_gather_bytes_per_rank": int(B * 64 * D * 4),
-            "denoising_steps_per_s": round(world * (T + n0) / ((pm + gm) * 1e-3), 2),
-            "trajectory_steps_per_s": round(world * B * (T + n0) / ((pm + gm) * 1e-3), 1), "scaling": "weak"}
+            "plan_ms_per_rank": {"min": round(min(per_rank_plan), 2), "median": round(statistics.median(per_rank_plan), 2),
+                                 "max": round(max(per_rank_plan), 2), "all": [round(v, 2) for v in per_rank_plan]},
+            "plan_ms_per_rank_max": round(pm, 2), "all_gather_ms_max": round(gm, 3),
+            "gather_ms": {"all_gather_into_tensor": {"median_over_ranks": round(statistics.median(r[2] for r in table), 3), "max": round(gm, 3)},
+                          "one_hop_send_recv": {"median_over_ranks": round(statistics.median(r[4] for r in table), 3), "max": round(hm, 3)}},
+            "gather_verified": "per-block bit-pattern checksums published by the owning ranks match on every rank; both variants bit-identical",
+            "all_gather_bytes_per_rank": int(B * 64 * D * 4),
+            "denoising_steps_per_s": round(world * (T + n0) / ((pm + best) * 1e-3), 2),
+            "trajectory_steps_per_s": round(world * B * (T + n0) / ((pm + best) * 1e-3), 1), "scaling": "weak"}
 
 
 def serving_leg(dm, D, T, n0, n_ctx=16, n=100, plans=3):
@@ -324,10 +358,8 @@ def training_leg(steps=40, B=32, T=25, D=4, opt=1, baseline=True):
     import mpd_public_amd as m
     from mpd_public_amd import synthetic as syn
     from mpd_public_amd.trainer import TrainStep, EMA
-    from oracle import unet as ounet   # baseline leg only
-    from oracle import train as otrain, diffusion as odiff, schedules as osched
     net = m.TemporalUnet(n_support_points=64, state_dim=D, unet_input_dim=32, dim_mults=m.UNET_DIM_MULTS[opt])
-    sd = syn.synth_state_dict(ounet.unet_param_shapes(D, 32, m.UNET_DIM_MULTS[opt]))
+    sd = syn.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})   # as build_model: shapes from the product
     net.load_state_dict(sd, strict=True)
     dm = m.GaussianDiffusionModel(model=net, n_diffusion_steps=T, predict_epsilon=True).cuda()
     ema_model = copy.deepcopy(dm)
@@ -352,7 +384,10 @@ def training_leg(steps=40, B=32, T=25, D=4, opt=1, baseline=True):
            "train_steps_per_s": round(1.0 / dt_native, 1), "ms_per_train_step": round(dt_native * 1e3, 3)}
     if not baseline:
         return rec
-    # the reference's way: autograd over ATen kernels + torch.optim.Adam, same GPU
+    # the reference's way: autograd over ATen kernels + torch.optim.Adam, same GPU (the functional U-Net of oracle/ on CUDA tensors;
+    # only this comparison leg touches oracle/)
+    from oracle import unet as ounet
+    from oracle import diffusion as odiff, schedules as osched
     params = {k: v.clone().cuda().requires_grad_(True) for k, v in sd.items()}
     opt_t = torch.optim.Adam(list(params.values()), lr=1e-4)
     buf = {k: v.cuda() for k, v in osched.make_buffers(T, "exponential").items()}
@@ -415,13 +450,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    ndev = torch.cuda.device_count()
+    rig = world > ndev   # development rig: more ranks than GPUs (e.g. --gpus 2 on a 1-GPU box) - ranks share GPUs, gloo rendezvous
+    dev_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU, RCCL over xGMI
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        if rig:   # RCCL refuses two ranks on one device; the rig exercises the sharding / gather / checksum code, not the fabric
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))  # nccl == RCCL on ROCm
 
     env_id, robot, D, mults, T, B, n0, guided, n_ctx = CONFIGS[args.config]
     dm, sd = build_model(D, mults, T, device)
@@ -463,10 +504,8 @@ def main():
         chain = one_plan()
     fence()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    per_rank_dt = [r[0] for r in _all_ranks(dist, [dt], device)]
+    dt = max(per_rank_dt)
     assert chain.shape == (T + n0 + 1, B, 64, D) and bool(torch.isfinite(chain[-1]).all())
 
     steps_per_plan = T + n0
@@ -484,6 +523,9 @@ def main():
                    "trajectory_steps_per_s": round(value * B, 1)},
         "plan_wall_clock_ms": round(dt / args.steps * 1e3, 3),
     }
+    if world > 1:
+        out["per_rank_ms_per_step"] = [round(v / args.steps * 1e3, 3) for v in per_rank_dt]
+        out["backend"] = dist.get_backend() + (" (single-GPU rig: ranks share a GPU, no xGMI traffic)" if rig else " (RCCL over xGMI)")
     if rank == 0 and not args.no_roofline:
         roof, unet_flops = roofline_leg(dm, B, T)
         out["roofline"] = roof

@@ -206,7 +206,9 @@ int mpdx_guide_step(const mpdx_guide_params* gp, float* x, float* grad_out, cons
 int mpdx_guide_step_scaled(const mpdx_guide_params* gp, float* x, float* grad_out, const float* hard_start, const float* hard_goal,
                            const uint32_t* absmax_in, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, float guide_scale,
                            void* stream);
-/* dev tool: cycle stamps (16 slots per wave x 8 waves, workgroup 0) of one guide launch (gradient-only mode) */
+/* dev tool: cycle stamps (16 slots per wave x 8 waves, workgroup 0) of one guide launch (gradient-only mode).
+ * The three *_trace entry points and the ablation masks of mpdx_bench_layer work only in a library built with -DMPDX_DEV_HOOKS
+ * (the production kernels carry no hooks); otherwise they return MPDX_E_STATE. */
 int mpdx_guide_trace(const mpdx_guide_params* gp, float* x, const uint32_t* absmax_in, int B, int H, int D, void* stream,
                      long long* stamps128);
 /* absmax_out[ctx] <- atomicMax over the context's trajectories (caller zeroes absmax_out first) */
@@ -266,7 +268,7 @@ int mpdx_unet_unit_layer(const mpdx_unet* u, int B, int i);
 /* 1 when launch unit i is a paired launch (blocks[0] + the same block's residual 1x1 conv in one conv_pair_kernel) */
 int mpdx_unet_unit_is_pair(const mpdx_unet* u, int B, int i);
 /* `reps` back-to-back launches of layer `layer` between two events; dbg = ablation mask (1 skip staging, 2 skip
- * MFMA loop, 4 skip epilogue, 8 skip weight loads); synchronises. */
+ * MFMA loop, 4 skip epilogue, 8 skip weight loads: -DMPDX_DEV_HOOKS builds only), 16 = replay from a hipGraph; synchronises. */
 int mpdx_bench_layer(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, const float* x, int layer, int B,
                      float* ws, void* stream, int reps, int dbg, float* ms_per_launch);
 /* tile the dispatcher picks for launch i at batch B: writes "MTxNT/WNxWK" into buf */

@@ -33,7 +33,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=on",
            "-Wall", "-Wno-unused-function", "-o", str(LIB)] + [str(s) for s in SOURCES]
-    cmd += os.environ.get("MPDX_BUILD_DEFS", "").split()   # dev builds, e.g. -DMPDX_LOOP_ABLATION (tools/ablate_loop.py)
+    cmd += os.environ.get("MPDX_BUILD_DEFS", "").split()   # dev builds: -DMPDX_DEV_HOOKS (tools/*_trace.py, ablate_layers.py), -DMPDX_LOOP_ABLATION (tools/ablate_loop.py)
     if verbose:
         print("[mpdx build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -28,6 +28,20 @@
 
 #include <type_traits>
 
+// Development hooks (cycle stamps, phase-ablation masks) exist only in builds with -DMPDX_DEV_HOOKS
+// (MPDX_BUILD_DEFS=-DMPDX_DEV_HOOKS python -m mpd_public_amd.build --force; -DMPDX_LOOP_ABLATION implies it): in the production
+// library the trace pointer is the constant nullptr and the ablation mask the constant 0, so every hook folds away at compile time.
+#if defined(MPDX_LOOP_ABLATION) && !defined(MPDX_DEV_HOOKS)
+#define MPDX_DEV_HOOKS 1
+#endif
+#ifdef MPDX_DEV_HOOKS
+#define MPDX_TRACE_PTR(p) (p)
+#define MPDX_DBG(a, bits) ((a).dbg & (bits))
+#else
+#define MPDX_TRACE_PTR(p) ((long long*)nullptr)
+#define MPDX_DBG(a, bits) (0)
+#endif
+
 namespace mpdx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -53,9 +67,9 @@ struct ConvArgs {
     int gs;              // GroupNorm channels per group
     int n_tiles_n;       // ceil(B*L_out / NT)
     int lg_c4n, lg_Lin, lg_Lout, lg_gs;  // log2 of cin_pad/4, L_in, L_out, gs (all powers of two): no integer division on device
-    int dbg;             // ablation mask for mpdx_bench_layer: 1 skip staging, 2 skip MFMA loop, 4 skip epilogue; only in builds with
-                         // -DMPDX_LOOP_ABLATION: 8 no weight-ring refills in the loop, 32 no B-fragment LDS reads
-    long long* trace;    // dev tool: s_memtime stamps of workgroups 0 and last / wave 0 (null in production)
+    int dbg;             // ablation mask for mpdx_bench_layer, honoured only in -DMPDX_DEV_HOOKS builds: 1 skip staging, 2 skip MFMA loop,
+                         // 4 skip epilogue; only with -DMPDX_LOOP_ABLATION: 8 no weight-ring refills in the loop, 32 no B-fragment LDS reads
+    long long* trace;    // s_memtime stamps of workgroups 0 and last / wave 0; read only in -DMPDX_DEV_HOOKS builds
     // training (train.hpp): per-trajectory time-bias rows (tbias + b * tb_stride; 0 on the planning path: one row for the batch)
     // and an optional second destination for the GroupNorm INPUT (conv + bias), which the backward pass differentiates through
     int tb_stride;
@@ -186,7 +200,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WN, wk = wave / WN;
     int tr_i = 0;
-#define CB_STAMP() do { if (a.trace && tid == 0 && (block_id == 0 || block_id == (int)gridDim.x - 1)) a.trace[(block_id ? 16 : 0) + tr_i] = (long long)__builtin_readcyclecounter(); ++tr_i; } while (0)
+#define CB_STAMP() do { if (MPDX_TRACE_PTR(a.trace) && tid == 0 && (block_id == 0 || block_id == (int)gridDim.x - 1)) a.trace[(block_id ? 16 : 0) + tr_i] = (long long)__builtin_readcyclecounter(); ++tr_i; } while (0)
     const int n_mt = a.C_out / MT;   // MT is a compile-time power of two; one uniform division per workgroup
     const int mt = block_id % n_mt, nt = block_id / n_mt;
     const int L_in = a.L_in, L_out = a.L_out;
@@ -244,7 +258,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
 #endif
 
     // ------------------------------------------------------------------ stage the horizon windows (+halo) into LDS
-    if (!(a.dbg & 1)) {
+    if (!MPDX_DBG(a, 1)) {
         // interior rows: idx -> (trajectory s, input position li, float4 column) by shifts; halo rows are zeroed separately
         const int total = (spt << a.lg_Lin) << a.lg_c4n;
         const bool vec_ok = ((a.c1 & 3) == 0) && ((a.c2 & 3) == 0);
@@ -323,7 +337,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
         }
     }
 #ifndef MPDX_RING_FIRST
-    if (a.dbg & 1) ring_init();
+    if (MPDX_DBG(a, 1)) ring_init();
 #endif
     CB_STAMP();  // 1: own staging loads issued/written
     __syncthreads();
@@ -358,7 +372,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
 
     // (An explicit one-k-group-ahead register pipeline of the B fragments was measured 2.7 % SLOWER than letting hipcc
     //  interleave the ds_reads of this unrolled body - interleaved A/B, cfg 2: 30.2 vs 29.4 ms per plan.)
-    for (int it0 = 0; it0 < niter && !(a.dbg & 2); it0 += PF) {
+    for (int it0 = 0; it0 < niter && !MPDX_DBG(a, 2); it0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int g = wk + (it0 + u) * WK;
@@ -405,7 +419,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
     CB_STAMP();  // 5: partials visible
 
     // ------------------------------------------------------------------ epilogue
-    if (a.dbg & 4) {
+    if (MPDX_DBG(a, 4)) {
         if (tid == 0 && red[0] == 123.456f) a.dst[0] = red[1];
         return;
     }

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_level_kernel(const FusedA
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     int tr = 0;
-    long long* const tr_base = (a.trace && b == 0 && lane == 0) ? a.trace + wave * 128 : nullptr;   // 128 slots per wave
+    long long* const tr_base = (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) ? a.trace + wave * 128 : nullptr;   // 128 slots per wave
     if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter();
     ++tr;
     f32x4 ring[kFusedRing];
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_program_kernel(const Fuse
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     int tr = 0;
-    long long* const tr_base = (a.trace && b == 0 && lane == 0) ? a.trace + wave * 128 : nullptr;
+    long long* const tr_base = (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) ? a.trace + wave * 128 : nullptr;
     if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter();
     ++tr;
     f32x4 ring[kFusedRing];

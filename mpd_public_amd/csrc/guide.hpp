@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
     const int N = gp.interpolate ? gp.n_interp : H;
     const bool live = lane < H;
     int tr_i = 0;
-#define G_STAMP() do { if (a.trace && b == 0 && lane == 0) a.trace[wv * 16 + tr_i] = (long long)__builtin_readcyclecounter(); ++tr_i; } while (0)
+#define G_STAMP() do { if (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) a.trace[wv * 16 + tr_i] = (long long)__builtin_readcyclecounter(); ++tr_i; } while (0)
     G_STAMP();  // 0 entry
     // LDS carve: unnormalised state [H][D] | point forces A,B [MAXF][N][QD] each | primitive table
     float* sx = sm;
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
         }
     }
     G_STAMP();  // 4 gathered + clipped
-    guide_gp_apply<QD>(a, b, ctx, lane, H, live, xn, xu, sx, total, base, (a.trace && b == 0 && lane == 0) ? a.trace + wv * 16 + 5 : nullptr);
+    guide_gp_apply<QD>(a, b, ctx, lane, H, live, xn, xu, sx, total, base, (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) ? a.trace + wv * 16 + 5 : nullptr);
 #undef G_STAMP
 }
 
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(512) void guide_step_panda_kernel(const GuideArgs a
     const int N = gp.interpolate ? gp.n_interp : H;
     const bool live = lane < H;
     int tr_i = 0;
-#define G_STAMP() do { if (a.trace && b == 0 && lane == 0) a.trace[wv * 16 + tr_i] = (long long)__builtin_readcyclecounter(); ++tr_i; } while (0)
+#define G_STAMP() do { if (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) a.trace[wv * 16 + tr_i] = (long long)__builtin_readcyclecounter(); ++tr_i; } while (0)
     G_STAMP();  // 0 entry
     float* sx = sm;                           // [H][D]  unnormalised state
     float* sfk = sx + H * D;                  // [N][kPandaFKS]
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(512) void guide_step_panda_kernel(const GuideArgs a
     // ---- phase 2: forces of this wave's sphere / pair group, every field, folded to joint gradients
     {
         const int half = wv & 1;
-        long long* trf = (a.trace && b == 0 && lane == 0) ? a.trace + wv * 16 + 8 : nullptr;  // slots 8..: per-field stamps
+        long long* trf = (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) ? a.trace + wv * 16 + 8 : nullptr;  // slots 8..: per-field stamps
         switch (wv >> 1) {  // the group is a template parameter: sphere -> frame is static, no per-joint masks
             case 0: panda_group_forces<0>(gp, sprim, sfk, sG, half, lane, N, trf); break;
             case 1: panda_group_forces<1>(gp, sprim, sfk, sG, half, lane, N, trf); break;
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(512) void guide_step_panda_kernel(const GuideArgs a
             for (int j = 0; j < QD; ++j) total[j] += sC[(f * H + lane) * QD + j];
         }
     }
-    guide_gp_apply<QD>(a, b, ctx, lane, H, live, xn, xu, sx, total, base, (a.trace && b == 0 && lane == 0) ? a.trace + wv * 16 + 6 : nullptr);
+    guide_gp_apply<QD>(a, b, ctx, lane, H, live, xn, xu, sx, total, base, (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) ? a.trace + wv * 16 + 6 : nullptr);
 #undef G_STAMP
 }
 

@@ -1502,6 +1502,10 @@ int mpdx_traj_metrics(const mpdx_guide_params* gp, const float* x_unnormalised, 
 
 /* dev tool: one guide launch with s_memtime stamps (16 slots per wave, 8 waves -> 128 values) of workgroup 0 */
 int mpdx_guide_trace(const mpdx_guide_params* gp, float* x, const uint32_t* absmax_in, int B, int H, int D, void* stream, long long* stamps64) {
+#ifndef MPDX_DEV_HOOKS
+    return fail(MPDX_E_STATE, "%s needs a development build of libmpdx.so (MPDX_BUILD_DEFS=-DMPDX_DEV_HOOKS python -m mpd_public_amd.build --force): "
+                "the production kernels carry no trace / ablation hooks", __func__);
+#endif
     if (!stamps64) return fail(MPDX_E_INVALID, "null argument");
     hipStream_t st = (hipStream_t)stream;
     long long* dev = nullptr;
@@ -1654,6 +1658,10 @@ int mpdx_unet_profile(mpdx_unet* u, const float* packed, const float* timetab, i
 /* dev tool: one launch of layer `layer` with s_memtime stamps (7 per workgroup) of the first and the last workgroup */
 int mpdx_layer_trace(mpdx_unet* u, const float* packed, const float* timetab, const float* x, int layer, int B, float* ws, void* stream,
                      long long* stamps32) {
+#ifndef MPDX_DEV_HOOKS
+    return fail(MPDX_E_STATE, "%s needs a development build of libmpdx.so (MPDX_BUILD_DEFS=-DMPDX_DEV_HOOKS python -m mpd_public_amd.build --force): "
+                "the production kernels carry no trace / ablation hooks", __func__);
+#endif
     if (!u || layer < 0 || layer >= (int)u->layers.size() || !stamps32) return fail(MPDX_E_INVALID, "bad argument");
     if (int rc = check_ready(u)) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -1672,6 +1680,10 @@ int mpdx_layer_trace(mpdx_unet* u, const float* packed, const float* timetab, co
 /* dev tool: run fused segment `seg` once with per-phase s_memtime stamps of workgroup 0 / wave 0; stamps_out[n] */
 int mpdx_fused_trace(mpdx_unet* u, const float* packed, const float* timetab, const float* x, int seg, int B, float* ws, void* stream,
                      long long* stamps_out, int cap, int* n_out, int* nops_out) {
+#ifndef MPDX_DEV_HOOKS
+    return fail(MPDX_E_STATE, "%s needs a development build of libmpdx.so (MPDX_BUILD_DEFS=-DMPDX_DEV_HOOKS python -m mpd_public_amd.build --force): "
+                "the production kernels carry no trace / ablation hooks", __func__);
+#endif
     if (!u || seg < 0 || seg >= (int)u->fused.size()) return fail(MPDX_E_INVALID, "bad segment");
     if (int rc = check_ready(u)) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -1761,6 +1773,9 @@ int mpdx_bench_layer(mpdx_unet* u, const float* packed, const float* timetab, co
     if (!u || !packed || !timetab || !x || !ws || !ms_per_launch) return fail(MPDX_E_INVALID, "null argument");
     if (int rc = check_ready(u)) return rc;
     if (layer < 0 || layer >= (int)u->layers.size()) return fail(MPDX_E_INVALID, "bad layer index");
+#ifndef MPDX_DEV_HOOKS
+    if (dbg & 15) return fail(MPDX_E_STATE, "phase-ablation masks need a development build of libmpdx.so (MPDX_BUILD_DEFS=-DMPDX_DEV_HOOKS)");
+#endif
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));

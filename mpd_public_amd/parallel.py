@@ -55,30 +55,90 @@ def plan_contexts(model, start: torch.Tensor, goal: torch.Tensor, n_samples: int
     return torch.cat(outs, dim=0), (lo, hi)
 
 
-def gather_trajectories(local: torch.Tensor, n_contexts: int, n_samples: int, group=None, force_collective: bool = False) -> torch.Tensor:
-    """All-gather the per-rank trajectory blocks into [n_contexts*n_samples, H, D] on every rank (one collective).
-    Blocks may differ by one context in size: they are padded to the largest block for the collective.
-    force_collective: issue the all-gather even in a world of one rank (exercises the RCCL path on a single GPU)."""
+def block_sizes(n_contexts: int, n_samples: int, world: int):
+    """Trajectories per rank block (shard_range of the contexts x n_samples)."""
+    return [(shard_range(n_contexts, world, r)[1] - shard_range(n_contexts, world, r)[0]) * n_samples for r in range(world)]
+
+
+def shard_checksum(x: torch.Tensor) -> torch.Tensor:
+    """Order-independent 64-bit checksum of a float32 tensor's BIT PATTERNS (sum of the int32 views in int64 plus the element
+    count): a transport check for the gather - a block that arrives with one bit flipped, truncated or in the wrong slot changes it."""
+    if x.numel() == 0:
+        return torch.zeros((), dtype=torch.int64, device=x.device)
+    return x.contiguous().view(torch.int32).to(torch.int64).sum() + x.numel()
+
+
+def verify_gather(full: torch.Tensor, local: torch.Tensor, n_contexts: int, n_samples: int, group=None) -> bool:
+    """Every rank publishes shard_checksum(local) (one 8-byte all-gather) and re-computes the checksum of every block of the
+    gathered tensor: True when all blocks match what their owners planned.  A world without a process group checks itself."""
+    import torch.distributed as dist
+    mine = shard_checksum(local).reshape(1)
+    if not dist.is_available() or not dist.is_initialized():
+        return bool(shard_checksum(full) == mine[0])
+    world = dist.get_world_size(group)
+    gloo = dist.get_backend(group) == "gloo"
+    sums = [torch.zeros_like(mine.cpu() if gloo else mine) for _ in range(world)]
+    dist.all_gather(sums, mine.cpu() if gloo else mine, group=group)
+    sizes = block_sizes(n_contexts, n_samples, world)
+    off, ok = 0, True
+    for r in range(world):
+        ok &= bool(shard_checksum(full[off:off + sizes[r]]).cpu() == sums[r].cpu()[0])
+        off += sizes[r]
+    return ok
+
+
+def gather_trajectories(local: torch.Tensor, n_contexts: int, n_samples: int, group=None, force_collective: bool = False,
+                        mode: Optional[str] = None) -> torch.Tensor:
+    """Gather the per-rank trajectory blocks into [n_contexts*n_samples, H, D] on every rank - the path's ONE exchange step.
+
+    mode "collective" (default; MPDX_GATHER=collective): one all_gather_into_tensor.  Blocks may differ by one context in size:
+        they are padded to the largest block for the collective.
+    mode "one_hop" (MPDX_GATHER=one_hop): world-1 isend + world-1 irecv per rank, issued as ONE batch (dist.batch_isend_irecv =
+        one grouped RCCL launch): every shard travels exactly once over the DIRECT xGMI link to each peer and lands in its slot of
+        the output (no padding, no ring: a ring all-gather forwards every block over world-1 hops and is bound by one link;
+        MI355X links are point to point, 7 per GPU - SURVEY.md section 5).  Same result, bit for bit; bench.py times both.
+    force_collective: take the collective path even in a world of one rank (exercises RCCL on a single GPU)."""
+    import os
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized():
         return local
     if dist.get_world_size(group) == 1 and not force_collective:
         return local
-    world = dist.get_world_size(group)
-    sizes = [(shard_range(n_contexts, world, r)[1] - shard_range(n_contexts, world, r)[0]) * n_samples for r in range(world)]
+    mode = mode or os.environ.get("MPDX_GATHER", "collective")
+    if mode not in ("collective", "one_hop"):
+        raise ValueError(f"gather mode {mode!r} (collective | one_hop)")
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = block_sizes(n_contexts, n_samples, world)
+    if local.shape[0] != sizes[rank]:
+        raise ValueError(f"rank {rank} holds {local.shape[0]} trajectories, its block of {n_contexts} contexts x {n_samples} has {sizes[rank]}")
+    # gloo moves host memory: stage through the CPU (the CPU tests' backend, and several ranks sharing one GPU in the single-GPU
+    # rig; production runs one rank per GPU on the nccl = RCCL backend, device to device)
+    via_host = local.is_cuda and dist.get_backend(group) == "gloo"
+    src = local.contiguous().cpu() if via_host else local.contiguous()
+    if mode == "one_hop" and world > 1:
+        out = src.new_empty((sum(sizes),) + tuple(src.shape[1:]))
+        offs = [sum(sizes[:r]) for r in range(world)]
+        out[offs[rank]:offs[rank] + sizes[rank]] = src
+        ops = []
+        for k in range(1, world):   # peer order rotated by rank: at step k every rank sends to rank+k and receives from rank-k
+            to, frm = (rank + k) % world, (rank - k) % world
+            to_g = dist.get_global_rank(group, to) if group is not None else to
+            frm_g = dist.get_global_rank(group, frm) if group is not None else frm
+            if sizes[rank]:
+                ops.append(dist.P2POp(dist.isend, src, to_g, group=group))
+            if sizes[frm]:
+                ops.append(dist.P2POp(dist.irecv, out[offs[frm]:offs[frm] + sizes[frm]], frm_g, group=group))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return out.to(local.device) if via_host else out
     mx = max(sizes)
-    pad = local
-    if local.shape[0] < mx:
-        pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
-    if local.is_cuda and dist.get_backend(group) == "gloo":
-        # gloo moves host memory: stage through the CPU (the CPU tests' backend, and two ranks sharing one GPU in the GPU test;
-        # production runs one rank per GPU on the nccl = RCCL backend, device to device)
-        host = pad.contiguous().cpu()
-        out_h = host.new_empty((world * mx,) + tuple(host.shape[1:]))
-        dist.all_gather_into_tensor(out_h, host, group=group)
-        out = out_h.to(local.device)
-    else:
-        out = local.new_empty((world * mx,) + tuple(local.shape[1:]))
-        dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
-    parts = [out[r * mx: r * mx + sizes[r]] for r in range(world)]
-    return torch.cat(parts, dim=0)
+    pad = src
+    if src.shape[0] < mx:
+        pad = torch.cat([src, src.new_zeros((mx - src.shape[0],) + tuple(src.shape[1:]))], dim=0)
+    out = src.new_empty((world * mx,) + tuple(src.shape[1:]))
+    dist.all_gather_into_tensor(out, pad, group=group)
+    if via_host:
+        out = out.to(local.device)
+    if all(sz == mx for sz in sizes):
+        return out
+    return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)

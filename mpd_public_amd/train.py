@@ -41,7 +41,7 @@ def experiment(dataset_subdir: str = "EnvSimple2D-RobotPointMass", include_veloc
                diffusion_model_class: str = "GaussianDiffusionModel", variance_schedule: str = "exponential", n_diffusion_steps: int = 25,
                predict_epsilon: bool = True, unet_input_dim: int = 32, unet_dim_mults_option: int = 1,
                loss_class: str = "GaussianDiffusionLoss", batch_size: int = 32, lr: float = 1e-4, num_train_steps: int = 500000,
-               use_ema: bool = True, use_amp: bool = False, steps_til_summary: int = 10, summary_class: str = None,
+               use_ema: bool = True, use_amp: bool = False, steps_til_summary: int = 10, summary_class: str = "SummaryTrajectoryGeneration",
                steps_til_ckpt: int = 50000, device: str = "cuda", debug: bool = True, seed: int = 0, results_dir: str = "logs",
                data_dir: str = "data_trajectories", **kwargs):
     if diffusion_model_class != "GaussianDiffusionModel" or loss_class != "GaussianDiffusionLoss":
@@ -83,6 +83,8 @@ def main(argv=None):
                                ("batch_size", int, 32), ("lr", float, 1e-4), ("num_train_steps", int, 500000), ("steps_til_summary", int, 10),
                                ("steps_til_ckpt", int, 50000), ("seed", int, 0)):
         ap.add_argument(f"--{name}", type=typ, default=default)
+    ap.add_argument("--summary_class", default="SummaryTrajectoryGeneration",   # train.py:48; "none" switches the summaries off
+                    type=lambda v: None if v.lower() in ("none", "") else v)
     a = ap.parse_args(argv)
     experiment(**vars(a))
 

@@ -95,6 +95,24 @@ class FlatParams:
         keys = self.order if full else (self.order[0], self.order[len(self.order) // 2], self.order[-1])
         return all(k in named and named[k].data_ptr() == base + 4 * self.slices[k][0] for k in keys)
 
+    def grads_bound(self, full: bool = False) -> bool:
+        """Is every parameter's .grad still its view of the flat gradient?  (optimizer.zero_grad(set_to_none=True), the autograd
+        bridge of model.loss() and `p.grad = None` all detach it.)"""
+        base = self.grad.data_ptr()
+        named = dict(self.unet.named_parameters())
+        keys = self.order if full else (self.order[0], self.order[len(self.order) // 2], self.order[-1])
+        return all(named[k].grad is not None and named[k].grad.data_ptr() == base + 4 * self.slices[k][0] for k in keys)
+
+    def bind_grads(self):
+        """Re-point every p.grad at its slice of the flat gradient (what the native backward pass writes): torch optimisers and
+        clip_grad_norm_ read p.grad, so a detached .grad would make them skip the parameter or apply a stale gradient silently."""
+        named = dict(self.unet.named_parameters())
+        for k in self.order:
+            off, cnt = self.slices[k]
+            p = named[k]
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                p.grad = self.grad[off:off + cnt].view(p.shape)
+
 
 def flat_params(unet) -> FlatParams:
     fp = getattr(unet, "_flat_params", None)
@@ -143,7 +161,7 @@ class TrainStep:
         self.unet._stamp = self.unet._param_stamp() if sync_engine else None
         self.unet._timetab, self.unet._timetab_T = None, 0
 
-    def loss_backward(self, x_start, hard_conds=None, t=None, noise=None, loss_scale=1.0):
+    def loss_backward(self, x_start, hard_conds=None, t=None, noise=None, loss_scale=1.0, bind_grads=True):
         """(loss, info) as model.loss(x, None, hard_conds) returns them, with d loss / d parameters left in every p.grad
         (overwritten, not accumulated - the reference zeroes the gradients before every backward, trainer.py:262-263)."""
         m = self.model
@@ -172,6 +190,8 @@ class TrainStep:
             self._freqs.data_ptr(), hs.data_ptr() if hs is not None else None, hg.data_ptr() if hg is not None else None, None,
             int(m.n_diffusion_steps), B, 1 if m.predict_epsilon else 0, 1 if m.loss_type == "l1" else 0, float(loss_scale),
             self.loss_buf.data_ptr(), self._ws.data_ptr(), _lib.current_stream()), "mpdx_train_loss_backward")
+        if bind_grads and not self.fp.grads_bound():   # the docstring's promise: the gradients ARE in p.grad after this call
+            self.fp.bind_grads()
         return self.loss_buf[0].clone(), {}
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, max_norm=None):
@@ -194,9 +214,12 @@ class _PLossesFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, step, x_start, hard_conds, t, noise, *params):
-        loss, _ = step.loss_backward(x_start, hard_conds, t=t, noise=noise)
+        loss, _ = step.loss_backward(x_start, hard_conds, t=t, noise=noise, bind_grads=False)
         ctx.step = step
         ctx.n_params = len(params)
+        # the flat gradient buffer is shared by every call: keep THIS call's gradients (a second model.loss() before backward() -
+        # summed losses, gradient accumulation - would otherwise overwrite them and both terms would back-propagate the last batch)
+        ctx.flat_grad = step.fp.grad.clone()
         return loss
 
     @staticmethod
@@ -206,7 +229,7 @@ class _PLossesFn(torch.autograd.Function):
         grads = []
         for name in fp.order:
             off, cnt = fp.slices[name]
-            grads.append((fp.grad[off:off + cnt].view(named[name].shape) * grad_out).clone())
+            grads.append(ctx.flat_grad[off:off + cnt].view(named[name].shape) * grad_out)
         return (None, None, None, None, None) + tuple(grads)
 
 
@@ -317,6 +340,7 @@ def train(model=None, train_dataloader=None, epochs=None, lr=None, steps_til_sum
     train_losses_l, validation_losses_l = [], []
     early_stopper = EarlyStopper(patience=early_stopper_patience, min_delta=0)   # trainer.py:161
     stop_training = False
+    total_val_loss = None   # no validation has run yet (the reference's variable does not exist until then)
     dev = next(model.parameters()).device
 
     def ema_update():
@@ -346,10 +370,13 @@ def train(model=None, train_dataloader=None, epochs=None, lr=None, steps_til_sum
                 lv = float(loss)   # the only host synchronisation of a step, on summary steps
                 train_losses_l.append((train_steps_current, {"diffusion_loss": lv}))
                 print(f"train_steps_current: {train_steps_current}  diffusion_loss {lv:.6f}")
-                if summary_fn is not None:
+                if summary_fn is not None:   # do_summary (trainer.py:88-113): no_grad, eval() around the call, train() after it
+                    sm = ema_model if ema_model is not None else model
                     with torch.no_grad():
-                        summary_fn(train_steps_current, ema_model if ema_model is not None else model, batch_dict=batch, loss_info=info,
+                        sm.eval()
+                        summary_fn(train_steps_current, sm, batch_dict=batch, loss_info=info,
                                    datasubset=train_subset, prefix="TRAINING ", debug=debug, tensor_args=tensor_args)
+                    sm.train()
                 if val_dataloader is not None:
                     vals = []
                     for step_val, vb in enumerate(val_dataloader):
@@ -362,12 +389,20 @@ def train(model=None, train_dataloader=None, epochs=None, lr=None, steps_til_sum
                         if step_val == steps_per_validation:
                             break
                     validation_losses_l.append((train_steps_current, {"VALIDATION diffusion_loss": float(np.mean(vals))}))
-                    if early_stopper.early_stop(float(np.sum(vals))):   # total_val_loss of trainer.py:232-255
-                        print(f"Early stopped training at {train_steps_current} steps.")
-                        stop_training = True
+                    total_val_loss = float(np.sum(vals))   # trainer.py:225-233
+            # trainer.py:269 evaluates the stopper EVERY training step with the last validation total (patience counts steps)
+            if total_val_loss is not None and early_stopper.early_stop(total_val_loss):
+                print(f"Early stopped training at {train_steps_current} steps.")
+                stop_training = True
             if optimizers is None:
                 step_fn.adam_step(lr, max_norm=max_norm)
             else:   # torch optimisers over the same (aliased) parameters, as the reference runs them
+                if not custom_loss:
+                    # the native pass wrote the flat gradient; an earlier model.loss() with autograd or zero_grad(set_to_none=True)
+                    # may have detached p.grad from it - without this the optimiser would skip every parameter, silently
+                    if not step_fn.fp.aliased(full=True):
+                        raise RuntimeError("the model's parameters no longer alias the flat training vector - build a new TrainStep")
+                    step_fn.fp.bind_grads()
                 if max_norm is not None:
                     torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)
                 for opt in optimizers:

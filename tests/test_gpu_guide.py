@@ -114,7 +114,10 @@ def test_guided_plan_vs_oracle_chain(env_id, robot_id, opt):
     d = np.abs(chain[-1] - ref[-1]).max(-1)        # [B, H]
     assert np.median(d) < 2e-3, np.median(d)
     assert (d > w[0]).mean() < 0.02, (d > w[0]).mean()     # isolated waypoints only ...
-    assert d.max() < 5 * w[0], d.max()                     # ... and by a few increments at most (measured: 1.0 - 1.6 w, build-dependent)
+    # ... and by a few increments at most.  Which waypoint flips depends on last-bit rounding of the ~20 guided U-Net passes before it
+    # (measured worst waypoint over builds: 1.0 - 1.6 w), so the bound is a COUNT: at most 2 of the 320 waypoints beyond 1.5 w, none beyond 5 w
+    assert int((d > 1.5 * w[0]).sum()) <= 2, (int((d > 1.5 * w[0]).sum()), d.max())
+    assert d.max() < 5 * w[0], d.max()
     # north_star: trajectory-level results identical to 3 s.f. (path length and smoothness of the planned trajectories)
     qd = ds.state_dim // 2
     for name, fn in (("path_length", lambda z: np.linalg.norm(np.diff(z[..., :qd], axis=1), axis=-1).sum(-1)),

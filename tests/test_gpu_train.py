@@ -321,3 +321,69 @@ def test_train_with_a_custom_loss_fn_takes_the_reference_path():
     ts.adam_step(1e-4, max_norm=1.0)
     for (k, pa), (_, pb) in zip(dm_a.model.named_parameters(), dm_b.model.named_parameters()):
         assert float((pa.detach() - pb.detach()).abs().max()) < 3e-7, k
+
+
+def test_torch_optimizer_sees_native_gradients_after_grads_were_detached():
+    """train(optimizers=[...]) with the default loss steps torch optimisers over p.grad, which the native pass fills
+    through views of the flat gradient.  An earlier model.loss() with autograd (or zero_grad(set_to_none=True)) detaches those
+    views; the step must re-bind them instead of silently skipping every parameter."""
+    from mpd_public_amd import trainer
+    D, opt, B = 4, 0, 8
+    x0, noise, hc = _batch(D, B)
+    batch = {"traj_normalized": x0, "hard_conds": hc}
+
+    class Loader:
+        def __iter__(self):
+            return iter([batch])
+
+        def __len__(self):
+            return 1
+
+    dm_a, dm_b = _model(D, opt), _model(D, opt)
+    dm_a.train()
+    # detach every p.grad the two ways the advisor names
+    l0, _ = dm_a.loss(x0.cuda(), None, {k: v.cuda() for k, v in hc.items()})   # autograd bridge: sets aliased p.grad to None
+    assert l0.requires_grad
+    optim = torch.optim.Adam(lr=1e-4, params=dm_a.parameters())
+    optim.zero_grad(set_to_none=True)
+    assert all(p.grad is None for p in dm_a.model.parameters())
+    before = {k: p.detach().clone() for k, p in dm_a.model.named_parameters()}
+    torch.manual_seed(21); dm_a.manual_seed(21)
+    trainer.train(model=dm_a, train_dataloader=Loader(), epochs=1, lr=1e-4, optimizers=[optim], use_ema=False, clip_grad=True, max_steps=1)
+    moved = [k for k, p in dm_a.model.named_parameters() if not torch.equal(p.detach(), before[k])]
+    assert len(moved) == len(before), f"only {len(moved)} of {len(before)} parameters were updated"
+    # ... and they moved to where the native step with the same draws moves them
+    ts = trainer.TrainStep(dm_b)
+    torch.manual_seed(21); dm_b.manual_seed(21)
+    ts.loss_backward(x0.cuda(), {k: v.cuda() for k, v in hc.items()})
+    ts.adam_step(1e-4, max_norm=1.0)
+    for (k, pa), (_, pb) in zip(dm_a.model.named_parameters(), dm_b.model.named_parameters()):
+        assert float((pa.detach() - pb.detach()).abs().max()) < 3e-7, k
+
+
+def test_two_losses_before_one_backward_keep_their_own_gradients():
+    """the autograd bridge keeps each call's gradients (the flat buffer is shared): (loss(x1) + loss(x2)).backward()
+    == the sum of the two separately computed gradients."""
+    D, opt, B = 4, 0, 6
+    dm = _model(D, opt)
+    dm.train()
+    x1, _, hc1 = _batch(D, B)
+    x2 = (x1 * 0.5).contiguous()
+    hc2 = {0: x2[:, 0, :].contiguous(), 63: x2[:, -1, :].contiguous()}
+    cu = lambda d: {k: v.cuda() for k, v in d.items()}   # noqa: E731
+    t = torch.arange(B, device="cuda").long() % dm.n_diffusion_steps
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    n1 = torch.randn((B, 64, D), device="cuda", generator=g)
+    n2 = torch.randn((B, 64, D), device="cuda", generator=g)
+    from mpd_public_amd.trainer import loss_with_grad
+
+    def grads(pairs):
+        for p in dm.model.parameters():
+            p.grad = None
+        tot = sum(loss_with_grad(dm, x.cuda(), cu(hc), t=t, noise=n) for x, hc, n in pairs)
+        tot.backward()
+        return {k: p.grad.detach().clone() for k, p in dm.model.named_parameters()}
+    ga, gb, gab = grads([(x1, hc1, n1)]), grads([(x2, hc2, n2)]), grads([(x1, hc1, n1), (x2, hc2, n2)])
+    assert any(float((ga[k] - gb[k]).abs().max()) > 0 for k in ga)
+    for k in ga:
+        assert torch.allclose(gab[k], ga[k] + gb[k], rtol=0, atol=1e-6 * float((ga[k].abs() + gb[k].abs()).max() + 1e-12)), k

@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from mpd_public_amd.parallel import shard_range, expand_contexts, plan_contexts, gather_trajectories
+from mpd_public_amd.parallel import shard_range, expand_contexts, plan_contexts, gather_trajectories, verify_gather, shard_checksum
 
 
 def test_shard_range_partitions_exactly():
@@ -51,6 +51,14 @@ def _worker(rank, world, port, C, n, max_batch, q):
     assert local.shape[0] == (hi - lo) * n
     full = gather_trajectories(local, C, n)
     ok = torch.equal(full, _reference(start, goal, n))
+    # the one-hop variant (world-1 direct sends + receives per rank, one batch) must deliver the same bits, and the checksum
+    # protocol must accept the gathered tensor and reject a corrupted one
+    hop = gather_trajectories(local, C, n, mode="one_hop")
+    ok &= torch.equal(hop, full)
+    ok &= verify_gather(full, local, C, n) and verify_gather(hop, local, C, n)
+    bad = full.clone()
+    bad[-1, 3, 1] += 1e-6
+    ok &= not verify_gather(bad, local, C, n)
     q.put((rank, bool(ok), tuple(full.shape)))
     dist.barrier()
     dist.destroy_process_group()
@@ -77,3 +85,10 @@ def test_sharded_plan_and_gather_gloo(world, C, n, max_batch):
     assert sorted(r[0] for r in res) == list(range(world))
     assert all(r[1] for r in res), res
     assert all(r[2] == (C * n, 64, 4) for r in res)
+
+
+def test_checksum_is_a_bit_pattern_sum():
+    x = torch.tensor([1.0, -2.5, 0.0, 3.25])
+    assert int(shard_checksum(x)) == int(x.view(torch.int32).to(torch.int64).sum()) + 4
+    assert int(shard_checksum(x[:0])) == 0
+    assert verify_gather(x, x, 1, 4)   # no process group: the tensor checks itself
