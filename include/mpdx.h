@@ -221,6 +221,44 @@ int mpdx_absmax(const float* x, uint32_t* absmax_out, int n_per_ctx, int B, int 
 int mpdx_traj_metrics(const mpdx_guide_params* gp, const float* x_unnormalised, float* out4, int n_check, int B, int H, int D,
                       void* stream);
 
+/* ---- baseline planners of the dataset-generation script: replaces `HybridPlanner(RRTConnect x n via
+ * MultiSampleBasedPlanner, GPMP2).optimize()` of scripts/generate_data/generate_trajectories.py:68-120.  The planners are
+ * un-vendored in the reference (mp_baselines submodule empty: PARITY UNPINNED); the published algorithms are restated
+ * (oracle/gpmp.py).  Trajectories and configurations are in RAW robot units (gp->identity_normalizer semantics).
+ *
+ * GPMP2 (Mukadam et al. 2018) - one Levenberg-Marquardt iteration per call for B trajectories:
+ *   F = 1/2 sum e_i^T Q^-1 e_i / sigma_gp^2 + 1/2 sum c^2 / sigma_obs^2   (constant-velocity GP prior of gp->dt / gp->sigma_gp between the
+ *   supports; hinge collision factors of gp->fields on the gp->n_interp interpolated points; start and goal states fixed).
+ *   state[b] = {F(x_b), lambda_b, accepted steps, F(last candidate)}: initialise to {3e38, lambda_init, 0, 0} and delta to 0.
+ *   Each call judges the pending candidate x + delta (accept if it lowers F: x <- x + delta, lambda *= lambda_down; else lambda *= lambda_up),
+ *   then (solve != 0) linearises at x and writes the next proposal  delta = -step (K^-1 + J^T J / sigma_obs^2 + lambda diag)^-1 grad F
+ *   (block-tridiagonal system, banded LDL^T in LDS).  Call iters times with solve = 1 and once more with solve = 0.
+ *   A trajectory whose accepted step no longer lowers F (relative 1e-7) or whose lambda reached lambda_max is CONVERGED: its lambda is
+ *   stored negated and further calls return at once for it.
+ *   adaptive == 0: every candidate is accepted and lambda stays fixed (damped Gauss-Newton with a fixed step). */
+typedef struct mpdx_gpmp_opts {
+    float   sigma_obs;
+    float   lambda_up, lambda_down, lambda_min, lambda_max;
+    float   step;
+    int32_t adaptive;
+} mpdx_gpmp_opts;
+int mpdx_gpmp_step(const mpdx_guide_params* gp, const mpdx_gpmp_opts* opts, float* x, float* delta, float* state, int B, int H, int D,
+                   int solve, void* stream);
+
+/* RRT-Connect (Kuffner & LaValle 2000) for n independent problems, the WHOLE search in one launch (one workgroup per problem):
+ *   start, goal [n, q]; nodes [n, 2, max_nodes, q] / parent [n, 2, max_nodes] the two trees (tree 0 from the start, tree 1 from the goal);
+ *   count [n, 2] nodes per tree; link [n, 2] the node indices where the trees met (-1: not solved within max_iters / max_nodes);
+ *   iters [n] iterations used.  Samples are uniform in [q_lo, q_hi] (Philox keyed by seed, problem, iteration); an edge is checked on
+ *   n_edge_checks interpolated configurations with the link radius only (as mpdx_traj_metrics). */
+typedef struct mpdx_rrt_opts {
+    float    q_lo[8], q_hi[8];
+    float    step;
+    int32_t  max_nodes, max_iters, max_connect_steps, n_edge_checks;
+    uint64_t seed;
+} mpdx_rrt_opts;
+int mpdx_rrt_connect(const mpdx_guide_params* gp, const mpdx_rrt_opts* opts, const float* start, const float* goal, float* nodes,
+                     int32_t* parent, int32_t* count, int32_t* link, int32_t* iters, int n, void* stream);
+
 /* ---- the whole planning loop: replaces GaussianDiffusionModel.p_sample_loop driven by run_inference
  * (diffusion_model_base.py:157-182,285-316) with sample_fn=ddpm_sample_fn.  Everything is enqueued on `stream`
  * without a single host synchronisation: the t-dependent branches of the reference (`t_single < 0`,

@@ -49,6 +49,16 @@ class GuideParams(C.Structure):
                 ("identity_normalizer", C.c_int32)]
 
 
+class GpmpOpts(C.Structure):
+    _fields_ = [("sigma_obs", C.c_float), ("lambda_up", C.c_float), ("lambda_down", C.c_float), ("lambda_min", C.c_float),
+                ("lambda_max", C.c_float), ("step", C.c_float), ("adaptive", C.c_int32)]
+
+
+class RrtOpts(C.Structure):
+    _fields_ = [("q_lo", C.c_float * 8), ("q_hi", C.c_float * 8), ("step", C.c_float), ("max_nodes", C.c_int32), ("max_iters", C.c_int32),
+                ("max_connect_steps", C.c_int32), ("n_edge_checks", C.c_int32), ("seed", C.c_uint64)]
+
+
 # every symbol include/mpdx.h declares: name -> (restype, argtypes)
 _vp, _sz, _i, _f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
 SIGNATURES = {
@@ -93,6 +103,8 @@ SIGNATURES = {
     "mpdx_train_loss_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "mpdx_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _f, _vp, _vp]),
     "mpdx_ema_update": (_i, [_vp, _vp, _sz, _f, _vp]),
+    "mpdx_gpmp_step": (_i, [C.POINTER(GuideParams), C.POINTER(GpmpOpts), _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mpdx_rrt_connect": (_i, [C.POINTER(GuideParams), C.POINTER(RrtOpts), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
 }
 
 

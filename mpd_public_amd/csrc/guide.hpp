@@ -64,9 +64,10 @@ struct GuideArgs {
 // sqrtf sequence.  The gradient is evaluated once, for the arg-min primitive, after the scan.  (The first version -
 // per primitive: load, exact sqrt, exact divide, compare, divergent branch - cost ~330 cycles per primitive and made
 // the 15-sphere objects field of the Panda 60-70 k cycles per launch.)
+// Returns the hinge value relu(margin - sdf) (0 when inactive); `force` = its gradient w.r.t. p.
 template <int DIM>
-__device__ __forceinline__ void objects_force(const float* __restrict__ prims, const mpdx_field& f, const float (&p)[DIM], float margin,
-                                              float (&force)[DIM]) {
+__device__ __forceinline__ float objects_force(const float* __restrict__ prims, const mpdx_field& f, const float (&p)[DIM], float margin,
+                                               float (&force)[DIM]) {
     float best = 3.0e38f;
     int bi = -1;  // arg-min: sphere index, or n_spheres + box index
     const float* sp = prims + f.sphere_off;
@@ -145,7 +146,9 @@ __device__ __forceinline__ void objects_force(const float* __restrict__ prims, c
             for (int j = 0; j < DIM; ++j)  // outside: gradient of |relu(d)|; inside (or on the surface): gradient of max_j d_j
                 force[j] = -(outside ? sg[j] * fmaxf(d[j], 0.f) * inv : (j == jm ? sg[j] : 0.f));
         }
+        return margin - best;
     }
+    return 0.f;
 }
 
 template <int DIM>

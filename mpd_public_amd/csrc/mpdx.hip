@@ -1839,3 +1839,4 @@ int mpdx_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* strea
 }  // extern "C"
 
 #include "train_host.hpp"
+#include "planner_host.hpp"

@@ -1,0 +1,685 @@
+// planner.hpp - the reference's BASELINE planners (scripts/generate_data/generate_trajectories.py:68-120: `HybridPlanner` =
+// RRT-Connect initialisation + GPMP2 optimisation, both from the un-vendored mp_baselines submodule - PARITY UNPINNED) as HIP kernels.
+//
+//   gpmp_lm_kernel      one Levenberg-Marquardt / Gauss-Newton iteration of GPMP2 (Mukadam et al., IJRR 2018, section 4) for a
+//                       batch of trajectories: MAP estimate of
+//                           F(theta) = 1/2 sum_i e_i^T Q^-1 e_i / sigma_gp^2  +  1/2 sum_{points, factors} c^2 / sigma_obs^2
+//                       e_i = theta_{i+1} - Phi theta_i (constant-velocity GP prior, Q^-1 = [[12/dt^3,-6/dt^2],[-6/dt^2,4/dt]] (x) I),
+//                       c = hinge obstacle / workspace / self-collision factors of every link sphere on the interpolated
+//                       trajectory (the SAME factors the guide differentiates: oracle/costs.py), start and goal states fixed.
+//                       The normal equations  (K^-1 + J^T J / sigma_obs^2 + lambda diag) delta = -grad  are BLOCK TRIDIAGONAL over the
+//                       H - 2 free support states (an interpolated point touches two neighbouring supports): assembled in LDS as a
+//                       banded matrix (half bandwidth 2d - 1, d = state dim) and solved by an in-LDS banded LDL^T - one workgroup
+//                       per trajectory, no global traffic besides the trajectory itself.
+//   rrt_connect_kernel  RRT-Connect (Kuffner & LaValle 2000), one workgroup per problem, the WHOLE bidirectional search in one
+//                       launch: sampling (Philox), nearest neighbour over the tree (lanes over nodes + wave arg-min), steering,
+//                       edge collision checks (lanes over interpolated configurations, the metrics kernel's FK / SDF functions)
+//                       and the greedy connect loop - no host round trip per extension.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "guide.hpp"
+
+namespace mpdx {
+
+struct GpmpArgs {
+    mpdx_guide_params gp;   // robot, fields, margins, dt, sigma_gp, interpolation (identity normaliser: raw robot units)
+    float* x;               // [B][H][D] current trajectories (in/out)
+    float* delta;           // [B][H][D] last proposed step (in: candidate = x + delta; out: the new proposal)
+    float* state;           // [B][4]: F(x), lambda, accepted steps, F(last candidate)
+    int B, H;
+    float sigma_obs;
+    float lam_up, lam_down, lam_min, lam_max;
+    float step;             // fraction of the Gauss-Newton step taken (1; mp_baselines-style fixed damping uses < 1)
+    int adaptive;           // 1: accept a candidate only if it lowers F and adapt lambda (Levenberg-Marquardt); 0: always accept, lambda fixed
+    int solve;              // 0: only judge the pending candidate (the call after the last iteration)
+};
+
+// accumulate one factor (hinge value c, Jacobian row j) into the point's packed normal-equation terms:
+// M (lower triangle of sum j j^T), v (sum c j), c2 (sum c^2)
+template <int QD>
+__device__ __forceinline__ void gn_accumulate(float c, const float (&j)[QD], float (&M)[QD * (QD + 1) / 2], float (&v)[QD], float& c2) {
+    int e = 0;
+#pragma unroll
+    for (int r = 0; r < QD; ++r) {
+#pragma unroll
+        for (int cc = 0; cc <= r; ++cc) M[e++] += j[r] * j[cc];
+        v[r] += c * j[r];
+    }
+    c2 += c * c;
+}
+
+// Linearise every collision factor of interpolated point i whose index parity / group matches `half` (2 threads per point).
+// q: the point's configuration.  Writes MSZ = QD(QD+1)/2 + QD + 1 floats.
+template <int QD, int DIM, int ROBOT, int HALF>
+__device__ __forceinline__ void gn_point(const mpdx_guide_params& gp, const float* sprim, const float (&q)[QD], float* out) {
+    constexpr int half = HALF;
+    constexpr int NT = QD * (QD + 1) / 2;
+    float M[NT], v[QD], c2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < NT; ++e) M[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < QD; ++j) v[j] = 0.f;
+    if constexpr (ROBOT == MPDX_ROBOT_POINTMASS) {
+        float p[DIM];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) p[j] = q[j];
+        const float margin = gp.link_margin + gp.cutoff_margin;
+        for (int f = 0; f < gp.n_fields; ++f) {
+            if ((f & 1) != half) continue;
+            if (gp.fields[f].kind == MPDX_FIELD_OBJECTS) {
+                float fo[DIM];
+                const float c = objects_force<DIM>(sprim, gp.fields[f], p, margin, fo);
+                if (c > 0.f) {
+                    float jr[QD];
+#pragma unroll
+                    for (int j = 0; j < QD; ++j) jr[j] = j < DIM ? fo[j] : 0.f;
+                    gn_accumulate<QD>(c, jr, M, v, c2);
+                }
+            } else if (gp.fields[f].kind == MPDX_FIELD_WORKSPACE) {
+#pragma unroll
+                for (int j = 0; j < DIM; ++j) {   // one factor per face: Jacobian -e_j / +e_j
+                    const float clo = margin - (p[j] - gp.fields[f].ws_min[j]), chi = margin - (gp.fields[f].ws_max[j] - p[j]);
+                    const int dj = j * (j + 1) / 2 + j;
+                    if (clo > 0.f) { M[dj] += 1.f; v[j] -= clo; c2 += clo * clo; }
+                    if (chi > 0.f) { M[dj] += 1.f; v[j] += chi; c2 += chi * chi; }
+                }
+            }
+        }
+    } else {
+        float O[7][3], Z[7][3];
+        panda_fk(q, O, Z);
+        float P[kPandaNS][3];
+#pragma unroll
+        for (int s = 0; s < kPandaNS; ++s)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) P[s][r] = O[kPandaSF[s] - 1][r] + kPandaSO[s] * Z[kPandaSF[s] - 1][r];
+        // d c / d theta_k = f . (z_k x (P - O_k)) for joints k <= frame of the sphere
+        auto jac_row = [&](const float (&f3)[3], int s, float sign, float (&jr)[QD]) {
+            const int fr = kPandaSF[s] - 1;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                if (k <= fr) {
+                    const float rx = P[s][0] - O[k][0], ry = P[s][1] - O[k][1], rz = P[s][2] - O[k][2];
+                    const float cx = Z[k][1] * rz - Z[k][2] * ry, cy = Z[k][2] * rx - Z[k][0] * rz, cz = Z[k][0] * ry - Z[k][1] * rx;
+                    jr[k] += sign * (f3[0] * cx + f3[1] * cy + f3[2] * cz);
+                }
+            }
+        };
+        constexpr int s_beg = half ? 6 : 0, s_end = half ? kPandaNS : 6;     // static sphere / pair ranges: P[s], kPandaSF[s] are compile-time
+        constexpr int p_beg = half ? 6 : 0, p_end = half ? kPandaNP : 6;
+        for (int f = 0; f < gp.n_fields; ++f) {
+            const int kind = gp.fields[f].kind;
+            if (kind == MPDX_FIELD_OBJECTS) {
+#pragma unroll
+                for (int s = s_beg; s < s_end; ++s) {
+                    const float p3[3] = {P[s][0], P[s][1], P[s][2]};
+                    float fo[3];
+                    const float c = objects_force<3>(sprim, gp.fields[f], p3, kPandaSR[s] + gp.cutoff_margin, fo);
+                    if (c > 0.f) {
+                        float jr[QD];
+#pragma unroll
+                        for (int k = 0; k < QD; ++k) jr[k] = 0.f;
+                        jac_row(fo, s, 1.f, jr);
+                        gn_accumulate<QD>(c, jr, M, v, c2);
+                    }
+                }
+            } else if (kind == MPDX_FIELD_WORKSPACE) {
+#pragma unroll
+                for (int s = s_beg; s < s_end; ++s) {
+                    const float margin = kPandaSR[s] + gp.cutoff_margin;
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) {
+                        const float clo = margin - (P[s][ax] - gp.fields[f].ws_min[ax]), chi = margin - (gp.fields[f].ws_max[ax] - P[s][ax]);
+                        if (clo > 0.f || chi > 0.f) {
+                            float e3[3] = {0.f, 0.f, 0.f};
+                            e3[ax] = 1.f;
+                            float jr[QD];
+#pragma unroll
+                            for (int k = 0; k < QD; ++k) jr[k] = 0.f;
+                            jac_row(e3, s, 1.f, jr);     // d P_ax / d theta
+                            if (clo > 0.f) {              // c = margin - (P - min): Jacobian -dP
+                                float jm[QD];
+#pragma unroll
+                                for (int k = 0; k < QD; ++k) jm[k] = -jr[k];
+                                gn_accumulate<QD>(clo, jm, M, v, c2);
+                            }
+                            if (chi > 0.f) gn_accumulate<QD>(chi, jr, M, v, c2);
+                        }
+                    }
+                }
+            } else if (kind == MPDX_FIELD_SELF) {
+#pragma unroll
+                for (int pr = p_beg; pr < p_end; ++pr) {
+                    const int sa_ = kPandaPA[pr], sb_ = kPandaPB[pr];
+                    const float dx = P[sa_][0] - P[sb_][0], dy = P[sa_][1] - P[sb_][1], dz = P[sa_][2] - P[sb_][2];
+                    const float d2 = dx * dx + dy * dy + dz * dz;
+                    const float dist = __builtin_amdgcn_sqrtf(d2);
+                    const float c = kPandaSR[sa_] + kPandaSR[sb_] - dist;
+                    if (c > 0.f && dist > 0.f) {
+                        const float inv = __builtin_amdgcn_rsqf(d2);
+                        const float u[3] = {dx * inv, dy * inv, dz * inv};   // d c / d P_a = -u, d c / d P_b = +u
+                        float jr[QD];
+#pragma unroll
+                        for (int k = 0; k < QD; ++k) jr[k] = 0.f;
+                        jac_row(u, sa_, -1.f, jr);
+                        jac_row(u, sb_, 1.f, jr);
+                        gn_accumulate<QD>(c, jr, M, v, c2);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NT; ++e) out[e] = M[e];
+#pragma unroll
+    for (int j = 0; j < QD; ++j) out[NT + j] = v[j];
+    out[NT + QD] = c2;
+}
+
+constexpr int kGpmpThreads = 256;
+
+template <int QD>
+inline size_t gpmp_lds_bytes(int H, int N, int n_prim_floats) {
+    constexpr int D = 2 * QD, MSZ = QD * (QD + 1) / 2 + QD + 1, BW = 2 * D;
+    const size_t n = (size_t)(H - 2) * D;
+    return (size_t)(2 * H * D + 2 * N * MSZ + n * BW + n + 64 + n_prim_floats) * sizeof(float);
+}
+
+template <int QD, int DIM, int ROBOT>
+__global__ __launch_bounds__(kGpmpThreads, 1) void gpmp_lm_kernel(const GpmpArgs a) {
+    constexpr int D = 2 * QD, NT = QD * (QD + 1) / 2, MSZ = NT + QD + 1, BW = 2 * D, NTHR = kGpmpThreads;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const mpdx_guide_params& gp = a.gp;
+    const int tid = threadIdx.x, b = blockIdx.x, H = a.H;
+    const int N = gp.interpolate ? gp.n_interp : H;
+    const int n = H - 2, NR = n * D;                 // free support states, unknowns
+    float* sx = sm;                                  // [H][D] linearisation point
+    float* sc = sx + H * D;                          // [H][D] candidate
+    float* sM = sc + H * D;                          // [2][N][MSZ] per-point normal-equation terms
+    float* band = sM + 2 * N * MSZ;                  // [NR][BW]: band[r][c] = A[r][r - c]
+    float* rhs = band + (size_t)NR * BW;             // [NR]
+    float* red = rhs + NR;                           // [64] reduction scratch
+    float* sprim = red + 64;
+    for (int i = tid; i < gp.n_prim_floats; i += NTHR) sprim[i] = gp.prims[i];
+    const size_t base = (size_t)b * H * D;
+    for (int i = tid; i < H * D; i += NTHR) {
+        const float xv = a.x[base + i];
+        const int h = i / D;
+        sx[i] = xv;
+        sc[i] = (h > 0 && h < H - 1) ? xv + a.delta[base + i] : xv;
+    }
+    float F_cur = a.state[(size_t)b * 4 + 0], lam = a.state[(size_t)b * 4 + 1], n_acc = a.state[(size_t)b * 4 + 2];
+    if (lam < 0.f) return;   // converged earlier (marked by a negative lambda): x is final, delta is zero - nothing left to do
+    __syncthreads();
+
+    const float scale = (N > 1) ? (float)(H - 1) / (float)(N - 1) : 0.f;
+    const float s_gp = 1.0f / (gp.sigma_gp * gp.sigma_gp), s_ob = 1.0f / (a.sigma_obs * a.sigma_obs);
+    const float dt = gp.dt;
+    const float qa = 12.0f / (dt * dt * dt), qb = -6.0f / (dt * dt), qc = 4.0f / dt;   // Q^-1 = [[qa, qb], [qb, qc]] (x) I
+
+    // linearise the collision factors at `src` and return F(src) (uniform over the workgroup)
+    auto linearise = [&](const float* src) -> float {
+        for (int idx = tid; idx < 2 * N; idx += NTHR) {
+            const int half = idx >= N ? 1 : 0, i = idx - half * N;   // N is a multiple of 64 in practice: the half is wave-uniform
+            int i0 = i, i1 = i;
+            float l0 = 1.f, l1 = 0.f;
+            if (gp.interpolate) {
+                const float u = scale * (float)i;
+                i0 = (int)u;
+                if (i0 > H - 1) i0 = H - 1;
+                i1 = i0 + 1 < H ? i0 + 1 : H - 1;
+                l1 = u - (float)i0;
+                l0 = 1.0f - l1;
+            }
+            float q[QD];
+#pragma unroll
+            for (int j = 0; j < QD; ++j) q[j] = l0 * src[i0 * D + j] + l1 * src[i1 * D + j];
+            if (half) gn_point<QD, DIM, ROBOT, 1>(gp, sprim, q, sM + (size_t)idx * MSZ);
+            else gn_point<QD, DIM, ROBOT, 0>(gp, sprim, q, sM + (size_t)idx * MSZ);
+        }
+        // cost: GP prior (one thread per factor) + collision (c2 of every point half)
+        float part = 0.f;
+        for (int i = tid; i < H - 1; i += NTHR) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < QD; ++j) {
+                const float eq = src[(i + 1) * D + j] - src[i * D + j] - dt * src[i * D + QD + j];
+                const float ev = src[(i + 1) * D + QD + j] - src[i * D + QD + j];
+                s += qa * eq * eq + 2.0f * qb * eq * ev + qc * ev * ev;
+            }
+            part += 0.5f * s_gp * s;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * N; idx += NTHR) part += 0.5f * s_ob * sM[(size_t)idx * MSZ + NT + QD];   // every [half][point] slot once
+        part = wave_sum(part);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = part;
+        __syncthreads();
+        float F = 0.f;
+#pragma unroll
+        for (int w = 0; w < NTHR / 64; ++w) F += red[w];
+        __syncthreads();
+        return F;
+    };
+
+    // ---- judge the pending candidate (ONE call site of the linearisation: the loop body runs once when the candidate is accepted,
+    //      twice when it is rejected - the factors must then be linearised again at the point we keep)
+    float F_cand = 0.f;
+    const bool first = !(F_cur < 3.0e37f);
+    bool converged = false;   // adaptive mode: an accepted step that no longer lowers F (relative 1e-7), or lambda at its ceiling
+    const float* src = sc;
+    for (int pass = 0; pass < 2; ++pass) {
+        const float F_eval = linearise(src);
+        if (pass == 1) { F_cur = F_eval; break; }
+        F_cand = F_eval;
+        bool accept = first || !a.adaptive || (F_cand < F_cur);
+        if (!(F_cand == F_cand)) accept = first;   // NaN candidate: never accept (keep the current point)
+        if (accept) {
+            for (int i = tid; i < H * D; i += NTHR) sx[i] = sc[i];
+            if (!first) {
+                n_acc += 1.f;
+                if (a.adaptive) { lam = fmaxf(lam * a.lam_down, a.lam_min); converged = (F_cur - F_cand) <= 1e-7f * F_cur; }
+            }
+            F_cur = F_cand;
+            __syncthreads();
+            break;
+        }
+        if (lam >= a.lam_max) { converged = true; break; }
+        lam = fminf(lam * a.lam_up, a.lam_max);
+        if (!a.solve) break;
+        src = sx;
+    }
+    if (converged) {
+        for (int i = tid; i < H * D; i += NTHR) { a.x[base + i] = sx[i]; a.delta[base + i] = 0.f; }
+        if (tid == 0) { a.state[(size_t)b * 4 + 0] = F_cur; a.state[(size_t)b * 4 + 1] = -lam; a.state[(size_t)b * 4 + 2] = n_acc; a.state[(size_t)b * 4 + 3] = F_cand; }
+        return;
+    }
+    if (!a.solve) {
+        for (int i = tid; i < H * D; i += NTHR) { a.x[base + i] = sx[i]; a.delta[base + i] = 0.f; }
+        if (tid == 0) { a.state[(size_t)b * 4 + 0] = F_cur; a.state[(size_t)b * 4 + 1] = lam; a.state[(size_t)b * 4 + 2] = n_acc; a.state[(size_t)b * 4 + 3] = F_cand; }
+        return;
+    }
+
+    // ---- assemble the banded normal equations (every structural entry is written once; the rest of the band is zero)
+    for (int i = tid; i < NR * BW; i += NTHR) band[i] = 0.f;
+    __syncthreads();
+    constexpr int T0 = NT, T1 = T0 + QD, T2 = T1 + QD, T3 = T2 + QD, T4 = T3 + QD * QD, T5 = T4 + 3 * QD;
+    for (int task = tid; task < n * T5; task += NTHR) {
+        const int bi = task / T5, e = task - bi * T5;   // bi: free block (support h = bi + 1)
+        const int h = bi + 1;
+        // points that touch support h: those with i0 in {h-1, h}
+        int plo = 0, phi = N - 1;
+        if (gp.interpolate && scale > 0.f) {
+            plo = (int)((float)(h - 1) / scale) - 1;
+            phi = (int)((float)(h + 1) / scale) + 1;
+            if (plo < 0) plo = 0;
+            if (phi > N - 1) phi = N - 1;
+        } else { plo = h; phi = h; }
+        auto point_w = [&](int i, int& i0, int& i1, float& l0, float& l1) {
+            i0 = i; i1 = i; l0 = 1.f; l1 = 0.f;
+            if (gp.interpolate) {
+                const float u = scale * (float)i;
+                i0 = (int)u;
+                if (i0 > H - 1) i0 = H - 1;
+                i1 = i0 + 1 < H ? i0 + 1 : H - 1;
+                l1 = u - (float)i0;
+                l0 = 1.0f - l1;
+            }
+        };
+        auto msum = [&](int i, int off) { return sM[(size_t)i * MSZ + off] + sM[((size_t)N + i) * MSZ + off]; };
+        if (e < T0) {            // pos-pos lower triangle of the diagonal block
+            int r = 0;
+            while ((r + 1) * (r + 2) / 2 <= e) ++r;
+            const int c = e - r * (r + 1) / 2;
+            float acc = 0.f;
+            for (int i = plo; i <= phi; ++i) {
+                int i0, i1; float l0, l1;
+                point_w(i, i0, i1, l0, l1);
+                float w = 0.f;
+                if (i0 == h) w += l0 * l0;
+                if (i1 == h && i1 != i0) w += l1 * l1;
+                if (w != 0.f) acc += w * msum(i, e);
+            }
+            float val = s_ob * acc + (r == c ? s_gp * 2.0f * qa : 0.f);
+            if (r == c) val *= (1.0f + lam);
+            band[(size_t)(bi * D + r) * BW + (r - c)] = val;
+        } else if (e < T1) {     // vel-vel diagonal (prior only: Q^-1 + Phi^T Q^-1 Phi = diag(24/dt^3, 8/dt))
+            const int j = e - T0;
+            band[(size_t)(bi * D + QD + j) * BW] = s_gp * 2.0f * qc * (1.0f + lam);
+        } else if (e < T3) {     // right-hand side = -gradient
+            const bool vel = e >= T2;
+            const int j = vel ? e - T2 : e - T1;
+            // prior: g_h = Q^-1 e_{h-1} - Phi^T Q^-1 e_h
+            const float eq0 = sx[h * D + j] - sx[(h - 1) * D + j] - dt * sx[(h - 1) * D + QD + j], ev0 = sx[h * D + QD + j] - sx[(h - 1) * D + QD + j];
+            const float eq1 = sx[(h + 1) * D + j] - sx[h * D + j] - dt * sx[h * D + QD + j], ev1 = sx[(h + 1) * D + QD + j] - sx[h * D + QD + j];
+            const float a0 = qa * eq0 + qb * ev0, b0 = qb * eq0 + qc * ev0, a1 = qa * eq1 + qb * ev1, b1 = qb * eq1 + qc * ev1;
+            float g = s_gp * (vel ? (b0 - b1 - dt * a1) : (a0 - a1));
+            if (!vel) {
+                float acc = 0.f;
+                for (int i = plo; i <= phi; ++i) {
+                    int i0, i1; float l0, l1;
+                    point_w(i, i0, i1, l0, l1);
+                    float w = 0.f;
+                    if (i0 == h) w += l0;
+                    if (i1 == h && i1 != i0) w += l1;
+                    if (w != 0.f) acc += w * msum(i, NT + j);
+                }
+                g += s_ob * acc;
+            }
+            rhs[bi * D + (vel ? QD : 0) + j] = -g;
+        } else if (bi + 1 < n) {  // coupling block (support h+1, support h): rows of block bi+1, columns of block bi
+            if (e < T4) {        // pos-pos: prior -qa on the diagonal + l0 l1 M of the points inside the segment (h, h+1)
+                const int r = (e - T3) / QD, c = (e - T3) - r * QD;
+                const int tri = r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r;
+                float acc = 0.f;
+                for (int i = plo; i <= phi; ++i) {
+                    int i0, i1; float l0, l1;
+                    point_w(i, i0, i1, l0, l1);
+                    if (i0 == h && i1 == h + 1) acc += l0 * l1 * msum(i, tri);
+                }
+                band[(size_t)((bi + 1) * D + r) * BW + (D + r - c)] = s_ob * acc + (r == c ? -s_gp * qa : 0.f);
+            } else {             // -Q^-1 Phi = [[-12/dt^3, -6/dt^2], [6/dt^2, 2/dt]] per joint
+                const int k = (e - T4) / QD, j = (e - T4) - k * QD;
+                if (k == 0) band[(size_t)((bi + 1) * D + j) * BW + (D + j - (QD + j))] = s_gp * (-(qa * dt + qb));            // (pos_j of h+1, vel_j of h)
+                else if (k == 1) band[(size_t)((bi + 1) * D + QD + j) * BW + (D + QD + j - j)] = s_gp * (-qb);                 // (vel_j of h+1, pos_j of h)
+                else band[(size_t)((bi + 1) * D + QD + j) * BW + (D + QD + j - (QD + j))] = s_gp * (-(qb * dt + qc));           // (vel_j of h+1, vel_j of h)
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- banded LDL^T with the forward substitution folded in (the right-hand side is one more row of every column update)
+    // column k: for 1 <= j <= i <= m:  A[k+i][k+j] -= A[k+i][k] A[k+j][k] / D_k ;  b[k+i] -= A[k+i][k] b[k] / D_k
+    // thread = (i, chunk of j): i in [1, BW-1], 4 j per chunk.  Rows beyond the next block are structurally zero: m <= 2d-1-(k mod d).
+    {
+        constexpr int JC = 4, NCH = (BW - 1 + JC - 1) / JC;
+        const int ti = tid / NCH + 1, tc = tid - (ti - 1) * NCH;   // ti in [1, ...], valid if ti <= BW-1
+        for (int k = 0; k < NR; ++k) {
+            int m = NR - 1 - k;
+            const int mb = 2 * D - 1 - (k % D);
+            if (m > mb) m = mb;
+            if (m > BW - 1) m = BW - 1;
+            if (ti <= m) {
+                const float dk = band[(size_t)k * BW];
+                const float lik = band[(size_t)(k + ti) * BW + ti] / dk;
+                if (tc == 0) rhs[k + ti] -= lik * rhs[k];
+#pragma unroll
+                for (int u = 0; u < JC; ++u) {
+                    const int j = tc * JC + u + 1;
+                    if (j <= ti) band[(size_t)(k + ti) * BW + (ti - j)] -= lik * band[(size_t)(k + j) * BW + j];
+                }
+            }
+            __syncthreads();
+        }
+        // z -> w = D^-1 z, then L^T x = w column by column from the bottom: x_i final, w_k -= L_ik x_i for the rows k above
+        for (int i = tid; i < NR; i += NTHR) rhs[i] /= band[(size_t)i * BW];
+        __syncthreads();
+        for (int i = NR - 1; i > 0; --i) {
+            const int c = tid + 1;   // column offset: k = i - c
+            if (c <= BW - 1 && i - c >= 0) {
+                const int k = i - c;
+                const float l = band[(size_t)i * BW + c];
+                if (l != 0.f) rhs[k] -= l / band[(size_t)k * BW] * rhs[i];
+            }
+            __syncthreads();
+        }
+    }
+    // ---- write back: the (possibly updated) current point, the new proposal, the state
+    for (int i = tid; i < H * D; i += NTHR) {
+        const int h = i / D;
+        a.x[base + i] = sx[i];
+        a.delta[base + i] = (h > 0 && h < H - 1) ? a.step * rhs[(h - 1) * D + (i - h * D)] : 0.f;
+    }
+    if (tid == 0) { a.state[(size_t)b * 4 + 0] = F_cur; a.state[(size_t)b * 4 + 1] = lam; a.state[(size_t)b * 4 + 2] = n_acc; a.state[(size_t)b * 4 + 3] = F_cand; }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// RRT-Connect.  One workgroup (256 threads) per problem; both trees' node coordinates live in LDS (2 x max_nodes x QD floats) and
+// are mirrored to global memory (with the parent links) for the host's path extraction.  All control flow is workgroup-uniform:
+// every decision is an LDS broadcast.
+struct RrtArgs {
+    mpdx_guide_params gp;       // robot + collision fields (edges are checked with the LINK radius only, as traj_metrics_kernel)
+    const float* start;         // [n][QD]
+    const float* goal;          // [n][QD]
+    float* nodes;               // [n][2][max_nodes][QD]   tree 0 grows from the start, tree 1 from the goal
+    int* parent;                // [n][2][max_nodes]
+    int* count;                 // [n][2]
+    int* link;                  // [n][2] node indices where the trees met (-1: not solved)
+    int* iters;                 // [n] iterations used
+    float q_lo[8], q_hi[8];     // sampling box
+    float step;
+    int max_nodes, max_iters, max_connect, n_checks;
+    unsigned long long seed;
+};
+
+__device__ __forceinline__ void philox_uniform4(uint64_t seed, uint64_t ctr, float (&u)[4]) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    u[0] = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f); u[1] = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    u[2] = ((float)(c2 >> 8) + 0.5f) * (1.0f / 16777216.0f); u[3] = ((float)(c3 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// does configuration q collide?  `part` / `nparts` split the Panda's link spheres and self-collision pairs over threads
+template <int QD, int DIM, int ROBOT>
+__device__ __forceinline__ bool config_hit(const mpdx_guide_params& gp, const float* sprim, const float (&q)[QD], int part, int nparts) {
+    bool hit = false;
+    if constexpr (ROBOT == MPDX_ROBOT_POINTMASS) {
+        if (part != 0) return false;
+        float p[DIM];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) p[j] = q[j];
+        for (int f = 0; f < gp.n_fields; ++f) {
+            if (gp.fields[f].kind == MPDX_FIELD_OBJECTS) hit |= objects_sdf<DIM>(sprim, gp.fields[f], p) < gp.link_margin;
+            else if (gp.fields[f].kind == MPDX_FIELD_WORKSPACE) {
+#pragma unroll
+                for (int j = 0; j < DIM; ++j) hit |= (p[j] - gp.fields[f].ws_min[j] < gp.link_margin) || (gp.fields[f].ws_max[j] - p[j] < gp.link_margin);
+            }
+        }
+    } else {
+        float O[7][3], Z[7][3];
+        panda_fk(q, O, Z);
+        float P[kPandaNS][3];
+#pragma unroll
+        for (int s = 0; s < kPandaNS; ++s)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) P[s][r] = O[kPandaSF[s] - 1][r] + kPandaSO[s] * Z[kPandaSF[s] - 1][r];
+        for (int f = 0; f < gp.n_fields; ++f) {
+            const int kind = gp.fields[f].kind;
+            if (kind == MPDX_FIELD_SELF) {
+#pragma unroll
+                for (int pr = 0; pr < kPandaNP; ++pr) {
+                    if (pr % nparts != part) continue;
+                    const float dx = P[kPandaPA[pr]][0] - P[kPandaPB[pr]][0], dy = P[kPandaPA[pr]][1] - P[kPandaPB[pr]][1],
+                                dz = P[kPandaPA[pr]][2] - P[kPandaPB[pr]][2];
+                    hit |= sqrtf(dx * dx + dy * dy + dz * dz) < kPandaSR[kPandaPA[pr]] + kPandaSR[kPandaPB[pr]];
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < kPandaNS; ++s) {
+                    if (s % nparts != part) continue;
+                    const float p3[3] = {P[s][0], P[s][1], P[s][2]};
+                    if (kind == MPDX_FIELD_OBJECTS) hit |= objects_sdf<3>(sprim, gp.fields[f], p3) < kPandaSR[s];
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) hit |= (p3[j] - gp.fields[f].ws_min[j] < kPandaSR[s]) || (gp.fields[f].ws_max[j] - p3[j] < kPandaSR[s]);
+                    }
+                }
+            }
+        }
+    }
+    return hit;
+}
+
+constexpr int kRrtThreads = 256;
+
+template <int QD, int DIM, int ROBOT>
+__global__ __launch_bounds__(kRrtThreads) void rrt_connect_kernel(const RrtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const mpdx_guide_params& gp = a.gp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int M = a.max_nodes;
+    float* tree = sm;                          // [2][M][QD]
+    float* sq = tree + 2 * M * QD;             // scratch: [0] qr/target, [1] qn/cur, [2] qnew/nxt  (QD floats each, padded to 8)
+    float* sred = sq + 3 * 8;                  // [4][2] per-wave arg-min
+    int* sint = (int*)(sred + 8);              // [0] nearest index
+    float* sprim = (float*)(sint + 8);
+    for (int i = tid; i < gp.n_prim_floats; i += kRrtThreads) sprim[i] = gp.prims[i];
+    float* gnodes = a.nodes + (size_t)b * 2 * M * QD;
+    int* gpar = a.parent + (size_t)b * 2 * M;
+    if (tid < QD) {
+        tree[tid] = a.start[(size_t)b * QD + tid]; tree[M * QD + tid] = a.goal[(size_t)b * QD + tid];
+        gnodes[tid] = tree[tid]; gnodes[(size_t)M * QD + tid] = tree[M * QD + tid];
+    }
+    if (tid == 0) { gpar[0] = -1; gpar[M] = -1; }
+    int cnt0 = 1, cnt1 = 1;                    // node counts, uniform (every thread tracks them; scalars: no dynamic register indexing)
+    auto cnt_of = [&](int t) { return t == 0 ? cnt0 : cnt1; };
+    int link0 = -1, link1 = -1, used = 0;
+    __syncthreads();
+
+    const int nchk = a.n_checks;
+    const int nparts = (ROBOT == MPDX_ROBOT_PANDA) ? (kRrtThreads / nchk < 12 ? kRrtThreads / nchk : 12) : 1;
+    // workgroup-wide: is the straight segment qa -> qb (LDS, QD floats each) collision free on nchk interpolated configurations?
+    auto edge_free = [&](const float* qa, const float* qb) -> bool {
+        const int c = tid % nchk, part = tid / nchk;
+        bool hit = false;
+        if (part < nparts) {
+            const float w = nchk > 1 ? (float)c / (float)(nchk - 1) : 0.f;
+            float q[QD];
+#pragma unroll
+            for (int j = 0; j < QD; ++j) q[j] = (1.0f - w) * qa[j] + w * qb[j];
+            hit = config_hit<QD, DIM, ROBOT>(gp, sprim, q, part, nparts);
+        }
+        // workgroup-wide OR through the dynamic LDS region (__syncthreads_or brings a static __shared__ word: it shifts the dynamic
+        // base and makes the 160-KiB opt-in fail)
+        const bool wave_hit = __ballot(hit) != 0ull;
+        if (lane == 0) sint[4 + wave] = wave_hit ? 1 : 0;
+        __syncthreads();
+        const bool any = (sint[4] | sint[5] | sint[6] | sint[7]) != 0;
+        __syncthreads();
+        return !any;
+    };
+    // workgroup-wide: index of the node of tree t nearest to target (LDS); lowest index wins ties
+    auto nearest = [&](int t, const float* target) -> int {
+        float best = 3.0e38f;
+        int bi = 0;
+        const float* tn = tree + (size_t)t * M * QD;
+        const int nt_ = cnt_of(t);
+        for (int i = tid; i < nt_; i += kRrtThreads) {
+            float d2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < QD; ++j) { const float d = tn[i * QD + j] - target[j]; d2 += d * d; }
+            if (d2 < best) { best = d2; bi = i; }
+        }
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            const float ob = __shfl_xor(best, s, 64);
+            const int oi = __shfl_xor(bi, s, 64);
+            if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { sred[wave * 2] = best; ((int*)sred)[wave * 2 + 1] = bi; }
+        __syncthreads();
+        float fb = sred[0];
+        int fi = ((int*)sred)[1];
+#pragma unroll
+        for (int w = 1; w < kRrtThreads / 64; ++w) {
+            const float ob = sred[w * 2];
+            const int oi = ((int*)sred)[w * 2 + 1];
+            if (ob < fb || (ob == fb && oi < fi)) { fb = ob; fi = oi; }
+        }
+        __syncthreads();
+        return fi;
+    };
+    // steer from `from` towards `to` by at most `step`: result -> out (LDS); returns whether `to` was reached.  Uniform.
+    auto steer = [&](const float* from, const float* to, float* out) -> bool {
+        float d2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < QD; ++j) { const float d = to[j] - from[j]; d2 += d * d; }
+        const float dist = sqrtf(d2);
+        const bool reach = dist <= a.step;
+        const float sc = reach ? 1.0f : a.step / fmaxf(dist, 1e-12f);
+        float o[QD];
+#pragma unroll
+        for (int j = 0; j < QD; ++j) o[j] = reach ? to[j] : from[j] + (to[j] - from[j]) * sc;
+        __syncthreads();   // everyone has read `from` / `to` (out may alias scratch that others still read)
+        if (tid == 0) {
+#pragma unroll
+            for (int j = 0; j < QD; ++j) out[j] = o[j];
+        }
+        __syncthreads();
+        return reach;
+    };
+    auto add_node = [&](int t, const float* q, int par) -> int {   // uniform; caller guarantees room in tree t
+        const int idx = cnt_of(t);
+        if (tid < QD) {
+            tree[((size_t)t * M + idx) * QD + tid] = q[tid];
+            gnodes[((size_t)t * M + idx) * QD + tid] = q[tid];
+        }
+        if (tid == 0) gpar[(size_t)t * M + idx] = par;
+        if (t == 0) cnt0 = idx + 1; else cnt1 = idx + 1;
+        __syncthreads();
+        return idx;
+    };
+
+    float* qr = sq, *qcur = sq + 8, *qnew = sq + 16;
+    bool done = false;
+    for (int it = 1; it <= a.max_iters && !done; ++it) {
+        used = it;
+        const int ta = it & 1, tb = 1 - ta;
+        if (cnt0 >= M || cnt1 >= M) break;   // a full tree ends the search (unsolved) instead of corrupting links
+        if (tid == 0) {
+            float u[8];
+            float u4[4];
+            philox_uniform4(a.seed, ((uint64_t)b << 32) | (uint64_t)(2 * it), u4);
+            u[0] = u4[0]; u[1] = u4[1]; u[2] = u4[2]; u[3] = u4[3];
+            philox_uniform4(a.seed, ((uint64_t)b << 32) | (uint64_t)(2 * it + 1), u4);
+            u[4] = u4[0]; u[5] = u4[1]; u[6] = u4[2]; u[7] = u4[3];
+#pragma unroll
+            for (int j = 0; j < QD; ++j) qr[j] = a.q_lo[j] + (a.q_hi[j] - a.q_lo[j]) * u[j];
+        }
+        __syncthreads();
+        const int ia = nearest(ta, qr);
+        const float* qn = tree + ((size_t)ta * M + ia) * QD;
+        steer(qn, qr, qnew);
+        if (!edge_free(qn, qnew)) continue;
+        const int inew = add_node(ta, qnew, ia);
+        // connect: walk the other tree from its nearest node towards qnew until blocked, full or there
+        int cur_idx = nearest(tb, qnew);
+        if (tid < QD) qcur[tid] = tree[((size_t)tb * M + cur_idx) * QD + tid];
+        __syncthreads();
+        for (int sstep = 0; sstep < a.max_connect; ++sstep) {
+            float* nxt = qr;   // the sample is no longer needed
+            const bool reach = steer(qcur, qnew, nxt);
+            if (!edge_free(qcur, nxt)) break;
+            if (reach) {       // the reached target IS qnew: record the link, do not duplicate the node
+                link0 = ta == 0 ? inew : cur_idx;
+                link1 = ta == 0 ? cur_idx : inew;
+                done = true;
+                break;
+            }
+            if (cnt_of(tb) >= M) break;
+            cur_idx = add_node(tb, nxt, cur_idx);
+            if (tid < QD) qcur[tid] = nxt[tid];
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        a.count[(size_t)b * 2] = cnt0; a.count[(size_t)b * 2 + 1] = cnt1;
+        a.link[(size_t)b * 2] = link0; a.link[(size_t)b * 2 + 1] = link1;
+        a.iters[b] = used;
+    }
+}
+
+template <int QD>
+inline size_t rrt_lds_bytes(int max_nodes, int n_prim_floats) {
+    return (size_t)(2 * max_nodes * QD + 3 * 8 + 8 + 8 + n_prim_floats) * sizeof(float);
+}
+
+}  // namespace mpdx

@@ -8,15 +8,18 @@ diffusion sampler on the same box.
 The reference's planners live in the un-vendored `mp_baselines` submodule (empty in /root/reference: PARITY UNPINNED, as for the
 guide's costs - DESIGN.md section 5).  What is built here, MI355X-first:
 
-  * RRT-Connect (Kuffner & LaValle 2000), BATCHED: the n trajectories of a context are n independent bidirectional trees grown in
-    lock-step as device tensors [n, 2, max_nodes, q]; nearest-neighbour search, steering and bookkeeping are torch ops on the GPU,
-    and every edge is collision-checked by the HIP metrics kernel (`mpdx_traj_metrics`: an edge is a 2-waypoint trajectory checked
-    on `n_edge_checks` interpolated points against the task's collision fields) - one launch per extension for the whole batch.
-    The reference's `MultiSampleBasedPlanner` runs its n RRTs one after the other in Python (:85-90).
-  * Trajectory optimisation on the GPMP2 objective (Mukadam et al. 2018: constant-velocity GP prior + hinge collision factors on the
-    interpolated trajectory): gradient descent with the HIP guide kernel (`csrc/guide.hpp`, hand-derived gradients, per-waypoint norm
-    clip as trust region, start/goal hard-conditioned) in raw robot units (`identity_normalizer`), `opt_iters` launches of ~6-16 us.
-    This is NOT GPMP2's Gauss-Newton step (that needs the un-vendored factor-graph code to pin); it minimises the same cost.
+  * RRT-Connect (Kuffner & LaValle 2000): the n trajectories of a context are n independent bidirectional searches, each run
+    START TO FINISH by one workgroup of ONE kernel launch (`mpdx_rrt_connect`, csrc/planner.hpp): Philox sampling, nearest
+    neighbour over the LDS-resident trees, steering, edge collision checks (the metrics kernel's FK / SDF functions on
+    `n_edge_checks` interpolated configurations) and the greedy connect loop all happen on the device - no host round trip per
+    extension.  The reference's `MultiSampleBasedPlanner` runs its n RRTs one after the other in Python (:85-90).
+  * GPMP2 (Mukadam et al. 2018): Levenberg-Marquardt on  1/2 |GP prior factors|^2 / sigma_gp^2 + 1/2 |hinge collision factors|^2 /
+    sigma_obs^2  with start and goal states fixed (`GPMP2`, `mpdx_gpmp_step`): per iteration and trajectory one workgroup linearises
+    every collision factor of the 128 interpolated points (FK Jacobians), assembles the BLOCK-TRIDIAGONAL normal equations over the 62
+    free support states as a banded matrix in LDS and solves them there (LDL^T).  `oracle/gpmp.py` restates one step (autograd
+    Jacobian + dense solve).
+  * `GPMPOptimizer`: first-order descent on the guide's (un-squared hinge) objective with the HIP guide kernel in raw units - kept as
+    the cheap smoother / as the raw-unit test vehicle of the guide kernel; the entry uses GPMP2.
 
 Rendering (`PlanningVisualizer`, :155-167) is out of scope.
 """
@@ -46,103 +49,61 @@ def edges_free(task, qa: torch.Tensor, qb: torch.Tensor, n_edge_checks: int = 16
 
 
 class RRTConnectBatch:
-    """n independent RRT-Connect problems (one start/goal pair, n samples - or per-problem starts/goals) grown in lock-step."""
+    """n independent RRT-Connect problems (one start/goal pair, n samples - or per-problem starts/goals): ONE launch of
+    rrt_connect_kernel grows all of them to completion (or to max_iters / a full tree)."""
+
+    _launches = 0
 
     def __init__(self, task, start: torch.Tensor, goal: torch.Tensor, n: int, step_size: float = 0.1, max_nodes: int = 2048,
                  n_edge_checks: int = 16, generator: Optional[torch.Generator] = None):
         dev = start.device
         if dev.type != "cuda":
-            raise RuntimeError("RRTConnectBatch runs on the GPU (libmpdx collision kernel); there is no CPU fallback")
+            raise RuntimeError("RRTConnectBatch runs on the GPU (libmpdx RRT-Connect kernel); there is no CPU fallback")
         self.task, self.n, self.step, self.M, self.nchk, self.gen = task, n, float(step_size), int(max_nodes), n_edge_checks, generator
         q = start.shape[-1]
         self.q = q
         self.lo, self.hi = task.q_limits(dev)
-        s = start.reshape(1, q).expand(n, q) if start.dim() == 1 else start
-        g = goal.reshape(1, q).expand(n, q) if goal.dim() == 1 else goal
+        self.start = (start.reshape(1, q).expand(n, q) if start.dim() == 1 else start).to(torch.float32).contiguous()
+        self.goal = (goal.reshape(1, q).expand(n, q) if goal.dim() == 1 else goal).to(torch.float32).contiguous()
         self.nodes = torch.zeros((n, 2, self.M, q), device=dev)          # tree 0 grows from the start, tree 1 from the goal
-        self.parent = torch.full((n, 2, self.M), -1, dtype=torch.long, device=dev)
-        self.count = torch.ones((n, 2), dtype=torch.long, device=dev)
-        self.nodes[:, 0, 0], self.nodes[:, 1, 0] = s, g
+        self.parent = torch.full((n, 2, self.M), -1, dtype=torch.int32, device=dev)
+        self.count = torch.ones((n, 2), dtype=torch.int32, device=dev)
+        self.link = torch.full((n, 2), -1, dtype=torch.int32, device=dev)  # node indices (tree 0, tree 1) where the trees met
+        self.iters = torch.zeros(n, dtype=torch.int32, device=dev)
         self.done = torch.zeros(n, dtype=torch.bool, device=dev)
-        self.link = torch.full((n, 2), -1, dtype=torch.long, device=dev)  # node indices (tree 0, tree 1) where the trees met
-        self.ar = torch.arange(n, device=dev)
-
-    def _nearest(self, tree: int, q: torch.Tensor) -> torch.Tensor:
-        d = torch.linalg.norm(self.nodes[:, tree] - q[:, None, :], dim=-1)                      # [n, M]
-        d = d.masked_fill(torch.arange(self.M, device=q.device)[None, :] >= self.count[:, tree, None], float("inf"))
-        return d.argmin(dim=1)
-
-    def _steer(self, qn: torch.Tensor, qt: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        d = qt - qn
-        dist = torch.linalg.norm(d, dim=-1, keepdim=True)
-        reach = dist[:, 0] <= self.step
-        return torch.where(reach[:, None], qt, qn + d * (self.step / dist.clamp_min(1e-12))), reach
-
-    def _add(self, tree: int, qnew: torch.Tensor, par: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
-        mask = mask & (self.count[:, tree] < self.M)
-        idx = self.count[:, tree].clamp_max(self.M - 1)
-        rows = self.ar[mask]
-        self.nodes[rows, tree, idx[mask]] = qnew[mask]
-        self.parent[rows, tree, idx[mask]] = par[mask]
-        self.count[:, tree] += mask.long()
-        return idx
+        self._gp = task._params(dev)   # robot + collision fields as the metrics kernel sees them (the task keeps the primitive table alive)
 
     def grow(self, max_iters: int = 4000, max_connect_steps: int = 64) -> int:
-        """Returns the number of iterations used.  One iteration = extend the active tree towards a random sample, then
-        connect the other tree greedily towards the new node (alternating trees)."""
-        dev = self.nodes.device
-        it = 0
-        for it in range(1, max_iters + 1):
-            ta = it & 1
-            tb = 1 - ta
-            live = ~self.done
-            qr = self.lo + (self.hi - self.lo) * torch.rand((self.n, self.q), device=dev, generator=self.gen)
-            ia = self._nearest(ta, qr)
-            qn = self.nodes[self.ar, ta, ia]
-            qnew, _ = self._steer(qn, qr)
-            ok = edges_free(self.task, qn, qnew, self.nchk) & live
-            inew = self._add(ta, qnew, ia, ok)
-            # connect: walk the other tree from its nearest node towards qnew until blocked or there
-            ib = self._nearest(tb, qnew)
-            cur = self.nodes[self.ar, tb, ib]
-            cur_idx = ib
-            active = ok.clone()
-            for _ in range(max_connect_steps):
-                if not bool(active.any()):
-                    break
-                nxt, reach = self._steer(cur, qnew)
-                free = edges_free(self.task, cur, nxt, self.nchk) & active
-                arrived = free & reach
-                # a reached target is the SAME configuration as qnew: do not duplicate it, just record the link
-                add_mask = free & ~reach
-                k = self._add(tb, nxt, cur_idx, add_mask)
-                self.link[arrived, ta] = inew[arrived]
-                self.link[arrived, tb] = cur_idx[arrived]
-                self.done |= arrived
-                cur = torch.where(add_mask[:, None], nxt, cur)
-                cur_idx = torch.where(add_mask, k, cur_idx)
-                active = add_mask
-            if bool(self.done.all()):
-                break
-        return it
+        """Runs the search; returns the largest number of iterations any problem used.  One iteration = extend the active tree
+        towards a random sample, then connect the other tree greedily towards the new node (alternating trees)."""
+        o = _lib.RrtOpts()
+        for j in range(self.q):
+            o.q_lo[j], o.q_hi[j] = float(self.lo[j]), float(self.hi[j])
+        o.step, o.max_nodes, o.max_iters, o.max_connect_steps, o.n_edge_checks = self.step, self.M, int(max_iters), int(max_connect_steps), int(self.nchk)
+        RRTConnectBatch._launches += 1
+        o.seed = (int(self.gen.initial_seed()) if self.gen is not None else 0) * 1000003 + RRTConnectBatch._launches
+        _lib.check(_lib.load().mpdx_rrt_connect(C.byref(self._gp), C.byref(o), self.start.data_ptr(), self.goal.data_ptr(), self.nodes.data_ptr(),
+                                                self.parent.data_ptr(), self.count.data_ptr(), self.link.data_ptr(), self.iters.data_ptr(),
+                                                self.n, _lib.current_stream()), "mpdx_rrt_connect")
+        self.done = self.link[:, 0] >= 0
+        return int(self.iters.max())
 
     def paths(self) -> List[Optional[torch.Tensor]]:
         """Per problem: [n_nodes, q] configurations from start to goal (None if the trees did not meet)."""
-        nodes, parent, link, done = self.nodes.cpu(), self.parent.cpu(), self.link.cpu(), self.done.cpu()
+        nodes, parent, link, done = self.nodes.cpu(), self.parent.cpu().tolist(), self.link.cpu().tolist(), self.done.cpu().tolist()
         out: List[Optional[torch.Tensor]] = []
         for i in range(self.n):
-            if not bool(done[i]):
+            if not done[i]:
                 out.append(None)
                 continue
             branch = []
             for tree in (0, 1):
-                seq, k = [], int(link[i, tree])
+                seq, k = [], link[i][tree]
                 while k >= 0:
-                    seq.append(nodes[i, tree, k])
-                    k = int(parent[i, tree, k])
-                branch.append(seq)
-            path = list(reversed(branch[0])) + branch[1]      # start ... meeting node | other tree's branch ... goal
-            out.append(torch.stack(path))
+                    seq.append(k)
+                    k = parent[i][tree][k]
+                branch.append(nodes[i, tree, seq])
+            out.append(torch.cat([branch[0].flip(0), branch[1]], dim=0))   # start ... meeting node | other tree's branch ... goal
         return out
 
 
@@ -220,6 +181,47 @@ class GPMPOptimizer:
         return (x, torch.stack(iters)) if return_iterations else x
 
 
+class GPMP2:
+    """GPMP2 (Mukadam et al., IJRR 2018) as Levenberg-Marquardt on the factor graph  GP prior + hinge collision factors, start and goal
+    states fixed - what `GPMP2(**planner_params).optimize()` does at generate_trajectories.py:107-120 (un-vendored there).  One kernel
+    launch per iteration for the whole batch (csrc/planner.hpp gpmp_lm_kernel); `oracle/gpmp.py` restates a step."""
+
+    def __init__(self, dataset: TrajectoryDataset, dt: float, sigma_gp: float = 1.0, sigma_obs: float = 1e-3, n_interp: int = 128,
+                 lambda_init: float = 1e-2, lambda_up: float = 10.0, lambda_down: float = 0.2, lambda_min: float = 1e-7, lambda_max: float = 1e7,
+                 step: float = 1.0, adaptive: bool = True, device="cuda"):
+        rob, task = dataset.robot, dataset.task
+        H = dataset.n_support_points
+        costs = [CostCollision(rob, H, field=f, sigma_coll=1.0) for f in task.get_collision_fields()]
+        costs.append(CostGPTrajectory(rob, H, dt, sigma_gp=sigma_gp))
+        self.gp, self._prims = build_device_params(rob, dataset.env.dim, task.obstacle_cutoff_margin, None, None, costs, [1.0] * len(costs), True,
+                                                   n_interp, False, 1.0, device, identity_normalizer=True)
+        self.opts = _lib.GpmpOpts()
+        self.opts.sigma_obs, self.opts.step, self.opts.adaptive = float(sigma_obs), float(step), int(bool(adaptive))
+        self.opts.lambda_up, self.opts.lambda_down, self.opts.lambda_min, self.opts.lambda_max = float(lambda_up), float(lambda_down), float(lambda_min), float(lambda_max)
+        self.lambda_init = float(lambda_init)
+        self.D = 2 * rob.q_dim
+        self.state = None
+
+    @torch.no_grad()
+    def optimize(self, trajs: torch.Tensor, opt_iters: int = 100, return_iterations: bool = False):
+        x = trajs.to(torch.float32).contiguous().clone()
+        if not x.is_cuda:
+            raise RuntimeError("GPMP2 runs on the GPU (libmpdx); there is no CPU fallback")
+        B, H, D = x.shape
+        delta = torch.zeros_like(x)
+        state = torch.zeros((B, 4), dtype=torch.float32, device=x.device)
+        state[:, 0], state[:, 1] = 3.0e38, self.lambda_init
+        lib, st = _lib.load(), _lib.current_stream()
+        iters = [x.clone()] if return_iterations else None
+        for it in range(int(opt_iters) + 1):   # the last call only judges the last proposal
+            _lib.check(lib.mpdx_gpmp_step(C.byref(self.gp), C.byref(self.opts), x.data_ptr(), delta.data_ptr(), state.data_ptr(), B, H, D,
+                                          1 if it < opt_iters else 0, st), "mpdx_gpmp_step")
+            if return_iterations and it > 0:
+                iters.append(x.clone())
+        self.state = state    # [B, 4]: F, lambda, accepted steps, F of the last candidate
+        return (x, torch.stack(iters)) if return_iterations else x
+
+
 # ------------------------------------------------------------------------------------------------ the entry
 def generate_collision_free_trajectories(env_id, robot_id, num_trajectories_per_context, results_dir, threshold_start_goal_pos=1.0,
                                          obstacle_cutoff_margin=0.03, n_tries=1000, rrt_max_time=300, gpmp_opt_iters=500,
@@ -264,7 +266,7 @@ def generate_collision_free_trajectories(env_id, robot_id, num_trajectories_per_
     times["rrt_connect_s"] = time.perf_counter() - t0
     # -------------------------------- optimisation-based refinement (:92-120)
     t1 = time.perf_counter()
-    opt = GPMPOptimizer(ds, dt, device=dev)
+    opt = GPMP2(ds, dt, device=dev)
     trajs_last_iter, trajs_iters = opt.optimize(trajs0, opt_iters=gpmp_opt_iters, return_iterations=True)
     torch.cuda.synchronize()
     times["gpmp_s"] = time.perf_counter() - t1

@@ -141,24 +141,28 @@ class CostCollision:
     def __init__(self, robot, n_support_points, field=None, sigma_coll=1.0, cutoff_margin=0.05, **kw):
         self.robot, self.field, self.sigma, self.cutoff = robot, field, sigma_coll, cutoff_margin
 
-    def __call__(self, trajs):
+    def factors(self, trajs):
+        """the individual hinge factors [B, N, n_factors] whose sum is the cost (one per link sphere for an objects field, one per
+        sphere and workspace FACE for the boundary field, one per sphere pair for the self-collision field): the residual vector of
+        GPMP2's obstacle factors (oracle/gpmp.py)."""
         q = trajs[..., : self.robot.q_dim]
         pts = self.robot.link_points(q)  # [B, N, K, dim]
         radii = self.robot.radii.to(trajs.dtype)
         f = self.field
         if f.kind == "objects":
-            hinge = torch.relu(radii + self.cutoff - f.sdf(pts))
-        elif f.kind == "workspace":
+            return torch.relu(radii + self.cutoff - f.sdf(pts))
+        if f.kind == "workspace":
             lo = pts - f.ws_min.to(trajs.dtype)
             hi = f.ws_max.to(trajs.dtype) - pts
             m = (radii + self.cutoff).unsqueeze(-1)
-            hinge = (torch.relu(m - lo) + torch.relu(m - hi)).sum(-1)
-        elif f.kind == "self":
+            return torch.cat([torch.relu(m - lo), torch.relu(m - hi)], dim=-1).flatten(-2)
+        if f.kind == "self":
             a, b = pts[..., f.pairs[:, 0], :], pts[..., f.pairs[:, 1], :]
-            hinge = torch.relu(radii[f.pairs[:, 0]] + radii[f.pairs[:, 1]] - torch.linalg.norm(a - b, dim=-1))
-        else:
-            raise NotImplementedError(f.kind)
-        return hinge.sum((-1, -2)) / (self.sigma ** 2)
+            return torch.relu(radii[f.pairs[:, 0]] + radii[f.pairs[:, 1]] - torch.linalg.norm(a - b, dim=-1))
+        raise NotImplementedError(f.kind)
+
+    def __call__(self, trajs):
+        return self.factors(trajs).sum((-1, -2)) / (self.sigma ** 2)
 
 
 class CostGPTrajectory:
