@@ -183,11 +183,9 @@ __device__ __forceinline__ float row_sum16(float v) {
 //   to it; after the last conv op both describe any valid block)
 // SAVE: the training forward's variant (every op also stores its output and its GroupNorm input through FusedArgs::save); the planning
 // kernels are instantiated without it (measured on one box: 22.54 vs 22.62 ms per cfg-2 plan with the stores merely compiled in)
-struct FusedNoHook { __device__ __forceinline__ void operator()() const {} };
-
-template <class S, bool SAVE = false, class HOOK = FusedNoHook>
+template <class S, bool SAVE = false>
 __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp& op, f32x4 (&ring)[kFusedRing], float* smem, int wave, int lane, int b,
-                                              const float* __restrict__ nbase, int nmax, long long* tr_base, int& tr, HOOK&& after_kloop = HOOK()) {
+                                              const float* __restrict__ nbase, int nmax, long long* tr_base, int& tr) {
     constexpr int P = kFusedRing, DB = MPDX_FUSED_DB, NTW = S::NTW, NJ = S::NJ;
     f32x4* const sm4 = (f32x4*)smem;
     const int j = lane & 15, q = lane >> 4;
@@ -269,7 +267,6 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
         __builtin_amdgcn_sched_barrier(0);
     }
     FOP_STAMP();   // k-loop issued
-    after_kloop();   // first op of a static program: the lazily fetched parameter block / skip tensor are deposited in LDS here
 
     // ------------------------------------------------------------------ epilogue (registers -> destination buffer)
     const float* par_op = smem + a.par_off + op.p_off;   // [bias | gamma | beta | rbias] x COUT
@@ -380,49 +377,13 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
 }
 
 // ---- prologue of a fused program (shared by the generic and the static kernels)
-// LAZY = true (static programs): the loads are issued in the order input window -> weight ring -> skip tensor -> parameters, and the
-// prologue's barrier waits for the INPUT only (loads return in order: everything issued behind it stays in flight); the parameter
-// block and the skip tensor are held in registers (FusedPending) and deposited in LDS behind the first op's k-loop
-// (fused_prologue_deposit) - their ~30 KB no longer head the program.  LAZY = false: everything is in LDS at the prologue's barrier.
-#ifdef MPDX_FUSED_EAGER_PARAMS   // dev A/B switch: the round-2 prologue (everything in LDS before the first op)
-constexpr bool kFusedLazyParams = false;
-#else
-constexpr bool kFusedLazyParams = true;
-#endif
-struct FusedPending {
-    static constexpr int SK = 1024 / kFusedThreads, PK = 2048 / kFusedThreads;
-    f32x4 sv[SK], pv[PK];
-};
-
-__device__ __forceinline__ void fused_prologue_deposit(const FusedArgs& a, const FusedPending& pd, float* smem, int tid) {
-    f32x4* const sm4 = (f32x4*)smem;
-    constexpr int NT_ = kFusedThreads;
-    const int s3c4 = a.c3 >> 2, n_s3 = a.L3 * s3c4;
-    const int npar4 = a.par_floats >> 2, ntt4 = a.tt_n >> 2;
-#pragma unroll
-    for (int k = 0; k < FusedPending::SK; ++k) {
-        const int idx = tid + k * NT_;
-        if (idx < n_s3) {
-            const int l = idx / s3c4, c = idx - l * s3c4;
-            sm4[a.s3_off4 + (l + 2) * a.s3_rs4 + a.s3_col4 + c] = pd.sv[k];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < FusedPending::PK; ++k) {
-        const int idx = tid + k * NT_;
-        if (idx < npar4) sm4[(a.par_off >> 2) + idx] = pd.pv[k];
-        else if (idx - npar4 < ntt4) sm4[(a.tt_off >> 2) + idx - npar4] = pd.pv[k];
-    }
-}
-
-template <bool LAZY>
-__device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, f32x4 (&ring)[kFusedRing], FusedPending& pd, int tid, int lane, int wave,
-                                               int b, long long* tr_base, int& tr) {
+__device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, f32x4 (&ring)[kFusedRing], int tid, int lane, int wave, int b,
+                                               long long* tr_base, int& tr) {
     f32x4* const sm4 = (f32x4*)smem;
 #define FUSED_STAMP() do { if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter(); ++tr; } while (0)
     // ---- prologue: every global load is issued first (weight ring of op 0, input window, parameters), the halo / padding
     //      zeros are written while they fly, and ONE barrier closes it.
-    if constexpr (!LAZY) fused_ring_request(ring, a.packed + a.ops[0].sbase + (size_t)(wave & a.msmask[0]) * a.slen[0] * 256 + lane * 4, a.slen[0]);
+    fused_ring_request(ring, a.packed + a.ops[0].sbase + (size_t)(wave & a.msmask[0]) * a.slen[0] * 256 + lane * 4, a.slen[0]);
 
     const int cin = a.gc1 + a.gc2;
     const int c4n = (cin + 3) >> 2;
@@ -469,13 +430,9 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, 
             }
         }
     }
-    if constexpr (LAZY) {   // the input window's requests are in the queue: now the ring (in-order return: the input lands first)
-        __builtin_amdgcn_sched_barrier(0);
-        fused_ring_request(ring, a.packed + a.ops[0].sbase + (size_t)(wave & a.msmask[0]) * a.slen[0] * 256 + lane * 4, a.slen[0]);
-    }
     // second staged input (skip tensor of a later concat): <= 4 float4 per thread
-    constexpr int SK = FusedPending::SK;
-    f32x4 (&sv)[SK] = pd.sv;
+    constexpr int SK = 1024 / NT_;
+    f32x4 sv[SK];
     const int s3c4 = a.c3 >> 2, n_s3 = a.L3 * s3c4;
 #pragma unroll
     for (int k = 0; k < SK; ++k) {
@@ -485,8 +442,8 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, 
     }
     // parameters of every op ([bias | gamma | beta | rbias] blocks, contiguous in `packed` behind the weight streams) and the
     // slice of this timestep's conditioning row the segment's blocks use: two straight copies
-    constexpr int PK = FusedPending::PK;   // float4 per thread (<= 2048 float4 = 32 KB of parameters)
-    f32x4 (&pv)[PK] = pd.pv;
+    constexpr int PK = 2048 / NT_;   // float4 per thread (<= 2048 float4 = 32 KB of parameters)
+    f32x4 pv[PK];
     const int npar4 = a.par_floats >> 2, ntt4 = a.tt_n >> 2;
 #pragma unroll
     for (int k = 0; k < PK; ++k) {
@@ -521,7 +478,20 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, 
         }
         if (idst[k] >= 0) sm4[idst[k]] = iv[k];
     }
-    if constexpr (!LAZY) fused_prologue_deposit(a, pd, smem, tid);
+#pragma unroll
+    for (int k = 0; k < SK; ++k) {
+        const int idx = tid + k * NT_;
+        if (idx < n_s3) {
+            const int l = idx / s3c4, c = idx - l * s3c4;
+            sm4[a.s3_off4 + (l + 2) * a.s3_rs4 + a.s3_col4 + c] = sv[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PK; ++k) {
+        const int idx = tid + k * NT_;
+        if (idx < npar4) sm4[(a.par_off >> 2) + idx] = pv[k];
+        else if (idx - npar4 < ntt4) sm4[(a.tt_off >> 2) + idx - npar4] = pv[k];
+    }
     lds_barrier();
     FUSED_STAMP();
 
@@ -631,8 +601,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_level_kernel(const FusedA
     ++tr;
     f32x4 ring[kFusedRing];
     FinalPre fp;
-    FusedPending pd;
-    fused_prologue<false>(a, smem, ring, pd, tid, lane, wave, b, tr_base, tr);
+    fused_prologue(a, smem, ring, tid, lane, wave, b, tr_base, tr);
     for (int oi = 0; oi < a.nops; ++oi) {
         const FusedOp op = a.ops[oi];
         if (oi + 1 < a.nops && a.ops[oi + 1].shape == kFusedShapeFinal) fused_final_prefetch(a, fp, tid, b);
@@ -669,8 +638,8 @@ MPDX_FUSED_SHAPES(X)
 #undef X
 
 template <int SH, int I, int NEXT_SH, int PREV_COUT, bool SAVE>
-__device__ __forceinline__ void fused_static_op(const FusedArgs& a, f32x4 (&ring)[kFusedRing], FinalPre& fp, const FusedPending& pd, float* smem, int tid,
-                                                int wave, int lane, int b, long long* tr_base, int& tr) {
+__device__ __forceinline__ void fused_static_op(const FusedArgs& a, f32x4 (&ring)[kFusedRing], FinalPre& fp, float* smem, int tid, int wave, int lane,
+                                                int b, long long* tr_base, int& tr) {
     if constexpr (NEXT_SH == kFusedShapeFinal) fused_final_prefetch(a, fp, tid, b);
     if constexpr (SH == kFusedShapeFinal) {
         fused_final_op<PREV_COUT>(a, a.ops[I], fp, smem, tid, lane, b);
@@ -684,12 +653,7 @@ __device__ __forceinline__ void fused_static_op(const FusedArgs& a, f32x4 (&ring
             nbase = a.packed + a.ops[I + 1].sbase + (size_t)(wave & (N::MSn < kFusedWaves ? N::MSn - 1 : kFusedWaves - 1)) * (N::SLEN * 256) + lane * 4;
             nmax = N::SLEN - 1;
         }
-        if constexpr (I == 0 && kFusedLazyParams) {   // the parameter block / skip tensor fetched lazily by the prologue land in LDS behind this op's k-loop
-            auto deposit = [&]() { fused_prologue_deposit(a, pd, smem, tid); lds_barrier(); };
-            fused_conv_op<typename FusedShapeOf<SH>::type, SAVE>(a, a.ops[I], ring, smem, wave, lane, b, nbase, nmax, tr_base, tr, deposit);
-        } else {
-            fused_conv_op<typename FusedShapeOf<SH>::type, SAVE>(a, a.ops[I], ring, smem, wave, lane, b, nbase, nmax, tr_base, tr);
-        }
+        fused_conv_op<typename FusedShapeOf<SH>::type, SAVE>(a, a.ops[I], ring, smem, wave, lane, b, nbase, nmax, tr_base, tr);
     }
 }
 
@@ -703,11 +667,11 @@ struct FusedSeq {
         else return 0;
     }
     template <int I, bool SAVE>
-    __device__ static __forceinline__ void run_from(const FusedArgs& a, f32x4 (&ring)[kFusedRing], FinalPre& fp, const FusedPending& pd, float* smem,
-                                                    int tid, int wave, int lane, int b, long long* tr_base, int& tr) {
+    __device__ static __forceinline__ void run_from(const FusedArgs& a, f32x4 (&ring)[kFusedRing], FinalPre& fp, float* smem, int tid, int wave, int lane,
+                                                    int b, long long* tr_base, int& tr) {
         if constexpr (I < N) {
-            fused_static_op<ids[I], I, (I + 1 < N ? ids[I + 1 < N ? I + 1 : I] : -1), prev_cout<I>(), SAVE>(a, ring, fp, pd, smem, tid, wave, lane, b, tr_base, tr);
-            run_from<I + 1, SAVE>(a, ring, fp, pd, smem, tid, wave, lane, b, tr_base, tr);
+            fused_static_op<ids[I], I, (I + 1 < N ? ids[I + 1 < N ? I + 1 : I] : -1), prev_cout<I>(), SAVE>(a, ring, fp, smem, tid, wave, lane, b, tr_base, tr);
+            run_from<I + 1, SAVE>(a, ring, fp, smem, tid, wave, lane, b, tr_base, tr);
         }
     }
 };
@@ -727,9 +691,8 @@ __global__ __launch_bounds__(kFusedThreads) void fused_program_kernel(const Fuse
     ++tr;
     f32x4 ring[kFusedRing];
     FinalPre fp;
-    FusedPending pd;
-    fused_prologue<kFusedLazyParams>(a, smem, ring, pd, tid, lane, wave, b, tr_base, tr);
-    SEQ::template run_from<0, SAVE>(a, ring, fp, pd, smem, tid, wave, lane, b, tr_base, tr);
+    fused_prologue(a, smem, ring, tid, lane, wave, b, tr_base, tr);
+    SEQ::template run_from<0, SAVE>(a, ring, fp, smem, tid, wave, lane, b, tr_base, tr);
 }
 
 // the programs of the standard networks
