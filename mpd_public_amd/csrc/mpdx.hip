@@ -17,6 +17,7 @@
 
 #include "../../include/mpdx.h"
 #include "conv_block.hpp"
+#include "conv_ws.hpp"
 #include "fused_level.hpp"
 #include "train.hpp"
 #include "guide.hpp"
@@ -1004,10 +1005,31 @@ static int make_conv_args(const mpdx_unet* u, const Layer& l, const float* packe
     return 0;
 }
 
+// Large batches: the 256 -> 256 Conv1dBlocks of the inner levels run on the weight-stationary persistent kernel (conv_ws.hpp;
+// bit-identical outputs).  From 8 position tiles per workgroup on (B >= 512 at L = 8); MPDX_WS=0 switches it off (read per call: A/B
+// runs and the bit-identity test flip it inside one process).
+static bool use_weight_stationary(const Layer& l, const ConvArgs& a, int B, int dbg) {
+    if (!(l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH && l.cout == 256 && l.c1 == 256 && l.c2 == 0 && l.gs == 32 && l.L_out == 8)) return false;
+    if (dbg || a.pre) return false;
+    if ((long)B * l.L_out < 16L * kWsGroups * 8) return false;
+    const char* e = getenv("MPDX_WS");
+    return !(e && atoi(e) == 0);
+}
+
+static int launch_weight_stationary(const Layer& l, ConvArgs& a, int B, hipStream_t st) {
+    a.n_tiles_n = (int)(((long)B * l.L_out + 15) / 16);
+    const size_t lds = conv_ws_lds_bytes<16>(l.L_out, a.rs);
+    auto kern = conv_ws_kernel<16>;
+    if (int rc = raise_lds_limit((const void*)kern)) return rc;
+    hipLaunchKernelGGL(kern, dim3((l.cout / 32) * kWsGroups), dim3(kWsThreads), lds, st, a);
+    return 0;
+}
+
 static int run_layer(const mpdx_unet* u, const Layer& l, const float* packed, const float* tt_row, const float* x,
                      float* ws, int B, hipStream_t st, int dbg = 0) {
     ConvArgs a;
     if (int rc = make_conv_args(u, l, packed, tt_row, x, ws, B, dbg, a)) return rc;
+    if (use_weight_stationary(l, a, B, dbg)) return launch_weight_stationary(l, a, B, st);
     if (l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH) return dispatch_tile<CONV_S1, 5, EPI_GN_MISH>(l, a, B, st);
     if (l.mode == CONV_S1 && l.ks == 1 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 1, EPI_BIAS>(l, a, B, st);
     if (l.mode == CONV_DOWN && l.ks == 3) return dispatch_tile_ksplit_only<CONV_DOWN, 3, EPI_BIAS>(l, a, B, st);

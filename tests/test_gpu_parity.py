@@ -56,6 +56,33 @@ def test_unet_forward_ragged_batches_vs_oracle(B, fused):
     np.testing.assert_allclose(y, ref, rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("B", [512, 777])
+def test_weight_stationary_inner_levels_are_bit_identical(B):
+    """Large batches run the 256 -> 256 Conv1dBlocks of the inner levels on the weight-stationary persistent kernel (csrc/conv_ws.hpp:
+    weights in registers, 16-position tiles, rotating epilogue duty): same k-group split, accumulation and reduction order and
+    epilogue as conv_block_kernel -> the U-Net output is BIT-identical to the per-layer kernels (MPDX_WS=0), for full and ragged
+    last tiles, and a trajectory's result does not depend on the batch it sits in."""
+    import os
+    net = _gpu_model(14, 1)
+    x = t(f"ws_x_{B}", (B, 64, 14)).cuda()
+    tt = torch.full((B,), 41, dtype=torch.long, device="cuda")
+    old = os.environ.get("MPDX_WS")
+    try:
+        os.environ["MPDX_WS"] = "1"
+        y_ws = net(x, tt, None)
+        os.environ["MPDX_WS"] = "0"
+        y_pl = net(x, tt, None)
+    finally:
+        if old is None:
+            os.environ.pop("MPDX_WS", None)
+        else:
+            os.environ["MPDX_WS"] = old
+    assert bool(torch.isfinite(y_ws).all()) and float(y_ws.abs().max()) > 1e-3
+    assert torch.equal(y_ws, y_pl)
+    small = net(x[5:9].contiguous(), tt[5:9], None)      # B = 4: the per-layer kernels in any case
+    assert torch.equal(small, y_ws[5:9])
+
+
 def test_unet_batch_independence():
     """GroupNorm is per sample: a trajectory's eps must not depend on its batch neighbours (bit-exact)."""
     net = _gpu_model(14, 1)
