@@ -16,6 +16,12 @@
 // the k-loop of tile i+1: its VALU work hides under the SIMD partner's MFMAs.  b = mt * 32 + p puts the eight channel tiles of a
 // position group on ONE XCD (block b runs on XCD b % 8): an activation window is fetched once per L2.
 //
+// Variants (template parameters): NC16 = padded input channels / 16, MT = channel tile = GroupNorm group size (32 at C_out = 256,
+// 16 at C_out = 128), R1 = the block's residual 1x1 convolution folded in (second weight set, second accumulator over the SAME LDS
+// window, bias-only epilogue by a third duty wave): conv_ws_kernel<32, 16, true> replaces the paired launch of ups[0]'s first
+// ResidualTemporalBlock (512 -> 128 k5 + 512 -> 128 1x1 on the channel concat, temporal_unet.py:158-160), which ran 16-position tiles
+// at 43 TF/s.
+//
 // Numerics.  Same k-group -> wave assignment, same accumulation order inside a wave, same K-partial order, same epilogue code as
 // conv_block_kernel<CONV_S1, 5, EPI_GN_MISH, 32, NT, 1, 8>: the outputs are BIT-IDENTICAL (tests/test_gpu_parity.py checks that).
 #pragma once
@@ -23,21 +29,24 @@
 
 namespace mpdx {
 
-constexpr int kWsGroups = 32;    // position groups: 8 channel tiles x 32 = 256 workgroups
+constexpr int kWsGroups = 32;    // position groups: (C_out / MT) channel tiles x 32 workgroups
 constexpr int kWsThreads = 512;
 
-template <int NC16>
+template <int NC16, int MT, bool R1>
 inline size_t conv_ws_lds_bytes(int L, int rs) {
     const size_t stage = (size_t)(16 / L) * (L + 4) * rs * sizeof(float);
-    const size_t red = (size_t)8 * 16 * (32 + 4) * sizeof(float);
-    return 2 * stage + 2 * red;
+    const size_t red = (size_t)8 * 16 * (MT + 4) * sizeof(float);
+    return 2 * stage + 2 * red * (R1 ? 2 : 1);
 }
 
-template <int NC16>
-__global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a) {
-    constexpr int KS = 5, PAD = 2, MT = 32, MS = 2, NT = 16, WK = 8, NG = NC16 * KS, NIT = NG / WK;
+template <int NC16, int MT, bool R1>
+__global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, const ConvArgs a2) {
+    constexpr int KS = 5, PAD = 2, MS = MT / 16, NT = 16, WK = 8, NG = NC16 * KS, NIT = NG / WK, NIT2 = NC16 / WK;
     constexpr int MTP4 = (MT + 4) / 4;
-    static_assert(NG % WK == 0, "k-groups split evenly over the 8 waves");
+    constexpr int EPL = MT / 8;                            // epilogue elements per lane: a region = MT channels x 8 positions over 64 lanes
+    static_assert(NG % WK == 0 && NC16 % WK == 0, "k-groups split evenly over the 8 waves");
+    static_assert(MT == 16 || MT == 32, "channel tile = GroupNorm group of 16 or 32 channels");
+    typedef float fvec __attribute__((ext_vector_type(EPL)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* const smem4 = (f32x4*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -47,7 +56,7 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a) {
     const int spt = NT >> a.lg_Lout;                       // trajectories per tile (2 at L = 8)
     const int stage4 = spt * LP * RS4;                     // float4 per window buffer
     const int red4 = WK * NT * MTP4;                       // float4 per reduction buffer
-    const int red_off4 = 2 * stage4;
+    const int red_off4 = 2 * stage4, red2_off4 = red_off4 + 2 * red4;
     const int n_tiles = a.n_tiles_n;
     const int c4n = a.cin_pad >> 2;
 
@@ -61,6 +70,14 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a) {
 #pragma unroll
         for (int m = 0; m < MS; ++m) af[it][m] = *(const f32x4*)(wbase + ((size_t)(m * nc16 + c16) * KS + ts) * 256);
     }
+    f32x4 af2[R1 ? NIT2 : 1][MS];
+    if constexpr (R1) {
+        const float* wbase2 = a2.wp + (size_t)(mt * MS) * nc16 * 256 + lane * 4;
+#pragma unroll
+        for (int it = 0; it < NIT2; ++it)
+#pragma unroll
+            for (int m = 0; m < MS; ++m) af2[it][m] = *(const f32x4*)(wbase2 + (size_t)(m * nc16 + wk + it * WK) * 256);
+    }
     // ---- halo rows of both window buffers (never overwritten by the window writes)
     for (int idx = tid; idx < 2 * spt * 2 * PAD * c4n; idx += kWsThreads) {
         const int c4 = idx & (c4n - 1), hr = idx >> a.lg_c4n;                 // hr over [buffer][trajectory][4 halo rows]
@@ -68,11 +85,10 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a) {
         const int lp = (k < PAD) ? k : (L + k);
         smem4[buf * stage4 + (s * LP + lp) * RS4 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    // window of a tile: spt * L * c4n float4 = 1024 at C = 256 -> 2 per thread
-    constexpr int SB = (16 * NC16 * 4) / kWsThreads;       // float4 per thread per window (NT positions x cin/4)
+    // window of a tile: NT positions x cin/4 float4 (1024 at C_in = 256, 2048 at 512)
+    constexpr int SB = (16 * NC16 * 4) / kWsThreads;
     static_assert(SB >= 1 && (16 * NC16 * 4) % kWsThreads == 0, "window divides over the threads");
-    int wdst[SB];                                          // LDS index (float4) inside a window buffer
-    int wrow[SB], wc[SB], ws_[SB];
+    int wdst[SB], wrow[SB], wc[SB], ws_[SB];
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
         const int idx = tid + u * kWsThreads;
@@ -88,7 +104,9 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a) {
         for (int u = 0; u < SB; ++u) {
             int b = s0 + ws_[u];
             b = b < a.B ? b : a.B - 1;
-            wv[u] = *(const f32x4*)(a.src1 + ((size_t)b * L + wrow[u]) * a.c1 + wc[u]);
+            const size_t pos = (size_t)b * L + wrow[u];
+            const float* src = (wc[u] < a.c1) ? a.src1 + pos * a.c1 + wc[u] : a.src2 + pos * a.c2 + (wc[u] - a.c1);   // channel concat (c1, c2 % 4 == 0)
+            wv[u] = *(const f32x4*)src;
         }
     };
     auto window_write = [&](int tile, int buf) {
@@ -102,10 +120,11 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a) {
     const int boff = ((j >> a.lg_Lout) * LP + (j & (L - 1))) * RS4 + q;
 
     // ---- epilogue operands of the region this lane would serve (channels are fixed per lane: loaded once)
-    const int e0 = lane * 4;
-    const int el = e0 >> 5, ec = e0 & 31;                   // region = 32 channels x 8 positions: lane -> (position, 4 channels)
+    const int e0 = lane * EPL;
+    const int el = e0 / MT, ec = e0 % MT;                   // region = MT channels x 8 positions: lane -> (position, EPL channels)
     const int co = mt * MT + ec;
-    const f32x4 bi = *(const f32x4*)(a.bias + co), ga = *(const f32x4*)(a.gamma + co), be = *(const f32x4*)(a.beta + co);
+    const fvec bi = *(const fvec*)(a.bias + co), ga = *(const fvec*)(a.gamma + co), be = *(const fvec*)(a.beta + co);
+    const float inv_re = 1.0f / (float)(MT * 8);
 
     int tile = p;
     if (tile < n_tiles) { window_load(tile); window_write(tile, 0); }
@@ -125,13 +144,15 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a) {
         const int r = (wk - 2 * i) & 7;
         const int b_ep = tile * spt + r;
         const size_t o_ep = ((size_t)(b_ep < a.B ? b_ep : 0) * L + el) * a.C_out + co;
-        f32x4 tb = {0.f, 0.f, 0.f, 0.f}, rs4 = {0.f, 0.f, 0.f, 0.f};
+        fvec tb = 0.f, rsv = 0.f;
         if (r < spt) {
-            if (a.tbias) tb = *(const f32x4*)(a.tbias + (size_t)(b_ep < a.B ? b_ep : 0) * a.tb_stride + co);
-            if (a.res) rs4 = *(const f32x4*)(a.res + o_ep);
+            if (a.tbias) tb = *(const fvec*)(a.tbias + (size_t)(b_ep < a.B ? b_ep : 0) * a.tb_stride + co);
+            if (a.res) rsv = *(const fvec*)(a.res + o_ep);
         }
         // ---------------------------------------------------------------- k-loop of this tile (window buffer `cur`)
-        f32x4 acc[MS] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4 acc[MS], acc2[MS];
+#pragma unroll
+        for (int m = 0; m < MS; ++m) acc[m] = acc2[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const f32x4* win = smem4 + cur * stage4 + boff;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -142,11 +163,24 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int m = 0; m < MS; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[it][m][e], bf[e], acc[m], 0, 0, 0);
         }
-        WS_STAMP(1);
-        // ---------------------------------------------------------------- K-partials -> reduction buffer `cur`
+        if constexpr (R1) {   // the residual 1x1 conv reads the centre row of the same window
 #pragma unroll
-        for (int m = 0; m < MS; ++m) smem4[red_off4 + cur * red4 + (wk * NT + j) * MTP4 + m * 4 + q] = acc[m];
-        // ---------------------------------------------------------------- next window -> the other buffer; fetch the one after it
+            for (int it = 0; it < NIT2; ++it) {
+                const f32x4 bf = win[PAD * RS4 + (wk + it * WK) * 4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int m = 0; m < MS; ++m) acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af2[it][m][e], bf[e], acc2[m], 0, 0, 0);
+            }
+        }
+        WS_STAMP(1);
+        // ---------------------------------------------------------------- K-partials -> reduction buffer(s) `cur`
+#pragma unroll
+        for (int m = 0; m < MS; ++m) {
+            smem4[red_off4 + cur * red4 + (wk * NT + j) * MTP4 + m * 4 + q] = acc[m];
+            if constexpr (R1) smem4[red2_off4 + cur * red4 + (wk * NT + j) * MTP4 + m * 4 + q] = acc2[m];
+        }
+        // ---------------------------------------------------------------- next window -> the other buffer
         const int nxt = tile + kWsGroups;
         if (nxt < n_tiles) window_write(nxt, cur ^ 1);
         WS_STAMP(2);
@@ -154,24 +188,40 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a) {
         WS_STAMP(3);
         // ---------------------------------------------------------------- epilogue: region r of this tile by duty wave (2 i + r) mod 8
         if (r < spt) {
-            const int b = b_ep;
             const int n = r * L + el;
-            const size_t o = o_ep;
-            const int ri = red_off4 + cur * red4 + n * MTP4 + (ec >> 2);
-            f32x4 v = smem4[ri];
+            const float* red = smem + (size_t)(red_off4 + cur * red4) * 4;
+            fvec v = *(const fvec*)(red + (size_t)n * (MT + 4) + ec);
 #pragma unroll
-            for (int k = 1; k < WK; ++k) v += smem4[ri + k * NT * MTP4];
+            for (int k = 1; k < WK; ++k) v += *(const fvec*)(red + (size_t)(k * NT + n) * (MT + 4) + ec);
             v += bi;
-            const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
-            const f32x4 d = v - mean;
-            const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 256.0f);
+            float s1 = 0.f;
+            if constexpr (EPL == 4) s1 = (v[0] + v[1]) + (v[2] + v[3]); else s1 = v[0] + v[1];
+            const float mean = wave_sum(s1) * inv_re;
+            const fvec d = v - mean;
+            float s2 = 0.f;
+            if constexpr (EPL == 4) s2 = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]); else s2 = d[0] * d[0] + d[1] * d[1];
+            const float var = wave_sum(s2) * inv_re;
             const float rstd = gn_rstd(var);
-            f32x4 y;
+            fvec y;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = mish(d[e] * rstd * ga[e] + be[e]);
+            for (int e = 0; e < EPL; ++e) y[e] = mish(d[e] * rstd * ga[e] + be[e]);
             y += tb;
-            y += rs4;
-            if (b < a.B) *(f32x4*)(a.dst + o) = y;
+            y += rsv;
+            if (b_ep < a.B) *(fvec*)(a.dst + o_ep) = y;
+        }
+        if constexpr (R1) {   // bias-only epilogue of the residual conv: duty wave (2 i + spt) mod 8
+            if (r == spt) {
+                const float* red = smem + (size_t)(red2_off4 + cur * red4) * 4;
+                for (int idx = lane; idx < NT * (MT / 4); idx += 64) {
+                    const int n = idx / (MT / 4), c = (idx - n * (MT / 4)) * 4;
+                    const int s = n >> a2.lg_Lout, l = n & (L - 1), b = tile * spt + s;
+                    f32x4 v = *(const f32x4*)(red + (size_t)n * (MT + 4) + c);
+#pragma unroll
+                    for (int k = 1; k < WK; ++k) v += *(const f32x4*)(red + (size_t)(k * NT + n) * (MT + 4) + c);
+                    v += *(const f32x4*)(a2.bias + mt * MT + c);
+                    if (b < a2.B) *(f32x4*)(a2.dst + ((size_t)b * L + l) * a2.C_out + mt * MT + c) = v;
+                }
+            }
         }
         WS_STAMP(4);
         // the window after next: requested AFTER the epilogue (hipcc waits for every outstanding load at the epilogue's first use of

@@ -1005,31 +1005,52 @@ static int make_conv_args(const mpdx_unet* u, const Layer& l, const float* packe
     return 0;
 }
 
-// Large batches: the 256 -> 256 Conv1dBlocks of the inner levels run on the weight-stationary persistent kernel (conv_ws.hpp;
-// bit-identical outputs).  From 8 position tiles per workgroup on (B >= 512 at L = 8); MPDX_WS=0 switches it off (read per call: A/B
-// runs and the bit-identity test flip it inside one process).
-static bool use_weight_stationary(const Layer& l, const ConvArgs& a, int B, int dbg) {
-    if (!(l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH && l.cout == 256 && l.c1 == 256 && l.c2 == 0 && l.gs == 32 && l.L_out == 8)) return false;
-    if (dbg || a.pre) return false;
-    if ((long)B * l.L_out < 16L * kWsGroups * 8) return false;
+// Large batches: the Conv1dBlocks of the inner levels (L = 8) run on the weight-stationary persistent kernels (conv_ws.hpp;
+// bit-identical outputs).  From 8 position tiles per workgroup on (B >= 512 at L = 8); MPDX_WS=0 switches them off (read per call: A/B
+// runs and the bit-identity test flip it inside one process).  Returns the variant: 0 none, 1 <16,32> (256 -> 256); with a paired
+// residual 1x1 conv l2: 3 <32,16,R1> (512 -> 128 on a channel concat).  Measured and NOT used (rocprofv3, B = 6400, us per launch,
+// weight-stationary vs per-layer kernels): 128 -> 128 <8,16>: 142.7 vs 95.9; 128 -> 256 + 1x1 <8,32,R1>: 268 vs 234 - with 5 k-groups per
+// wave a tile's 20-40 MFMAs per wave do not cover its barrier and window hand-over; kept: 256 -> 256: 319 vs 332, 512 -> 128 + 1x1: 387 vs 468.
+static int weight_stationary_variant(const Layer& l, const Layer* l2, const ConvArgs& a, int B, int dbg) {
+    if (!(l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH && l.L_out == 8 && l.L_in == 8)) return 0;
+    if (dbg || a.pre || (l.c1 & 3) || (l.c2 & 3) || l.cin_pad != l.c1 + l.c2) return 0;
+    if ((long)B * l.L_out < 16L * kWsGroups * 8) return 0;
     const char* e = getenv("MPDX_WS");
-    return !(e && atoi(e) == 0);
+    if (e && atoi(e) == 0) return 0;
+    if (l2 && e && atoi(e) == 2) return 0;   // dev A/B: 2 = single layers only
+    if (l2) {
+        if (!(l2->mode == CONV_S1 && l2->ks == 1 && l2->epi == EPI_BIAS && l2->cout == l.cout && l2->L_out == 8 && l2->c1 == l.c1 && l2->c2 == l.c2)) return 0;
+        if (l.cout == 128 && l.gs == 16 && l.cin_pad == 512) return 3;
+        return 0;
+    }
+    if (l.cout == 256 && l.gs == 32 && l.cin_pad == 256) return 1;
+    return 0;
 }
 
-static int launch_weight_stationary(const Layer& l, ConvArgs& a, int B, hipStream_t st) {
+template <int NC16, int MT, bool R1>
+static int launch_ws(const Layer& l, ConvArgs& a, const ConvArgs& a2, int B, hipStream_t st) {
     a.n_tiles_n = (int)(((long)B * l.L_out + 15) / 16);
-    const size_t lds = conv_ws_lds_bytes<16>(l.L_out, a.rs);
-    auto kern = conv_ws_kernel<16>;
+    const size_t lds = conv_ws_lds_bytes<NC16, MT, R1>(l.L_out, a.rs);
+    if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "weight-stationary conv needs %zu B of LDS", lds);
+    auto kern = conv_ws_kernel<NC16, MT, R1>;
     if (int rc = raise_lds_limit((const void*)kern)) return rc;
-    hipLaunchKernelGGL(kern, dim3((l.cout / 32) * kWsGroups), dim3(kWsThreads), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((l.cout / MT) * kWsGroups), dim3(kWsThreads), lds, st, a, a2);
     return 0;
+}
+
+static int launch_weight_stationary(int variant, const Layer& l, ConvArgs& a, const ConvArgs& a2, int B, hipStream_t st) {
+    switch (variant) {
+        case 1: return launch_ws<16, 32, false>(l, a, a2, B, st);
+        case 3: return launch_ws<32, 16, true>(l, a, a2, B, st);
+    }
+    return fail(MPDX_E_STATE, "no weight-stationary variant %d", variant);
 }
 
 static int run_layer(const mpdx_unet* u, const Layer& l, const float* packed, const float* tt_row, const float* x,
                      float* ws, int B, hipStream_t st, int dbg = 0) {
     ConvArgs a;
     if (int rc = make_conv_args(u, l, packed, tt_row, x, ws, B, dbg, a)) return rc;
-    if (use_weight_stationary(l, a, B, dbg)) return launch_weight_stationary(l, a, B, st);
+    if (const int v = weight_stationary_variant(l, nullptr, a, B, dbg)) return launch_weight_stationary(v, l, a, a, B, st);
     if (l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH) return dispatch_tile<CONV_S1, 5, EPI_GN_MISH>(l, a, B, st);
     if (l.mode == CONV_S1 && l.ks == 1 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 1, EPI_BIAS>(l, a, B, st);
     if (l.mode == CONV_DOWN && l.ks == 3) return dispatch_tile_ksplit_only<CONV_DOWN, 3, EPI_BIAS>(l, a, B, st);
@@ -1073,6 +1094,7 @@ static int run_pair(const mpdx_unet* u, const Layer& l1, const Layer& l2, const 
     ConvArgs a1, a2;
     if (int rc = make_conv_args(u, l1, packed, tt_row, x, ws, B, 0, a1)) return rc;
     if (int rc = make_conv_args(u, l2, packed, tt_row, x, ws, B, 0, a2)) return rc;
+    if (const int v = weight_stationary_variant(l1, &l2, a1, B, 0)) return launch_weight_stationary(v, l1, a1, a2, B, st);
     a1.n_tiles_n = a2.n_tiles_n = (int)(((long)B * l1.L_out + NT - 1) / NT);
 #define MPDX_PAIR_TILE(mt, nt) if (MT == mt && NT == nt) return launch_pair<mt, nt>(a1, a2, l1, l2, st) == 1 ? 0 : fail(MPDX_E_INVALID, "pair launch failed");
     MPDX_PAIR_TILE(32, 64) MPDX_PAIR_TILE(32, 32) MPDX_PAIR_TILE(16, 64) MPDX_PAIR_TILE(16, 32) MPDX_PAIR_TILE(32, 16) MPDX_PAIR_TILE(16, 16)
