@@ -382,6 +382,24 @@ def training_leg(steps=40, B=32, T=25, D=4, opt=1, baseline=True):
     dt_native = (time.perf_counter() - t0) / steps
     rec = {"workload": f"p_losses + backward + clip_grad_norm_ + Adam + EMA/10, batch {B} x H=64 x D={D}, T={T}, dim_mults option {opt}, fp32",
            "train_steps_per_s": round(1.0 / dt_native, 1), "ms_per_train_step": round(dt_native * 1e3, 3)}
+    # roofline of the iteration: algorithmic FLOPs = 3 x the forward pass (forward + input gradients + weight gradients of every
+    # convolution; GroupNorm / Mish / Adam are O(activations + parameters)), the forward count from the library's own layer table
+    try:
+        from mpd_public_amd import _lib
+        lib = _lib.load()
+        hdl, packed, tab, wsb = dm.model.engine(T, B)
+        cap = 128
+        ms_ = (C.c_float * cap)(); fl_ = (C.c_double * cap)(); nm_ = (C.c_char_p * cap)(); n_ = C.c_int()
+        _lib.check(lib.mpdx_unet_profile(hdl, packed.data_ptr(), tab.data_ptr(), dm.model._timetab_T, x0.data_ptr(), 0, B, wsb.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream, cap, ms_, fl_, nm_, C.byref(n_)), "mpdx_unet_profile")
+        fwd = float(sum(fl_[k] for k in range(n_.value)))
+        tf = 3.0 * fwd / dt_native / 1e12
+        rec["roofline"] = {"bound": "launch latency (a chain of ~140 dependent 3-60 us kernels; fp32 MFMA for the convolutions)",
+                           "algorithmic_flop_per_iteration": 3.0 * fwd, "forward_flop": fwd, "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 4),
+                           "launches_per_iteration": "see profiles/r03_train_kernel_stats.csv (rocprofv3 of this loop)"}
+    except Exception as e:   # the record must survive a failing helper
+        rec["roofline"] = {"error": f"{type(e).__name__}: {e}"}
     if not baseline:
         return rec
     # the reference's way: autograd over ATen kernels + torch.optim.Adam, same GPU (the functional U-Net of oracle/ on CUDA tensors;
