@@ -79,10 +79,11 @@ def _unit_classes(lib, hdl, B, names, flops, n):
             lib.mpdx_unet_layer_tile(hdl, li, B, buf, 64)
             tile = buf.value.decode()
             kind = "conv_k5_gn_mish" if ".block.0." in nm else ("conv_k1" if "residual" in nm else ("down_k3s2" if "downs" in nm else "up_k4s2"))
+            ws = tile.startswith("ws")   # weight-stationary persistent kernel (large batches)
             if lib.mpdx_unet_unit_is_pair(hdl, B, i):
-                out.append((f"conv_k5_gn_mish+conv_k1 pair[{tile}] {flops[i]:.3e} flop", "conv_pair_kernel"))
+                out.append((f"conv_k5_gn_mish+conv_k1 pair[{tile}] {flops[i]:.3e} flop", "conv_ws_kernel" if ws else "conv_pair_kernel"))
             else:
-                out.append((f"{kind}[{tile}] {flops[i]:.3e} flop", "conv_block_kernel"))
+                out.append((f"{kind}[{tile}] {flops[i]:.3e} flop", "conv_ws_kernel" if ws else "conv_block_kernel"))
         elif nm.startswith("fused"):
             out.append(("fused level programs (fused_program_kernel<...>: whole-trajectory U-Net levels)", "fused_program_kernel"))
         else:

@@ -1863,6 +1863,13 @@ int mpdx_unet_layer_tile(const mpdx_unet* u, int i, int B, char* buf, size_t buf
     if (!u || !buf || i < 0 || i >= (int)u->layers.size()) return fail(MPDX_E_INVALID, "bad layer index");
     const Layer& l = u->layers[i];
     int MT, NT;
+    ConvArgs dummy;
+    memset(&dummy, 0, sizeof(dummy));
+    const Layer* l2 = (i + 1 < (int)u->layers.size() && pair_tile(l, u->layers[i + 1], B, MT, NT)) ? &u->layers[i + 1] : nullptr;
+    if (const int v = weight_stationary_variant(l, l2, dummy, B, 0)) {   // "ws": the weight-stationary persistent kernel (conv_ws.hpp)
+        snprintf(buf, buflen, "ws %dx16/1x8%s", v == 1 ? 32 : 16, v == 3 ? "+1x1" : "");
+        return 0;
+    }
     choose_tile(l, B, MT, NT);
     if (l.cout % MT) MT = 16;
     const bool ks = layer_ksplit(l);
