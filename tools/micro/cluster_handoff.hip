@@ -302,6 +302,96 @@ __global__ __launch_bounds__(512) void layer_kernel(const Args a, int layer) {
     }
 }
 
+
+// ---- EARLY-LAUNCH variant of the per-layer chain: consecutive launches ALTERNATE between two streams, so launch n+1 starts while launch n
+// still runs (each stream keeps its own barrier semantics: at most two launches are resident), prefetches what does not depend on
+// launch n (here: the weight fragments of its k-loop), then waits on DEVICE-SIDE arrival counters of launch n (one per XCD-slot, eight
+// in all: a workgroup's lanes 0..7 poll them relaxed) and stages launch n's tiles with sc1 loads; every workgroup publishes its
+// tile with sc1 (write-through) stores, drains, and arrives on counter[blockIdx % 8].  No host event between launches.
+__global__ __launch_bounds__(512) void layer_early_kernel(const Args a, int layer, unsigned* counters /*[layers][8]*/, unsigned expect_per_slot, int* gaveup) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = blockIdx.x >> 3, m = blockIdx.x & 7, me = blockIdx.x, nwg = gridDim.x, par = layer & 1;
+    if (tid < 256) smem[tid] = 0.f;
+    // (1) independent of the predecessor: this wave's weight fragments (the real kernels: first ring fill, parameters, halo zeros)
+    const float* wb = a.w + ((size_t)((layer * 8 + m) & 15) * 8 + wave) * 8192 + lane * 4;
+    f32x4 a0 = *(const f32x4*)(wb), a1 = *(const f32x4*)(wb + 128 * 64);
+    // (2) wait for the predecessor launch: all of its workgroups have arrived
+    if (layer > 0) {
+        if (tid < 8) {
+            const unsigned* cnt = counters + (size_t)(layer - 1) * 8 + tid;
+            int spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect_per_slot) {
+                if (++spins > SPIN_MAX) { atomicAdd(gaveup, 1); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+        auto rf = __builtin_amdgcn_make_buffer_rsrc((void*)a.xf, 0, 0x7fffffff, 0x00020000);
+        const unsigned base = (unsigned)(((size_t)(par ^ 1) * nwg + c * 8 + wave) * TILE_F) * 4u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(rf, base + (unsigned)(k * 64 + lane) * 16u, 0, 16);
+            *(u32x4*)(smem + 256 + wave * TILE_F + (k * 64 + lane) * 4) = g;
+        }
+    }
+    __syncthreads();
+    int wrong = 0;
+    if (layer > 0) for (int i = lane; i < TILE_F; i += 64) wrong += (smem[256 + wave * TILE_F + i] != expect_val(layer - 1, c * 8 + wave, i));
+    if (wrong) atomicAdd(a.bad, wrong);
+    f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int g = 0; g < a.mfma_per_wave / 16; ++g) {
+        if (g) { a0 = *(const f32x4*)(wb + (g & 31) * 256); a1 = *(const f32x4*)(wb + (g & 31) * 256 + 128 * 64); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], smem[lane + e], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], smem[lane + e], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], smem[lane + 64 + e], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], smem[lane + 64 + e], acc[3], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (wave < 4) {
+        const int i0 = (wave * 64 + lane) * 4;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = expect_val(layer, me, i0 + e) + acc[e][0] * 0.f;
+        auto rf = __builtin_amdgcn_make_buffer_rsrc((void*)a.xf, 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rf, (unsigned)(((size_t)par * nwg + me) * TILE_F + i0) * 4u, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(counters + (size_t)layer * 8 + (blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+static int run_early(Args a, int mpw, int nstreams) {
+    a.mfma_per_wave = mpw;
+    const int layers = a.layers, nwg = a.nc * 8;
+    unsigned* counters; int* gave;
+    CK(hipMalloc(&counters, (size_t)layers * 8 * 4)); CK(hipMalloc(&gave, 4));
+    hipStream_t st[2]; CK(hipStreamCreate(&st[0])); CK(hipStreamCreate(&st[1]));
+    hipEvent_t e0, e1, ej; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&ej));
+    float sum = 0.f; int hbad = 0, hg = 0;
+    for (int rep = 0; rep < 6; ++rep) {
+        CK(hipMemsetAsync(counters, 0, (size_t)layers * 8 * 4, st[0])); CK(hipMemsetAsync(a.bad, 0, 8, st[0])); CK(hipMemsetAsync(gave, 0, 4, st[0]));
+        CK(hipEventRecord(e0, st[0]));
+        CK(hipStreamWaitEvent(st[1], e0, 0));
+        for (int l = 0; l < layers; ++l)
+            hipLaunchKernelGGL(layer_early_kernel, dim3(nwg), dim3(512), (256 + 8 * TILE_F) * sizeof(float), st[nstreams == 2 ? (l & 1) : 0], a, l, counters,
+                               (unsigned)(nwg / 8), gave);
+        CK(hipEventRecord(ej, st[1])); CK(hipStreamWaitEvent(st[0], ej, 0));
+        CK(hipEventRecord(e1, st[0])); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        int b2[2], g; CK(hipMemcpy(b2, a.bad, 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&g, gave, 4, hipMemcpyDeviceToHost));
+        hbad += b2[0]; hg += g;
+        if (rep) sum += ms;
+    }
+    printf("%-34s %d stream(s), device-side deps  nc %2d  mfma/wave %4d : %6.2f us per layer  mismatches %d  give-ups %d\n", "one launch per layer, EARLY launch", nstreams,
+           a.nc, mpw, sum / 5 * 1000 / layers, hbad, hg);
+    CK(hipFree(counters)); CK(hipFree(gave));
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const int layers = argc > 1 ? atoi(argv[1]) : 64;
     Args a; memset(&a, 0, sizeof(a));
@@ -339,6 +429,8 @@ int main(int argc, char** argv) {
                 if (rep) sum += ms;
             }
             printf("%-34s launches                 nc %2d  mfma/wave %4d : %6.2f us per layer\n", "one launch per layer (reference)", nc, mpw, sum / 5 * 1000 / layers);
+            if (run_early(a, mpw, 1)) return 1;
+            if (run_early(a, mpw, 2)) return 1;
         }
     }
     // MFMA loop alone (no hand-off, no launches): the compute floor of the emulated layer
