@@ -48,7 +48,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 enum : int { CONV_S1 = 0, CONV_DOWN = 1, CONV_UPT = 2 };
-enum : int { EPI_BIAS = 0, EPI_GN_MISH = 1 };
+enum : int { EPI_BIAS = 0, EPI_GN_MISH = 1, EPI_GN_MISH_GEN = 2 };   // _GEN: GroupNorm regions other than 128 / 256 elements (horizons other than 64)
 
 struct ConvArgs {
     const float* src1;   // [B][L_in][c1]
@@ -423,6 +423,92 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
         if (tid == 0 && red[0] == 123.456f) a.dst[0] = red[1];
         return;
     }
+    if constexpr (EPI == EPI_GN_MISH_GEN) {
+        // GroupNorm regions (group x horizon) of 64, 512, 1024 or 2048 elements - horizons other than the shipped 64 (n_support_points
+        // 16 ... 128).  Kept OUT of the EPI_GN_MISH instantiations: compiled into the hot kernels, the extra variants cost 3.5 % of the
+        // cfg-2 plan (22.55 vs 21.80 ms, A/B on one box).  One wave per region; lane -> elements in (position, channel) order,
+        // channels fastest: re = 256 * NCH: NCH float4 chunks per lane, chunk k = elements (k * 64 + lane) * 4 ..+3; re = 64: one per lane.
+        const int gs = a.gs;
+        const int lg_gpt = (MT == 32 ? 5 : 4) - a.lg_gs;   // log2(groups per tile)
+        const int gpt = 1 << lg_gpt;
+        const int nreg = spt << lg_gpt;
+        const int re = gs << a.lg_Lout;
+        const float inv_re = 1.0f / (float)re;   // power of two: exact
+        auto region4 = [&](auto nch_, int s, int gl, int b) {
+            constexpr int NCH = decltype(nch_)::value;
+            f32x4 v[NCH], tb[NCH], rs4[NCH], ga[NCH], be[NCH];
+            size_t o[NCH];
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int e0 = (k * 64 + lane) * 4;
+                const int l = e0 >> a.lg_gs, c = gl * gs + (e0 & (gs - 1));
+                const int n = s * L_out + l, co = mt * MT + c;
+                o[k] = ((size_t)(b < a.B ? b : 0) * L_out + l) * a.C_out + co;
+                const f32x4 bi = *(const f32x4*)(a.bias + co);
+                ga[k] = *(const f32x4*)(a.gamma + co); be[k] = *(const f32x4*)(a.beta + co);
+                tb[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; rs4[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (a.tbias) tb[k] = *(const f32x4*)(a.tbias + (size_t)(b < a.B ? b : 0) * a.tb_stride + co);
+                if (a.res) rs4[k] = *(const f32x4*)(a.res + o[k]);
+                const int ri = n * MTP4 + (c >> 2);
+                v[k] = smem4[ri];
+#pragma unroll
+                for (int kk = 1; kk < WK; ++kk) v[k] += smem4[ri + kk * NT * MTP4];
+                v[k] += bi;
+                if (a.pre && b < a.B) *(f32x4*)(a.pre + o[k]) = v[k];
+                sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+            }
+            const float mean = wave_sum(sum) * inv_re;
+            float sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                v[k] = v[k] - mean;
+                sq += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
+            }
+            const float var = wave_sum(sq) * inv_re;
+            const float rstd = gn_rstd(var);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = mish(v[k][e] * rstd * ga[k][e] + be[k][e]);
+                y += tb[k];
+                y += rs4[k];
+                if (b < a.B) *(f32x4*)(a.dst + o[k]) = y;
+            }
+        };
+        for (int r = wave; r < nreg; r += NWAVE) {
+            const int s = r >> lg_gpt, gl = r & (gpt - 1);
+            const int b = s0 + s;
+            if (re >= 512) {
+                switch (re >> 8) {
+                    case 2: region4(std::integral_constant<int, 2>{}, s, gl, b); break;
+                    case 4: region4(std::integral_constant<int, 4>{}, s, gl, b); break;
+                    default: region4(std::integral_constant<int, 8>{}, s, gl, b); break;
+                }
+            } else {  // re == 64: one element per lane
+                const int l = lane >> a.lg_gs, c = gl * gs + (lane & (gs - 1));
+                const int n = s * L_out + l, co = mt * MT + c;
+                const size_t o = ((size_t)(b < a.B ? b : 0) * L_out + l) * a.C_out + co;
+                float tb = 0.f, rs1 = 0.f;
+                if (a.tbias) tb = a.tbias[(size_t)(b < a.B ? b : 0) * a.tb_stride + co];
+                if (a.res) rs1 = a.res[o];
+                float v = red[(size_t)n * MTP + c];
+#pragma unroll
+                for (int k = 1; k < WK; ++k) v += red[((size_t)(k * NT + n)) * MTP + c];
+                v += a.bias[co];
+                if (a.pre && b < a.B) a.pre[o] = v;
+                const float mean = wave_sum(v) * inv_re;
+                const float d = v - mean;
+                const float var = wave_sum(d * d) * inv_re;
+                const float rstd = gn_rstd(var);
+                float y = mish(d * rstd * a.gamma[co] + a.beta[co]);
+                y += tb;
+                y += rs1;
+                if (b < a.B) a.dst[o] = y;
+            }
+        }
+    } else
     if (EPI == EPI_GN_MISH) {
         const int gs = a.gs;
         const int lg_gpt = (MT == 32 ? 5 : 4) - a.lg_gs;   // log2(groups per tile)

@@ -916,6 +916,11 @@ static void choose_tile(const Layer& l, int B, int& MT, int& NT) {
         int mt = 0, nt = 0;
         if (sscanf(ov, "%dx%d", &mt, &nt) == 2 && mt >= min_mt && nt >= min_nt && l.cout % mt == 0 && nt % l.L_out == 0) { MT = mt; NT = nt; return; }
     }
+    if (min_nt > 64) {   // a level with more than 64 positions (n_support_points = 128): one trajectory per tile
+        NT = min_nt;
+        MT = (min_mt <= 16 && l.cout % 16 == 0) ? 16 : 32;
+        return;
+    }
     static const int target = getenv("MPDX_TARGET_WGS") ? atoi(getenv("MPDX_TARGET_WGS")) : 160;
     auto wgs = [&](int mt, int nt) { return (long)(l.cout / mt) * ((npos + nt - 1) / nt); };
     const int pad = (l.mode == CONV_S1) ? l.ks / 2 : 1;
@@ -962,6 +967,7 @@ static int dispatch_tile(const Layer& l, ConvArgs& a, int B, hipStream_t st) {
         return launch_conv<MODE, KS, EPI, mt, nt, nt / 16, 8 / (nt / 16)>(a, st);               \
     }
     MPDX_TILE(32, 64) MPDX_TILE(32, 32) MPDX_TILE(16, 64) MPDX_TILE(16, 32) MPDX_TILE(32, 16) MPDX_TILE(16, 16)
+    if constexpr (EPI != EPI_GN_MISH) { MPDX_TILE(16, 128) MPDX_TILE(32, 128) }   // 128-position levels have regions >= 512: _GEN only
 #undef MPDX_TILE
     return fail(MPDX_E_INVALID, "no instantiation for tile %dx%d", MT, NT);
 }
@@ -975,7 +981,7 @@ static int dispatch_tile_ksplit_only(const Layer& l, ConvArgs& a, int B, hipStre
     a.n_tiles_n = (int)(((long)B * l.L_out + NT - 1) / NT);
 #define MPDX_TILE(mt, nt) \
     if (MT == mt && NT == nt) return launch_conv<MODE, KS, EPI, mt, nt, 1, 8>(a, st);
-    MPDX_TILE(32, 64) MPDX_TILE(32, 32) MPDX_TILE(16, 64) MPDX_TILE(16, 32)
+    MPDX_TILE(32, 64) MPDX_TILE(32, 32) MPDX_TILE(16, 64) MPDX_TILE(16, 32) MPDX_TILE(16, 128) MPDX_TILE(32, 128)
     if constexpr (MODE != CONV_UPT) { MPDX_TILE(32, 16) MPDX_TILE(16, 16) }
 #undef MPDX_TILE
     return fail(MPDX_E_INVALID, "no instantiation for tile %dx%d", MT, NT);
@@ -1051,7 +1057,11 @@ static int run_layer(const mpdx_unet* u, const Layer& l, const float* packed, co
     ConvArgs a;
     if (int rc = make_conv_args(u, l, packed, tt_row, x, ws, B, dbg, a)) return rc;
     if (const int v = weight_stationary_variant(l, nullptr, a, B, dbg)) return launch_weight_stationary(v, l, a, a, B, st);
-    if (l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH) return dispatch_tile<CONV_S1, 5, EPI_GN_MISH>(l, a, B, st);
+    if (l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH) {
+        const int re = l.gs * l.L_out;   // regions other than 128 / 256 elements (horizons other than 64): the general-region instantiations
+        if (re != 128 && re != 256) return dispatch_tile<CONV_S1, 5, EPI_GN_MISH_GEN>(l, a, B, st);
+        return dispatch_tile<CONV_S1, 5, EPI_GN_MISH>(l, a, B, st);
+    }
     if (l.mode == CONV_S1 && l.ks == 1 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 1, EPI_BIAS>(l, a, B, st);
     if (l.mode == CONV_DOWN && l.ks == 3) return dispatch_tile_ksplit_only<CONV_DOWN, 3, EPI_BIAS>(l, a, B, st);
     if (l.mode == CONV_UPT && l.ks == 4) return dispatch_tile_ksplit_only<CONV_UPT, 4, EPI_BIAS>(l, a, B, st);
@@ -1078,6 +1088,7 @@ static bool pair_tile(const Layer& l1, const Layer& l2, int B, int& MT, int& NT)
     static const bool off = getenv("MPDX_PAIR") && atoi(getenv("MPDX_PAIR")) == 0;
     if (off) return false;
     if (!(l1.mode == CONV_S1 && l1.ks == 5 && l1.epi == EPI_GN_MISH && l2.mode == CONV_S1 && l2.ks == 1 && l2.epi == EPI_BIAS)) return false;
+    if (l1.gs * l1.L_out != 128 && l1.gs * l1.L_out != 256) return false;   // general GroupNorm regions: no paired instantiations
     if (l1.src1 != l2.src1 || l1.src2 != l2.src2 || l1.cout != l2.cout || l1.L_out != l2.L_out || !layer_ksplit(l1)) return false;
     choose_tile(l1, B, MT, NT);   // the k5 block decides the tile; the 1x1 conv has no constraint beyond it
     if (l1.cout % MT) MT = 16;
@@ -1365,16 +1376,17 @@ int mpdx_unet_create(const mpdx_unet_cfg* cfg, mpdx_unet** out) {
     if (cfg->time_emb_dim != 32) return fail(MPDX_E_INVALID, "time_emb_dim must be 32 (TimeEncoder(32, .), temporal_unet.py:66)");
     if (cfg->unet_input_dim % 16) return fail(MPDX_E_INVALID, "unet_input_dim must be a multiple of 16");
     const int H = cfg->n_support_points;
-    if (H < 16 || (H & (H - 1)) || (H >> (cfg->n_levels - 1)) < 8)
-        return fail(MPDX_E_INVALID, "n_support_points %d must be a power of two with >= 8 points at the coarsest level", H);
+    if (H < 16 || H > 128 || (H & (H - 1)) || (H >> (cfg->n_levels - 1)) < 2)
+        return fail(MPDX_E_INVALID, "n_support_points %d must be a power of two in [16, 128] with >= 2 points at the coarsest level", H);
     mpdx_unet* u = new mpdx_unet();
     u->cfg = *cfg;
     build_model(u);
-    // GroupNorm regions must be 128 or 256 elements (one wave, 2 or 4 channels per lane)
+    // GroupNorm regions (group x horizon) of 64 ... 2048 elements: one wave per region, 1, 2 or 4 x {1, 2, 4, 8} elements per lane
+    // (conv_block.hpp).  The whole-trajectory fused programs exist for the shapes of H = 64 only; other horizons run one launch per layer.
     for (const Layer& l : u->layers)
         if (l.epi == EPI_GN_MISH) {
             const int re = l.gs * l.L_out;
-            if ((re != 128 && re != 256) || l.gs < 4 || 32 % l.gs) {
+            if (re < 64 || re > 2048 || (re & (re - 1)) || l.gs < 4 || 32 % l.gs) {
                 std::string nm = l.name;
                 delete u;
                 return fail(MPDX_E_INVALID, "layer %s: GroupNorm region of %d elements (group of %d) unsupported", nm.c_str(), re, l.gs);

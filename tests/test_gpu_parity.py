@@ -83,6 +83,38 @@ def test_weight_stationary_inner_levels_are_bit_identical(B):
     assert torch.equal(small, y_ws[5:9])
 
 
+@pytest.mark.parametrize("H,mults,D", [(128, (1, 2, 4, 8), 4), (32, (1, 2, 4, 8), 4), (32, (1, 2, 4), 14)])
+def test_other_horizons_unet_and_plan_vs_oracle(H, mults, D):
+    """n_support_points other than the shipped 64 (temporal_unet.py:24 takes any horizon the strided convs divide): powers of two from
+    16 to 128 run one launch per layer (the whole-trajectory programs exist for H = 64), GroupNorm regions of 64 ... 2048 elements on
+    the general-region instantiations (conv_block.hpp EPI_GN_MISH_GEN).  The U-Net output and a full unguided plan equal the oracle's."""
+    import mpd_public_amd as m
+    from mpd_public_amd import synthetic as syn
+    from oracle.unet import unet_forward
+    from oracle import diffusion as odiff
+    net = m.TemporalUnet(n_support_points=H, state_dim=D, unet_input_dim=32, dim_mults=mults)
+    sd = syn.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    B = 5
+    x = t(f"hz_x_{H}_{D}", (B, H, D))
+    for tt in (0, 13):
+        tv = torch.full((B,), tt, dtype=torch.long)
+        y = net(x.cuda(), tv.cuda(), None).cpu().numpy()
+        np.testing.assert_allclose(y, unet_forward(sd, x, tv).numpy(), rtol=0, atol=2e-5, err_msg=f"H={H} t={tt}")
+    T, n0 = 25, 3
+    dm = m.GaussianDiffusionModel(model=net, variance_schedule="exponential", n_diffusion_steps=T, predict_epsilon=True).cuda().eval()
+    noise = t(f"hz_noise_{H}_{D}", (T + n0 + 1, B, H, D))
+    hc = {0: t(f"hz_hc0_{D}", (D,), "uniform"), H - 1: t(f"hz_hc1_{D}", (D,), "uniform")}
+    chain = dm.run_inference(None, {k: v.cuda() for k, v in hc.items()}, n_samples=B, horizon=H, return_chain=True, sample_fn=m.ddpm_sample_fn,
+                             n_diffusion_steps_without_noise=n0, noise_std_extra_schedule_fn=lambda tt_: 0.5, noise=noise.cuda()).cpu()
+    ref = odiff.run_inference(sd, hc, noise, T, n_diffusion_steps_without_noise=n0, noise_std=0.5)
+    assert chain.shape == ref.shape == (T + n0 + 1, B, H, D)
+    assert torch.equal(chain[-1][:, 0], hc[0].expand(B, D)) and torch.equal(chain[-1][:, H - 1], hc[H - 1].expand(B, D))
+    np.testing.assert_allclose(chain.numpy(), ref.numpy(), rtol=0, atol=2e-3)
+    np.testing.assert_allclose(chain[-1].numpy(), ref[-1].numpy(), rtol=0, atol=5e-4)
+
+
 def test_unet_batch_independence():
     """GroupNorm is per sample: a trajectory's eps must not depend on its batch neighbours (bit-exact)."""
     net = _gpu_model(14, 1)
