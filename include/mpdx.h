@@ -36,7 +36,7 @@ typedef struct mpdx_unet mpdx_unet; /* opaque */
  * for the only configuration the reference builds: conditioning_type=None, self_attention=False. */
 typedef struct mpdx_unet_cfg {
     int32_t state_dim;                  /* D */
-    int32_t n_support_points;           /* H (64) */
+    int32_t n_support_points;           /* H: 64 in every shipped configuration; a power of two in [16, 128] (GroupNorm regions >= 64 elements) */
     int32_t unet_input_dim;             /* 32 */
     int32_t n_levels;                   /* len(dim_mults) */
     int32_t dim_mults[MPDX_MAX_LEVELS]; /* (1,2,4,8) or (1,2,4): UNET_DIM_MULTS, temporal_unet.py:14-17 */

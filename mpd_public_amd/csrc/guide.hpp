@@ -232,23 +232,17 @@ __global__ __launch_bounds__(64) void traj_metrics_kernel(const mpdx_guide_param
     float* sx = sm;
     float* sprim = sx + H * D;
     for (int i = lane; i < gp.n_prim_floats; i += 64) sprim[i] = gp.prims[i];
-    const bool live = lane < H;
-    float xu[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        xu[d] = live ? x[((size_t)b * H + lane) * D + d] : 0.f;
-        if (live) sx[lane * D + d] = xu[d];
-    }
+    for (int i = lane; i < H * D; i += 64) sx[i] = x[(size_t)b * H * D + i];
     __syncthreads();
     float plen = 0.f, smooth = 0.f;
-    if (live && lane < H - 1) {
+    for (int h = lane; h < H - 1; h += 64) {   // (H <= 64: one segment per lane, as before)
         float a2 = 0.f, v2 = 0.f;
 #pragma unroll
         for (int j = 0; j < QD; ++j) {
-            const float dq = sx[(lane + 1) * D + j] - xu[j], dv = sx[(lane + 1) * D + QD + j] - xu[QD + j];
+            const float dq = sx[(h + 1) * D + j] - sx[h * D + j], dv = sx[(h + 1) * D + QD + j] - sx[h * D + QD + j];
             a2 += dq * dq; v2 += dv * dv;
         }
-        plen = sqrtf(a2); smooth = sqrtf(v2);
+        plen += sqrtf(a2); smooth += sqrtf(v2);
     }
     const int N = n_check;
     const float scale = (N > 1) ? (float)(H - 1) / (float)(N - 1) : 0.f;
@@ -341,31 +335,32 @@ __device__ __forceinline__ void clip_waypoint_grad(const mpdx_guide_params& gp, 
 //     x = x + (-grad);  [+ the step's noise term on the last guide iteration];  hard conditioning;  max|x| for the next
 // range test.  One wave, lane = support point.  tr: optional two cycle stamps (dev tool).
 template <int QD>
-__device__ __forceinline__ void guide_gp_apply(const GuideArgs& a, int b, int ctx, int lane, int H, bool live, const float (&xn)[2 * QD],
+__device__ __forceinline__ void guide_gp_apply(const GuideArgs& a, int b, int ctx, int lane, int h, int H, bool live, const float (&xn)[2 * QD],
                                                const float (&xu)[2 * QD], const float* sx, float (&total)[2 * QD], size_t base, long long* tr) {
     constexpr int D = 2 * QD;
-    const bool interior = live && lane > 0 && lane < H - 1;
+    const bool interior = live && h > 0 && h < H - 1;
     if (a.gp.use_gp) {
         const float dt = a.gp.dt, s2 = (a.gp.gp_half_factor ? 0.5f : 1.0f) / (a.gp.sigma_gp * a.gp.sigma_gp);
         const float c_qq = 24.0f / (dt * dt * dt), c_qv = 12.0f / (dt * dt), c_vv = 8.0f / dt;
-        float av[QD], bv[QD];  // a_h = d c_h / d e_q,  b_h = d c_h / d e_v  for the segment (h, h+1)
-#pragma unroll
-        for (int j = 0; j < QD; ++j) {
-            float eq = 0.f, ev = 0.f;
-            if (live && lane < H - 1) {
-                eq = sx[(lane + 1) * D + j] - xu[j] - dt * xu[QD + j];
-                ev = sx[(lane + 1) * D + QD + j] - xu[QD + j];
-            }
-            av[j] = (c_qq * eq - c_qv * ev) * s2;
-            bv[j] = (-c_qv * eq + c_vv * ev) * s2;
-        }
+        // a_h = d c_h / d e_q,  b_h = d c_h / d e_v  for the segment (h, h+1); (ap, bp) the same for the segment (h-1, h).  Both are
+        // computed from the LDS-staged state (the neighbour's registers hold exactly these floats): no cross-lane traffic, so the
+        // support index may cross a wave boundary (H up to 128: two waves of supports)
         float g[D];
 #pragma unroll
         for (int j = 0; j < QD; ++j) {
-            float ap = __shfl_up(av[j], 1, 64), bp = __shfl_up(bv[j], 1, 64);
-            if (lane == 0) { ap = 0.f; bp = 0.f; }
-            g[j] = ap - av[j];
-            g[QD + j] = bp - bv[j] - dt * av[j];
+            float eq = 0.f, ev = 0.f, eqp = 0.f, evp = 0.f;
+            if (live && h < H - 1) {
+                eq = sx[(h + 1) * D + j] - xu[j] - dt * xu[QD + j];
+                ev = sx[(h + 1) * D + QD + j] - xu[QD + j];
+            }
+            if (live && h > 0) {
+                eqp = sx[h * D + j] - sx[(h - 1) * D + j] - dt * sx[(h - 1) * D + QD + j];
+                evp = sx[h * D + QD + j] - sx[(h - 1) * D + QD + j];
+            }
+            const float av = (c_qq * eq - c_qv * ev) * s2, bv = (-c_qv * eq + c_vv * ev) * s2;
+            const float ap = (c_qq * eqp - c_qv * evp) * s2, bp = (-c_qv * eqp + c_vv * evp) * s2;
+            g[j] = ap - av;
+            g[QD + j] = bp - bv - dt * av;
         }
         clip_waypoint_grad<D>(a.gp, g, 0);
         if (interior) {
@@ -387,8 +382,8 @@ __device__ __forceinline__ void guide_gp_apply(const GuideArgs& a, int b, int ct
                 float r = __fadd_rn(xn[d], inc);
                 if (a.rng.on) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.noise_scale, philox_normal_at(a.rng.seed, a.rng.offset, a.rng.elem0 + base + d)), a.noise_extra));
                 else if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.noise_scale, a.noise[base + d]), a.noise_extra));
-                if (a.hs && lane == 0) r = a.hs[(size_t)b * D + d];
-                if (a.hg && lane == H - 1) r = a.hg[(size_t)b * D + d];
+                if (a.hs && h == 0) r = a.hs[(size_t)b * D + d];
+                if (a.hg && h == H - 1) r = a.hg[(size_t)b * D + d];
                 a.x[base + d] = r;
                 if (a.chain) a.chain[base + d] = r;
                 vmax = fmaxf(vmax, fabsf(r));
@@ -421,7 +416,10 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
     const int b = blockIdx.x;
     const int H = a.H;
     const int N = gp.interpolate ? gp.n_interp : H;
-    const bool live = lane < H;
+    // support points: lane of wave sw = support sw * 64 + lane; H <= 64: one support wave (wave 0), H <= 128: two (waves 0, 1)
+    const int nsw = (H + 63) >> 6;
+    const int hs_ = (wv < nsw ? wv : 0) * 64 + lane;   // this thread's support index (waves >= nsw shadow block 0: their copy is unused)
+    const bool live = hs_ < H;
     int tr_i = 0;
 #define G_STAMP() do { if (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) a.trace[wv * 16 + tr_i] = (long long)__builtin_readcyclecounter(); ++tr_i; } while (0)
     G_STAMP();  // 0 entry
@@ -436,14 +434,14 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
     const int ctx = b / a.n_per_ctx;
     const bool clipall = __uint_as_float(a.amax_in[ctx]) > 1.0001f;  // x.max() > 1+eps or x.min() < -1-eps (eps = 1e-4)
     float xn[D], xu[D];
-    const size_t base = ((size_t)b * H + (live ? lane : 0)) * D;
+    const size_t base = ((size_t)b * H + (live ? hs_ : 0)) * D;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         xn[d] = live ? a.x[base + d] : 0.f;
         const float c = clipall ? fminf(fmaxf(xn[d], -1.f), 1.f) : xn[d];
         const float u01 = __fadd_rn(c, 1.0f) * 0.5f;
         xu[d] = gp.identity_normalizer ? xn[d] : __fadd_rn(__fmul_rn(u01, __fsub_rn(gp.maxs[d], gp.mins[d])), gp.mins[d]);
-        if (live && wv == 0) sx[lane * D + d] = xu[d];
+        if (live && wv < nsw) sx[hs_ * D + d] = xu[d];
     }
     __syncthreads();
     G_STAMP();  // 1 state unnormalised + staged
@@ -493,67 +491,79 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
     // ---- gather to support points (transpose of the interpolation), clip, zero ends, weight: wave f handles field f and
     //      leaves its clipped, weighted gradient in LDS; wave 0 then adds the fields in order (same additions as one wave
     //      looping over the fields)
-    const bool interior = live && lane > 0 && lane < H - 1;
     float* sC = sB;   // [MAXF][H][QD]: overlays sB after the barrier below (every gatherer has its sums in registers by then)
-    float cg[QD];
+    constexpr int NSB = 2;   // support blocks of 64 (H <= 128)
+    float cg[NSB][QD];
 #pragma unroll
-    for (int j = 0; j < QD; ++j) cg[j] = 0.f;
+    for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+        for (int j = 0; j < QD; ++j) cg[sb][j] = 0.f;
     const bool gatherer = wv < gp.n_fields;
-    if (gatherer && live) {
+    if (gatherer) {
         const int f = wv;
-        int ilo = lane, ihi = lane;
-        if (gp.interpolate && scale > 0.f) {
-            ilo = (int)((float)lane / scale) - 2;
-            ihi = (int)((float)(lane + 1) / scale) + 2;
-            if (ilo < 0) ilo = 0;
-            if (ihi > N - 1) ihi = N - 1;
-        }
-        float g[QD];
 #pragma unroll
-        for (int j = 0; j < QD; ++j) g[j] = 0.f;
-        for (int i = ilo; i <= ihi; ++i) {
-            int i0 = i, i1 = i;
-            if (gp.interpolate) {
-                const float u = scale * (float)i;
-                i0 = (int)u;
-                if (i0 > H - 1) i0 = H - 1;
-                i1 = i0 + 1 < H ? i0 + 1 : H - 1;
+        for (int sb = 0; sb < NSB; ++sb) {
+            const int hg_ = sb * 64 + lane;   // the support this lane gathers in block sb
+            if (sb >= nsw || hg_ >= H) continue;
+            int ilo = hg_, ihi = hg_;
+            if (gp.interpolate && scale > 0.f) {
+                ilo = (int)((float)(hg_ - 1) / scale) - 1;   // points of the segments (hg-1, hg) and (hg, hg+1): any number per segment
+                ihi = (int)((float)(hg_ + 1) / scale) + 1;
+                if (ilo < 0) ilo = 0;
+                if (ihi > N - 1) ihi = N - 1;
             }
-            if (i0 == lane) {
+            float g[QD];
 #pragma unroll
-                for (int j = 0; j < QD; ++j) g[j] += sA[(f * N + i) * QD + j];
+            for (int j = 0; j < QD; ++j) g[j] = 0.f;
+            for (int i = ilo; i <= ihi; ++i) {
+                int i0 = i, i1 = i;
+                if (gp.interpolate) {
+                    const float u = scale * (float)i;
+                    i0 = (int)u;
+                    if (i0 > H - 1) i0 = H - 1;
+                    i1 = i0 + 1 < H ? i0 + 1 : H - 1;
+                }
+                if (i0 == hg_) {
+#pragma unroll
+                    for (int j = 0; j < QD; ++j) g[j] += sA[(f * N + i) * QD + j];
+                }
+                if (i1 == hg_ && gp.interpolate) {
+#pragma unroll
+                    for (int j = 0; j < QD; ++j) g[j] += sB[(f * N + i) * QD + j];
+                }
             }
-            if (i1 == lane && gp.interpolate) {
+            // clip over ALL D dims of (g + 1e-6): the velocity dims of a collision gradient are 0
+            clip_waypoint_grad<QD>(gp, g, QD);
+            if (hg_ > 0 && hg_ < H - 1) {
 #pragma unroll
-                for (int j = 0; j < QD; ++j) g[j] += sB[(f * N + i) * QD + j];
+                for (int j = 0; j < QD; ++j) cg[sb][j] = gp.fields[f].weight * g[j];
             }
-        }
-        // clip over ALL D dims of (g + 1e-6): the velocity dims of a collision gradient are 0
-        clip_waypoint_grad<QD>(gp, g, QD);
-        if (interior) {
-#pragma unroll
-            for (int j = 0; j < QD; ++j) cg[j] = gp.fields[f].weight * g[j];
         }
     }
     static_assert(WPT >= MAXF, "one gathering wave per field");
     __syncthreads();   // every gatherer has read its sA / sB slabs
-    if (gatherer && live) {
+    if (gatherer) {
 #pragma unroll
-        for (int j = 0; j < QD; ++j) sC[(wv * H + lane) * QD + j] = cg[j];
+        for (int sb = 0; sb < NSB; ++sb) {
+            const int hg_ = sb * 64 + lane;
+            if (sb >= nsw || hg_ >= H) continue;
+#pragma unroll
+            for (int j = 0; j < QD; ++j) sC[(wv * H + hg_) * QD + j] = cg[sb][j];
+        }
     }
     __syncthreads();
-    if (wv != 0) return;   // wave 0 finishes the trajectory (no further workgroup barriers below)
+    if (wv >= nsw) return;   // the support wave(s) finish the trajectory (no further workgroup barriers below)
     float total[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) total[d] = 0.f;
     if (live) {
         for (int f = 0; f < gp.n_fields; ++f) {
 #pragma unroll
-            for (int j = 0; j < QD; ++j) total[j] += sC[(f * H + lane) * QD + j];
+            for (int j = 0; j < QD; ++j) total[j] += sC[(f * H + hs_) * QD + j];
         }
     }
     G_STAMP();  // 4 gathered + clipped
-    guide_gp_apply<QD>(a, b, ctx, lane, H, live, xn, xu, sx, total, base, (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) ? a.trace + wv * 16 + 5 : nullptr);
+    guide_gp_apply<QD>(a, b, ctx, lane, hs_, H, live, xn, xu, sx, total, base, (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) ? a.trace + wv * 16 + 5 : nullptr);
 #undef G_STAMP
 }
 
@@ -646,7 +656,10 @@ __global__ __launch_bounds__(512) void guide_step_panda_kernel(const GuideArgs a
     const int b = blockIdx.x;
     const int H = a.H;
     const int N = gp.interpolate ? gp.n_interp : H;
-    const bool live = lane < H;
+    // support points: lane of wave sw = support sw * 64 + lane; H <= 64: one support wave (wave 0), H <= 128: two (waves 0, 1)
+    const int nsw = (H + 63) >> 6;
+    const int hs_ = (wv < nsw ? wv : 0) * 64 + lane;
+    const bool live = hs_ < H;
     int tr_i = 0;
 #define G_STAMP() do { if (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) a.trace[wv * 16 + tr_i] = (long long)__builtin_readcyclecounter(); ++tr_i; } while (0)
     G_STAMP();  // 0 entry
@@ -661,14 +674,14 @@ __global__ __launch_bounds__(512) void guide_step_panda_kernel(const GuideArgs a
     const int ctx = b / a.n_per_ctx;
     const bool clipall = __uint_as_float(a.amax_in[ctx]) > 1.0001f;
     float xn[D], xu[D];
-    const size_t base = ((size_t)b * H + (live ? lane : 0)) * D;
+    const size_t base = ((size_t)b * H + (live ? hs_ : 0)) * D;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         xn[d] = live ? a.x[base + d] : 0.f;
         const float c = clipall ? fminf(fmaxf(xn[d], -1.f), 1.f) : xn[d];
         const float u01 = __fadd_rn(c, 1.0f) * 0.5f;
         xu[d] = gp.identity_normalizer ? xn[d] : __fadd_rn(__fmul_rn(u01, __fsub_rn(gp.maxs[d], gp.mins[d])), gp.mins[d]);
-        if (live && wv == 0) sx[lane * D + d] = xu[d];
+        if (live && wv < nsw) sx[hs_ * D + d] = xu[d];
     }
     __syncthreads();
     G_STAMP();  // 1 state unnormalised + staged
@@ -721,63 +734,67 @@ __global__ __launch_bounds__(512) void guide_step_panda_kernel(const GuideArgs a
     __syncthreads();
     G_STAMP();  // 4 all waves done
 
-    // ---- phase 3: wave f gathers field f to the support points, clips, weights
-    const bool interior = live && lane > 0 && lane < H - 1;
-    if (wv < gp.n_fields && live) {
+    // ---- phase 3: wave f gathers field f to the support points (one or two blocks of 64), clips, weights
+    if (wv < gp.n_fields) {
         const int f = wv;
-        int ilo = lane, ihi = lane;
-        if (gp.interpolate && scale > 0.f) {
-            ilo = (int)((float)lane / scale) - 2;
-            ihi = (int)((float)(lane + 1) / scale) + 2;
-            if (ilo < 0) ilo = 0;
-            if (ihi > N - 1) ihi = N - 1;
-        }
-        float g[QD];
-#pragma unroll
-        for (int j = 0; j < QD; ++j) g[j] = 0.f;
-        for (int i = ilo; i <= ihi; ++i) {
-            int i0 = i, i1 = i;
-            float l0 = 1.f, l1 = 0.f;
-            if (gp.interpolate) {
-                const float u = scale * (float)i;
-                i0 = (int)u;
-                if (i0 > H - 1) i0 = H - 1;
-                i1 = i0 + 1 < H ? i0 + 1 : H - 1;
-                l1 = u - (float)i0;
-                l0 = 1.0f - l1;
+        for (int sb = 0; sb < nsw; ++sb) {
+            const int hg_ = sb * 64 + lane;
+            if (hg_ >= H) continue;
+            int ilo = hg_, ihi = hg_;
+            if (gp.interpolate && scale > 0.f) {
+                ilo = (int)((float)(hg_ - 1) / scale) - 1;   // points of the segments (hg-1, hg) and (hg, hg+1): any number per segment
+                ihi = (int)((float)(hg_ + 1) / scale) + 1;
+                if (ilo < 0) ilo = 0;
+                if (ihi > N - 1) ihi = N - 1;
             }
-            const bool m0 = i0 == lane, m1 = i1 == lane && gp.interpolate;
-            if (m0 || m1) {
+            float g[QD];
 #pragma unroll
-                for (int j = 0; j < QD; ++j) {
-                    float v = 0.f;
+            for (int j = 0; j < QD; ++j) g[j] = 0.f;
+            for (int i = ilo; i <= ihi; ++i) {
+                int i0 = i, i1 = i;
+                float l0 = 1.f, l1 = 0.f;
+                if (gp.interpolate) {
+                    const float u = scale * (float)i;
+                    i0 = (int)u;
+                    if (i0 > H - 1) i0 = H - 1;
+                    i1 = i0 + 1 < H ? i0 + 1 : H - 1;
+                    l1 = u - (float)i0;
+                    l0 = 1.0f - l1;
+                }
+                const bool m0 = i0 == hg_, m1 = i1 == hg_ && gp.interpolate;
+                if (m0 || m1) {
 #pragma unroll
-                    for (int pt = 0; pt < NP; ++pt) v += sG[((f * NP + pt) * N + i) * QD + j];
-                    if (m0) g[j] += l0 * v;
-                    if (m1) g[j] += l1 * v;
+                    for (int j = 0; j < QD; ++j) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int pt = 0; pt < NP; ++pt) v += sG[((f * NP + pt) * N + i) * QD + j];
+                        if (m0) g[j] += l0 * v;
+                        if (m1) g[j] += l1 * v;
+                    }
                 }
             }
-        }
-        // clip over ALL D dims of (g + 1e-6): the velocity dims of a collision gradient are 0
-        clip_waypoint_grad<QD>(gp, g, QD);
+            // clip over ALL D dims of (g + 1e-6): the velocity dims of a collision gradient are 0
+            clip_waypoint_grad<QD>(gp, g, QD);
+            const bool interior = hg_ > 0 && hg_ < H - 1;
 #pragma unroll
-        for (int j = 0; j < QD; ++j) sC[(f * H + lane) * QD + j] = interior ? gp.fields[f].weight * g[j] : 0.f;
+            for (int j = 0; j < QD; ++j) sC[(f * H + hg_) * QD + j] = interior ? gp.fields[f].weight * g[j] : 0.f;
+        }
     }
     __syncthreads();
     G_STAMP();  // 5 gathered + clipped
-    if (wv != 0) return;
+    if (wv >= nsw) return;
 
-    // ---- phase 4: sum over fields, GP prior, apply
+    // ---- phase 4 (the support wave(s)): sum over fields, GP prior, apply
     float total[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) total[d] = 0.f;
     if (live) {
         for (int f = 0; f < gp.n_fields; ++f) {
 #pragma unroll
-            for (int j = 0; j < QD; ++j) total[j] += sC[(f * H + lane) * QD + j];
+            for (int j = 0; j < QD; ++j) total[j] += sC[(f * H + hs_) * QD + j];
         }
     }
-    guide_gp_apply<QD>(a, b, ctx, lane, H, live, xn, xu, sx, total, base, (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) ? a.trace + wv * 16 + 6 : nullptr);
+    guide_gp_apply<QD>(a, b, ctx, lane, hs_, H, live, xn, xu, sx, total, base, (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) ? a.trace + wv * 16 + 6 : nullptr);
 #undef G_STAMP
 }
 

@@ -1331,7 +1331,7 @@ static int launch_guide(const mpdx_guide_params* gp, float* x, float* grad_out, 
                         const float* noise = nullptr, float noise_scale = 0.f, float noise_extra = 0.f, float* chain = nullptr,
                         float guide_scale = 1.0f, const NoiseRng* rng = nullptr) {
     if (!gp || !x || !amax_in) return fail(MPDX_E_INVALID, "null argument");
-    if (H > 64 || H < 2) return fail(MPDX_E_INVALID, "guide kernel maps one support point per lane: H=%d unsupported (max 64)", H);
+    if (H > 128 || H < 2) return fail(MPDX_E_INVALID, "guide kernel: one support point per lane of one or two waves: H=%d unsupported (max 128)", H);
     if (D != 2 * gp->q_dim || D > 16) return fail(MPDX_E_INVALID, "state dim %d != 2*q_dim (%d)", D, gp->q_dim);
     if (gp->n_fields < 0 || gp->n_fields > MPDX_MAX_FIELDS) return fail(MPDX_E_INVALID, "n_fields %d", gp->n_fields);
     if (gp->interpolate && (gp->n_interp < H || gp->n_interp > 8 * H)) return fail(MPDX_E_INVALID, "n_interp %d unsupported", gp->n_interp);
@@ -1539,7 +1539,7 @@ int mpdx_guide_step_scaled(const mpdx_guide_params* gp, float* x, float* grad_ou
 
 int mpdx_traj_metrics(const mpdx_guide_params* gp, const float* x_unnormalised, float* out4, int n_check, int B, int H, int D, void* stream) {
     if (!gp || !x_unnormalised || !out4 || B <= 0) return fail(MPDX_E_INVALID, "bad argument");
-    if (H > 64 || H < 2) return fail(MPDX_E_INVALID, "H=%d unsupported (max 64)", H);
+    if (H > 128 || H < 2) return fail(MPDX_E_INVALID, "H=%d unsupported (max 128)", H);
     if (D != 2 * gp->q_dim || D > 16) return fail(MPDX_E_INVALID, "state dim %d != 2*q_dim (%d)", D, gp->q_dim);
     if (n_check < 2) n_check = H;
     const size_t lds = (size_t)(H * D + gp->n_prim_floats) * sizeof(float);
