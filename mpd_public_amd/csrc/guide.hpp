@@ -583,24 +583,48 @@ constexpr int kPandaFKS = 75;   // floats per interpolated point in LDS: O[7][3]
 constexpr int kPandaParts = 4;  // sphere groups {0-2, 3-5, 6-8, 9-10}; pair groups of 3
 
 // phase 2 of guide_step_panda_kernel for sphere / pair group PART and point half `half`
-template <int PART>
+// FKREG: the forward kinematics of the point are evaluated HERE from the LDS-staged state (sx, H, D, scale) instead of being read from
+// the per-point FK table of phase 1 (sfk): 4 x the FK work, no 38-KB table - the large-batch variant of the kernel (below).
+template <int PART, bool FKREG>
 __device__ __forceinline__ void panda_group_forces(const mpdx_guide_params& gp, const float* sprim, const float* sfk, float* sG, int half, int lane, int N,
-                                                   long long* tr) {
-    constexpr int QD = 7, NP = kPandaParts;
+                                                   long long* tr, const float* sx = nullptr, int H = 0, float scale = 0.f) {
+    constexpr int QD = 7, NP = kPandaParts, D = 14;
     constexpr int s_beg = PART * 3, s_end = (s_beg + 3 < kPandaNS) ? s_beg + 3 : kPandaNS;
     constexpr int p_beg = PART * 3, p_end = (p_beg + 3 < kPandaNP) ? p_beg + 3 : kPandaNP;
     for (int i = half * 64 + lane; i < N; i += 128) {
-        const float* fk = sfk + i * kPandaFKS;
         float O[7][3], Z[7][3], P[kPandaNS][3];
+        if constexpr (FKREG) {
+            int i0 = i, i1 = i;
+            float l0 = 1.f, l1 = 0.f;
+            if (gp.interpolate) {
+                const float u = scale * (float)i;
+                i0 = (int)u;
+                if (i0 > H - 1) i0 = H - 1;
+                i1 = i0 + 1 < H ? i0 + 1 : H - 1;
+                l1 = u - (float)i0;
+                l0 = 1.0f - l1;
+            }
+            float q[QD];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
+            for (int j = 0; j < QD; ++j) q[j] = l0 * sx[i0 * D + j] + l1 * sx[i1 * D + j];
+            panda_fk(q, O, Z);
 #pragma unroll
-            for (int r = 0; r < 3; ++r) { O[k][r] = fk[k * 3 + r]; Z[k][r] = fk[21 + k * 3 + r]; }
-        }
+            for (int s = 0; s < kPandaNS; ++s) {
 #pragma unroll
-        for (int s = 0; s < kPandaNS; ++s) {  // only the spheres this group touches stay live
+                for (int r = 0; r < 3; ++r) P[s][r] = O[kPandaSF[s] - 1][r] + kPandaSO[s] * Z[kPandaSF[s] - 1][r];
+            }
+        } else {
+            const float* fk = sfk + i * kPandaFKS;
 #pragma unroll
-            for (int r = 0; r < 3; ++r) P[s][r] = fk[42 + s * 3 + r];
+            for (int k = 0; k < 7; ++k) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { O[k][r] = fk[k * 3 + r]; Z[k][r] = fk[21 + k * 3 + r]; }
+            }
+#pragma unroll
+            for (int s = 0; s < kPandaNS; ++s) {  // only the spheres this group touches stay live
+#pragma unroll
+                for (int r = 0; r < 3; ++r) P[s][r] = fk[42 + s * 3 + r];
+            }
         }
         for (int f = 0; f < gp.n_fields; ++f) {
             float FF[7][3], FM[7][3];  // per frame: force on its spheres, their moment about the world origin
@@ -647,7 +671,11 @@ __device__ __forceinline__ void panda_group_forces(const mpdx_guide_params& gp, 
     }
 }
 
-__global__ __launch_bounds__(512) void guide_step_panda_kernel(const GuideArgs a) {
+// DENSE (large batches): no FK table in LDS (the forces phase evaluates the FK in registers, four times per point) and registers capped
+// at 128: 70 KB of LDS and 4 waves per SIMD -> TWO workgroups per CU, where the latency-bound phases of one overlap the other's
+// (the default variant: 107 KB, 166 VGPRs, one workgroup per CU; at B = 100 there is one workgroup per CU anyway).  Same arithmetic.
+template <bool DENSE>
+__global__ __launch_bounds__(512, DENSE ? 4 : 2) void guide_step_panda_kernel(const GuideArgs a) {
     constexpr int QD = 7, D = 14, MAXF = MPDX_MAX_FIELDS, NP = kPandaParts, WPT = 8;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const mpdx_guide_params& gp = a.gp;
@@ -664,8 +692,8 @@ __global__ __launch_bounds__(512) void guide_step_panda_kernel(const GuideArgs a
 #define G_STAMP() do { if (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) a.trace[wv * 16 + tr_i] = (long long)__builtin_readcyclecounter(); ++tr_i; } while (0)
     G_STAMP();  // 0 entry
     float* sx = sm;                           // [H][D]  unnormalised state
-    float* sfk = sx + H * D;                  // [N][kPandaFKS]
-    float* sG = sfk + N * kPandaFKS;          // [MAXF][NP][N][QD]  partial joint gradients
+    float* sfk = sx + H * D;                  // [N][kPandaFKS]   (not in the DENSE variant)
+    float* sG = sfk + (DENSE ? 0 : N * kPandaFKS);   // [MAXF][NP][N][QD]  partial joint gradients
     float* sC = sG + MAXF * NP * N * QD;      // [MAXF][H][QD]      clipped, weighted per-field support-point gradients
     float* sprim = sC + MAXF * H * QD;
     for (int i = threadIdx.x; i < gp.n_prim_floats; i += 64 * WPT) sprim[i] = gp.prims[i];
@@ -688,7 +716,7 @@ __global__ __launch_bounds__(512) void guide_step_panda_kernel(const GuideArgs a
 
     // ---- phase 1: interpolate + FK, once per point
     const float scale = (N > 1) ? (float)(H - 1) / (float)(N - 1) : 0.f;  // align_corners=True
-    for (int i = wv * 64 + lane; i < N; i += 64 * WPT) {
+    for (int i = wv * 64 + lane; i < N && !DENSE; i += 64 * WPT) {
         int i0 = i, i1 = i;
         float l0 = 1.f, l1 = 0.f;
         if (gp.interpolate) {
@@ -716,7 +744,7 @@ __global__ __launch_bounds__(512) void guide_step_panda_kernel(const GuideArgs a
             for (int r = 0; r < 3; ++r) fk[42 + s * 3 + r] = O[kPandaSF[s] - 1][r] + kPandaSO[s] * Z[kPandaSF[s] - 1][r];
         }
     }
-    __syncthreads();
+    if (!DENSE) __syncthreads();
     G_STAMP();  // 2 FK in LDS
 
     // ---- phase 2: forces of this wave's sphere / pair group, every field, folded to joint gradients
@@ -724,10 +752,10 @@ __global__ __launch_bounds__(512) void guide_step_panda_kernel(const GuideArgs a
         const int half = wv & 1;
         long long* trf = (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) ? a.trace + wv * 16 + 8 : nullptr;  // slots 8..: per-field stamps
         switch (wv >> 1) {  // the group is a template parameter: sphere -> frame is static, no per-joint masks
-            case 0: panda_group_forces<0>(gp, sprim, sfk, sG, half, lane, N, trf); break;
-            case 1: panda_group_forces<1>(gp, sprim, sfk, sG, half, lane, N, trf); break;
-            case 2: panda_group_forces<2>(gp, sprim, sfk, sG, half, lane, N, trf); break;
-            default: panda_group_forces<3>(gp, sprim, sfk, sG, half, lane, N, trf); break;
+            case 0: panda_group_forces<0, DENSE>(gp, sprim, sfk, sG, half, lane, N, trf, sx, H, scale); break;
+            case 1: panda_group_forces<1, DENSE>(gp, sprim, sfk, sG, half, lane, N, trf, sx, H, scale); break;
+            case 2: panda_group_forces<2, DENSE>(gp, sprim, sfk, sG, half, lane, N, trf, sx, H, scale); break;
+            default: panda_group_forces<3, DENSE>(gp, sprim, sfk, sG, half, lane, N, trf, sx, H, scale); break;
         }
     }
     G_STAMP();  // 3 this wave's forces done
@@ -809,10 +837,10 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     if ((threadIdx.x & 63) == 0) atomicMax(out + ctx, __float_as_uint(m));
 }
 
-inline size_t guide_lds_bytes(const mpdx_guide_params& gp, int H, int D) {
+inline size_t guide_lds_bytes(const mpdx_guide_params& gp, int H, int D, bool dense = false) {
     const int N = gp.interpolate ? gp.n_interp : H;
     if (gp.robot == MPDX_ROBOT_PANDA)
-        return (size_t)(H * D + N * kPandaFKS + MPDX_MAX_FIELDS * kPandaParts * N * 7 + MPDX_MAX_FIELDS * H * 7 + gp.n_prim_floats) * sizeof(float);
+        return (size_t)(H * D + (dense ? 0 : N * kPandaFKS) + MPDX_MAX_FIELDS * kPandaParts * N * 7 + MPDX_MAX_FIELDS * H * 7 + gp.n_prim_floats) * sizeof(float);
     return (size_t)(H * D + 2 * MPDX_MAX_FIELDS * N * (D / 2) + gp.n_prim_floats) * sizeof(float);
 }
 

@@ -1345,15 +1345,23 @@ static int launch_guide(const mpdx_guide_params* gp, float* x, float* grad_out, 
     if (rng) a.rng = *rng;
     if (gp->clip_grad && gp->clip_rule != 0 && gp->clip_rule != 1) return fail(MPDX_E_INVALID, "clip_rule %d (0 = 'norm', 1 = 'value')", gp->clip_rule);
     a.trace = g_guide_trace;
-    const size_t lds = guide_lds_bytes(*gp, H, D);
+    // Panda at large batch: the dense variant (no FK table, 128 VGPRs: two workgroups per CU); MPDX_GUIDE_DENSE=0/1 forces it off / on
+    static const int dense_env = getenv("MPDX_GUIDE_DENSE") ? atoi(getenv("MPDX_GUIDE_DENSE")) : -1;
+    const bool dense = gp->robot == MPDX_ROBOT_PANDA && (dense_env >= 0 ? dense_env != 0 : B >= 512) && guide_lds_bytes(*gp, H, D, true) <= 80 * 1024;
+    const size_t lds = guide_lds_bytes(*gp, H, D, dense);
     if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "guide needs %zu B of LDS (n_interp %d too large)", lds, gp->n_interp);
     if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 2 && gp->ws_dim == 2)
         hipLaunchKernelGGL((guide_step_kernel<2, 2, MPDX_ROBOT_POINTMASS, 8>), dim3(B), dim3(512), lds, st, a);
     else if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 3 && gp->ws_dim == 3)
         hipLaunchKernelGGL((guide_step_kernel<3, 3, MPDX_ROBOT_POINTMASS, 8>), dim3(B), dim3(512), lds, st, a);
     else if (gp->robot == MPDX_ROBOT_PANDA && gp->q_dim == 7 && gp->ws_dim == 3) {
-        if (int rc = raise_lds_limit((const void*)guide_step_panda_kernel)) return rc;
-        hipLaunchKernelGGL(guide_step_panda_kernel, dim3(B), dim3(512), lds, st, a);
+        if (dense) {
+            if (int rc = raise_lds_limit((const void*)guide_step_panda_kernel<true>)) return rc;
+            hipLaunchKernelGGL(guide_step_panda_kernel<true>, dim3(B), dim3(512), lds, st, a);
+        } else {
+            if (int rc = raise_lds_limit((const void*)guide_step_panda_kernel<false>)) return rc;
+            hipLaunchKernelGGL(guide_step_panda_kernel<false>, dim3(B), dim3(512), lds, st, a);
+        }
     }
     else
         return fail(MPDX_E_INVALID, "unsupported robot %d / q_dim %d / ws_dim %d", gp->robot, gp->q_dim, gp->ws_dim);
