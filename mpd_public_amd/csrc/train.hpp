@@ -361,15 +361,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const ReduceAllAr
     const ReduceAllArgs::E e = a.e[blockIdx.y];
     const float* part = a.ws + e.part;
     float* g = a.grad + e.g;
-    const size_t per = (size_t)e.M * e.N * e.KS;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
+    const unsigned per = (unsigned)e.M * e.N * e.KS, KS = (unsigned)e.KS, N = (unsigned)e.N;   // (32-bit index arithmetic, as pack_train_kernel)
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < per; i += gridDim.x * 256u) {
         float s = 0.f;
 #pragma unroll 8
         for (int z = 0; z < e.S; ++z) s += part[(size_t)z * per + i];
-        const int k = (int)(i % e.KS);
-        const size_t mn = i / e.KS;
-        const int n = (int)(mn % e.N), m = (int)(mn / e.N);
-        g[((size_t)m * e.n_tot + e.n_off + n) * e.KS + k] = s;
+        const unsigned k = i % KS, mn = i / KS;
+        const unsigned n = mn % N, m = mn / N;
+        g[((size_t)m * e.n_tot + e.n_off + n) * KS + k] = s;
     }
 }
 
@@ -388,41 +387,44 @@ struct PackDesc {
 
 __global__ __launch_bounds__(256) void pack_train_kernel(const PackDesc* __restrict__ descs, const float* __restrict__ flat, float* __restrict__ packed,
                                                          float* __restrict__ packedT) {
+    // (index arithmetic in 32 bits: a pack is far below 2^32 floats, and the 64-bit divisions of the first version - four per element -
+    //  were what the kernel spent its time on: 42 us per call for 8 M outputs)
     const PackDesc d = descs[blockIdx.y];
     const float* src = flat + d.src;
-    const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned stride = gridDim.x * 256u, i0 = blockIdx.x * 256u + threadIdx.x;
+    const unsigned n = (unsigned)d.n, pn = (unsigned)d.pn;
     if (d.kind == 0) {   // PK_VEC
-        for (size_t i = i0; i < d.pn; i += stride) packed[d.dst + i] = i < d.n ? src[i] : 0.f;
+        for (unsigned i = i0; i < pn; i += stride) packed[d.dst + i] = i < n ? src[i] : 0.f;
         return;
     }
-    const int nc16 = d.cin_pad >> 4;
-    for (size_t i = i0; i < d.pn; i += stride) {   // forward layout [m16][c16][slot][lane][4]
-        const int e = i & 3, lane = (i >> 2) & 63;
-        size_t r = i >> 8;
-        const int slot = r % d.nslot; r /= d.nslot;
-        const int c16 = r % nc16; const int m16 = (int)(r / nc16);
-        const int co = m16 * 16 + (lane & 15);
-        const int ci = c16 * 16 + (lane >> 4) * 4 + e;
+    const unsigned nc16 = (unsigned)d.cin_pad >> 4, nslot = (unsigned)d.nslot, cin = (unsigned)d.cin, cout = (unsigned)d.cout, ks = (unsigned)d.ks;
+    for (unsigned i = i0; i < pn; i += stride) {   // forward layout [m16][c16][slot][lane][4]
+        const unsigned e = i & 3, lane = (i >> 2) & 63;
+        unsigned r = i >> 8;
+        const unsigned slot = r % nslot; r /= nslot;
+        const unsigned c16 = r % nc16, m16 = r / nc16;
+        const unsigned co = m16 * 16 + (lane & 15);
+        const unsigned ci = c16 * 16 + (lane >> 4) * 4 + e;
         float v = 0.f;
-        if (ci < d.cin) {
-            if (d.kind == 2) v = src[((size_t)ci * d.cout + co) * d.ks + upt_slot_to_k(slot)];
-            else v = src[((size_t)co * d.cin + ci) * d.ks + slot];
+        if (ci < cin) {
+            if (d.kind == 2) v = src[(ci * cout + co) * ks + (unsigned)upt_slot_to_k((int)slot)];
+            else v = src[(co * cin + ci) * ks + slot];
         }
         packed[d.dst + i] = v;
     }
     if (d.dstT == ~0ull || !packedT) return;
-    const int tnc16 = d.t_cin_pad >> 4;
-    for (size_t i = i0; i < d.pnT; i += stride) {   // dgrad layout: a CONV_S1 weight [t_cout][t_cin][t_ks]
-        const int e = i & 3, lane = (i >> 2) & 63;
-        size_t r = i >> 8;
-        const int slot = r % d.t_ks; r /= d.t_ks;
-        const int c16 = r % tnc16; const int m16 = (int)(r / tnc16);
-        const int o = m16 * 16 + (lane & 15);            // output channel of the dgrad conv = input channel of the layer
-        const int ii = c16 * 16 + (lane >> 4) * 4 + e;   // input channel of the dgrad conv = output channel of the layer
+    const unsigned tnc16 = (unsigned)d.t_cin_pad >> 4, tks = (unsigned)d.t_ks, tcin = (unsigned)d.t_cin, tcout = (unsigned)d.t_cout, pnT = (unsigned)d.pnT;
+    for (unsigned i = i0; i < pnT; i += stride) {   // dgrad layout: a CONV_S1 weight [t_cout][t_cin][t_ks]
+        const unsigned e = i & 3, lane = (i >> 2) & 63;
+        unsigned r = i >> 8;
+        const unsigned slot = r % tks; r /= tks;
+        const unsigned c16 = r % tnc16, m16 = r / tnc16;
+        const unsigned o = m16 * 16 + (lane & 15);            // output channel of the dgrad conv = input channel of the layer
+        const unsigned ii = c16 * 16 + (lane >> 4) * 4 + e;   // input channel of the dgrad conv = output channel of the layer
         float v = 0.f;
-        if (ii < d.t_cin && o < d.t_cout) {
-            if (d.t_mode == 0) v = src[((size_t)ii * d.cin + o) * d.ks + (d.ks - 1 - slot)];      // W[co = ii][ci = o][k - 1 - k']
-            else if (slot > 0) v = src[((size_t)o * d.cout + ii) * d.ks + (slot - 1)];            // W[ci = o][co = ii][k' - 1]
+        if (ii < tcin && o < tcout) {
+            if (d.t_mode == 0) v = src[(ii * cin + o) * ks + (ks - 1 - slot)];      // W[co = ii][ci = o][k - 1 - k']
+            else if (slot > 0) v = src[(o * cout + ii) * ks + (slot - 1)];          // W[ci = o][co = ii][k' - 1]
         }
         packedT[d.dstT + i] = v;
     }
@@ -447,9 +449,14 @@ struct TimeTrainArgs {
     int cout[40], toff[40];
 };
 
-__global__ __launch_bounds__(128) void time_train_fwd_kernel(const TimeTrainArgs a) {
+// one block of 512 threads per sample; every stage spreads its dot products over all threads it can use and keeps its loads in flight
+// together (the first version ran encoder.3 on 32 threads x 32 dependent loads and the table on 128 threads: 17 us per call)
+__global__ __launch_bounds__(512) void time_train_fwd_kernel(const TimeTrainArgs a) {
     __shared__ float emb[32], h1m[128], tm[32];
+    __shared__ int s_toff[41];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < a.nblk) s_toff[tid] = a.toff[tid];
+    if (tid == 0) s_toff[a.nblk] = a.row;
     if (tid < 16) {
         const float arg = (float)a.t[b] * a.freqs[tid];
         emb[tid] = sinf(arg);
@@ -458,43 +465,56 @@ __global__ __launch_bounds__(128) void time_train_fwd_kernel(const TimeTrainArgs
         a.emb[(size_t)b * 32 + tid + 16] = emb[tid + 16];
     }
     __syncthreads();
-    {
+    if (tid < 128) {
         const f32x4* w = (const f32x4*)(a.flat + a.w1 + tid * 32);   // parameter offsets are multiples of 4 floats
         float s = a.flat[a.b1 + tid];
+        f32x4 wv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wv[k] = w[k];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const f32x4 wv = w[k];
-            s = fmaf(wv[0], emb[4 * k], s); s = fmaf(wv[1], emb[4 * k + 1], s); s = fmaf(wv[2], emb[4 * k + 2], s); s = fmaf(wv[3], emb[4 * k + 3], s);
+            s = fmaf(wv[k][0], emb[4 * k], s); s = fmaf(wv[k][1], emb[4 * k + 1], s); s = fmaf(wv[k][2], emb[4 * k + 2], s); s = fmaf(wv[k][3], emb[4 * k + 3], s);
         }
         a.h1[(size_t)b * 128 + tid] = s;
         h1m[tid] = mish(s);
         a.h1m[(size_t)b * 128 + tid] = h1m[tid];
     }
     __syncthreads();
-    if (tid < 32) {
-        const f32x4* w = (const f32x4*)(a.flat + a.w3 + tid * 128);
-        float s = a.flat[a.b3 + tid];
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) {
-            const f32x4 wv = w[k];
-            s = fmaf(wv[0], h1m[4 * k], s); s = fmaf(wv[1], h1m[4 * k + 1], s); s = fmaf(wv[2], h1m[4 * k + 2], s); s = fmaf(wv[3], h1m[4 * k + 3], s);
+    {   // encoder.3: row r = tid >> 4 (32 rows), 16 lanes per row take two float4 each; the sum runs k ascending inside a lane, lanes by DPP row sum
+        const int r = tid >> 4, l16 = tid & 15;
+        const f32x4* w = (const f32x4*)(a.flat + a.w3 + r * 128);
+        const f32x4 w0 = w[l16 * 2], w1 = w[l16 * 2 + 1];
+        const float* h = h1m + l16 * 8;
+        float s = w0[0] * h[0];
+        s = fmaf(w0[1], h[1], s); s = fmaf(w0[2], h[2], s); s = fmaf(w0[3], h[3], s);
+        s = fmaf(w1[0], h[4], s); s = fmaf(w1[1], h[5], s); s = fmaf(w1[2], h[6], s); s = fmaf(w1[3], h[7], s);
+        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));
+        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, true));
+        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, true));
+        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xF, 0xF, true));
+        if (l16 == 0) {
+            s += a.flat[a.b3 + r];
+            a.temb[(size_t)b * 32 + r] = s;
+            tm[r] = mish(s);
+            a.tm[(size_t)b * 32 + r] = tm[r];
         }
-        a.temb[(size_t)b * 32 + tid] = s;
-        tm[tid] = mish(s);
-        a.tm[(size_t)b * 32 + tid] = tm[tid];
     }
     __syncthreads();
-    for (int blk = 0; blk < a.nblk; ++blk)
-        for (int c = tid; c < a.cout[blk]; c += 128) {
-            const f32x4* w = (const f32x4*)(a.flat + a.woff[blk] + c * 32);
-            float s = a.flat[a.boff[blk] + c];
+    for (int rr = tid; rr < a.row; rr += 512) {   // the table row of this sample: tb[row] = W_blk[c] . mish(temb) + b_blk[c]
+        int blk = 0;
+        while (blk + 1 < a.nblk && rr >= s_toff[blk + 1]) ++blk;
+        const int c = rr - s_toff[blk];
+        const f32x4* w = (const f32x4*)(a.flat + a.woff[blk] + c * 32);
+        float s = a.flat[a.boff[blk] + c];
+        f32x4 wv[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const f32x4 wv = w[k];
-                s = fmaf(wv[0], tm[4 * k], s); s = fmaf(wv[1], tm[4 * k + 1], s); s = fmaf(wv[2], tm[4 * k + 2], s); s = fmaf(wv[3], tm[4 * k + 3], s);
-            }
-            a.tb[(size_t)b * a.row + a.toff[blk] + c] = s;
+        for (int k = 0; k < 8; ++k) wv[k] = w[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            s = fmaf(wv[k][0], tm[4 * k], s); s = fmaf(wv[k][1], tm[4 * k + 1], s); s = fmaf(wv[k][2], tm[4 * k + 2], s); s = fmaf(wv[k][3], tm[4 * k + 3], s);
         }
+        a.tb[(size_t)b * a.row + rr] = s;
+    }
 }
 
 // cond_mlp weight / bias gradients: for row index c (a channel of some block):  dW[c][e] = sum_b dT[b][c] * mish(temb[b][e]),
@@ -509,80 +529,134 @@ struct TimeBwdArgs {
     const float* tm;            // mish(temb), mish(h1) as the forward kernel stored them
     const float* h1m;
     float* dtm;                 // [B][32]  gradient wrt mish(temb), then wrt temb
-    float* dh1;                 // [B][128] gradient wrt h1
+    float* dh1;                 // [B][128] gradient wrt h1 (kept in LDS by time_bwd_all_kernel; unused)
+    unsigned* ticket;           // zero at launch: the sample blocks of time_bwd_all_kernel count themselves here
     unsigned long long w1, b1, w3, b3;
     int B, row, nblk;
     unsigned long long woff[40], boff[40];
     int cout[40], toff[40];
 };
 
-__global__ __launch_bounds__(256) void time_bwd_cond_kernel(const TimeBwdArgs a) {
-    // blockIdx.x: 8 rows of the table per block; thread = (row in block, e)
-    const int rr = blockIdx.x * 8 + (threadIdx.x >> 5), e = threadIdx.x & 31;
-    if (rr >= a.row) return;
-    int blk = 0;
-    while (blk + 1 < a.nblk && rr >= a.toff[blk + 1]) ++blk;   // toff ascending
-    const int c = rr - a.toff[blk];
-    float sw = 0.f, sb = 0.f;
-    for (int b = 0; b < a.B; ++b) {
-        const float d = a.dT[(size_t)b * a.row + rr];
-        sw = fmaf(d, a.tm[(size_t)b * 32 + e], sw);
-        sb += d;
+// The whole backward pass of the time conditioning in ONE launch of 1024-thread blocks (it used to be four dependent launches of
+// latency-bound scalar loops, 52 us per iteration at batch 32):
+//   blocks [0, B)        sample b:  dtm[b][e] = mish'(temb[b][e]) * sum_rows dT[b][row] * W_row[e]   (rows over 32 parts, dT row and the
+//                        rows' weight offsets staged in LDS, loads eight deep), then a ticket; the LAST sample block to finish runs the
+//                        tail: time_mlp.encoder.3 (dW3, db3, dh1 = mish'(h1) * W3^T dtemb) and encoder.1 (dW1, db1), 32 samples at a
+//                        time out of LDS - no block ever waits for another
+//   blocks [B, B + ...)  cond_mlp weight / bias gradients, 32 table rows per block:  dW[c][e] = sum_b dT[b][c] * mish(temb[b][e]),
+//                        db[c] = sum_b dT[b][c]
+// Every sum runs in the order of the four kernels it replaces (b ascending; table rows by part, parts ascending).
+constexpr int kTimeBwdMaxRow = 2560;
+__global__ __launch_bounds__(1024) void time_bwd_all_kernel(const TimeBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float sh[10240];   // 40 KB: stage 1 [dT row | row offsets | partial sums], tail [dtm | h1m | dh1 | emb]
+    __shared__ int s_toff[41];
+    __shared__ unsigned s_woff[40];
+    __shared__ unsigned s_ticket;
+    const int tid = threadIdx.x;
+    if (tid < a.nblk) { s_toff[tid] = a.toff[tid]; s_woff[tid] = (unsigned)a.woff[tid]; }
+    if (tid == 0) s_toff[a.nblk] = a.row;
+    __syncthreads();
+    auto block_of = [&](int r) { int blk = 0; while (blk + 1 < a.nblk && r >= s_toff[blk + 1]) ++blk; return blk; };   // toff ascending
+    if ((int)blockIdx.x >= a.B) {   // ---------------------------------------------- cond_mlp gradients of 32 table rows
+        const int rr = ((int)blockIdx.x - a.B) * 32 + (tid >> 5), e = tid & 31;
+        if (rr >= a.row) return;
+        const int blk = block_of(rr);
+        const int c = rr - s_toff[blk];
+        float sw = 0.f, sb = 0.f;
+#pragma unroll 8
+        for (int b = 0; b < a.B; ++b) {
+            const float d = a.dT[(size_t)b * a.row + rr];
+            sw = fmaf(d, a.tm[(size_t)b * 32 + e], sw);
+            sb += d;
+        }
+        a.grad[a.woff[blk] + (size_t)c * 32 + e] = sw;
+        if (e == 0) a.grad[a.boff[blk] + c] = sb;
+        return;
     }
-    a.grad[a.woff[blk] + (size_t)c * 32 + e] = sw;
-    if (e == 0) a.grad[a.boff[blk] + c] = sb;
-}
-
-// gradient wrt temb:  dtm[b][e] = mish'(temb[b][e]) * sum_rows dT[b][row] * W_row[e]        one block per sample
-__global__ __launch_bounds__(1024) void time_bwd_temb_kernel(const TimeBwdArgs a) {
-    __shared__ float red[32][32];
-    const int b = blockIdx.x, e = threadIdx.x & 31, part = threadIdx.x >> 5;
-    float s = 0.f;
-    for (int blk = 0; blk < a.nblk; ++blk)
-        for (int c = part; c < a.cout[blk]; c += 32)
-            s = fmaf(a.dT[(size_t)b * a.row + a.toff[blk] + c], a.flat[a.woff[blk] + (size_t)c * 32 + e], s);
-    red[part][e] = s;
+    // ------------------------------------------------------------------------------- sample b: gradient wrt temb
+    const int b = blockIdx.x, e = tid & 31, part = tid >> 5;
+    float* const dTs = sh;
+    unsigned* const roff = (unsigned*)(sh + kTimeBwdMaxRow);
+    float* const red = sh + 2 * kTimeBwdMaxRow;   // [32][32]
+    for (int r = tid; r < a.row; r += 1024) {
+        dTs[r] = a.dT[(size_t)b * a.row + r];
+        const int blk = block_of(r);
+        roff[r] = s_woff[blk] + (unsigned)(r - s_toff[blk]) * 32u;
+    }
+    __syncthreads();
+    {
+        float s = 0.f;
+#pragma unroll 8
+        for (int r = part; r < a.row; r += 32) s = fmaf(dTs[r], a.flat[roff[r] + e], s);
+        red[part * 32 + e] = s;
+    }
     __syncthreads();
     if (part == 0) {
         float t = 0.f;
-        for (int p = 0; p < 32; ++p) t += red[p][e];
+        for (int p = 0; p < 32; ++p) t += red[p * 32 + e];
         a.dtm[(size_t)b * 32 + e] = t * mish_grad(a.temb[(size_t)b * 32 + e]);
     }
-}
-
-// time_mlp.encoder.3 (Linear 128 -> 32): dW3[e][k] = sum_b dtemb[b][e] mish(h1[b][k]); db3; dh1[b][k] = mish'(h1) sum_e dtemb[b][e] W3[e][k]
-// grid: 32 blocks (e) x 128 threads (k) for the weight gradient, then B blocks for dh1 (blockIdx.x >= 32)
-__global__ __launch_bounds__(128) void time_bwd_l3_kernel(const TimeBwdArgs a) {
-    const int k = threadIdx.x;
-    if (blockIdx.x < 32) {
-        const int e = blockIdx.x;
-        float sw = 0.f, sb = 0.f;
-        for (int b = 0; b < a.B; ++b) {
-            const float d = a.dtm[(size_t)b * 32 + e];
-            sw = fmaf(d, a.h1m[(size_t)b * 128 + k], sw);
-            sb += d;
+    __threadfence();   // this block's dtm row is visible device-wide before its ticket
+    __syncthreads();
+    if (tid == 0) s_ticket = atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    if (s_ticket != (unsigned)a.B - 1u) return;
+    __threadfence();   // the last block: every other sample's dtm row is visible to the loads below
+    // ------------------------------------------------------------------------------- tail (one block): encoder.3 and encoder.1
+    float* const dtmS = sh;            // [32][32]
+    float* const h1mS = sh + 1024;     // [32][128]
+    float* const dh1S = sh + 5120;     // [32][128]
+    float* const embS = sh + 9216;     // [32][32]
+    const int k = tid & 127, q8 = tid >> 7;     // encoder.3: this thread's column k; rows e = q8 + 8 i (dW3), samples bb = q8 + 8 i (dh1)
+    const int j = tid & 31, k0 = tid >> 5;      // encoder.1: this thread's column j; rows k = k0 + 32 i
+    float w3g[4] = {0.f, 0.f, 0.f, 0.f}, b3g[4] = {0.f, 0.f, 0.f, 0.f}, w1g[4] = {0.f, 0.f, 0.f, 0.f}, b1g[4] = {0.f, 0.f, 0.f, 0.f};
+    float w3c[32];   // W3[e][k], e = 0..31 (this thread's column)
+#pragma unroll
+    for (int ee = 0; ee < 32; ++ee) w3c[ee] = a.flat[a.w3 + (size_t)ee * 128 + k];
+    for (int b0 = 0; b0 < a.B; b0 += 32) {
+        const int nb = a.B - b0 < 32 ? a.B - b0 : 32;
+        __syncthreads();
+        for (int i = tid; i < nb * 32; i += 1024) { dtmS[i] = a.dtm[(size_t)b0 * 32 + i]; embS[i] = a.emb[(size_t)b0 * 32 + i]; }
+        for (int i = tid; i < nb * 128; i += 1024) h1mS[i] = a.h1m[(size_t)b0 * 128 + i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // dW3[e][k] += sum_b dtemb[b][e] mish(h1[b][k]);  db3[e] += sum_b dtemb[b][e]
+            const int ee = q8 + 8 * i;
+            for (int bb = 0; bb < nb; ++bb) {
+                const float d = dtmS[bb * 32 + ee];
+                w3g[i] = fmaf(d, h1mS[bb * 128 + k], w3g[i]);
+                b3g[i] += d;
+            }
         }
-        a.grad[a.w3 + (size_t)e * 128 + k] = sw;
-        if (k == 0) a.grad[a.b3 + e] = sb;
-    } else {
-        const int b = blockIdx.x - 32;
-        float s = 0.f;
-        for (int e = 0; e < 32; ++e) s = fmaf(a.dtm[(size_t)b * 32 + e], a.flat[a.w3 + (size_t)e * 128 + k], s);
-        a.dh1[(size_t)b * 128 + k] = s * mish_grad(a.h1[(size_t)b * 128 + k]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // dh1[b][k] = mish'(h1[b][k]) sum_e dtemb[b][e] W3[e][k]
+            const int bb = q8 + 8 * i;
+            if (bb < nb) {
+                float s = 0.f;
+#pragma unroll
+                for (int ee = 0; ee < 32; ++ee) s = fmaf(dtmS[bb * 32 + ee], w3c[ee], s);
+                dh1S[bb * 128 + k] = s * mish_grad(a.h1[(size_t)(b0 + bb) * 128 + k]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // dW1[k][j] += sum_b dh1[b][k] emb[b][j];  db1[k] += sum_b dh1[b][k]
+            const int kk = k0 + 32 * i;
+            for (int bb = 0; bb < nb; ++bb) {
+                const float d = dh1S[bb * 128 + kk];
+                w1g[i] = fmaf(d, embS[bb * 32 + j], w1g[i]);
+                b1g[i] += d;
+            }
+        }
     }
-}
-
-// time_mlp.encoder.1 (Linear 32 -> 128): dW1[k][j] = sum_b dh1[b][k] emb[b][j]; db1[k] = sum_b dh1[b][k].   128 blocks x 32 threads
-__global__ __launch_bounds__(32) void time_bwd_l1_kernel(const TimeBwdArgs a) {
-    const int k = blockIdx.x, j = threadIdx.x;
-    float sw = 0.f, sb = 0.f;
-    for (int b = 0; b < a.B; ++b) {
-        const float d = a.dh1[(size_t)b * 128 + k];
-        sw = fmaf(d, a.emb[(size_t)b * 32 + j], sw);
-        sb += d;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ee = q8 + 8 * i, kk = k0 + 32 * i;
+        a.grad[a.w3 + (size_t)ee * 128 + k] = w3g[i];
+        if (k == 0) a.grad[a.b3 + ee] = b3g[i];
+        a.grad[a.w1 + (size_t)kk * 32 + j] = w1g[i];
+        if (j == 0) a.grad[a.b1 + kk] = b1g[i];
     }
-    a.grad[a.w1 + (size_t)k * 32 + j] = sw;
-    if (j == 0) a.grad[a.b1 + k] = sb;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

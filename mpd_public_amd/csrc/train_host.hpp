@@ -71,7 +71,7 @@ static int ensure_pack_descs(mpdx_unet* u) {
 
 // workspace layout for a batch of B (float offsets)
 struct TrainWs {
-    size_t xn, eps, dE, out0, pre0, grad0, tmpX, dU, zst, pvec, wpart, rpart, emb, h1, temb, tm, h1m, tb, dT, dtm, dh1, zeros, norm, total;
+    size_t xn, eps, dE, out0, pre0, grad0, tmpX, dU, zst, pvec, wpart, rpart, emb, h1, temb, tm, h1m, tb, dT, dtm, dh1, zeros, ticket, norm, total;
     size_t slotB;          // floats of one activation slot for the batch
     size_t wpart_floats;
     // deferred reductions (one launch each at the end of the backward pass): every layer keeps its own partial sums
@@ -133,6 +133,7 @@ static TrainWs train_ws(const mpdx_unet* u, int B) {
     w.tb = take((size_t)B * u->tt_row); w.dT = take((size_t)B * u->tt_row);
     w.dtm = take((size_t)B * 32); w.dh1 = take((size_t)B * 128);
     w.zeros = take(1024);
+    w.ticket = take(4);      // directly behind `zeros`: one memset clears both
     w.norm = take(1024 + 8);
     w.total = o;
     return w;
@@ -364,7 +365,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
 
     // ---- forward, every layer's output (and GroupNorm input) kept
     HIP_TRY(hipMemsetAsync(ws + w.grad0, 0, (size_t)n * w.slotB * sizeof(float), st));
-    HIP_TRY(hipMemsetAsync(ws + w.zeros, 0, 1024 * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(ws + w.zeros, 0, (1024 + 4) * sizeof(float), st));   // the zero bias of the dgrad convolutions + the time backward's ticket
     {
         const size_t ne = (size_t)B * H * D;
         hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)std::min<size_t>((ne + 255) / 256, 2048)), dim3(256), 0, st, x_start, noise, t_dev,
@@ -386,9 +387,10 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             ta.woff[i] = u->params[u->tt_w[i]].foff; ta.boff[i] = u->params[u->tt_b[i]].foff;
             ta.cout[i] = u->tt_cout[i]; ta.toff[i] = u->tt_off[i];
         }
-        hipLaunchKernelGGL(time_train_fwd_kernel, dim3(B), dim3(128), 0, st, ta);
+        hipLaunchKernelGGL(time_train_fwd_kernel, dim3(B), dim3(512), 0, st, ta);
         tb.flat = flat; tb.grad = grads_flat; tb.dT = ws + w.dT; tb.emb = ta.emb; tb.h1 = ta.h1; tb.temb = ta.temb; tb.tm = ta.tm; tb.h1m = ta.h1m;
-        tb.dtm = ws + w.dtm; tb.dh1 = ws + w.dh1;
+        tb.dtm = ws + w.dtm; tb.dh1 = ws + w.dh1; tb.ticket = (unsigned*)(ws + w.ticket);
+        if (tb.row > kTimeBwdMaxRow) return fail(MPDX_E_INVALID, "time table row of %d floats (the training kernels take %d)", tb.row, kTimeBwdMaxRow);
         tb.w1 = ta.w1; tb.b1 = ta.b1; tb.w3 = ta.w3; tb.b3 = ta.b3;
         tb.B = B; tb.row = ta.row; tb.nblk = ta.nblk;
         for (int i = 0; i < ta.nblk; ++i) { tb.woff[i] = ta.woff[i]; tb.boff[i] = ta.boff[i]; tb.cout[i] = ta.cout[i]; tb.toff[i] = ta.toff[i]; }
@@ -573,10 +575,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     if (df.red.n) hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(48, df.red.n), dim3(256), 0, st, df.red);
     if (df.col.n) hipLaunchKernelGGL(colsum_all_kernel, dim3(2, df.col.n), dim3(256), 0, st, df.col);
     // time MLP
-    hipLaunchKernelGGL(time_bwd_cond_kernel, dim3((tb.row + 7) / 8), dim3(256), 0, st, tb);
-    hipLaunchKernelGGL(time_bwd_temb_kernel, dim3(B), dim3(1024), 0, st, tb);
-    hipLaunchKernelGGL(time_bwd_l3_kernel, dim3(32 + B), dim3(128), 0, st, tb);
-    hipLaunchKernelGGL(time_bwd_l1_kernel, dim3(128), dim3(32), 0, st, tb);
+    hipLaunchKernelGGL(time_bwd_all_kernel, dim3(B + (tb.row + 31) / 32), dim3(1024), 0, st, tb);
     HIP_TRY(hipGetLastError());
     return 0;
 }
