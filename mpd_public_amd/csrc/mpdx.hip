@@ -364,6 +364,8 @@ struct mpdx_unet {
     std::vector<TrainLayer> tl;
     std::vector<mpdx::PackDesc> pack_descs_host;
     void* pack_descs_dev = nullptr;
+    void* pack_chunks_dev = nullptr;   // PackChunk table of pack_train_kernel
+    size_t n_pack_chunks = 0;
 };
 
 namespace mpdx {
@@ -1409,6 +1411,7 @@ int mpdx_unet_create(const mpdx_unet_cfg* cfg, mpdx_unet** out) {
 
 void mpdx_unet_destroy(mpdx_unet* u) {
     if (u && u->pack_descs_dev) (void)hipFree(u->pack_descs_dev);
+    if (u && u->pack_chunks_dev) (void)hipFree(u->pack_chunks_dev);
     if (u && u->jobs_dev) (void)hipFree(u->jobs_dev);
     delete u;
 }

@@ -356,19 +356,33 @@ struct ReduceAllArgs {
     float* grad;
     int n;
     struct E { unsigned long long part, g; int S, M, N, KS, n_tot, n_off; } e[96];
+    int cstart[97];   // first block of entry j (1024 outputs per block); cstart[n] = blocks of the launch
 };
+// one block = 1024 outputs of one entry (found by bisection of cstart): every block has work, a thread's loads fly together
 __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const ReduceAllArgs a) {
-    const ReduceAllArgs::E e = a.e[blockIdx.y];
+    int lo = 0, hi = a.n;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)blockIdx.x >= a.cstart[mid]) lo = mid; else hi = mid; }
+    const ReduceAllArgs::E e = a.e[lo];
     const float* part = a.ws + e.part;
     float* g = a.grad + e.g;
     const unsigned per = (unsigned)e.M * e.N * e.KS, KS = (unsigned)e.KS, N = (unsigned)e.N;   // (32-bit index arithmetic, as pack_train_kernel)
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < per; i += gridDim.x * 256u) {
-        float s = 0.f;
-#pragma unroll 8
-        for (int z = 0; z < e.S; ++z) s += part[(size_t)z * per + i];
-        const unsigned k = i % KS, mn = i / KS;
+    const unsigned base = (blockIdx.x - (unsigned)a.cstart[lo]) * 1024u + threadIdx.x;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int z = 0; z < e.S; ++z) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned i = base + k * 256u;
+            s[k] += part[(size_t)z * per + (i < per ? i : 0u)];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned i = base + k * 256u;
+        if (i >= per) continue;
+        const unsigned kk = i % KS, mn = i / KS;
         const unsigned n = mn % N, m = mn / N;
-        g[((size_t)m * e.n_tot + e.n_off + n) * KS + k] = s;
+        g[((size_t)m * e.n_tot + e.n_off + n) * KS + kk] = s[k];
     }
 }
 
@@ -385,48 +399,67 @@ struct PackDesc {
     int t_mode;                          // 0: transpose + flip (Conv1d), 1: ConvTranspose1d k4 -> 5 taps
 };
 
-__global__ __launch_bounds__(256) void pack_train_kernel(const PackDesc* __restrict__ descs, const float* __restrict__ flat, float* __restrict__ packed,
-                                                         float* __restrict__ packedT) {
-    // (index arithmetic in 32 bits: a pack is far below 2^32 floats, and the 64-bit divisions of the first version - four per element -
-    //  were what the kernel spent its time on: 42 us per call for 8 M outputs)
-    const PackDesc d = descs[blockIdx.y];
+// One block = one CHUNK of 1024 outputs of one pack of one parameter (table built once on the host): every block of the launch has work,
+// a thread's four loads fly together (unconditional, from clamped addresses; zeros selected afterwards), index arithmetic in 32 bits.
+// (First version: grid (64, parameters), each thread looping over its parameter with one dependent load per trip and four 64-bit
+//  divisions per element - 42 us per call for 8 M outputs.)
+struct PackChunk { int desc; int which; unsigned first; unsigned pad; };   // which: 0 forward pack (vectors too), 1 dgrad pack
+
+__global__ __launch_bounds__(256) void pack_train_kernel(const PackDesc* __restrict__ descs, const PackChunk* __restrict__ chunks, const float* __restrict__ flat,
+                                                         float* __restrict__ packed, float* __restrict__ packedT) {
+    const PackChunk c = chunks[blockIdx.x];
+    const PackDesc d = descs[c.desc];
     const float* src = flat + d.src;
-    const unsigned stride = gridDim.x * 256u, i0 = blockIdx.x * 256u + threadIdx.x;
-    const unsigned n = (unsigned)d.n, pn = (unsigned)d.pn;
-    if (d.kind == 0) {   // PK_VEC
-        for (unsigned i = i0; i < pn; i += stride) packed[d.dst + i] = i < n ? src[i] : 0.f;
-        return;
-    }
-    const unsigned nc16 = (unsigned)d.cin_pad >> 4, nslot = (unsigned)d.nslot, cin = (unsigned)d.cin, cout = (unsigned)d.cout, ks = (unsigned)d.ks;
-    for (unsigned i = i0; i < pn; i += stride) {   // forward layout [m16][c16][slot][lane][4]
-        const unsigned e = i & 3, lane = (i >> 2) & 63;
-        unsigned r = i >> 8;
-        const unsigned slot = r % nslot; r /= nslot;
-        const unsigned c16 = r % nc16, m16 = r / nc16;
-        const unsigned co = m16 * 16 + (lane & 15);
-        const unsigned ci = c16 * 16 + (lane >> 4) * 4 + e;
-        float v = 0.f;
-        if (ci < cin) {
-            if (d.kind == 2) v = src[(ci * cout + co) * ks + (unsigned)upt_slot_to_k((int)slot)];
-            else v = src[(co * cin + ci) * ks + slot];
+    const unsigned n = (unsigned)d.n;
+    const unsigned cin = (unsigned)d.cin, cout = (unsigned)d.cout, ks = (unsigned)d.ks;
+    unsigned idx[4], sa[4];
+    bool in[4], ok[4];
+    float v[4];
+    if (c.which == 0) {
+        const unsigned pn = (unsigned)d.pn, nc16 = (unsigned)d.cin_pad >> 4, nslot = (unsigned)d.nslot;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned i = c.first + k * 256u + threadIdx.x;
+            idx[k] = i; in[k] = i < pn;
+            if (d.kind == 0) { ok[k] = i < n; sa[k] = i; }   // PK_VEC
+            else {   // forward layout [m16][c16][slot][lane][4]
+                const unsigned e = i & 3, lane = (i >> 2) & 63;
+                unsigned r = i >> 8;
+                const unsigned slot = r % nslot; r /= nslot;
+                const unsigned c16 = r % nc16, m16 = r / nc16;
+                const unsigned co = m16 * 16 + (lane & 15), ci = c16 * 16 + (lane >> 4) * 4 + e;
+                ok[k] = ci < cin;
+                sa[k] = d.kind == 2 ? (ci * cout + co) * ks + (unsigned)upt_slot_to_k((int)slot) : (co * cin + ci) * ks + slot;
+            }
+            ok[k] = ok[k] && in[k];
         }
-        packed[d.dst + i] = v;
-    }
-    if (d.dstT == ~0ull || !packedT) return;
-    const unsigned tnc16 = (unsigned)d.t_cin_pad >> 4, tks = (unsigned)d.t_ks, tcin = (unsigned)d.t_cin, tcout = (unsigned)d.t_cout, pnT = (unsigned)d.pnT;
-    for (unsigned i = i0; i < pnT; i += stride) {   // dgrad layout: a CONV_S1 weight [t_cout][t_cin][t_ks]
-        const unsigned e = i & 3, lane = (i >> 2) & 63;
-        unsigned r = i >> 8;
-        const unsigned slot = r % tks; r /= tks;
-        const unsigned c16 = r % tnc16, m16 = r / tnc16;
-        const unsigned o = m16 * 16 + (lane & 15);            // output channel of the dgrad conv = input channel of the layer
-        const unsigned ii = c16 * 16 + (lane >> 4) * 4 + e;   // input channel of the dgrad conv = output channel of the layer
-        float v = 0.f;
-        if (ii < tcin && o < tcout) {
-            if (d.t_mode == 0) v = src[(ii * cin + o) * ks + (ks - 1 - slot)];      // W[co = ii][ci = o][k - 1 - k']
-            else if (slot > 0) v = src[(o * cout + ii) * ks + (slot - 1)];          // W[ci = o][co = ii][k' - 1]
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = src[ok[k] ? sa[k] : 0u];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (in[k]) packed[d.dst + idx[k]] = ok[k] ? v[k] : 0.f;
+    } else {   // dgrad layout: a CONV_S1 weight [t_cout][t_cin][t_ks]
+        if (!packedT) return;
+        const unsigned tnc16 = (unsigned)d.t_cin_pad >> 4, tks = (unsigned)d.t_ks, tcin = (unsigned)d.t_cin, tcout = (unsigned)d.t_cout, pnT = (unsigned)d.pnT;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned i = c.first + k * 256u + threadIdx.x;
+            idx[k] = i; in[k] = i < pnT;
+            const unsigned e = i & 3, lane = (i >> 2) & 63;
+            unsigned r = i >> 8;
+            const unsigned slot = r % tks; r /= tks;
+            const unsigned c16 = r % tnc16, m16 = r / tnc16;
+            const unsigned o = m16 * 16 + (lane & 15);            // output channel of the dgrad conv = input channel of the layer
+            const unsigned ii = c16 * 16 + (lane >> 4) * 4 + e;   // input channel of the dgrad conv = output channel of the layer
+            ok[k] = in[k] && ii < tcin && o < tcout && (d.t_mode == 0 || slot > 0);
+            sa[k] = d.t_mode == 0 ? (ii * cin + o) * ks + (ks - 1 - slot)      // W[co = ii][ci = o][k - 1 - k']
+                                  : (o * cout + ii) * ks + (slot - 1);          // W[ci = o][co = ii][k' - 1]
         }
-        packedT[d.dstT + i] = v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = src[ok[k] ? sa[k] : 0u];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (in[k]) packedT[d.dstT + idx[k]] = ok[k] ? v[k] : 0.f;
     }
 }
 

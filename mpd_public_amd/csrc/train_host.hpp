@@ -64,6 +64,18 @@ static void build_train_plan(mpdx_unet* u) {
 
 static int ensure_pack_descs(mpdx_unet* u) {
     if (u->pack_descs_dev) return 0;
+    // the chunk table of pack_train_kernel: 1024 outputs of one pack of one parameter per block
+    std::vector<PackChunk> chunks;
+    for (size_t k = 0; k < u->pack_descs_host.size(); ++k) {
+        const PackDesc& d = u->pack_descs_host[k];
+        if (d.pn >= (1ull << 32) || d.pnT >= (1ull << 32) || d.n >= (1ull << 32)) return fail(MPDX_E_INVALID, "parameter %zu: more than 2^32 packed floats", k);
+        for (unsigned long long f = 0; f < d.pn; f += 1024) chunks.push_back(PackChunk{(int)k, 0, (unsigned)f, 0u});
+        if (d.dstT != ~0ull)
+            for (unsigned long long f = 0; f < d.pnT; f += 1024) chunks.push_back(PackChunk{(int)k, 1, (unsigned)f, 0u});
+    }
+    u->n_pack_chunks = chunks.size();
+    HIP_TRY(hipMalloc(&u->pack_chunks_dev, chunks.size() * sizeof(PackChunk)));
+    HIP_TRY(hipMemcpy(u->pack_chunks_dev, chunks.data(), chunks.size() * sizeof(PackChunk), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&u->pack_descs_dev, u->pack_descs_host.size() * sizeof(PackDesc)));
     HIP_TRY(hipMemcpy(u->pack_descs_dev, u->pack_descs_host.data(), u->pack_descs_host.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
     return 0;
@@ -329,8 +341,8 @@ int mpdx_train_pack(mpdx_unet* u, const float* flat, float* packed, float* packe
     if (!u || !flat || !packed) return fail(MPDX_E_INVALID, "null argument");
     build_train_plan(u);
     if (int rc = ensure_pack_descs(u)) return rc;
-    hipLaunchKernelGGL(pack_train_kernel, dim3(64, (unsigned)u->params.size()), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)u->pack_descs_dev, flat,
-                       packed, packedT);
+    hipLaunchKernelGGL(pack_train_kernel, dim3((unsigned)u->n_pack_chunks), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)u->pack_descs_dev,
+                       (const PackChunk*)u->pack_chunks_dev, flat, packed, packedT);
     HIP_TRY(hipGetLastError());
     for (auto& p : u->params) if (!p.done) { p.done = true; u->n_done++; }
     u->pack_version++;
@@ -572,7 +584,15 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             if (l.mode == CONV_UPT && t.src1_l >= 0) launch_acc(grd(t.src1_l), ws + w.tmpX, B, l.L_in, l.c1, dgl.L_out, Cin, 0, 2, st);
         }
     }
-    if (df.red.n) hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(48, df.red.n), dim3(256), 0, st, df.red);
+    if (df.red.n) {
+        int blocks = 0;
+        for (int k = 0; k < df.red.n; ++k) {
+            df.red.cstart[k] = blocks;
+            blocks += (int)(((size_t)df.red.e[k].M * df.red.e[k].N * df.red.e[k].KS + 1023) / 1024);
+        }
+        df.red.cstart[df.red.n] = blocks;
+        hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(blocks), dim3(256), 0, st, df.red);
+    }
     if (df.col.n) hipLaunchKernelGGL(colsum_all_kernel, dim3(2, df.col.n), dim3(256), 0, st, df.col);
     // time MLP
     hipLaunchKernelGGL(time_bwd_all_kernel, dim3(B + (tb.row + 31) / 32), dim3(1024), 0, st, tb);
