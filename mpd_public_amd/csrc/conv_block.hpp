@@ -48,7 +48,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 enum : int { CONV_S1 = 0, CONV_DOWN = 1, CONV_UPT = 2 };
-enum : int { EPI_BIAS = 0, EPI_GN_MISH = 1, EPI_GN_MISH_GEN = 2 };   // _GEN: GroupNorm regions other than 128 / 256 elements (horizons other than 64)
+enum : int { EPI_BIAS = 0, EPI_GN_MISH = 1, EPI_GN_MISH_GEN = 2, EPI_GN_BWD = 3 };   // _GEN: GroupNorm regions other than 128 / 256 elements (horizons other than 64)
 
 struct ConvArgs {
     const float* src1;   // [B][L_in][c1]
@@ -78,6 +78,13 @@ struct ConvArgs {
     // back into its two sources; either destination may be null = not needed), and with `accum` the result is ADDED to the destination
     float* dst2;
     int c_split, accum;
+    // EPI_GN_BWD only (training): the convolution's result is the gradient wrt the OUTPUT of the Conv1dBlock that produced this
+    // convolution's input; the epilogue takes it through that block's Mish + GroupNorm backward (gn_mish_bwd_kernel's arithmetic) and
+    // stores the gradient wrt the block's convolution output in dst.  `res` = that block's GroupNorm input (the forward's `pre`),
+    // gamma / beta = its GroupNorm parameters, bias = zeros; bw_pg / bw_pb / bw_pbias [B][C_out]: per-trajectory channel sums of
+    // (g * vhat), (g), (du);  bw_dT (or null): per-trajectory channel sums of the incoming gradient (the block's time-bias gradient)
+    float* bw_pg; float* bw_pb; float* bw_pbias; float* bw_dT;
+    int bw_dT_stride;
 };
 
 // wave64 all-reduce (sum) with DPP row operations + 4 readlanes instead of a 6-step ds_bpermute butterfly:
@@ -125,6 +132,15 @@ __device__ __forceinline__ float mish(float x) {
     const float n = e * (e + 2.0f);
     const float r = x * (n * __builtin_amdgcn_rcpf(n + 2.0f));
     return x > 20.0f ? x : r;   // (x > 44: n overflows, r is NaN, the select takes x)
+}
+
+// d/dv [ v * tanh(softplus(v)) ]   (training: GroupNorm + Mish backward)
+__device__ __forceinline__ float mish_grad(float v) {
+    const float e = __expf(fminf(v, 20.0f));
+    const float n = (1.0f + e) * (1.0f + e);
+    const float th = (n - 1.0f) / (n + 1.0f);          // tanh(softplus(v))
+    const float sg = e / (1.0f + e);                   // sigmoid(v)
+    return th + v * (1.0f - th * th) * sg;
 }
 
 // 1/sqrt(var + eps) of GroupNorm on v_rsq_f32 (~1 ulp) instead of the IEEE sqrt + divide sequences (~40 dependent instructions)
@@ -507,6 +523,84 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                 y += rs1;
                 if (b < a.B) a.dst[o] = y;
             }
+        }
+    } else
+    if constexpr (EPI == EPI_GN_BWD) {
+        // Mish + GroupNorm BACKWARD of the Conv1dBlock below this input-gradient convolution, one wave per GroupNorm region exactly as
+        // EPI_GN_MISH places them (lane -> EPL consecutive channels of one position): the arithmetic and the summation orders of
+        // gn_mish_bwd_kernel (train.hpp), which this epilogue replaces together with its launch.
+        const int gs = a.gs;
+        const int lg_gpt = (MT == 32 ? 5 : 4) - a.lg_gs;
+        const int gpt = 1 << lg_gpt;
+        const int nreg = spt << lg_gpt;
+        const int re = gs << a.lg_Lout;    // 256 or 128 (checked on the host)
+        auto region = [&](auto epl_, int s, int gl, int b) {
+            constexpr int EPL = decltype(epl_)::value;
+            const float inv_n = 1.0f / (float)(64 * EPL);
+            const int e0 = lane * EPL;
+            const int l = e0 >> a.lg_gs, c = gl * gs + (e0 & (gs - 1));
+            const int n = s * L_out + l, co = mt * MT + c;
+            const int bb = b < a.B ? b : 0;
+            const size_t o = ((size_t)bb * L_out + l) * a.C_out + co;
+            float u[EPL], gy[EPL], ga[EPL], be[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { u[e] = a.res[o + e]; ga[e] = a.gamma[co + e]; be[e] = a.beta[co + e]; }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                float v = red[(size_t)n * MTP + c + e];
+#pragma unroll
+                for (int k = 1; k < WK; ++k) v += red[((size_t)(k * NT + n)) * MTP + c + e];
+                gy[e] = v + a.bias[co + e];
+            }
+            float sm = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) sm += u[e];
+            const float mean = wave_sum(sm) * inv_n;
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { u[e] -= mean; q += u[e] * u[e]; }
+            const float var = wave_sum(q) * inv_n;
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+            float vh[EPL], gm[EPL], dvh[EPL];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                vh[e] = u[e] * rstd;
+                gm[e] = gy[e] * mish_grad(vh[e] * ga[e] + be[e]);
+                dvh[e] = gm[e] * ga[e];
+                s1 += dvh[e];
+                s2 += dvh[e] * vh[e];
+            }
+            s1 = wave_sum(s1) * inv_n;
+            s2 = wave_sum(s2) * inv_n;
+            float du[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                du[e] = rstd * (dvh[e] - s1 - vh[e] * s2);
+                if (b < a.B) a.dst[o + e] = du[e];
+            }
+            float r[4 * EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { r[e] = gm[e] * vh[e]; r[EPL + e] = gm[e]; r[2 * EPL + e] = du[e]; r[3 * EPL + e] = gy[e]; }
+            for (int off = gs / EPL; off < 64; off <<= 1) {
+#pragma unroll
+                for (int k = 0; k < 4 * EPL; ++k) r[k] += __shfl_xor(r[k], off, 64);
+            }
+            if (l == 0 && b < a.B) {
+                const size_t po = (size_t)b * a.C_out + co;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    a.bw_pg[po + e] = r[e];
+                    a.bw_pb[po + e] = r[EPL + e];
+                    a.bw_pbias[po + e] = r[2 * EPL + e];
+                    if (a.bw_dT) a.bw_dT[(size_t)b * a.bw_dT_stride + co + e] = r[3 * EPL + e];
+                }
+            }
+        };
+        for (int r = wave; r < nreg; r += NWAVE) {
+            const int s = r >> lg_gpt, gl = r & (gpt - 1);
+            if (re == 256) region(std::integral_constant<int, 4>{}, s, gl, s0 + s);
+            else region(std::integral_constant<int, 2>{}, s, gl, s0 + s);
         }
     } else
     if (EPI == EPI_GN_MISH) {

@@ -30,14 +30,6 @@
 
 namespace mpdx {
 
-// d/dv [ v * tanh(softplus(v)) ]
-__device__ __forceinline__ float mish_grad(float v) {
-    const float e = __expf(fminf(v, 20.0f));
-    const float n = (1.0f + e) * (1.0f + e);
-    const float th = (n - 1.0f) / (n + 1.0f);          // tanh(softplus(v))
-    const float sg = e / (1.0f + e);                   // sigmoid(v)
-    return th + v * (1.0f - th * th) * sg;
-}
 __device__ __forceinline__ float mish_ref(float v) {   // same formula as the forward kernels' mish()
     return mish(v);
 }
@@ -314,10 +306,11 @@ struct BwdPairArgs {
     int gx[2], gy[2];    // their grids: x = N tiles, y = M tiles, z = batch splits
     int ks_w;            // taps of the weight gradient (1, 3, 4 or 5)
 };
-template <int KS_D, int MT, int NT>
+// EPI_D = EPI_GN_BWD: the dgrad blocks also take their result through the Mish + GroupNorm backward of the Conv1dBlock below (conv_block.hpp)
+template <int KS_D, int MT, int NT, int EPI_D = EPI_BIAS>
 __global__ __launch_bounds__(512) void bwd_pair_kernel(const BwdPairArgs a) {
     if ((int)blockIdx.x < a.n_dgrad) {
-        conv_block_body<CONV_S1, KS_D, EPI_BIAS, MT, NT, 1, 8>(a.cd, blockIdx.x);
+        conv_block_body<CONV_S1, KS_D, EPI_D, MT, NT, 1, 8>(a.cd, blockIdx.x);
         return;
     }
     if (threadIdx.x >= 256) return;

@@ -246,7 +246,9 @@ static int launch_wgrad(const float* A, int LA, int lda, int a_off, int M, const
 }
 
 // dgrad convolution + the layer's weight-gradient GEMM(s) in ONE launch (bwd_pair_kernel); the jobs must use distinct partial buffers
-template <int KS_D>
+// GN_BWD: the dgrad blocks run the EPI_GN_BWD epilogue (cd carries its operands; `dgl` then has epi = EPI_GN_MISH and the group size
+// of the Conv1dBlock below, so that the tile holds whole GroupNorm regions)
+template <int KS_D, bool GN_BWD = false>
 static int launch_bwd_pair(const Layer& dgl, ConvArgs& cd, int B, const WgradJob* jobs, int njobs, hipStream_t st) {
     int MT, NT;
     choose_tile(dgl, B, MT, NT);
@@ -271,7 +273,7 @@ static int launch_bwd_pair(const Layer& dgl, ConvArgs& cd, int B, const WgradJob
     if (MT == mt && NT == nt) {                                                                           \
         lds = std::max(lds, conv_block_lds_bytes<CONV_S1, KS_D, mt, nt, 8>(cd.L_in, cd.L_out, cd.rs));      \
         if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "backward pair needs %zu B of LDS", lds);        \
-        auto kern = bwd_pair_kernel<KS_D, mt, nt>;                                                        \
+        auto kern = bwd_pair_kernel<KS_D, mt, nt, GN_BWD ? EPI_GN_BWD : EPI_BIAS>;                         \
         if (lds > 64 * 1024)                                                                              \
             if (int rc = raise_lds_limit((const void*)kern)) return rc;                                   \
         hipLaunchKernelGGL(kern, dim3(total), dim3(512), lds, st, a);                                     \
@@ -494,13 +496,21 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         run_wgrad(fj, st);
         if (!fb) launch_rowsum(dE, rows, D, rpart, gflat(bi), st, &df);
     }
+    // A Conv1dBlock j whose output feeds exactly one k5 convolution i (blocks[0] -> blocks[1] of a ResidualTemporalBlock) gets its
+    // Mish + GroupNorm backward as the EPILOGUE of i's input-gradient convolution (EPI_GN_BWD): one launch less per residual block.
+    std::vector<int> consumers(n, 0);
+    for (int i = 0; i < n; ++i)
+        for (int sl : {u->tl[i].src1_l, u->tl[i].src2_l, u->tl[i].res_l})
+            if (sl >= 0) consumers[sl]++;
+    static const bool gnfuse_off = getenv("MPDX_TRAIN_GN_FUSE") && atoi(getenv("MPDX_TRAIN_GN_FUSE")) == 0;   // dev A/B switch
+    std::vector<char> du_ready(n, 0);   // grd(j) already holds the gradient wrt layer j's CONVOLUTION output
     for (int i = n - 1; i >= 0; --i) {
         const Layer& l = u->layers[i];
         const auto& t = u->tl[i];
         const int Cin = l.c1 + l.c2;
         float* gy = grd(i);
         const float* dy = gy;   // gradient wrt the convolution output (after the GroupNorm/Mish backward for Conv1dBlocks)
-        if (l.epi == EPI_GN_MISH) {
+        if (l.epi == EPI_GN_MISH && !du_ready[i]) {
             GnBwdArgs g;
             memset(&g, 0, sizeof(g));
             if (t.res_l >= 0) g.gres = grd(t.res_l);
@@ -574,7 +584,35 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
                 a.dst = t.src1_l >= 0 ? grd(t.src1_l) : nullptr;
                 if (l.c2 > 0) { a.c_split = l.c1; a.dst2 = t.src2_l >= 0 ? grd(t.src2_l) : nullptr; }
             }
-            if (paired) {
+            const int j = t.src1_l;
+            bool gn_fused = false;
+            if (paired && !gnfuse_off && l.mode == CONV_S1 && l.ks == 5 && l.c2 == 0 && j >= 0 && j != n - 1 && consumers[j] == 1 &&
+                u->layers[j].epi == EPI_GN_MISH && u->tl[j].res_l < 0 && u->layers[j].cout == l.c1 && df.on && df.col.n + 3 <= 120) {
+                const Layer& lj = u->layers[j];
+                const int re = lj.gs * lj.L_out;
+                if ((re == 256 || re == 128) && lj.L_out == dgl.L_out) {
+                    Layer dg2 = dgl;
+                    dg2.epi = EPI_GN_MISH; dg2.gs = lj.gs;
+                    a.accum = 0; a.dst = grd(j); a.dst2 = nullptr; a.c_split = 0;
+                    a.res = pre(j);
+                    a.gamma = flat + u->params[lj.gamma].foff; a.beta = flat + u->params[lj.beta].foff;
+                    a.gs = lj.gs; a.lg_gs = 0;
+                    while ((1 << a.lg_gs) < lj.gs) ++a.lg_gs;
+                    a.bw_pg = ws + df.pcur; a.bw_pb = a.bw_pg + (size_t)B * lj.cout; a.bw_pbias = a.bw_pb + (size_t)B * lj.cout;
+                    const int prm[3] = {lj.gamma, lj.beta, lj.b};
+                    for (int k = 0; k < 3; ++k) {
+                        auto& e = df.col.e[df.col.n++];
+                        e.part = df.pcur + (size_t)k * B * lj.cout; e.out = u->params[prm[k]].foff; e.rows = B; e.C = lj.cout;
+                    }
+                    df.pcur += (size_t)3 * B * lj.cout;
+                    if (lj.tb_off >= 0) { a.bw_dT = ws + w.dT + lj.tb_off; a.bw_dT_stride = u->tt_row; }
+                    if (int rc = launch_bwd_pair<5, true>(dg2, a, B, jobs, njobs, st)) return rc;
+                    du_ready[j] = 1;
+                    gn_fused = true;
+                }
+            }
+            if (gn_fused) {
+            } else if (paired) {
                 int rc;
                 if (dgl.ks == 5) rc = launch_bwd_pair<5>(dgl, a, B, jobs, njobs, st);
                 else if (dgl.ks == 3) rc = launch_bwd_pair<3>(dgl, a, B, jobs, njobs, st);
