@@ -83,7 +83,10 @@ struct ConvArgs {
     // stores the gradient wrt the block's convolution output in dst.  `res` = that block's GroupNorm input (the forward's `pre`),
     // gamma / beta = its GroupNorm parameters, bias = zeros; bw_pg / bw_pb / bw_pbias [B][C_out]: per-trajectory channel sums of
     // (g * vhat), (g), (du);  bw_dT (or null): per-trajectory channel sums of the incoming gradient (the block's time-bias gradient)
-    float* bw_pg; float* bw_pb; float* bw_pbias; float* bw_dT;
+    // With `accum` the convolution's result is ADDED to what dst already holds (the other consumers of that block's output have put
+    // their gradients there) before the backward; bw_gres (or null): the gradient buffer of the block's identity-residual branch, += the
+    // incoming gradient.
+    float* bw_pg; float* bw_pb; float* bw_pbias; float* bw_dT; float* bw_gres;
     int bw_dT_stride;
 };
 
@@ -551,6 +554,14 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
 #pragma unroll
                 for (int k = 1; k < WK; ++k) v += red[((size_t)(k * NT + n)) * MTP + c + e];
                 gy[e] = v + a.bias[co + e];
+            }
+            if (a.accum) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) gy[e] += a.dst[o + e];
+            }
+            if (a.bw_gres && b < a.B) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) a.bw_gres[o + e] += gy[e];
             }
             float sm = 0.f;
 #pragma unroll

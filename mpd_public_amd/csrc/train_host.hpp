@@ -498,10 +498,12 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     }
     // A Conv1dBlock j whose output feeds exactly one k5 convolution i (blocks[0] -> blocks[1] of a ResidualTemporalBlock) gets its
     // Mish + GroupNorm backward as the EPILOGUE of i's input-gradient convolution (EPI_GN_BWD): one launch less per residual block.
-    std::vector<int> consumers(n, 0);
-    for (int i = 0; i < n; ++i)
+    // With several consumers the LAST one in backward order (the lowest layer index) carries the epilogue; the others have added
+    // their gradients to grd(j) by then.
+    std::vector<int> first_consumer(n, n);
+    for (int i = n - 1; i >= 0; --i)
         for (int sl : {u->tl[i].src1_l, u->tl[i].src2_l, u->tl[i].res_l})
-            if (sl >= 0) consumers[sl]++;
+            if (sl >= 0) first_consumer[sl] = i;
     static const bool gnfuse_off = getenv("MPDX_TRAIN_GN_FUSE") && atoi(getenv("MPDX_TRAIN_GN_FUSE")) == 0;   // dev A/B switch
     std::vector<char> du_ready(n, 0);   // grd(j) already holds the gradient wrt layer j's CONVOLUTION output
     for (int i = n - 1; i >= 0; --i) {
@@ -586,14 +588,15 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             }
             const int j = t.src1_l;
             bool gn_fused = false;
-            if (paired && !gnfuse_off && l.mode == CONV_S1 && l.ks == 5 && l.c2 == 0 && j >= 0 && j != n - 1 && consumers[j] == 1 &&
-                u->layers[j].epi == EPI_GN_MISH && u->tl[j].res_l < 0 && u->layers[j].cout == l.c1 && df.on && df.col.n + 3 <= 120) {
+            if (paired && !gnfuse_off && l.mode == CONV_S1 && l.ks == 5 && l.c2 == 0 && j >= 0 && j != n - 1 && first_consumer[j] == i && t.res_l != j &&
+                u->layers[j].epi == EPI_GN_MISH && u->layers[j].cout == l.c1 && df.on && df.col.n + 3 <= 120) {
                 const Layer& lj = u->layers[j];
                 const int re = lj.gs * lj.L_out;
                 if ((re == 256 || re == 128) && lj.L_out == dgl.L_out) {
                     Layer dg2 = dgl;
                     dg2.epi = EPI_GN_MISH; dg2.gs = lj.gs;
-                    a.accum = 0; a.dst = grd(j); a.dst2 = nullptr; a.c_split = 0;
+                    a.accum = 1; a.dst = grd(j); a.dst2 = nullptr; a.c_split = 0;   // (grd(j): zeros, or the other consumers' gradients)
+                    if (u->tl[j].res_l >= 0) a.bw_gres = grd(u->tl[j].res_l);
                     a.res = pre(j);
                     a.gamma = flat + u->params[lj.gamma].foff; a.beta = flat + u->params[lj.beta].foff;
                     a.gs = lj.gs; a.lg_gs = 0;
