@@ -352,14 +352,14 @@ struct ReduceAllArgs {
     int cstart[97];   // first block of entry j (1024 outputs per block); cstart[n] = blocks of the launch
 };
 // one block = 1024 outputs of one entry (found by bisection of cstart): every block has work, a thread's loads fly together
-__global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const ReduceAllArgs a) {
+__device__ __forceinline__ void wgrad_reduce_all_body(const ReduceAllArgs& a, const int block_id, const int tid) {
     int lo = 0, hi = a.n;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)blockIdx.x >= a.cstart[mid]) lo = mid; else hi = mid; }
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (block_id >= a.cstart[mid]) lo = mid; else hi = mid; }
     const ReduceAllArgs::E e = a.e[lo];
     const float* part = a.ws + e.part;
     float* g = a.grad + e.g;
     const unsigned per = (unsigned)e.M * e.N * e.KS, KS = (unsigned)e.KS, N = (unsigned)e.N;   // (32-bit index arithmetic, as pack_train_kernel)
-    const unsigned base = (blockIdx.x - (unsigned)a.cstart[lo]) * 1024u + threadIdx.x;
+    const unsigned base = (unsigned)(block_id - a.cstart[lo]) * 1024u + (unsigned)tid;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
     for (int z = 0; z < e.S; ++z) {
@@ -378,6 +378,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const ReduceAllAr
         g[((size_t)m * e.n_tot + e.n_off + n) * KS + kk] = s[k];
     }
 }
+
+__global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const ReduceAllArgs a) { wgrad_reduce_all_body(a, (int)blockIdx.x, (int)threadIdx.x); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // Packing for a training step, ONE launch for every parameter (blockIdx.y = parameter): flat reference layout ->
@@ -573,7 +575,7 @@ struct TimeBwdArgs {
 //                        db[c] = sum_b dT[b][c]
 // Every sum runs in the order of the four kernels it replaces (b ascending; table rows by part, parts ascending).
 constexpr int kTimeBwdMaxRow = 2560;
-__global__ __launch_bounds__(1024) void time_bwd_all_kernel(const TimeBwdArgs a) {
+__device__ __forceinline__ void time_bwd_all_body(const TimeBwdArgs& a, const int block_id) {
     __shared__ __attribute__((aligned(16))) float sh[10240];   // 40 KB: stage 1 [dT row | row offsets | partial sums], tail [dtm | h1m | dh1 | emb]
     __shared__ int s_toff[41];
     __shared__ unsigned s_woff[40];
@@ -583,8 +585,8 @@ __global__ __launch_bounds__(1024) void time_bwd_all_kernel(const TimeBwdArgs a)
     if (tid == 0) s_toff[a.nblk] = a.row;
     __syncthreads();
     auto block_of = [&](int r) { int blk = 0; while (blk + 1 < a.nblk && r >= s_toff[blk + 1]) ++blk; return blk; };   // toff ascending
-    if ((int)blockIdx.x >= a.B) {   // ---------------------------------------------- cond_mlp gradients of 32 table rows
-        const int rr = ((int)blockIdx.x - a.B) * 32 + (tid >> 5), e = tid & 31;
+    if (block_id >= a.B) {   // ---------------------------------------------- cond_mlp gradients of 32 table rows
+        const int rr = (block_id - a.B) * 32 + (tid >> 5), e = tid & 31;
         if (rr >= a.row) return;
         const int blk = block_of(rr);
         const int c = rr - s_toff[blk];
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(1024) void time_bwd_all_kernel(const TimeBwdArgs a)
         return;
     }
     // ------------------------------------------------------------------------------- sample b: gradient wrt temb
-    const int b = blockIdx.x, e = tid & 31, part = tid >> 5;
+    const int b = block_id, e = tid & 31, part = tid >> 5;
     float* const dTs = sh;
     unsigned* const roff = (unsigned*)(sh + kTimeBwdMaxRow);
     float* const red = sh + 2 * kTimeBwdMaxRow;   // [32][32]
@@ -684,6 +686,10 @@ __global__ __launch_bounds__(1024) void time_bwd_all_kernel(const TimeBwdArgs a)
         if (j == 0) a.grad[a.b1 + kk] = b1g[i];
     }
 }
+
+// (Measured and rejected: these blocks and the weight-gradient reductions in ONE launch - 59 us against 32 + 27 us apart: under the
+//  reductions' memory traffic every dependent load of this chain takes several times longer.)
+__global__ __launch_bounds__(1024) void time_bwd_all_kernel(const TimeBwdArgs a) { time_bwd_all_body(a, (int)blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // Loss gradient (helpers.py:71-99; mean over B*H*D of |e| or e^2 [* weights]):  dE = s * w * d|e|^p / de / (B H D), zero where

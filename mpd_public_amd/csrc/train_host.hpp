@@ -588,7 +588,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             }
             const int j = t.src1_l;
             bool gn_fused = false;
-            if (paired && !gnfuse_off && l.mode == CONV_S1 && l.ks == 5 && l.c2 == 0 && j >= 0 && j != n - 1 && first_consumer[j] == i && t.res_l != j &&
+            if (paired && !gnfuse_off && ((l.mode == CONV_S1 && l.ks == 5) || (l.mode == CONV_DOWN && dgl.ks == 3)) && l.c2 == 0 && j >= 0 && j != n - 1 && first_consumer[j] == i && t.res_l != j &&
                 u->layers[j].epi == EPI_GN_MISH && u->layers[j].cout == l.c1 && df.on && df.col.n + 3 <= 120) {
                 const Layer& lj = u->layers[j];
                 const int re = lj.gs * lj.L_out;
@@ -609,7 +609,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
                     }
                     df.pcur += (size_t)3 * B * lj.cout;
                     if (lj.tb_off >= 0) { a.bw_dT = ws + w.dT + lj.tb_off; a.bw_dT_stride = u->tt_row; }
-                    if (int rc = launch_bwd_pair<5, true>(dg2, a, B, jobs, njobs, st)) return rc;
+                    if (int rc = dgl.ks == 5 ? launch_bwd_pair<5, true>(dg2, a, B, jobs, njobs, st) : launch_bwd_pair<3, true>(dg2, a, B, jobs, njobs, st)) return rc;
                     du_ready[j] = 1;
                     gn_fused = true;
                 }
@@ -635,8 +635,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(blocks), dim3(256), 0, st, df.red);
     }
     if (df.col.n) hipLaunchKernelGGL(colsum_all_kernel, dim3(2, df.col.n), dim3(256), 0, st, df.col);
-    // time MLP
-    hipLaunchKernelGGL(time_bwd_all_kernel, dim3(B + (tb.row + 31) / 32), dim3(1024), 0, st, tb);
+    hipLaunchKernelGGL(time_bwd_all_kernel, dim3(B + (tb.row + 31) / 32), dim3(1024), 0, st, tb);   // the time conditioning's backward
     HIP_TRY(hipGetLastError());
     return 0;
 }
