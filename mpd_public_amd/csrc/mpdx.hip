@@ -247,14 +247,13 @@ __global__ __launch_bounds__(1024) void weighted_loss_kernel(const float* pred, 
     __shared__ double part[16];
     const size_t n = (size_t)B * H * D;
     double acc = 0.0;
-    for (size_t i = threadIdx.x; i < n; i += 1024) {
-        const int d = i % D;
-        const size_t p = i / D;
-        const int l = p % H;
-        const size_t b = p / H;
+#pragma unroll 4
+    for (unsigned i = threadIdx.x; i < (unsigned)n; i += 1024u) {   // (32-bit index arithmetic; n = B * H * D is far below 2^32 here)
+        const unsigned d = i % (unsigned)D, p = i / (unsigned)D;
+        const unsigned l = p % (unsigned)H, b = p / (unsigned)H;
         float v = pred[i];
         if (hs && l == 0) v = hs[b * D + d];
-        if (hg && l == H - 1) v = hg[b * D + d];
+        if (hg && l == (unsigned)(H - 1)) v = hg[b * D + d];
         const float e = __fsub_rn(v, targ[i]);
         float q = l1 ? fabsf(e) : __fmul_rn(e, e);
         if (weights) q = __fmul_rn(q, weights[(size_t)l * D + d]);
@@ -1192,11 +1191,11 @@ __global__ void restream_kernel(float* __restrict__ packed, size_t src, size_t d
 struct CopyJobDev { unsigned long long src, dst; int n0, ss0, ds0, n1, ss1, ds1, n_inner; };
 __global__ __launch_bounds__(256) void restream_all_kernel(float* __restrict__ packed, const CopyJobDev* __restrict__ jobs) {
     const CopyJobDev j = jobs[blockIdx.y];
-    const size_t total = (size_t)j.n0 * j.n1 * j.n_inner;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int k = (int)(i % j.n_inner);
-        const size_t r = i / j.n_inner;
-        const int i1 = (int)(r % j.n1), i0 = (int)(r / j.n1);
+    const unsigned total = (unsigned)j.n0 * (unsigned)j.n1 * (unsigned)j.n_inner, ni = (unsigned)j.n_inner, n1 = (unsigned)j.n1;   // (32-bit index arithmetic)
+#pragma unroll 4
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned k = i % ni, r = i / ni;
+        const unsigned i1 = r % n1, i0 = r / n1;
         packed[j.dst + (size_t)i0 * j.ds0 + (size_t)i1 * j.ds1 + k] = packed[j.src + (size_t)i0 * j.ss0 + (size_t)i1 * j.ss1 + k];
     }
 }
@@ -1216,7 +1215,7 @@ static int ensure_fused_streams(mpdx_unet* u, const float* packed, hipStream_t s
         }
     }
     if (u->n_jobs)
-        hipLaunchKernelGGL(restream_all_kernel, dim3(16, (unsigned)u->n_jobs), dim3(256), 0, st, const_cast<float*>(packed), (const CopyJobDev*)u->jobs_dev);
+        hipLaunchKernelGGL(restream_all_kernel, dim3(64, (unsigned)u->n_jobs), dim3(256), 0, st, const_cast<float*>(packed), (const CopyJobDev*)u->jobs_dev);
     HIP_TRY(hipGetLastError());
     u->streams_for = packed; u->streams_version = u->pack_version;
     return 0;
