@@ -387,3 +387,32 @@ def test_two_losses_before_one_backward_keep_their_own_gradients():
     assert any(float((ga[k] - gb[k]).abs().max()) > 0 for k in ga)
     for k in ga:
         assert torch.allclose(gab[k], ga[k] + gb[k], rtol=0, atol=1e-6 * float((ga[k].abs() + gb[k].abs()).max() + 1e-12)), k
+
+
+def test_gn_backward_epilogue_matches_the_separate_kernel():
+    """The Mish + GroupNorm backward runs as the EPILOGUE of the input-gradient convolution above it (EPI_GN_BWD, conv_block.hpp) for 28 of
+    the 33 Conv1dBlocks of an iteration; MPDX_TRAIN_GN_FUSE=0 (read once per process) launches gn_mish_bwd_kernel for every block instead.
+    Same arithmetic and summation orders: the flat gradient vectors of the two processes are identical bit for bit."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    from mpd_public_amd.trainer import TrainStep
+    dm = _model(4, 1)
+    x0, noise, hc = _batch(4)
+    ts = TrainStep(dm)
+    ts.loss_backward(x0.cuda(), {k: v.cuda() for k, v in hc.items()}, t=TTS[0].cuda(), noise=noise.cuda())
+    here = hashlib.sha256(ts.fp.grad.detach().cpu().numpy().tobytes()).hexdigest()
+    code = (
+        "import sys, hashlib, torch; sys.path[:0] = [%r, %r]\n"
+        "import test_gpu_train as T\n"
+        "from mpd_public_amd.trainer import TrainStep\n"
+        "dm = T._model(4, 1); x0, noise, hc = T._batch(4); ts = TrainStep(dm)\n"
+        "ts.loss_backward(x0.cuda(), {k: v.cuda() for k, v in hc.items()}, t=T.TTS[0].cuda(), noise=noise.cuda())\n"
+        "print('GRADHASH', hashlib.sha256(ts.fp.grad.detach().cpu().numpy().tobytes()).hexdigest())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MPDX_TRAIN_GN_FUSE="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    there = [ln.split()[1] for ln in out.stdout.splitlines() if ln.startswith("GRADHASH")][0]
+    assert here == there
