@@ -76,6 +76,7 @@ struct ConvArgs {
     float* pre;          // [B][L_out][C_out] or null
     // EPI_BIAS only (the input-gradient convolutions of train_host.hpp): channels >= c_split go to dst2 (a channel concat is split
     // back into its two sources; either destination may be null = not needed), and with `accum` the result is ADDED to the destination
+    // (bit 0: dst, bit 1: dst2 - the first writer of a gradient buffer in a backward pass stores, the others add: no memset)
     float* dst2;
     int c_split, accum;
     // EPI_GN_BWD only (training): the convolution's result is the gradient wrt the OUTPUT of the Conv1dBlock that produced this
@@ -88,6 +89,7 @@ struct ConvArgs {
     // incoming gradient.
     float* bw_pg; float* bw_pb; float* bw_pbias; float* bw_dT; float* bw_gres;
     int bw_dT_stride;
+    int bw_gres_store;   // this launch is the FIRST writer of bw_gres in the pass: store instead of +=
 };
 
 // wave64 all-reduce (sum) with DPP row operations + 4 readlanes instead of a 6-step ds_bpermute butterfly:
@@ -555,13 +557,13 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                 for (int k = 1; k < WK; ++k) v += red[((size_t)(k * NT + n)) * MTP + c + e];
                 gy[e] = v + a.bias[co + e];
             }
-            if (a.accum) {
+            if (a.accum & 1) {
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) gy[e] += a.dst[o + e];
             }
             if (a.bw_gres && b < a.B) {
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) a.bw_gres[o + e] += gy[e];
+                for (int e = 0; e < EPL; ++e) a.bw_gres[o + e] = a.bw_gres_store ? gy[e] : a.bw_gres[o + e] + gy[e];
             }
             float sm = 0.f;
 #pragma unroll
@@ -697,7 +699,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
             }
             if (b < a.B && d) {
                 f32x4* q = (f32x4*)(d + ((size_t)b * L_out + l) * ld + cc);
-                if (a.accum) v += *q;
+                if (a.accum & (d == a.dst2 ? 2 : 1)) v += *q;
                 *q = v;
             }
         }

@@ -52,6 +52,7 @@ struct GnBwdArgs {
     float* pbias;
     float* dT;        // or null
     float* gres;      // or null: gradient buffer of the block's residual branch, += gy (the residual add passes it through)
+    int gres_store;   // this launch is the first writer of gres in the pass: = gy
     int dT_stride;
     int B, L, C, gs, lg_gs, n_groups;
 };
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnBwdArgs a) {
     for (int e = 0; e < EPL; ++e) { u[e] = a.pre[o + e]; gy[e] = a.gy[o + e]; ga[e] = a.gamma[c + e]; be[e] = a.beta[c + e]; }
     if (a.gres) {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) a.gres[o + e] += gy[e];
+        for (int e = 0; e < EPL; ++e) a.gres[o + e] = a.gres_store ? gy[e] : a.gres[o + e] + gy[e];
     }
     const float inv_n = 1.0f / (float)(64 * EPL);
     float s = 0.f;
@@ -177,13 +178,14 @@ __global__ __launch_bounds__(256) void rowsum_part_kernel(const float* __restric
 
 // dst[b][l][c] += src[b][l * step][c_off + c]      dst dense [B][L][Cd];  src [B][Ls][Cs]
 __global__ __launch_bounds__(256) void acc_slice_kernel(float* __restrict__ dst, const float* __restrict__ src, int B, int L, int Cd, int Ls, int Cs,
-                                                        int c_off, int step) {
+                                                        int c_off, int step, int store) {
     const size_t total = (size_t)B * L * Cd;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % Cd);
         const size_t r = i / Cd;
         const int l = (int)(r % L), b = (int)(r / L);
-        dst[i] += src[((size_t)b * Ls + (size_t)l * step) * Cs + c_off + c];
+        const float v = src[((size_t)b * Ls + (size_t)l * step) * Cs + c_off + c];
+        dst[i] = store ? v : dst[i] + v;
     }
 }
 

@@ -305,9 +305,9 @@ static void launch_rowsum(const float* x, size_t rows, int C, float* part, float
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, 1), dim3(256), 0, st, c);
 }
 
-static void launch_acc(float* dst, const float* src, int B, int L, int Cd, int Ls, int Cs, int c_off, int step, hipStream_t st) {
+static void launch_acc(float* dst, const float* src, int B, int L, int Cd, int Ls, int Cs, int c_off, int step, int store, hipStream_t st) {
     const size_t total = (size_t)B * L * Cd;
-    hipLaunchKernelGGL(acc_slice_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, dst, src, B, L, Cd, Ls, Cs, c_off, step);
+    hipLaunchKernelGGL(acc_slice_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st, dst, src, B, L, Cd, Ls, Cs, c_off, step, store);
 }
 
 }  // namespace mpdx
@@ -378,7 +378,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     auto gflat = [&](int pidx) { return grads_flat + u->params[pidx].foff; };
 
     // ---- forward, every layer's output (and GroupNorm input) kept
-    HIP_TRY(hipMemsetAsync(ws + w.grad0, 0, (size_t)n * w.slotB * sizeof(float), st));
+    // (no memset of the gradient buffers: the first writer of each in the backward pass stores, the later ones add - `first_write`)
     HIP_TRY(hipMemsetAsync(ws + w.zeros, 0, (1024 + 4) * sizeof(float), st));   // the zero bias of the dgrad convolutions + the time backward's ticket
     {
         const size_t ne = (size_t)B * H * D;
@@ -506,16 +506,23 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             if (sl >= 0) first_consumer[sl] = i;
     static const bool gnfuse_off = getenv("MPDX_TRAIN_GN_FUSE") && atoi(getenv("MPDX_TRAIN_GN_FUSE")) == 0;   // dev A/B switch
     std::vector<char> du_ready(n, 0);   // grd(j) already holds the gradient wrt layer j's CONVOLUTION output
+    std::vector<char> written(n, 0);    // grd(j) has been written in this pass (launches execute in the order they are enqueued here)
+    written[n - 1] = 1;                 // final_dgrad_kernel above
+    auto first_write = [&](int j) { const bool f = !written[j]; written[j] = 1; return f; };
     for (int i = n - 1; i >= 0; --i) {
         const Layer& l = u->layers[i];
         const auto& t = u->tl[i];
         const int Cin = l.c1 + l.c2;
         float* gy = grd(i);
         const float* dy = gy;   // gradient wrt the convolution output (after the GroupNorm/Mish backward for Conv1dBlocks)
+        if (!written[i]) {   // nothing downstream of this layer carries a gradient: it is zero
+            HIP_TRY(hipMemsetAsync(gy, 0, w.slotB * sizeof(float), st));
+            written[i] = 1;
+        }
         if (l.epi == EPI_GN_MISH && !du_ready[i]) {
             GnBwdArgs g;
             memset(&g, 0, sizeof(g));
-            if (t.res_l >= 0) g.gres = grd(t.res_l);
+            if (t.res_l >= 0) { g.gres = grd(t.res_l); g.gres_store = first_write(t.res_l) ? 1 : 0; }
             g.gy = gy; g.pre = pre(i); g.gamma = flat + u->params[l.gamma].foff; g.beta = flat + u->params[l.beta].foff;
             g.du = ws + w.dU;
             g.pg = ws + w.pvec; g.pb = g.pg + (size_t)B * 512; g.pbias = g.pb + (size_t)B * 512;
@@ -582,9 +589,12 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             a.bias = ws + w.zeros;
             if (l.mode == CONV_UPT) a.dst = ws + w.tmpX;   // full-resolution result, every second position is the gradient
             else {   // added straight into the gradient buffer(s) of the layer's input(s)
-                a.accum = 1;
                 a.dst = t.src1_l >= 0 ? grd(t.src1_l) : nullptr;
-                if (l.c2 > 0) { a.c_split = l.c1; a.dst2 = t.src2_l >= 0 ? grd(t.src2_l) : nullptr; }
+                if (t.src1_l >= 0 && !first_write(t.src1_l)) a.accum |= 1;
+                if (l.c2 > 0) {
+                    a.c_split = l.c1; a.dst2 = t.src2_l >= 0 ? grd(t.src2_l) : nullptr;
+                    if (t.src2_l >= 0 && !first_write(t.src2_l)) a.accum |= 2;
+                }
             }
             const int j = t.src1_l;
             bool gn_fused = false;
@@ -595,8 +605,8 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
                 if ((re == 256 || re == 128) && lj.L_out == dgl.L_out) {
                     Layer dg2 = dgl;
                     dg2.epi = EPI_GN_MISH; dg2.gs = lj.gs;
-                    a.accum = 1; a.dst = grd(j); a.dst2 = nullptr; a.c_split = 0;   // (grd(j): zeros, or the other consumers' gradients)
-                    if (u->tl[j].res_l >= 0) a.bw_gres = grd(u->tl[j].res_l);
+                    a.dst = grd(j); a.dst2 = nullptr; a.c_split = 0;   // (a.accum bit 0 as set above: the other consumers' gradients are in grd(j))
+                    if (u->tl[j].res_l >= 0) { a.bw_gres = grd(u->tl[j].res_l); a.bw_gres_store = first_write(u->tl[j].res_l) ? 1 : 0; }
                     a.res = pre(j);
                     a.gamma = flat + u->params[lj.gamma].foff; a.beta = flat + u->params[lj.beta].foff;
                     a.gs = lj.gs; a.lg_gs = 0;
@@ -622,7 +632,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
                 else rc = launch_bwd_pair<1>(dgl, a, B, jobs, njobs, st);
                 if (rc) return rc;
             } else if (int rc = launch_layer(dgl, a, B, st)) return rc;
-            if (l.mode == CONV_UPT && t.src1_l >= 0) launch_acc(grd(t.src1_l), ws + w.tmpX, B, l.L_in, l.c1, dgl.L_out, Cin, 0, 2, st);
+            if (l.mode == CONV_UPT && t.src1_l >= 0) launch_acc(grd(t.src1_l), ws + w.tmpX, B, l.L_in, l.c1, dgl.L_out, Cin, 0, 2, first_write(t.src1_l) ? 1 : 0, st);
         }
     }
     if (df.red.n) {

@@ -43,3 +43,5 @@ fi
 MPDX_BENCH_TABLE=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras 2>&1 >/dev/null | grep "^#" > $O/launch_table.txt
 timeout 200 ./tools/micro/cluster_handoff 64 > $O/cluster_handoff.txt 2>&1
 head -4 $O/cfg2_kernel_stats.csv | cut -c1-160
+timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log > $O/pytest_gpu_tail.txt; cat $O/pytest_gpu_tail.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
