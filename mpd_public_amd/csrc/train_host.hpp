@@ -516,6 +516,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         float* gy = grd(i);
         const float* dy = gy;   // gradient wrt the convolution output (after the GroupNorm/Mish backward for Conv1dBlocks)
         if (!written[i]) {   // nothing downstream of this layer carries a gradient: it is zero
+            if (getenv("MPDX_DEBUG_TRAIN")) fprintf(stderr, "[mpdx] backward: layer %d %s has no gradient-carrying consumer (zeroed)\n", i, l.name.c_str());
             HIP_TRY(hipMemsetAsync(gy, 0, w.slotB * sizeof(float), st));
             written[i] = 1;
         }
