@@ -125,6 +125,8 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
     const int co = mt * MT + ec;
     const fvec bi = *(const fvec*)(a.bias + co), ga = *(const fvec*)(a.gamma + co), be = *(const fvec*)(a.beta + co);
     const float inv_re = 1.0f / (float)(MT * 8);
+    f32x4 bias2 = {0.f, 0.f, 0.f, 0.f};   // R1: the residual conv's bias chunk of this lane (loaded once: a load inside the epilogue is a round trip on the tile's critical path)
+    if constexpr (R1) bias2 = *(const f32x4*)(a2.bias + mt * MT + (lane % (MT / 4)) * 4);
 
     int tile = p;
     if (tile < n_tiles) { window_load(tile); window_write(tile, 0); }
@@ -144,11 +146,14 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
         const int r = (wk - 2 * i) & 7;
         const int b_ep = tile * spt + r;
         const size_t o_ep = ((size_t)(b_ep < a.B ? b_ep : 0) * L + el) * a.C_out + co;
-        fvec tb = 0.f, rsv = 0.f;
-        if (r < spt) {
-            if (a.tbias) tb = *(const fvec*)(a.tbias + (size_t)(b_ep < a.B ? b_ep : 0) * a.tb_stride + co);
-            if (a.res) rsv = *(const fvec*)(a.res + o_ep);
-        }
+        // UNCONDITIONAL loads (every wave, from valid addresses; zeros are selected in the epilogue): as conditional loads into
+        // zero-initialised registers they made hipcc put s_waitcnt vmcnt(0) HERE, at the top of every tile - every wave then sat out the
+        // round trip of the window loads it had issued a moment ago, at the bottom of the previous tile, with the matrix pipes idle
+        // (~1.5 k of the 7.3 k cycles of a tile: tools/ws_trace.py, the gap between `epilogue done` and the next `tile top`).
+        const float* const tb_p = a.tbias ? a.tbias + (size_t)(b_ep < a.B ? b_ep : 0) * a.tb_stride + co : a.bias + co;
+        const float* const rs_p = a.res ? a.res + o_ep : a.bias + co;
+        fvec tb = *(const fvec*)tb_p, rsv = *(const fvec*)rs_p;
+        __builtin_amdgcn_sched_barrier(0);   // requested HERE (hipcc would sink them behind the k-loop, next to the barrier)
         // ---------------------------------------------------------------- k-loop of this tile (window buffer `cur`)
         f32x4 acc[MS], acc2[MS];
 #pragma unroll
@@ -186,6 +191,10 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
         WS_STAMP(2);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         WS_STAMP(3);
+        // (every wave "uses" the two operands here, where they have long arrived and nothing else is in flight: a load still pending on
+        //  their registers at the loop's back edge - the six waves without a duty never read them - costs the same vmcnt(0) at the top
+        //  of the next tile; behind the epilogue the wait would include the duty waves' store)
+        asm volatile("" :: "v"(tb), "v"(rsv));
         // ---------------------------------------------------------------- epilogue: region r of this tile by duty wave (2 i + r) mod 8
         if (r < spt) {
             const int n = r * L + el;
@@ -205,20 +214,22 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
             fvec y;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) y[e] = mish(d[e] * rstd * ga[e] + be[e]);
-            y += tb;
-            y += rsv;
+            const fvec zv = 0.f;
+            y += a.tbias ? tb : zv;
+            y += a.res ? rsv : zv;
             if (b_ep < a.B) *(fvec*)(a.dst + o_ep) = y;
         }
         if constexpr (R1) {   // bias-only epilogue of the residual conv: duty wave (2 i + spt) mod 8
             if (r == spt) {
                 const float* red = smem + (size_t)(red2_off4 + cur * red4) * 4;
+                static_assert(64 % (MT / 4) == 0, "a lane keeps its channel chunk over the passes");
                 for (int idx = lane; idx < NT * (MT / 4); idx += 64) {
                     const int n = idx / (MT / 4), c = (idx - n * (MT / 4)) * 4;
                     const int s = n >> a2.lg_Lout, l = n & (L - 1), b = tile * spt + s;
                     f32x4 v = *(const f32x4*)(red + (size_t)n * (MT + 4) + c);
 #pragma unroll
                     for (int k = 1; k < WK; ++k) v += *(const f32x4*)(red + (size_t)(k * NT + n) * (MT + 4) + c);
-                    v += *(const f32x4*)(a2.bias + mt * MT + c);
+                    v += bias2;   // (c == (lane % (MT / 4)) * 4 in every pass)
                     if (b < a2.B) *(f32x4*)(a2.dst + ((size_t)b * L + l) * a2.C_out + mt * MT + c) = v;
                 }
             }
