@@ -133,17 +133,20 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
     if (tile + kWsGroups < n_tiles) window_load(tile + kWsGroups);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    // dev tool (-DMPDX_DEV_HOOKS, mpdx_layer_trace): stamps of workgroup 0, waves 0 / 1 (slots 0..15 / 16..31), tiles 8 and 9:
-    // tile top | k-loop issued | partials + window written | barrier passed | epilogue done
-    long long* const trp = (MPDX_TRACE_PTR(a.trace) && blockIdx.x == 0 && lane == 0 && wk < 2) ? a.trace + wk * 16 : nullptr;
-#define WS_STAMP(k) do { if (trp && (i == 8 || i == 9)) trp[(i - 8) * 5 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+    // dev tool (-DMPDX_DEV_HOOKS, mpdx_layer_trace): stamps of workgroup 0, ALL EIGHT waves (4 slots each), kept in registers and written
+    // when the kernel ends (a stamp stored on the spot is a VMEM write the next vmcnt(0) waits for - it would time itself):
+    // tile 8 top | tile 8 k-loop issued | tile 8 barrier passed | tile 9 top
+    long long* const trp = (MPDX_TRACE_PTR(a.trace) && blockIdx.x == 0 && lane == 0) ? a.trace + wk * 4 : nullptr;
+    long long st_[4] = {0, 0, 0, 0};
+#define WS_STAMP(k) do { if (trp) { if (i == 8 && (k) == 0) st_[0] = (long long)__builtin_readcyclecounter(); if (i == 8 && (k) == 1) st_[1] = (long long)__builtin_readcyclecounter(); \
+                                    if (i == 8 && (k) == 3) st_[2] = (long long)__builtin_readcyclecounter(); if (i == 9 && (k) == 0) st_[3] = (long long)__builtin_readcyclecounter(); } } while (0)
     for (int i = 0; tile < n_tiles; ++i, tile += kWsGroups) {
         const int cur = i & 1;
         WS_STAMP(0);
         // this wave's epilogue duty for the tile (region r = trajectory r of the tile): its global operands are requested BEFORE the
         // k-loop - a duty wave that waits ~1 us for the residual after the barrier idles its SIMD's matrix pipe once its partner's
         // k-loop is through (measured: 318 us per layer with the loads behind the barrier)
-        const int r = (wk - 2 * i) & 7;
+        const int r = wk < 4 ? ((wk - 2 * i) & 3) : 7;   // duties rotate over waves 0 .. 3 only: the OLDER wave of each SIMD (see below)
         const int b_ep = tile * spt + r;
         const size_t o_ep = ((size_t)(b_ep < a.B ? b_ep : 0) * L + el) * a.C_out + co;
         // UNCONDITIONAL loads (every wave, from valid addresses; zeros are selected in the epilogue): as conditional loads into
@@ -197,6 +200,12 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
         asm volatile("" :: "v"(tb), "v"(rsv));
         // ---------------------------------------------------------------- epilogue: region r of this tile by duty wave (2 i + r) mod 8
         if (r < spt) {
+            // raised issue priority for the duty: the tile's critical path is THIS wave (epilogue, then its k-loop), while its SIMD
+            // partner is already in the next k-loop.  Stamps inside the epilogue (all eight waves, tools/ws_trace.py): 0.5 k cycles for
+            // the eight partial reads, 0.8-1.1 k for the statistics, 1.8-2.2 k for Mish + store - a chain of dependent VALU instructions
+            // next to a partner that streams MFMAs advances at ~20 cycles per instruction.  With the priority and the duties on the
+            // older wave of each SIMD: 302 -> 293 us per 256->256 launch at B = 6400.
+            __builtin_amdgcn_s_setprio(3);
             const int n = r * L + el;
             const float* red = smem + (size_t)(red_off4 + cur * red4) * 4;
             fvec v = *(const fvec*)(red + (size_t)n * (MT + 4) + ec);
@@ -218,6 +227,7 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
             y += a.tbias ? tb : zv;
             y += a.res ? rsv : zv;
             if (b_ep < a.B) *(fvec*)(a.dst + o_ep) = y;
+            __builtin_amdgcn_s_setprio(0);
         }
         if constexpr (R1) {   // bias-only epilogue of the residual conv: duty wave (2 i + spt) mod 8
             if (r == spt) {
@@ -241,6 +251,7 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
         if (nxt + kWsGroups < n_tiles) window_load(nxt + kWsGroups);
     }
 #undef WS_STAMP
+    if (trp) { trp[0] = st_[0]; trp[1] = st_[1]; trp[2] = st_[2]; trp[3] = st_[3]; }
 }
 
 }  // namespace mpdx

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Cycle stamps of the weight-stationary conv kernel (dev tool: needs a -DMPDX_DEV_HOOKS build and a GPU): workgroup 0, waves 0 / 1,
-tiles 8 and 9: tile top | k-loop issued | partials + next window written | barrier passed | epilogue done."""
+all eight waves: tile 8 top | k-loop issued | barrier passed | tile 9 top (kept in registers, written at kernel end)."""
 import ctypes as C, os, sys
 os.environ["MPDX_FUSED"] = "0"
 from pathlib import Path
@@ -22,8 +22,9 @@ _lib.check(lib.mpdx_unet_profile(hdl, packed.data_ptr(), tab.data_ptr(), 128, x.
 i = [k for k in range(n.value) if names[k].decode().startswith("mid_block1.blocks.1")][0]
 stamps = (C.c_longlong * 32)()
 _lib.check(lib.mpdx_layer_trace(hdl, packed.data_ptr(), tab.data_ptr(), x.data_ptr(), i, B, ws.data_ptr(), st, stamps))
-lab = ["tile top", "k-loop issued", "partials+window", "barrier passed", "epilogue done"]
-for w in range(2):
-    v = [stamps[w * 16 + k] for k in range(10)]
-    t0 = stamps[0]
-    print(f"wave {w}: " + "  ".join(f"{lab[k % 5]} {v[k] - t0}" for k in range(10)))
+lab = ["tile 8 top", "k-loop issued", "barrier passed", "tile 9 top"]
+t0 = min(stamps[w * 4] for w in range(8))
+for w in range(8):
+    v = [stamps[w * 4 + k] - t0 for k in range(4)]
+    duty = "duty (epilogue of tile 8 before the k-loop of tile 9)" if (w < 4 and ((w - 16) & 3) < 2) else ""
+    print(f"wave {w} (SIMD {w % 4}): " + "  ".join(f"{lab[k]} {v[k]}" for k in range(4)) + f"   k-loop {v[1] - v[0]}  to barrier {v[2] - v[1]}  barrier -> next top {v[3] - v[2]}  {duty}")
