@@ -269,6 +269,11 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
     FOP_STAMP();   // k-loop issued
 
     // ------------------------------------------------------------------ epilogue (registers -> destination buffer)
+    // At large batch two or three workgroups share a CU: this wave's statistics + epilogue - chains of dependent VALU instructions -
+    // then run next to a SIMD partner that streams MFMAs, at ~20 cycles per instruction (measured in conv_ws.hpp); raised issue
+    // priority until the op's closing barrier.  (Measured, same-box A/B: cfg 5 542.45 -> 542.1 ms, cfg 2 21.88 -> 21.82 ms - within
+    // noise; kept because it is free.  At B = 100 there is one wave per SIMD and nothing to arbitrate.)
+    __builtin_amdgcn_s_setprio(2);
     const float* par_op = smem + a.par_off + op.p_off;   // [bias | gamma | beta | rbias] x COUT
     // this lane's 4 output channels in tile t (M-passes: tile t is tile row ms + 4 t)
     int c0t[NTW], mst[NTW];
@@ -371,6 +376,7 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
         }
     }
     FOP_STAMP();   // epilogue done (this wave)
+    __builtin_amdgcn_s_setprio(0);
     lds_barrier();
     FOP_STAMP();
 #undef FOP_STAMP
