@@ -32,16 +32,21 @@ namespace mpdx {
 constexpr int kWsGroups = 32;    // position groups: (C_out / MT) channel tiles x 32 workgroups
 constexpr int kWsThreads = 512;
 
-template <int NC16, int MT, bool R1>
+// NS = position sub-tiles per tile.  NS = 1: 16 positions = two GroupNorm regions = two duty waves, i.e. two of the four SIMDs carry an
+// epilogue in a tile and the other two wait for them at the barrier.  NS = 2 (very large batches): 32 positions = FOUR regions, one duty
+// wave on EVERY SIMD (waves 0 .. 3), the A fragments feed two B fragments each, half as many barriers and hand-overs per position; the
+// K-partials then have ONE buffer (2 x 50 KB of windows + 37 KB) and a second barrier per tile in front of their writes.
+template <int NC16, int MT, bool R1, int NS = 1>
 inline size_t conv_ws_lds_bytes(int L, int rs) {
-    const size_t stage = (size_t)(16 / L) * (L + 4) * rs * sizeof(float);
-    const size_t red = (size_t)8 * 16 * (MT + 4) * sizeof(float);
-    return 2 * stage + 2 * red * (R1 ? 2 : 1);
+    const size_t stage = (size_t)(16 * NS / L) * (L + 4) * rs * sizeof(float);
+    const size_t red = (size_t)8 * 16 * NS * (MT + 4) * sizeof(float);
+    return 2 * stage + (NS == 1 ? 2 : 1) * red * (R1 ? 2 : 1);
 }
 
-template <int NC16, int MT, bool R1>
+template <int NC16, int MT, bool R1, int NS = 1>
 __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, const ConvArgs a2) {
-    constexpr int KS = 5, PAD = 2, MS = MT / 16, NT = 16, WK = 8, NG = NC16 * KS, NIT = NG / WK, NIT2 = NC16 / WK;
+    constexpr int KS = 5, PAD = 2, MS = MT / 16, NT = 16 * NS, WK = 8, NG = NC16 * KS, NIT = NG / WK, NIT2 = NC16 / WK;
+    constexpr int NRED = NS == 1 ? 2 : 1;                  // K-partial buffers
     constexpr int MTP4 = (MT + 4) / 4;
     constexpr int EPL = MT / 8;                            // epilogue elements per lane: a region = MT channels x 8 positions over 64 lanes
     static_assert(NG % WK == 0 && NC16 % WK == 0, "k-groups split evenly over the 8 waves");
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
     const int spt = NT >> a.lg_Lout;                       // trajectories per tile (2 at L = 8)
     const int stage4 = spt * LP * RS4;                     // float4 per window buffer
     const int red4 = WK * NT * MTP4;                       // float4 per reduction buffer
-    const int red_off4 = 2 * stage4, red2_off4 = red_off4 + 2 * red4;
+    const int red_off4 = 2 * stage4, red2_off4 = red_off4 + NRED * red4;
     const int n_tiles = a.n_tiles_n;
     const int c4n = a.cin_pad >> 2;
 
@@ -86,8 +91,8 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
         smem4[buf * stage4 + (s * LP + lp) * RS4 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     // window of a tile: NT positions x cin/4 float4 (1024 at C_in = 256, 2048 at 512)
-    constexpr int SB = (16 * NC16 * 4) / kWsThreads;
-    static_assert(SB >= 1 && (16 * NC16 * 4) % kWsThreads == 0, "window divides over the threads");
+    constexpr int SB = (NT * NC16 * 4) / kWsThreads;
+    static_assert(SB >= 1 && (NT * NC16 * 4) % kWsThreads == 0, "window divides over the threads");
     int wdst[SB], wrow[SB], wc[SB], ws_[SB];
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
@@ -117,7 +122,9 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
 
     // lane's B row in a window (tile-local position n = j), and its column in the reduction buffer
     const int j = lane & 15, q = lane >> 4;
-    const int boff = ((j >> a.lg_Lout) * LP + (j & (L - 1))) * RS4 + q;
+    int boff[NS];   // position sub-tile ns: tile-local position n = ns * 16 + j
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) boff[ns] = (((ns * 16 + j) >> a.lg_Lout) * LP + (j & (L - 1))) * RS4 + q;
 
     // ---- epilogue operands of the region this lane would serve (channels are fixed per lane: loaded once)
     const int e0 = lane * EPL;
@@ -146,7 +153,8 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
         // this wave's epilogue duty for the tile (region r = trajectory r of the tile): its global operands are requested BEFORE the
         // k-loop - a duty wave that waits ~1 us for the residual after the barrier idles its SIMD's matrix pipe once its partner's
         // k-loop is through (measured: 318 us per layer with the loads behind the barrier)
-        const int r = wk < 4 ? ((wk - 2 * i) & 3) : 7;   // duties rotate over waves 0 .. 3 only: the OLDER wave of each SIMD (see below)
+        // duties go to waves 0 .. 3 only: the OLDER wave of each SIMD (see below); two regions per tile rotate over them, four take all
+        const int r = NS == 1 ? (wk < 4 ? ((wk - 2 * i) & 3) : 7) : (wk <= 4 ? wk : 7);
         const int b_ep = tile * spt + r;
         const size_t o_ep = ((size_t)(b_ep < a.B ? b_ep : 0) * L + el) * a.C_out + co;
         // UNCONDITIONAL loads (every wave, from valid addresses; zeros are selected in the epilogue): as conditional loads into
@@ -158,36 +166,50 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
         fvec tb = *(const fvec*)tb_p, rsv = *(const fvec*)rs_p;
         __builtin_amdgcn_sched_barrier(0);   // requested HERE (hipcc would sink them behind the k-loop, next to the barrier)
         // ---------------------------------------------------------------- k-loop of this tile (window buffer `cur`)
-        f32x4 acc[MS], acc2[MS];
+        f32x4 acc[NS][MS], acc2[NS][MS];
 #pragma unroll
-        for (int m = 0; m < MS; ++m) acc[m] = acc2[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const f32x4* win = smem4 + cur * stage4 + boff;
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+            for (int m = 0; m < MS; ++m) acc[ns][m] = acc2[ns][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4* win = smem4 + cur * stage4;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int g = wk + it * WK, c16 = g / KS, ts = g - c16 * KS;
-            const f32x4 bf = win[ts * RS4 + c16 * 4];
+            f32x4 bf[NS];
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) bf[ns] = win[boff[ns] + ts * RS4 + c16 * 4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int m = 0; m < MS; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[it][m][e], bf[e], acc[m], 0, 0, 0);
+                for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+                    for (int m = 0; m < MS; ++m) acc[ns][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[it][m][e], bf[ns][e], acc[ns][m], 0, 0, 0);
         }
         if constexpr (R1) {   // the residual 1x1 conv reads the centre row of the same window
 #pragma unroll
             for (int it = 0; it < NIT2; ++it) {
-                const f32x4 bf = win[PAD * RS4 + (wk + it * WK) * 4];
+                f32x4 bf[NS];
+#pragma unroll
+                for (int ns = 0; ns < NS; ++ns) bf[ns] = win[boff[ns] + PAD * RS4 + (wk + it * WK) * 4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int m = 0; m < MS; ++m) acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af2[it][m][e], bf[e], acc2[m], 0, 0, 0);
+                    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+                        for (int m = 0; m < MS; ++m) acc2[ns][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af2[it][m][e], bf[ns][e], acc2[ns][m], 0, 0, 0);
             }
         }
         WS_STAMP(1);
-        // ---------------------------------------------------------------- K-partials -> reduction buffer(s) `cur`
+        // ---------------------------------------------------------------- K-partials -> reduction buffer(s)
+        const int rcur = NRED == 2 ? cur : 0;
+        if constexpr (NRED == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the duty waves are through with the previous tile's partials
 #pragma unroll
-        for (int m = 0; m < MS; ++m) {
-            smem4[red_off4 + cur * red4 + (wk * NT + j) * MTP4 + m * 4 + q] = acc[m];
-            if constexpr (R1) smem4[red2_off4 + cur * red4 + (wk * NT + j) * MTP4 + m * 4 + q] = acc2[m];
-        }
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+            for (int m = 0; m < MS; ++m) {
+                smem4[red_off4 + rcur * red4 + (wk * NT + ns * 16 + j) * MTP4 + m * 4 + q] = acc[ns][m];
+                if constexpr (R1) smem4[red2_off4 + rcur * red4 + (wk * NT + ns * 16 + j) * MTP4 + m * 4 + q] = acc2[ns][m];
+            }
         // ---------------------------------------------------------------- next window -> the other buffer
         const int nxt = tile + kWsGroups;
         if (nxt < n_tiles) window_write(nxt, cur ^ 1);
@@ -207,7 +229,7 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
             // older wave of each SIMD: 302 -> 293 us per 256->256 launch at B = 6400.
             __builtin_amdgcn_s_setprio(3);
             const int n = r * L + el;
-            const float* red = smem + (size_t)(red_off4 + cur * red4) * 4;
+            const float* red = smem + (size_t)(red_off4 + rcur * red4) * 4;
             fvec v = *(const fvec*)(red + (size_t)n * (MT + 4) + ec);
 #pragma unroll
             for (int k = 1; k < WK; ++k) v += *(const fvec*)(red + (size_t)(k * NT + n) * (MT + 4) + ec);
@@ -231,7 +253,7 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
         }
         if constexpr (R1) {   // bias-only epilogue of the residual conv: duty wave (2 i + spt) mod 8
             if (r == spt) {
-                const float* red = smem + (size_t)(red2_off4 + cur * red4) * 4;
+                const float* red = smem + (size_t)(red2_off4 + rcur * red4) * 4;
                 static_assert(64 % (MT / 4) == 0, "a lane keeps its channel chunk over the passes");
                 for (int idx = lane; idx < NT * (MT / 4); idx += 64) {
                     const int n = idx / (MT / 4), c = (idx - n * (MT / 4)) * 4;
