@@ -26,5 +26,5 @@ lab = ["tile 8 top", "k-loop issued", "barrier passed", "tile 9 top"]
 t0 = min(stamps[w * 4] for w in range(8))
 for w in range(8):
     v = [stamps[w * 4 + k] - t0 for k in range(4)]
-    duty = "duty (epilogue of tile 8 before the k-loop of tile 9)" if (w < 4 and ((w - 16) & 3) < 2) else ""
+    duty = "duty" if w < 4 else ""
     print(f"wave {w} (SIMD {w % 4}): " + "  ".join(f"{lab[k]} {v[k]}" for k in range(4)) + f"   k-loop {v[1] - v[0]}  to barrier {v[2] - v[1]}  barrier -> next top {v[3] - v[2]}  {duty}")
