@@ -184,6 +184,9 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
                 for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
                     for (int m = 0; m < MS; ++m) acc[ns][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[it][m][e], bf[ns][e], acc[ns][m], 0, 0, 0);
+            // the next tile's window goes to the OTHER buffer (free since the previous tile's closing barrier) in the middle of the
+            // k-loop - its loads were issued at the end of the previous tile - instead of between the k-loop and the barrier
+            if (it == NIT / 2 && tile + kWsGroups < n_tiles) window_write(tile + kWsGroups, cur ^ 1);
         }
         if constexpr (R1) {   // the residual 1x1 conv reads the centre row of the same window
 #pragma unroll
@@ -212,7 +215,6 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
             }
         // ---------------------------------------------------------------- next window -> the other buffer
         const int nxt = tile + kWsGroups;
-        if (nxt < n_tiles) window_write(nxt, cur ^ 1);
         WS_STAMP(2);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         WS_STAMP(3);
