@@ -56,12 +56,12 @@ def test_unet_forward_ragged_batches_vs_oracle(B, fused):
     np.testing.assert_allclose(y, ref, rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize("B", [512, 777])
+@pytest.mark.parametrize("B", [512, 777, 2051])
 def test_weight_stationary_inner_levels_are_bit_identical(B):
     """Large batches run the 256 -> 256 Conv1dBlocks of the inner levels on the weight-stationary persistent kernel (csrc/conv_ws.hpp:
-    weights in registers, 16-position tiles, rotating epilogue duty): same k-group split, accumulation and reduction order and
-    epilogue as conv_block_kernel -> the U-Net output is BIT-identical to the per-layer kernels (MPDX_WS=0), for full and ragged
-    last tiles, and a trajectory's result does not depend on the batch it sits in."""
+    weights in registers, 16-position tiles with a rotating epilogue duty, 32-position tiles from B = 2048 on): same k-group split,
+    accumulation and reduction order and epilogue as conv_block_kernel -> the U-Net output is BIT-identical to the per-layer kernels
+    (MPDX_WS=0), for full and ragged last tiles, and a trajectory's result does not depend on the batch it sits in."""
     import os
     net = _gpu_model(14, 1)
     x = t(f"ws_x_{B}", (B, 64, 14)).cuda()
