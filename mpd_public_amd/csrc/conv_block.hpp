@@ -730,28 +730,4 @@ inline size_t conv_block_lds_bytes(int L_in, int L_out, int rs) {
     return stage > red ? stage : red;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// weight repacking: reference layout -> MFMA A-fragment order  Wp[m16][c16][slot][lane][4]
-//   conv:   src [C_out][C_in][k]        (nn.Conv1d)
-//   convT:  src [C_in][C_out][k]        (nn.ConvTranspose1d)
-__global__ void pack_conv_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int C_out, int C_in,
-                                         int ksz, int cin_pad, int nslot, int transposed) {
-    const int nc16 = cin_pad >> 4;
-    const size_t total = (size_t)(C_out >> 4) * nc16 * nslot * 256;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int e = i & 3, lane = (i >> 2) & 63;
-        size_t r = i >> 8;
-        const int slot = r % nslot; r /= nslot;
-        const int c16 = r % nc16; const int m16 = r / nc16;
-        const int co = m16 * 16 + (lane & 15);
-        const int ci = c16 * 16 + (lane >> 4) * 4 + e;
-        float v = 0.f;
-        if (ci < C_in) {
-            if (transposed) v = src[((size_t)ci * C_out + co) * ksz + upt_slot_to_k(slot)];
-            else v = src[((size_t)co * C_in + ci) * ksz + slot];
-        }
-        dst[i] = v;
-    }
-}
-
 }  // namespace mpdx

@@ -826,16 +826,6 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void guide_step_panda_kernel(co
 #undef G_STAMP
 }
 
-// per-context max|x| (the range test of LimitsNormalizer.unnormalize) for the API path
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, uint32_t* out, size_t per_ctx, int n_ctx) {
-    const int ctx = blockIdx.y;
-    const float* p = x + (size_t)ctx * per_ctx;
-    float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_ctx; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(p[i]));
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out + ctx, __float_as_uint(m));
-}
 
 inline size_t guide_lds_bytes(const mpdx_guide_params& gp, int H, int D, bool dense = false) {
     const int N = gp.interpolate ? gp.n_interp : H;

@@ -1,0 +1,30 @@
+// k_ws.hip - the weight-stationary persistent conv kernels (conv_ws.hpp).
+#include "host.hpp"
+
+namespace mpdx {
+
+template <int NC16, int MT, bool R1, int NS = 1>
+static int launch_ws(const Layer& l, ConvArgs& a, const ConvArgs& a2, int B, hipStream_t st) {
+    a.n_tiles_n = (int)(((long)B * l.L_out + 16 * NS - 1) / (16 * NS));
+    const size_t lds = conv_ws_lds_bytes<NC16, MT, R1, NS>(l.L_out, a.rs);
+    if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "weight-stationary conv needs %zu B of LDS", lds);
+    auto kern = conv_ws_kernel<NC16, MT, R1, NS>;
+    if (int rc = raise_lds_limit((const void*)kern)) return rc;
+    hipLaunchKernelGGL(kern, dim3((l.cout / MT) * kWsGroups), dim3(kWsThreads), lds, st, a, a2);
+    return 0;
+}
+
+int launch_weight_stationary(int variant, const Layer& l, ConvArgs& a, const ConvArgs& a2, int B, hipStream_t st) {
+    switch (variant) {
+        case 1: {   // 32-position tiles (one duty wave on every SIMD) from 16 tiles per workgroup on
+            static const int ns_env = getenv("MPDX_WS_NS") ? atoi(getenv("MPDX_WS_NS")) : 0;   // dev A/B: 1 / 2 force the tile
+            const bool big = ns_env ? ns_env == 2 : (long)B * l.L_out >= 32L * kWsGroups * 16;
+            if (big && conv_ws_lds_bytes<16, 32, false, 2>(l.L_out, a.rs) <= 160 * 1024) return launch_ws<16, 32, false, 2>(l, a, a2, B, st);
+            return launch_ws<16, 32, false>(l, a, a2, B, st);
+        }
+        case 3: return launch_ws<32, 16, true>(l, a, a2, B, st);
+    }
+    return fail(MPDX_E_STATE, "no weight-stationary variant %d", variant);
+}
+
+}  // namespace mpdx

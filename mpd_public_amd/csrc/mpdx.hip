@@ -1,47 +1,23 @@
 // mpdx.hip - libmpdx.so: host-side layer plan + C ABI (include/mpdx.h) + the small streaming kernels.
 //
 // gfx950 only.  No CUDA shims, no dual paths.  All device memory is caller-owned; nothing here synchronises.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <set>
-#include <string>
-#include <unordered_map>
-#include <vector>
-
-#include "../../include/mpdx.h"
-#include "conv_block.hpp"
-#include "conv_ws.hpp"
-#include "fused_level.hpp"
-#include "train.hpp"
-#include "guide.hpp"
+#include "host.hpp"
 
 namespace mpdx {
 
 // ------------------------------------------------------------------------------------------------ error plumbing
 static thread_local char g_err[512] = "";
-static int fail(int code, const char* fmt, ...) {
+int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
 }
-#define HIP_TRY(expr)                                                                                 \
-    do {                                                                                              \
-        hipError_t e_ = (expr);                                                                       \
-        if (e_ != hipSuccess) return fail((int)e_, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) must be applied once per (device, kernel): guarded by a mutex and keyed by
 // the current device, so that several host threads / several GPUs in one process are safe.
-static int raise_lds_limit(const void* kern) {
+int raise_lds_limit(const void* kern) {
     static std::mutex mu;
     static std::set<std::pair<int, const void*>> done;
     int dev = 0;
@@ -55,13 +31,12 @@ static int raise_lds_limit(const void* kern) {
 
 // MPDX_DEBUG=1: check hipGetLastError() after every launch group of mpdx_plan (2: also synchronise the stream there, so
 // that an asynchronous fault is attributed to the step that caused it).  Off by default: the plan never synchronises.
-static int debug_level() {
+int debug_level() {
     static const int lv = getenv("MPDX_DEBUG") ? atoi(getenv("MPDX_DEBUG")) : 0;
     return lv;
 }
 
 static long long* g_conv_trace = nullptr;   // dev tool (mpdx_layer_trace)
-static long long* g_guide_trace = nullptr;  // dev tool (mpdx_guide_trace)
 
 // ------------------------------------------------------------------------------------------------ small kernels
 
@@ -110,27 +85,6 @@ __global__ __launch_bounds__(128) void timetab_kernel(const TimeTabArgs a) {
     }
 }
 
-// final_conv[1] (Conv1d(32 -> D, k=1), temporal_unet.py:113-116) fused with the DDPM posterior step
-// (diffusion_model_base.py:121-155, sample_functions.py:31-62) and hard conditioning (sample_functions.py:5-8).
-// One thread per (trajectory, horizon index); the arithmetic is rounded op by op exactly as the reference's
-// separate elementwise ATen kernels are (no fma contraction), so given the same eps the update is bit-identical.
-struct FinalArgs {
-    const float* h;      // [B][H][C] output of final_conv[0]
-    const float* w;      // [D][C]
-    const float* bias;   // [D]
-    const float* x_in;   // [B][H][D]
-    const float* noise;  // [B][H][D] or null
-    const float* hs;     // hard start [B][D] or null
-    const float* hg;     // hard goal  [B][D] or null
-    float* out;          // eps (mode 0) or x_next (mode 1/2)
-    float* chain;        // optional second destination
-    uint32_t* absmax;    // optional per-context max|out| (bit pattern)
-    int B, H, D, C;
-    int mode;            // 0: eps only; 1: full step; 2: posterior mean only (guide insertion point); 3: DDIM update
-    int n_per_ctx;
-    mpdx_step_coefs k;
-    NoiseRng rng;        // rng.on: the step's noise is drawn in place (noise pointer ignored)
-};
 
 __global__ __launch_bounds__(256) void final_step_kernel(const FinalArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -287,85 +241,35 @@ __global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ d
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// weight repacking: reference layout -> MFMA A-fragment order  Wp[m16][c16][slot][lane][4]
+//   conv:   src [C_out][C_in][k]        (nn.Conv1d)
+//   convT:  src [C_in][C_out][k]        (nn.ConvTranspose1d)
+__global__ void pack_conv_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int C_out, int C_in,
+                                         int ksz, int cin_pad, int nslot, int transposed) {
+    const int nc16 = cin_pad >> 4;
+    const size_t total = (size_t)(C_out >> 4) * nc16 * nslot * 256;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = i & 3, lane = (i >> 2) & 63;
+        size_t r = i >> 8;
+        const int slot = r % nslot; r /= nslot;
+        const int c16 = r % nc16; const int m16 = r / nc16;
+        const int co = m16 * 16 + (lane & 15);
+        const int ci = c16 * 16 + (lane >> 4) * 4 + e;
+        float v = 0.f;
+        if (ci < C_in) {
+            if (transposed) v = src[((size_t)ci * C_out + co) * ksz + upt_slot_to_k(slot)];
+            else v = src[((size_t)co * C_in + ci) * ksz + slot];
+        }
+        dst[i] = v;
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------------ host-side model
-enum ParamKind { PK_VEC = 0, PK_CONV = 1, PK_CONVT = 2 };
-
-struct Param {
-    std::string name;
-    int32_t shape[3] = {0, 0, 0};
-    int32_t ndim = 0;
-    size_t n = 0;       // floats in the reference tensor
-    size_t off = 0;     // offset (floats) in the packed buffer
-    size_t foff = 0;    // offset (floats) in the flat reference-layout parameter vector (training, train_host.hpp)
-    size_t pn = 0;      // floats in the packed buffer
-    int kind = PK_VEC;
-    int cout = 0, cin = 0, ksz = 0, cin_pad = 0, nslot = 0;
-    bool done = false;
-};
-
-enum { SRC_X = -1, SRC_NONE = -2 };
-
-struct Layer {
-    int mode = CONV_S1, ks = 5, epi = EPI_GN_MISH;
-    int c1 = 0, c2 = 0, cout = 0, L_in = 0, L_out = 0, gs = 0;
-    int src1 = SRC_NONE, src2 = SRC_NONE, dst = 0, res = SRC_NONE;  // workspace slots
-    int w = -1, b = -1, gamma = -1, beta = -1;                       // param indices
-    int tb_off = -1;                                                 // offset in a time-table row
-    int cin_pad = 0, rs = 0;
-    std::string name;
-};
 
 }  // namespace mpdx
 
-struct mpdx_unet {
-    mpdx_unet_cfg cfg;
-    std::vector<mpdx::Param> params;
-    std::unordered_map<std::string, int> pidx;
-    std::vector<mpdx::Layer> layers;
-    size_t packed_floats = 0;
-    size_t slot_floats = 0;   // per-trajectory floats of one activation slot
-    int n_slots = 0;
-    int tt_row = 0;           // floats per time-table row
-    std::vector<int> tt_w, tt_b, tt_cout, tt_off;  // cond_mlp param indices per block
-    int final_slot = 0;       // slot holding final_conv[0]'s output
-    int n_done = 0;
-    // launch units: fused whole-trajectory segments (fused_level.hpp) or single layers
-    struct CopyJob { size_t src, dst; int n0, ss0, ds0, n1, ss1, ds1, n_inner; };   // strided copy inside `packed` (float units)
-    struct Fused {
-        int first = 0, count = 0;       // layer range [first, first+count)
-        bool has_final = false;         // final_conv[1] + DDPM step folded in
-        int in1 = 0, in2 = 0;           // input slots (SRC_X / SRC_NONE allowed)
-        int in3 = mpdx::SRC_NONE;       // slot of a skip tensor concatenated INSIDE the program (FusedArgs::gsrc3)
-        int gout_slot[3] = {-1, -1, -1};
-        size_t lds_bytes = 0;
-        mpdx::FusedArgs tmpl;
-        int program = -1;               // index of the matching static program (fused_program_kernel), -1: generic op-list kernel
-        std::vector<CopyJob> jobs;      // assemble the stream-ordered weight copies + the contiguous parameter block
-        std::vector<int> op_layer;      // conv op k computes layer op_layer[k] (a folded residual conv has no op of its own)
-        int in3_consumer = -1;          // layer whose second source is the in3 skip tensor
-    };
-    std::vector<Fused> fused;
-    void* jobs_dev = nullptr;           // device copy of every segment's CopyJobs (restream_all_kernel)
-    int n_jobs = 0;
-    const float* streams_for = nullptr; // `packed` buffer the fused streams were last assembled in
-    int pack_version = 0, streams_version = -1;
-    struct Unit { int fused; int layer; bool pair; };   // fused >= 0: fused[fused]; else layers[layer] (pair: + layers[layer+1] in one launch)
-    std::vector<int> owner;                  // layer -> fused segment (-1: per-layer launch)
-    // training (train_host.hpp)
-    struct TrainLayer {
-        int src1_l = -2, src2_l = -2, res_l = -2;   // layer that produced the tensor (-1: the network input, -2: none)
-        bool need_dgrad = false;
-        size_t dgrad_woff = 0;                      // offset of the dgrad weights in packedT
-        mpdx::Layer dg;                             // the stride-1 convolution that computes the input gradient
-    };
-    bool train_ready = false;
-    size_t flat_floats = 0, packedT_floats = 0;
-    std::vector<TrainLayer> tl;
-    std::vector<mpdx::PackDesc> pack_descs_host;
-    void* pack_descs_dev = nullptr;
-    void* pack_chunks_dev = nullptr;   // PackChunk table of pack_train_kernel
-    size_t n_pack_chunks = 0;
-};
 
 namespace mpdx {
 
@@ -407,7 +311,7 @@ static int add_param(mpdx_unet* u, const std::string& name, std::initializer_lis
 // LDS row stride (floats) for the staged window: smallest pad that minimises ds_read_b128 bank conflicts of the
 // B-fragment gather (lane (j,q) reads 16 B at row(j)*rs + 4q; ds_read_b128 is served in the four 16-lane groups
 // listed in MI355X_MICROARCH.md section LDS; bank = dword address mod 64).
-static int pick_row_stride(int cin_pad, int mode, int L_in, int L_out, int LP) {
+int pick_row_stride(int cin_pad, int mode, int L_in, int L_out, int LP) {
     static const int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
                                       {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
                                       {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
@@ -890,25 +794,13 @@ static void build_units(mpdx_unet* u) {
     u->owner = owner;
 }
 
-// ------------------------------------------------------------------------------------------------ conv dispatch
-template <int MODE, int KS, int EPI, int MT, int NT, int WN, int WK>
-static int launch_conv(const ConvArgs& a, hipStream_t st) {
-    const size_t lds = conv_block_lds_bytes<MODE, KS, MT, NT, WK>(a.L_in, a.L_out, a.rs);
-    if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "conv tile needs %zu B of LDS", lds);
-    auto kern = conv_block_kernel<MODE, KS, EPI, MT, NT, WN, WK>;
-    if (lds > 64 * 1024)
-        if (int rc = raise_lds_limit((const void*)kern)) return rc;
-    const int grid = (a.C_out / MT) * a.n_tiles_n;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WN * WK), lds, st, a);
-    return 0;
-}
 
 // tile choice.  Measured on MI355X at B=100 (tools/ablate_layers.py): per-launch time is dominated by fixed costs
 // (launch boundary ~3 us, epilogue ~1.9 us), halving the tile to co-schedule two workgroups per CU does NOT pay
 // (the MFMA phase gets slower: every output column re-streams the weights), so: the largest tile that still
 // gives >= `target` workgroups (default 160 of the 256 CUs), growing with the batch for weight reuse.
 // MPDX_TILE=MTxNT / MPDX_TARGET_WGS override (development).
-static void choose_tile(const Layer& l, int B, int& MT, int& NT) {
+void choose_tile(const Layer& l, int B, int& MT, int& NT) {
     const int min_mt = (l.epi == EPI_GN_MISH && l.gs > 16) ? 32 : 16;
     const int min_nt = std::max(l.mode == CONV_UPT ? 32 : 16, l.L_out);
     const long npos = (long)B * l.L_out;
@@ -944,7 +836,7 @@ static void choose_tile(const Layer& l, int B, int& MT, int& NT) {
 }
 
 static int layer_ntap(const Layer& l) { return l.mode == CONV_UPT ? 2 : l.ks; }
-static bool layer_ksplit(const Layer& l) {
+bool layer_ksplit(const Layer& l) {
     if (!(l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH)) return true;
     static const int forced = getenv("MPDX_KSPLIT") ? atoi(getenv("MPDX_KSPLIT")) : -1;   // dev: 0 = (NT/16) x (8/(NT/16)) waves, 1 = 1 x 8
     if (forced >= 0) return forced != 0;
@@ -954,39 +846,6 @@ static double layer_flops(const Layer& l, int B) {
     return 2.0 * l.cout * (double)B * l.L_out * (l.c1 + l.c2) * layer_ntap(l);
 }
 
-template <int MODE, int KS, int EPI>
-static int dispatch_tile(const Layer& l, ConvArgs& a, int B, hipStream_t st) {
-    int MT, NT;
-    choose_tile(l, B, MT, NT);
-    if (l.cout % MT) MT = 16;
-    if (l.cout % MT || NT % l.L_out) return fail(MPDX_E_INVALID, "layer %s: no tile for C_out=%d L=%d", l.name.c_str(), l.cout, l.L_out);
-    a.n_tiles_n = (int)(((long)B * l.L_out + NT - 1) / NT);
-    const bool ksplit = layer_ksplit(l);
-#define MPDX_TILE(mt, nt)                                                                        \
-    if (MT == mt && NT == nt) {                                                                  \
-        if (ksplit) return launch_conv<MODE, KS, EPI, mt, nt, 1, 8>(a, st);                      \
-        return launch_conv<MODE, KS, EPI, mt, nt, nt / 16, 8 / (nt / 16)>(a, st);               \
-    }
-    MPDX_TILE(32, 64) MPDX_TILE(32, 32) MPDX_TILE(16, 64) MPDX_TILE(16, 32) MPDX_TILE(32, 16) MPDX_TILE(16, 16)
-    if constexpr (EPI != EPI_GN_MISH) { MPDX_TILE(16, 128) MPDX_TILE(32, 128) }   // 128-position levels have regions >= 512: _GEN only
-#undef MPDX_TILE
-    return fail(MPDX_E_INVALID, "no instantiation for tile %dx%d", MT, NT);
-}
-
-template <int MODE, int KS, int EPI>
-static int dispatch_tile_ksplit_only(const Layer& l, ConvArgs& a, int B, hipStream_t st) {
-    int MT, NT;
-    choose_tile(l, B, MT, NT);
-    if (l.cout % MT) MT = 16;
-    if (l.cout % MT || NT % l.L_out) return fail(MPDX_E_INVALID, "layer %s: no tile for C_out=%d L=%d", l.name.c_str(), l.cout, l.L_out);
-    a.n_tiles_n = (int)(((long)B * l.L_out + NT - 1) / NT);
-#define MPDX_TILE(mt, nt) \
-    if (MT == mt && NT == nt) return launch_conv<MODE, KS, EPI, mt, nt, 1, 8>(a, st);
-    MPDX_TILE(32, 64) MPDX_TILE(32, 32) MPDX_TILE(16, 64) MPDX_TILE(16, 32) MPDX_TILE(16, 128) MPDX_TILE(32, 128)
-    if constexpr (MODE != CONV_UPT) { MPDX_TILE(32, 16) MPDX_TILE(16, 16) }
-#undef MPDX_TILE
-    return fail(MPDX_E_INVALID, "no instantiation for tile %dx%d", MT, NT);
-}
 
 static int make_conv_args(const mpdx_unet* u, const Layer& l, const float* packed, const float* tt_row, const float* x, float* ws, int B,
                           int dbg, ConvArgs& a) {
@@ -1034,59 +893,13 @@ static int weight_stationary_variant(const Layer& l, const Layer* l2, const Conv
     return 0;
 }
 
-template <int NC16, int MT, bool R1, int NS = 1>
-static int launch_ws(const Layer& l, ConvArgs& a, const ConvArgs& a2, int B, hipStream_t st) {
-    a.n_tiles_n = (int)(((long)B * l.L_out + 16 * NS - 1) / (16 * NS));
-    const size_t lds = conv_ws_lds_bytes<NC16, MT, R1, NS>(l.L_out, a.rs);
-    if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "weight-stationary conv needs %zu B of LDS", lds);
-    auto kern = conv_ws_kernel<NC16, MT, R1, NS>;
-    if (int rc = raise_lds_limit((const void*)kern)) return rc;
-    hipLaunchKernelGGL(kern, dim3((l.cout / MT) * kWsGroups), dim3(kWsThreads), lds, st, a, a2);
-    return 0;
-}
-
-static int launch_weight_stationary(int variant, const Layer& l, ConvArgs& a, const ConvArgs& a2, int B, hipStream_t st) {
-    switch (variant) {
-        case 1: {   // 32-position tiles (one duty wave on every SIMD) from 16 tiles per workgroup on
-            static const int ns_env = getenv("MPDX_WS_NS") ? atoi(getenv("MPDX_WS_NS")) : 0;   // dev A/B: 1 / 2 force the tile
-            const bool big = ns_env ? ns_env == 2 : (long)B * l.L_out >= 32L * kWsGroups * 16;
-            if (big && conv_ws_lds_bytes<16, 32, false, 2>(l.L_out, a.rs) <= 160 * 1024) return launch_ws<16, 32, false, 2>(l, a, a2, B, st);
-            return launch_ws<16, 32, false>(l, a, a2, B, st);
-        }
-        case 3: return launch_ws<32, 16, true>(l, a, a2, B, st);
-    }
-    return fail(MPDX_E_STATE, "no weight-stationary variant %d", variant);
-}
 
 static int run_layer(const mpdx_unet* u, const Layer& l, const float* packed, const float* tt_row, const float* x,
                      float* ws, int B, hipStream_t st, int dbg = 0) {
     ConvArgs a;
     if (int rc = make_conv_args(u, l, packed, tt_row, x, ws, B, dbg, a)) return rc;
     if (const int v = weight_stationary_variant(l, nullptr, a, B, dbg)) return launch_weight_stationary(v, l, a, a, B, st);
-    if (l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH) {
-        const int re = l.gs * l.L_out;   // regions other than 128 / 256 elements (horizons other than 64): the general-region instantiations
-        if (re != 128 && re != 256) return dispatch_tile<CONV_S1, 5, EPI_GN_MISH_GEN>(l, a, B, st);
-        return dispatch_tile<CONV_S1, 5, EPI_GN_MISH>(l, a, B, st);
-    }
-    if (l.mode == CONV_S1 && l.ks == 1 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 1, EPI_BIAS>(l, a, B, st);
-    if (l.mode == CONV_DOWN && l.ks == 3) return dispatch_tile_ksplit_only<CONV_DOWN, 3, EPI_BIAS>(l, a, B, st);
-    if (l.mode == CONV_UPT && l.ks == 4) return dispatch_tile_ksplit_only<CONV_UPT, 4, EPI_BIAS>(l, a, B, st);
-    return fail(MPDX_E_INVALID, "layer %s: unsupported conv (mode %d k %d epi %d)", l.name.c_str(), l.mode, l.ks, l.epi);
-}
-
-// blocks[0] + residual 1x1 conv of the same ResidualTemporalBlock in one launch (both read the block's input).
-// Returns 1 if the pair was launched, 0 if the shapes do not qualify (caller launches them separately), <0 on error.
-template <int MT, int NT>
-static int launch_pair(const ConvArgs& a1, const ConvArgs& a2, const Layer& l1, const Layer& l2, hipStream_t st) {
-    const size_t lds = std::max(conv_block_lds_bytes<CONV_S1, 5, MT, NT, 8>(l1.L_in, l1.L_out, l1.rs),
-                                conv_block_lds_bytes<CONV_S1, 1, MT, NT, 8>(l2.L_in, l2.L_out, l2.rs));
-    if (lds > 160 * 1024) return 0;
-    auto kern = conv_pair_kernel<MT, NT>;
-    if (lds > 64 * 1024)
-        if (raise_lds_limit((const void*)kern)) return -1;
-    const int n1 = (a1.C_out / MT) * a1.n_tiles_n, n2 = (a2.C_out / MT) * a2.n_tiles_n;
-    hipLaunchKernelGGL(kern, dim3(n1 + n2), dim3(512), lds, st, a1, a2, n1);
-    return 1;
+    return launch_conv_layer(l, a, B, st);
 }
 
 // blocks[0] + residual 1x1 conv of one ResidualTemporalBlock qualify for ONE launch (conv_pair_kernel)?  On success the tile.
@@ -1113,13 +926,10 @@ static int run_pair(const mpdx_unet* u, const Layer& l1, const Layer& l2, const 
     if (int rc = make_conv_args(u, l2, packed, tt_row, x, ws, B, 0, a2)) return rc;
     if (const int v = weight_stationary_variant(l1, &l2, a1, B, 0)) return launch_weight_stationary(v, l1, a1, a2, B, st);
     a1.n_tiles_n = a2.n_tiles_n = (int)(((long)B * l1.L_out + NT - 1) / NT);
-#define MPDX_PAIR_TILE(mt, nt) if (MT == mt && NT == nt) return launch_pair<mt, nt>(a1, a2, l1, l2, st) == 1 ? 0 : fail(MPDX_E_INVALID, "pair launch failed");
-    MPDX_PAIR_TILE(32, 64) MPDX_PAIR_TILE(32, 32) MPDX_PAIR_TILE(16, 64) MPDX_PAIR_TILE(16, 32) MPDX_PAIR_TILE(32, 16) MPDX_PAIR_TILE(16, 16)
-#undef MPDX_PAIR_TILE
-    return fail(MPDX_E_INVALID, "no pair instantiation for tile %dx%d", MT, NT);
+    return launch_conv_pair(MT, NT, a1, a2, l1, l2, st) == 1 ? 0 : fail(MPDX_E_INVALID, "pair launch failed (tile %dx%d)", MT, NT);
 }
 
-static int check_ready(const mpdx_unet* u) {
+int check_ready(const mpdx_unet* u) {
     if (u->n_done != (int)u->params.size())
         return fail(MPDX_E_STATE, "%d of %zu parameters packed; call mpdx_unet_pack_param for every state-dict tensor first",
                     u->n_done, u->params.size());
@@ -1132,7 +942,7 @@ static int check_ready(const mpdx_unet* u) {
 // everywhere.  Measured on MI355X: U-Net pass D=14, round-2 generic kernel: B=800 1.305 vs 1.337 ms (fused vs per-layer), 1600: 2.04 vs
 // 2.16, 3200: 3.52 vs 3.57, 6400 equal; static programs at B=6400 (cfg5 plan): 644 vs 726 ms.  (Round 1's kernel crossed over at
 // B~600.)  MPDX_FUSED=0/1 forces none/all, MPDX_FUSED_MASK=<bits> selects segments.
-static unsigned fused_mask(int B) {
+unsigned fused_mask(int B) {
     (void)B;
     // read on every call (two getenv per pass): tests and A/B runs switch the path inside one process
     const char* f = getenv("MPDX_FUSED");
@@ -1172,7 +982,10 @@ static int run_final(mpdx_unet* u, const float* packed, FinalArgs& fa, int B, fl
     fa.w = packed + u->params[u->pidx.at("final_conv.1.weight")].off;
     fa.bias = packed + u->params[u->pidx.at("final_conv.1.bias")].off;
     fa.B = B; fa.H = c.n_support_points; fa.D = c.state_dim; fa.C = c.unet_input_dim;
-    const int n = B * c.n_support_points;
+    return launch_final_step(fa, st);
+}
+int launch_final_step(const FinalArgs& fa, hipStream_t st) {
+    const int n = fa.B * fa.H;
     const size_t lds = (size_t)(fa.D * fa.C + fa.D) * sizeof(float);
     hipLaunchKernelGGL(final_step_kernel, dim3((n + 255) / 256), dim3(256), lds, st, fa);
     return 0;
@@ -1207,7 +1020,7 @@ __global__ __launch_bounds__(256) void restream_all_kernel(float* __restrict__ p
 
 // The fused segments read stream-ordered copies of their weights and one contiguous parameter block (fused_level.hpp);
 // (re)assemble them in `packed` after the state dict was (re)packed.  Enqueues copies on `st`; no synchronisation.
-static int ensure_fused_streams(mpdx_unet* u, const float* packed, hipStream_t st) {
+int ensure_fused_streams(mpdx_unet* u, const float* packed, hipStream_t st) {
     if (u->streams_for == packed && u->streams_version == u->pack_version) return 0;
     if (!u->jobs_dev) {   // the job table never changes after build_units
         std::vector<CopyJobDev> all;
@@ -1226,9 +1039,8 @@ static int ensure_fused_streams(mpdx_unet* u, const float* packed, hipStream_t s
     return 0;
 }
 
-static int launch_fused_args(const mpdx_unet::Fused& f, const FusedArgs& a, int B, hipStream_t st, bool save = false);
 // programs that exist in the training-forward variant (the two of the standard 4-level network, and the generic op-list kernel)
-static bool fused_save_variant(const mpdx_unet::Fused& f) { return f.program == 3 || f.program == 5 || f.program < 0; }
+bool fused_save_variant(const mpdx_unet::Fused& f) { return f.program == 3 || f.program == 5 || f.program < 0; }
 static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packed, const float* tt_row, const float* x, float* ws,
                      int B, const FinalArgs* fa, hipStream_t st) {
     const size_t slot = u->slot_floats * (size_t)B;
@@ -1250,52 +1062,6 @@ static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packe
     return launch_fused_args(f, a, B, st);
 }
 
-static int launch_fused_args(const mpdx_unet::Fused& f, const FusedArgs& a, int B, hipStream_t st, bool save) {
-    if (save) {
-        if (!fused_save_variant(f)) return fail(MPDX_E_STATE, "fused program %d has no training variant", f.program);
-        if (f.program == 3) {
-            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqUpAB, true>)) return rc;
-            hipLaunchKernelGGL((fused_program_kernel<FusedSeqUpAB, true>), dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
-        } else if (f.program == 5) {
-            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqDown3, true>)) return rc;
-            hipLaunchKernelGGL((fused_program_kernel<FusedSeqDown3, true>), dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
-        } else {
-            if (int rc = raise_lds_limit((const void*)fused_level_kernel<true>)) return rc;
-            hipLaunchKernelGGL(fused_level_kernel<true>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
-        }
-        return 0;
-    }
-    switch (f.program) {
-        case 0:
-            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqDown>)) return rc;
-            hipLaunchKernelGGL(fused_program_kernel<FusedSeqDown>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
-            break;
-        case 1:
-            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqUpA>)) return rc;
-            hipLaunchKernelGGL(fused_program_kernel<FusedSeqUpA>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
-            break;
-        case 2:
-            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqUpB>)) return rc;
-            hipLaunchKernelGGL(fused_program_kernel<FusedSeqUpB>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
-            break;
-        case 3:
-            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqUpAB>)) return rc;
-            hipLaunchKernelGGL(fused_program_kernel<FusedSeqUpAB>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
-            break;
-        case 4:
-            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqMid2>)) return rc;
-            hipLaunchKernelGGL(fused_program_kernel<FusedSeqMid2>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
-            break;
-        case 5:
-            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqDown3>)) return rc;
-            hipLaunchKernelGGL(fused_program_kernel<FusedSeqDown3>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
-            break;
-        default:
-            if (int rc = raise_lds_limit((const void*)fused_level_kernel<false>)) return rc;
-            hipLaunchKernelGGL(fused_level_kernel<false>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
-    }
-    return 0;
-}
 
 // one launch unit of the pass (the SAME function serves the planning path, the profiler and the in-situ timer)
 static int run_unit(mpdx_unet* u, const mpdx_unet::Unit& un, const float* packed, const float* row, const float* x, float* ws, int B,
@@ -1332,47 +1098,6 @@ static int run_unet_and_final(mpdx_unet* u, const float* packed, const float* ti
     return 0;
 }
 
-static int launch_guide(const mpdx_guide_params* gp, float* x, float* grad_out, const float* hs, const float* hg,
-                        const uint32_t* amax_in, uint32_t* amax_out, int n_per_ctx, int B, int H, int D, hipStream_t st,
-                        const float* noise = nullptr, float noise_scale = 0.f, float noise_extra = 0.f, float* chain = nullptr,
-                        float guide_scale = 1.0f, const NoiseRng* rng = nullptr) {
-    if (!gp || !x || !amax_in) return fail(MPDX_E_INVALID, "null argument");
-    if (H > 128 || H < 2) return fail(MPDX_E_INVALID, "guide kernel: one support point per lane of one or two waves: H=%d unsupported (max 128)", H);
-    if (D != 2 * gp->q_dim || D > 16) return fail(MPDX_E_INVALID, "state dim %d != 2*q_dim (%d)", D, gp->q_dim);
-    if (gp->n_fields < 0 || gp->n_fields > MPDX_MAX_FIELDS) return fail(MPDX_E_INVALID, "n_fields %d", gp->n_fields);
-    if (gp->interpolate && (gp->n_interp < H || gp->n_interp > 8 * H)) return fail(MPDX_E_INVALID, "n_interp %d unsupported", gp->n_interp);
-    if (gp->n_prim_floats > 0 && !gp->prims) return fail(MPDX_E_INVALID, "primitive table missing");
-    GuideArgs a;
-    a.gp = *gp; a.x = x; a.grad_out = grad_out; a.hs = hs; a.hg = hg; a.amax_in = amax_in; a.amax_out = amax_out;
-    a.B = B; a.H = H; a.D = D; a.n_per_ctx = n_per_ctx > 0 ? n_per_ctx : B;
-    a.noise = noise; a.noise_scale = noise_scale; a.noise_extra = noise_extra; a.chain = chain;
-    a.guide_scale = guide_scale;
-    memset(&a.rng, 0, sizeof(a.rng));
-    if (rng) a.rng = *rng;
-    if (gp->clip_grad && gp->clip_rule != 0 && gp->clip_rule != 1) return fail(MPDX_E_INVALID, "clip_rule %d (0 = 'norm', 1 = 'value')", gp->clip_rule);
-    a.trace = g_guide_trace;
-    // Panda at large batch: the dense variant (no FK table, 128 VGPRs: two workgroups per CU); MPDX_GUIDE_DENSE=0/1 forces it off / on
-    static const int dense_env = getenv("MPDX_GUIDE_DENSE") ? atoi(getenv("MPDX_GUIDE_DENSE")) : -1;
-    const bool dense = gp->robot == MPDX_ROBOT_PANDA && (dense_env >= 0 ? dense_env != 0 : B >= 512) && guide_lds_bytes(*gp, H, D, true) <= 80 * 1024;
-    const size_t lds = guide_lds_bytes(*gp, H, D, dense);
-    if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "guide needs %zu B of LDS (n_interp %d too large)", lds, gp->n_interp);
-    if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 2 && gp->ws_dim == 2)
-        hipLaunchKernelGGL((guide_step_kernel<2, 2, MPDX_ROBOT_POINTMASS, 8>), dim3(B), dim3(512), lds, st, a);
-    else if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 3 && gp->ws_dim == 3)
-        hipLaunchKernelGGL((guide_step_kernel<3, 3, MPDX_ROBOT_POINTMASS, 8>), dim3(B), dim3(512), lds, st, a);
-    else if (gp->robot == MPDX_ROBOT_PANDA && gp->q_dim == 7 && gp->ws_dim == 3) {
-        if (dense) {
-            if (int rc = raise_lds_limit((const void*)guide_step_panda_kernel<true>)) return rc;
-            hipLaunchKernelGGL(guide_step_panda_kernel<true>, dim3(B), dim3(512), lds, st, a);
-        } else {
-            if (int rc = raise_lds_limit((const void*)guide_step_panda_kernel<false>)) return rc;
-            hipLaunchKernelGGL(guide_step_panda_kernel<false>, dim3(B), dim3(512), lds, st, a);
-        }
-    }
-    else
-        return fail(MPDX_E_INVALID, "unsupported robot %d / q_dim %d / ws_dim %d", gp->robot, gp->q_dim, gp->ws_dim);
-    return 0;
-}
 
 }  // namespace mpdx
 
@@ -1536,75 +1261,6 @@ int mpdx_weighted_loss(const float* pred, const float* targ, const float* weight
     return 0;
 }
 
-int mpdx_guide_step(const mpdx_guide_params* gp, float* x, float* grad_out, const float* hard_start, const float* hard_goal,
-                    const uint32_t* absmax_in, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, void* stream) {
-    if (int rc = launch_guide(gp, x, grad_out, hard_start, hard_goal, absmax_in, absmax_out, n_per_ctx, B, H, D, (hipStream_t)stream)) return rc;
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-int mpdx_guide_step_scaled(const mpdx_guide_params* gp, float* x, float* grad_out, const float* hard_start, const float* hard_goal,
-                           const uint32_t* absmax_in, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, float guide_scale, void* stream) {
-    if (int rc = launch_guide(gp, x, grad_out, hard_start, hard_goal, absmax_in, absmax_out, n_per_ctx, B, H, D, (hipStream_t)stream, nullptr, 0.f,
-                              0.f, nullptr, guide_scale))
-        return rc;
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-int mpdx_traj_metrics(const mpdx_guide_params* gp, const float* x_unnormalised, float* out4, int n_check, int B, int H, int D, void* stream) {
-    if (!gp || !x_unnormalised || !out4 || B <= 0) return fail(MPDX_E_INVALID, "bad argument");
-    if (H > 128 || H < 2) return fail(MPDX_E_INVALID, "H=%d unsupported (max 128)", H);
-    if (D != 2 * gp->q_dim || D > 16) return fail(MPDX_E_INVALID, "state dim %d != 2*q_dim (%d)", D, gp->q_dim);
-    if (n_check < 2) n_check = H;
-    const size_t lds = (size_t)(H * D + gp->n_prim_floats) * sizeof(float);
-    hipStream_t st = (hipStream_t)stream;
-    if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 2 && gp->ws_dim == 2)
-        hipLaunchKernelGGL((traj_metrics_kernel<2, 2, MPDX_ROBOT_POINTMASS>), dim3(B), dim3(64), lds, st, *gp, x_unnormalised, out4, B, H, n_check);
-    else if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 3 && gp->ws_dim == 3)
-        hipLaunchKernelGGL((traj_metrics_kernel<3, 3, MPDX_ROBOT_POINTMASS>), dim3(B), dim3(64), lds, st, *gp, x_unnormalised, out4, B, H, n_check);
-    else if (gp->robot == MPDX_ROBOT_PANDA && gp->q_dim == 7 && gp->ws_dim == 3)
-        hipLaunchKernelGGL((traj_metrics_kernel<7, 3, MPDX_ROBOT_PANDA>), dim3(B), dim3(64), lds, st, *gp, x_unnormalised, out4, B, H, n_check);
-    else
-        return fail(MPDX_E_INVALID, "unsupported robot %d / q_dim %d / ws_dim %d", gp->robot, gp->q_dim, gp->ws_dim);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-/* dev tool: one guide launch with s_memtime stamps (16 slots per wave, 8 waves -> 128 values) of workgroup 0 */
-int mpdx_guide_trace(const mpdx_guide_params* gp, float* x, const uint32_t* absmax_in, int B, int H, int D, void* stream, long long* stamps64) {
-#ifndef MPDX_DEV_HOOKS
-    return fail(MPDX_E_STATE, "%s needs a development build of libmpdx.so (MPDX_BUILD_DEFS=-DMPDX_DEV_HOOKS python -m mpd_public_amd.build --force): "
-                "the production kernels carry no trace / ablation hooks", __func__);
-#endif
-    if (!stamps64) return fail(MPDX_E_INVALID, "null argument");
-    hipStream_t st = (hipStream_t)stream;
-    long long* dev = nullptr;
-    HIP_TRY(hipMalloc(&dev, 128 * sizeof(long long)));
-    HIP_TRY(hipMemsetAsync(dev, 0, 128 * sizeof(long long), st));
-    static float* scratch = nullptr;
-    static size_t scratch_n = 0;
-    const size_t need = (size_t)B * H * D;
-    if (scratch_n < need) { if (scratch) (void)hipFree(scratch); HIP_TRY(hipMalloc(&scratch, need * sizeof(float))); scratch_n = need; }
-    g_guide_trace = dev;
-    int rc = launch_guide(gp, x, scratch, nullptr, nullptr, absmax_in, nullptr, B, B, H, D, st);
-    g_guide_trace = nullptr;
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipMemcpy(stamps64, dev, 128 * sizeof(long long), hipMemcpyDeviceToHost));
-    (void)hipFree(dev);
-    return rc;
-}
-
-int mpdx_absmax(const float* x, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, void* stream) {
-    if (!x || !absmax_out || B <= 0) return fail(MPDX_E_INVALID, "bad argument");
-    const int npc = n_per_ctx > 0 ? n_per_ctx : B;
-    if (B % npc) return fail(MPDX_E_INVALID, "B=%d is not a multiple of n_per_ctx=%d", B, npc);
-    const size_t per = (size_t)npc * H * D;
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<size_t>((per + 255) / 256, 64), B / npc), dim3(256), 0, (hipStream_t)stream, x,
-                       absmax_out, per, B / npc);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
 
 int mpdx_plan(mpdx_unet* u, const float* packed, const float* timetab, int T, const mpdx_step_coefs* coefs, int n_without_noise,
               float* x, const float* noise, const float* hard_start, const float* hard_goal, float* chain, int B, float* ws,
@@ -1916,5 +1572,3 @@ int mpdx_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* strea
 
 }  // extern "C"
 
-#include "train_host.hpp"
-#include "planner_host.hpp"

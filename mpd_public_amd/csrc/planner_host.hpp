@@ -2,6 +2,19 @@
 #pragma once
 #include "planner.hpp"
 
+namespace mpdx {
+// the argument checks launch_guide applies to a guide parameter block, for the planners that copy it into their kernel arguments
+// (gn_point / config_hit index gp.fields; the GPMP2 kernel's support-window arithmetic assumes n_interp >= H).  H == 0: no horizon (RRT).
+static int check_planner_params(const mpdx_guide_params* gp, int H, int D) {
+    if (D != 2 * gp->q_dim || D > 16) return fail(MPDX_E_INVALID, "state dim %d != 2*q_dim (%d)", D, gp->q_dim);
+    if (gp->n_fields < 0 || gp->n_fields > MPDX_MAX_FIELDS) return fail(MPDX_E_INVALID, "n_fields %d", gp->n_fields);
+    if (gp->n_prim_floats > 0 && !gp->prims) return fail(MPDX_E_INVALID, "primitive table missing");
+    if (H > 0 && gp->interpolate && (gp->n_interp < 2 || gp->n_interp < H || gp->n_interp > 8 * H))
+        return fail(MPDX_E_INVALID, "n_interp %d unsupported for H=%d", gp->n_interp, H);
+    return 0;
+}
+}  // namespace mpdx
+
 extern "C" {
 
 int mpdx_gpmp_step(const mpdx_guide_params* gp, const mpdx_gpmp_opts* o, float* x, float* delta, float* state, int B, int H, int D, int solve,
@@ -11,6 +24,7 @@ int mpdx_gpmp_step(const mpdx_guide_params* gp, const mpdx_gpmp_opts* o, float* 
     if (H < 4 || D != 2 * gp->q_dim) return fail(MPDX_E_INVALID, "GPMP2 step: H=%d D=%d q_dim=%d", H, D, gp->q_dim);
     if (!gp->use_gp || !(gp->dt > 0.f) || !(o->sigma_obs > 0.f))
         return fail(MPDX_E_INVALID, "GPMP2 step needs the GP prior (dt, sigma_gp) and sigma_obs > 0");
+    if (int rc = check_planner_params(gp, H, D)) return rc;
     GpmpArgs a;
     memset(&a, 0, sizeof(a));
     a.gp = *gp; a.x = x; a.delta = delta; a.state = state; a.B = B; a.H = H;
@@ -42,6 +56,9 @@ int mpdx_rrt_connect(const mpdx_guide_params* gp, const mpdx_rrt_opts* o, const 
     if (!gp || !o || !start || !goal || !nodes || !parent || !count || !link || !iters || n <= 0) return fail(MPDX_E_INVALID, "null argument");
     if (o->max_nodes < 2 || o->n_edge_checks < 2 || o->n_edge_checks > kRrtThreads || !(o->step > 0.f))
         return fail(MPDX_E_INVALID, "RRT-Connect: max_nodes %d, n_edge_checks %d, step %g", o->max_nodes, o->n_edge_checks, (double)o->step);
+    if (o->max_iters < 0 || o->max_connect_steps < 0)
+        return fail(MPDX_E_INVALID, "RRT-Connect: max_iters %d, max_connect_steps %d", o->max_iters, o->max_connect_steps);
+    if (int rc = check_planner_params(gp, 0, 2 * gp->q_dim)) return rc;
     RrtArgs a;
     memset(&a, 0, sizeof(a));
     a.gp = *gp; a.start = start; a.goal = goal; a.nodes = nodes; a.parent = parent; a.count = count; a.link = link; a.iters = iters;

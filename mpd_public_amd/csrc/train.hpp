@@ -27,6 +27,7 @@
 // (state-dict) layout, so torch Parameters can alias it.
 #pragma once
 #include "conv_block.hpp"
+#include "train_types.hpp"
 
 namespace mpdx {
 
@@ -387,20 +388,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const ReduceAllAr
 // Packing for a training step, ONE launch for every parameter (blockIdx.y = parameter): flat reference layout ->
 //   packed  : the forward layout of conv_block.hpp (pack_conv_weights_kernel) / plain copies for vectors
 //   packedT : the dgrad layout (see the file header); only for convolutions whose input gradient is needed
-struct PackDesc {
-    unsigned long long src, dst, dstT;   // float offsets (dstT == ~0: no dgrad copy)
-    unsigned long long n, pn, pnT;       // floats: reference tensor, forward pack, dgrad pack
-    int kind;                            // PK_VEC / PK_CONV / PK_CONVT
-    int cout, cin, ks, cin_pad, nslot;   // forward geometry
-    int t_cout, t_cin, t_ks, t_cin_pad;  // dgrad geometry (a CONV_S1 convolution t_cin -> t_cout with t_ks taps)
-    int t_mode;                          // 0: transpose + flip (Conv1d), 1: ConvTranspose1d k4 -> 5 taps
-};
+// struct PackDesc: train_types.hpp (the host model keeps a table of them)
 
 // One block = one CHUNK of 1024 outputs of one pack of one parameter (table built once on the host): every block of the launch has work,
 // a thread's four loads fly together (unconditional, from clamped addresses; zeros selected afterwards), index arithmetic in 32 bits.
 // (First version: grid (64, parameters), each thread looping over its parameter with one dependent load per trip and four 64-bit
 //  divisions per element - 42 us per call for 8 M outputs.)
-struct PackChunk { int desc; int which; unsigned first; unsigned pad; };   // which: 0 forward pack (vectors too), 1 dgrad pack
+// struct PackChunk: train_types.hpp
 
 __global__ __launch_bounds__(256) void pack_train_kernel(const PackDesc* __restrict__ descs, const PackChunk* __restrict__ chunks, const float* __restrict__ flat,
                                                          float* __restrict__ packed, float* __restrict__ packedT) {

@@ -151,15 +151,7 @@ static TrainWs train_ws(const mpdx_unet* u, int B) {
     return w;
 }
 
-static int launch_layer(const Layer& l, ConvArgs& a, int B, hipStream_t st) {
-    if (l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH) return dispatch_tile<CONV_S1, 5, EPI_GN_MISH>(l, a, B, st);
-    if (l.mode == CONV_S1 && l.ks == 1 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 1, EPI_BIAS>(l, a, B, st);
-    if (l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 5, EPI_BIAS>(l, a, B, st);
-    if (l.mode == CONV_S1 && l.ks == 3 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 3, EPI_BIAS>(l, a, B, st);
-    if (l.mode == CONV_DOWN && l.ks == 3) return dispatch_tile_ksplit_only<CONV_DOWN, 3, EPI_BIAS>(l, a, B, st);
-    if (l.mode == CONV_UPT && l.ks == 4) return dispatch_tile_ksplit_only<CONV_UPT, 4, EPI_BIAS>(l, a, B, st);
-    return fail(MPDX_E_INVALID, "layer %s: unsupported conv (mode %d k %d epi %d)", l.name.c_str(), l.mode, l.ks, l.epi);
-}
+static int launch_layer(const Layer& l, ConvArgs& a, int B, hipStream_t st) { return launch_conv_layer(l, a, B, st); }
 
 static int fill_geom(const Layer& l, int B, ConvArgs& a) {
     a.c1 = l.c1; a.c2 = l.c2;
@@ -382,8 +374,9 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     HIP_TRY(hipMemsetAsync(ws + w.zeros, 0, (1024 + 4) * sizeof(float), st));   // the zero bias of the dgrad convolutions + the time backward's ticket
     {
         const size_t ne = (size_t)B * H * D;
-        hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)std::min<size_t>((ne + 255) / 256, 2048)), dim3(256), 0, st, x_start, noise, t_dev,
-                           sqrt_alphas_cumprod_dev, sqrt_one_minus_alphas_cumprod_dev, hard_start, hard_goal, xn, B, H, D, T);
+        (void)ne;
+        if (int rc = mpdx_q_sample(x_start, noise, t_dev, sqrt_alphas_cumprod_dev, sqrt_one_minus_alphas_cumprod_dev, hard_start, hard_goal, xn, B, H, D, T, st))
+            return rc;
     }
     TimeTrainArgs ta;
     memset(&ta, 0, sizeof(ta));
@@ -404,7 +397,8 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         hipLaunchKernelGGL(time_train_fwd_kernel, dim3(B), dim3(512), 0, st, ta);
         tb.flat = flat; tb.grad = grads_flat; tb.dT = ws + w.dT; tb.emb = ta.emb; tb.h1 = ta.h1; tb.temb = ta.temb; tb.tm = ta.tm; tb.h1m = ta.h1m;
         tb.dtm = ws + w.dtm; tb.dh1 = ws + w.dh1; tb.ticket = (unsigned*)(ws + w.ticket);
-        if (tb.row > kTimeBwdMaxRow) return fail(MPDX_E_INVALID, "time table row of %d floats (the training kernels take %d)", tb.row, kTimeBwdMaxRow);
+        if (ta.row > kTimeBwdMaxRow)   // time_bwd_all_kernel carves dTs | roff | red out of LDS at fixed offsets of kTimeBwdMaxRow
+            return fail(MPDX_E_INVALID, "time table row of %d floats (the training kernels take %d)", ta.row, kTimeBwdMaxRow);
         tb.w1 = ta.w1; tb.b1 = ta.b1; tb.w3 = ta.w3; tb.b3 = ta.b3;
         tb.B = B; tb.row = ta.row; tb.nblk = ta.nblk;
         for (int i = 0; i < ta.nblk; ++i) { tb.woff[i] = ta.woff[i]; tb.boff[i] = ta.boff[i]; tb.cout[i] = ta.cout[i]; tb.toff[i] = ta.toff[i]; }
@@ -467,10 +461,9 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         fa.bias = packed + u->params[u->pidx.at("final_conv.1.bias")].off;
         fa.out = eps; fa.mode = 0; fa.n_per_ctx = 1;
         fa.B = B; fa.H = H; fa.D = D; fa.C = c.unet_input_dim;
-        const int np = B * H;
-        if (!eps_done) hipLaunchKernelGGL(final_step_kernel, dim3((np + 255) / 256), dim3(256), (size_t)(fa.D * fa.C + fa.D) * sizeof(float), st, fa);
+        if (!eps_done) launch_final_step(fa, st);
         const float* target = predict_epsilon ? noise : x_start;
-        hipLaunchKernelGGL(weighted_loss_kernel, dim3(1), dim3(1024), 0, st, (const float*)eps, target, weights_hd, hard_start, hard_goal, l1, loss_out, B, H, D);
+        if (int rc = mpdx_weighted_loss((const float*)eps, target, weights_hd, hard_start, hard_goal, l1, loss_out, B, H, D, st)) return rc;
         const size_t ne = (size_t)B * H * D;
         hipLaunchKernelGGL(loss_grad_kernel, dim3((unsigned)std::min<size_t>((ne + 255) / 256, 1024)), dim3(256), 0, st, (const float*)eps, target, weights_hd,
                            hard_start ? 1 : 0, hard_goal ? 1 : 0, l1, loss_scale, dE, B, H, D);

@@ -60,17 +60,38 @@ def block_sizes(n_contexts: int, n_samples: int, world: int):
     return [(shard_range(n_contexts, world, r)[1] - shard_range(n_contexts, world, r)[0]) * n_samples for r in range(world)]
 
 
+_CK_MULT = 0x9E3779B1   # odd 32-bit constant: the position weight (index * _CK_MULT + 1) is odd, hence never zero mod 2^64
+
+
 def shard_checksum(x: torch.Tensor) -> torch.Tensor:
-    """Order-independent 64-bit checksum of a float32 tensor's BIT PATTERNS (sum of the int32 views in int64 plus the element
-    count): a transport check for the gather - a block that arrives with one bit flipped, truncated or in the wrong slot changes it."""
+    """POSITION-WEIGHTED 64-bit checksum of a float32 tensor's BIT PATTERNS: sum_i bits_i * (i * odd_const + 1) + numel in
+    wrapping int64 arithmetic.  A transport check for the gather: a flipped bit, a truncated block, a block in the wrong slot,
+    and - unlike a plain sum - trajectories permuted inside a block or two compensating bit errors at different positions all
+    change it (a detection code, not a cryptographic one)."""
+    return block_checksums(x, [x.shape[0] if x.dim() else x.numel()])[0]
+
+
+def block_checksums(x: torch.Tensor, sizes) -> torch.Tensor:
+    """shard_checksum of every consecutive block of `sizes[r]` leading-dimension entries of x, as one int64 vector computed by
+    a handful of tensor ops (positions are block-local, so a block's checksum does not depend on where it sits in x)."""
+    world = len(sizes)
+    out = torch.zeros(world, dtype=torch.int64, device=x.device)
     if x.numel() == 0:
-        return torch.zeros((), dtype=torch.int64, device=x.device)
-    return x.contiguous().view(torch.int32).to(torch.int64).sum() + x.numel()
+        return out
+    per = x[0].numel() if x.dim() > 1 else 1
+    bits = x.contiguous().view(torch.int32).reshape(-1).to(torch.int64)
+    counts = torch.tensor([int(s) * per for s in sizes], dtype=torch.int64, device=x.device)
+    starts = torch.cumsum(counts, 0) - counts
+    block = torch.repeat_interleave(torch.arange(world, device=x.device), counts, output_size=bits.numel())
+    local = torch.arange(bits.numel(), dtype=torch.int64, device=x.device) - starts[block]
+    out.index_add_(0, block, bits * (local * _CK_MULT + 1))
+    return out + counts
 
 
 def verify_gather(full: torch.Tensor, local: torch.Tensor, n_contexts: int, n_samples: int, group=None) -> bool:
     """Every rank publishes shard_checksum(local) (one 8-byte all-gather) and re-computes the checksum of every block of the
-    gathered tensor: True when all blocks match what their owners planned.  A world without a process group checks itself."""
+    gathered tensor (one batched tensor op, ONE host synchronisation): True when all blocks match what their owners planned.
+    A world without a process group checks itself."""
     import torch.distributed as dist
     mine = shard_checksum(local).reshape(1)
     if not dist.is_available() or not dist.is_initialized():
@@ -80,15 +101,15 @@ def verify_gather(full: torch.Tensor, local: torch.Tensor, n_contexts: int, n_sa
     sums = [torch.zeros_like(mine.cpu() if gloo else mine) for _ in range(world)]
     dist.all_gather(sums, mine.cpu() if gloo else mine, group=group)
     sizes = block_sizes(n_contexts, n_samples, world)
-    off, ok = 0, True
-    for r in range(world):
-        ok &= bool(shard_checksum(full[off:off + sizes[r]]).cpu() == sums[r].cpu()[0])
-        off += sizes[r]
-    return ok
+    if full.shape[0] != sum(sizes):
+        return False
+    got = block_checksums(full, sizes)
+    want = torch.cat([s.reshape(1) for s in sums]).to(got.device)
+    return bool(torch.equal(got, want))
 
 
 def gather_trajectories(local: torch.Tensor, n_contexts: int, n_samples: int, group=None, force_collective: bool = False,
-                        mode: Optional[str] = None) -> torch.Tensor:
+                        mode: Optional[str] = None, timeout_s: Optional[float] = None) -> torch.Tensor:
     """Gather the per-rank trajectory blocks into [n_contexts*n_samples, H, D] on every rank - the path's ONE exchange step.
 
     mode "collective" (default; MPDX_GATHER=collective): one all_gather_into_tensor.  Blocks may differ by one context in size:
@@ -97,7 +118,9 @@ def gather_trajectories(local: torch.Tensor, n_contexts: int, n_samples: int, gr
         one grouped RCCL launch): every shard travels exactly once over the DIRECT xGMI link to each peer and lands in its slot of
         the output (no padding, no ring: a ring all-gather forwards every block over world-1 hops and is bound by one link;
         MI355X links are point to point, 7 per GPU - SURVEY.md section 5).  Same result, bit for bit; bench.py times both.
-    force_collective: take the collective path even in a world of one rank (exercises RCCL on a single GPU)."""
+    force_collective: take the collective path even in a world of one rank (exercises RCCL on a single GPU).
+    timeout_s: bound every wait of the one-hop form (a peer that failed before posting its sends then raises here instead of
+        blocking this rank forever); None = wait without a limit."""
     import os
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized():
@@ -129,7 +152,11 @@ def gather_trajectories(local: torch.Tensor, n_contexts: int, n_samples: int, gr
             if sizes[frm]:
                 ops.append(dist.P2POp(dist.irecv, out[offs[frm]:offs[frm] + sizes[frm]], frm_g, group=group))
         for w in (dist.batch_isend_irecv(ops) if ops else []):
-            w.wait()
+            if timeout_s is None:
+                w.wait()
+            else:
+                from datetime import timedelta
+                w.wait(timedelta(seconds=float(timeout_s)))
         return out.to(local.device) if via_host else out
     mx = max(sizes)
     pad = src

@@ -19,6 +19,7 @@ from __future__ import annotations
 import copy
 import ctypes as C
 import math
+import weakref
 import os
 from math import ceil
 
@@ -184,6 +185,7 @@ class TrainStep:
             self._ws = torch.empty(int(lib.mpdx_train_workspace_floats(h, B)), dtype=torch.float32, device=dev)
             self._ws_B = B
         self.pack(sync_engine=False)
+        self._snapshot_pending()   # an autograd loss whose backward() has not run yet still needs the gradients about to be overwritten
         _lib.check(lib.mpdx_train_loss_backward(
             h, self.fp.flat.data_ptr(), self._packed().data_ptr(), self.fp.packedT.data_ptr(), self.fp.grad.data_ptr(), x_start.data_ptr(),
             noise.data_ptr(), t.data_ptr(), m.sqrt_alphas_cumprod.data_ptr(), m.sqrt_one_minus_alphas_cumprod.data_ptr(),
@@ -193,6 +195,16 @@ class TrainStep:
         if bind_grads and not self.fp.grads_bound():   # the docstring's promise: the gradients ARE in p.grad after this call
             self.fp.bind_grads()
         return self.loss_buf[0].clone(), {}
+
+    def _snapshot_pending(self):
+        """The flat gradient buffer is shared by every native pass.  An autograd loss (_PLossesFn) normally reads it in place in its
+        backward(); only when ANOTHER pass is about to overwrite it first (summed losses, gradient accumulation: a second
+        model.loss() before backward()) is that loss's gradient copied out - lazily, here."""
+        ref = getattr(self, "_pending", None)
+        holder = ref() if ref is not None else None
+        if holder is not None and holder.flat is None:
+            holder.flat = self.fp.grad.clone()
+        self._pending = None
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, max_norm=None):
         """clip_grad_norm_(max_norm) if given, then one torch.optim.Adam step (defaults as trainer.py:140); returns the
@@ -217,20 +229,31 @@ class _PLossesFn(torch.autograd.Function):
         loss, _ = step.loss_backward(x_start, hard_conds, t=t, noise=noise, bind_grads=False)
         ctx.step = step
         ctx.n_params = len(params)
-        # the flat gradient buffer is shared by every call: keep THIS call's gradients (a second model.loss() before backward() -
-        # summed losses, gradient accumulation - would otherwise overwrite them and both terms would back-propagate the last batch)
-        ctx.flat_grad = step.fp.grad.clone()
+        # THIS call's gradients sit in the shared flat buffer; they are copied out only if another native pass runs before this
+        # loss's backward() (TrainStep._snapshot_pending) - the common single-loss iteration makes no parameter-sized copy
+        ctx.holder = _GradHolder()
+        step._pending = weakref.ref(ctx.holder)
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
         fp = ctx.step.fp
+        flat = ctx.holder.flat if ctx.holder.flat is not None else fp.grad
+        scaled = flat * grad_out   # ONE parameter-sized product; the per-parameter gradients are views of it
         named = dict(fp.unet.named_parameters())
         grads = []
         for name in fp.order:
             off, cnt = fp.slices[name]
-            grads.append(ctx.flat_grad[off:off + cnt].view(named[name].shape) * grad_out)
+            grads.append(scaled[off:off + cnt].view(named[name].shape))
         return (None, None, None, None, None) + tuple(grads)
+
+
+class _GradHolder:
+    """weakly referenced by TrainStep._pending: `flat` is filled only when the shared gradient buffer is about to be overwritten"""
+    __slots__ = ("flat", "__weakref__")
+
+    def __init__(self):
+        self.flat = None
 
 
 def loss_with_grad(model, x_start, hard_conds=None, t=None, noise=None):

@@ -87,8 +87,24 @@ def test_sharded_plan_and_gather_gloo(world, C, n, max_batch):
     assert all(r[2] == (C * n, 64, 4) for r in res)
 
 
-def test_checksum_is_a_bit_pattern_sum():
+def test_checksum_is_position_weighted_over_bit_patterns():
+    from mpd_public_amd.parallel import block_checksums, _CK_MULT
     x = torch.tensor([1.0, -2.5, 0.0, 3.25])
-    assert int(shard_checksum(x)) == int(x.view(torch.int32).to(torch.int64).sum()) + 4
+    bits = x.view(torch.int32).to(torch.int64)
+    want = sum(int(b) * (i * _CK_MULT + 1) for i, b in enumerate(bits)) + 4
+    want = (want + 2 ** 63) % 2 ** 64 - 2 ** 63   # wrapping int64 arithmetic
+    assert int(shard_checksum(x)) == want
     assert int(shard_checksum(x[:0])) == 0
     assert verify_gather(x, x, 1, 4)   # no process group: the tensor checks itself
+    # what a plain sum of bit patterns cannot see: a permutation inside the block, two compensating bit errors
+    y = torch.randn(6, 8, 4)
+    perm = y[[1, 0, 2, 3, 4, 5]]
+    assert int(shard_checksum(perm)) != int(shard_checksum(y))
+    z = y.clone().view(torch.int32)
+    z.view(-1)[3] += 1
+    z.view(-1)[77] -= 1
+    assert int(z.to(torch.int64).sum()) == int(y.view(torch.int32).to(torch.int64).sum())   # the plain sum is blind to it
+    assert int(shard_checksum(z.view(torch.float32))) != int(shard_checksum(y))
+    # block-local positions: a block's checksum does not depend on where it sits in the gathered tensor
+    cs = block_checksums(y, [2, 1, 3])
+    assert [int(v) for v in cs] == [int(shard_checksum(y[0:2])), int(shard_checksum(y[2:3])), int(shard_checksum(y[3:6]))]
