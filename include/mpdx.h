@@ -206,6 +206,11 @@ int mpdx_guide_step(const mpdx_guide_params* gp, float* x, float* grad_out, cons
 int mpdx_guide_step_scaled(const mpdx_guide_params* gp, float* x, float* grad_out, const float* hard_start, const float* hard_goal,
                            const uint32_t* absmax_in, uint32_t* absmax_out, int n_per_ctx, int B, int H, int D, float guide_scale,
                            void* stream);
+/* measurement helper (bench.py `guided` sub-record): `reps` back-to-back guide launches in gradient-only mode (grad_out
+ * <- guide(x); x and the flags untouched, so every launch does the same work) bracketed by ONE HIP-event pair on `stream`;
+ * *ms_avg = average time per launch.  Replaces nothing in the reference: guides.py:173-211 is what one launch computes.  Synchronises. */
+int mpdx_guide_time(const mpdx_guide_params* gp, float* x, float* grad_out, const uint32_t* absmax_in, int n_per_ctx, int B, int H, int D,
+                    int reps, void* stream, float* ms_avg);
 /* dev tool: cycle stamps (16 slots per wave x 8 waves, workgroup 0) of one guide launch (gradient-only mode).
  * The three *_trace entry points and the ablation masks of mpdx_bench_layer work only in a library built with -DMPDX_DEV_HOOKS
  * (the production kernels carry no hooks); otherwise they return MPDX_E_STATE. */

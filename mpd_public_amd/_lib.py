@@ -82,6 +82,7 @@ SIGNATURES = {
                         C.POINTER(GuideParams), _i, _i, _vp, _i, C.c_uint64, C.c_uint64, _vp]),
     "mpdx_guide_step": (_i, [C.POINTER(GuideParams), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mpdx_guide_step_scaled": (_i, [C.POINTER(GuideParams), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "mpdx_guide_time": (_i, [C.POINTER(GuideParams), _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.POINTER(C.c_float)]),
     "mpdx_traj_metrics": (_i, [C.POINTER(GuideParams), _vp, _vp, _i, _i, _i, _i, _vp]),
     "mpdx_guide_trace": (_i, [C.POINTER(GuideParams), _vp, _vp, _i, _i, _i, _vp, C.POINTER(C.c_longlong)]),
     "mpdx_absmax": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

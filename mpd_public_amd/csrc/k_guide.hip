@@ -99,6 +99,26 @@ int mpdx_traj_metrics(const mpdx_guide_params* gp, const float* x_unnormalised, 
     return 0;
 }
 
+int mpdx_guide_time(const mpdx_guide_params* gp, float* x, float* grad_out, const uint32_t* absmax_in, int n_per_ctx, int B, int H, int D,
+                    int reps, void* stream, float* ms_avg) {
+    if (!gp || !x || !grad_out || !absmax_in || !ms_avg || reps < 1) return fail(MPDX_E_INVALID, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    int rc = 0;
+    for (int i = 0; i < 3 && !rc; ++i) rc = launch_guide(gp, x, grad_out, nullptr, nullptr, absmax_in, nullptr, n_per_ctx, B, H, D, st);
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int i = 0; i < reps && !rc; ++i) rc = launch_guide(gp, x, grad_out, nullptr, nullptr, absmax_in, nullptr, n_per_ctx, B, H, D, st);
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0.f;
+    if (!rc) HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_avg = ms / (float)reps;
+    return rc;
+}
+
 /* dev tool: one guide launch with s_memtime stamps (16 slots per wave, 8 waves -> 128 values) of workgroup 0 */
 int mpdx_guide_trace(const mpdx_guide_params* gp, float* x, const uint32_t* absmax_in, int B, int H, int D, void* stream, long long* stamps64) {
 #ifndef MPDX_DEV_HOOKS

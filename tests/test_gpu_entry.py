@@ -94,3 +94,28 @@ def test_experiment_loads_reference_format_checkpoint(tmp_path):
     assert a["trajs_iters"].shape == b["trajs_iters"].shape == (31, 6, 64, 4)
     assert torch.isfinite(a["trajs_iters"]).all()
     assert not torch.allclose(a["trajs_iters"][-1], b["trajs_iters"][-1])   # the checkpoint's weights were used
+
+
+@pytest.mark.parametrize("robot_id,env_id", [("RobotPointMass", "EnvDense2D"), ("RobotPanda", "EnvSpheres3D")])
+def test_plan_diversity_and_cost_metrics_vs_oracle(robot_id, env_id):
+    """compute_variance_waypoints (both definitions), compute_smoothness, compute_path_length (inference.py:24,311-327; un-vendored:
+    parity unpinned) on device tensors against the plain-loop float64 restatement of oracle/metrics.py."""
+    import mpd_public_amd as m
+    from mpd_public_amd.planning import compute_variance_waypoints, compute_smoothness, compute_path_length
+    from oracle import metrics as om
+    ds = m.TrajectoryDataset(env_id, robot_id, tensor_args={"device": "cuda", "dtype": torch.float32})
+    qd = ds.state_dim // 2
+    xn = obstacle_hugging_trajs(ds, 9, seed=f"var/{env_id}", scale=0.9)
+    xu = ds.unnormalize_trajectories(xn.cuda())
+    ref = xu.cpu().numpy()
+    np.testing.assert_allclose(compute_path_length(xu, ds.robot).cpu().numpy(), om.compute_path_length(ref, qd), rtol=5e-6)
+    np.testing.assert_allclose(compute_smoothness(xu, ds.robot).cpu().numpy(), om.compute_smoothness(ref, qd), rtol=5e-6)
+    for definition in ("position_variance", "pairwise_distance"):
+        got = compute_variance_waypoints(xu, ds.robot, definition=definition)
+        want = om.compute_variance_waypoints(ref, qd, definition)
+        assert want > 0
+        assert abs(got - want) <= 2e-5 * want, (definition, got, want)
+    assert compute_variance_waypoints(xu[:1], ds.robot) == 0.0
+    # best-trajectory selection of the entry (inference.py:319-322) on the same numbers
+    cost = om.compute_path_length(ref, qd) + om.compute_smoothness(ref, qd)
+    assert int(torch.argmin(compute_path_length(xu, ds.robot) + compute_smoothness(xu, ds.robot))) == int(np.argmin(cost))

@@ -90,3 +90,22 @@ def test_cost_gradients_match_finite_differences(env_id, robot_id):
             assert abs(fd - g.flatten()[k]) <= 1e-3 * max(1.0, abs(fd)), (type(term).__name__, k, float(fd), float(g.flatten()[k]))
         active += int(flat.max() > 0)
     assert active == len(comp.cost_l), "every cost term must be active on the probe trajectories"
+
+
+def test_oracle_metrics_closed_forms():
+    """oracle/metrics.py (un-vendored torch_robotics metrics, inference.py:24,311-327) against closed forms."""
+    from oracle import metrics as om
+    H, qd = 16, 3
+    s = np.linspace(0.0, 1.0, H)[:, None]
+    line = np.concatenate([s * np.array([[3.0, 4.0, 0.0]]), np.zeros((H, qd))], -1)            # straight line of length 5, zero velocity
+    c = np.array([0.3, -0.4, 1.2])
+    two = np.stack([line, line + np.concatenate([c, np.zeros(qd)])[None]])                      # a second copy offset by c
+    np.testing.assert_allclose(om.compute_path_length(two, qd), [5.0, 5.0], rtol=1e-12)
+    np.testing.assert_allclose(om.compute_smoothness(two, qd), [0.0, 0.0], atol=1e-15)
+    # two samples a, a + c: unbiased variance per coordinate c_j^2 / 2 -> H * |c|^2 / 2
+    np.testing.assert_allclose(om.compute_variance_waypoints(two, qd), H * (c ** 2).sum() / 2, rtol=1e-12)
+    assert om.compute_variance_waypoints(two[:1], qd) == 0.0
+    # three copies at offsets 0, c, 3c: pair distances |c|, 3|c|, 2|c| at every waypoint -> variance |c|^2 per waypoint
+    three = np.stack([line, line + np.concatenate([c, np.zeros(qd)])[None], line + np.concatenate([3 * c, np.zeros(qd)])[None]])
+    np.testing.assert_allclose(om.compute_variance_waypoints(three, qd, "pairwise_distance"), H * (c ** 2).sum(), rtol=1e-12)
+    assert om.compute_variance_waypoints(np.stack([line, line, line]), qd, "pairwise_distance") == 0.0
