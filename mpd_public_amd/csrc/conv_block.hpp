@@ -120,11 +120,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-    return (r0 + r1) + (r2 + r3);
+    // the four row sums r0 .. r3 -> (r3 + r2) + (r1 + r0) in row 3, by two row broadcasts (rows 1 and 3 add lane 15 of the row before
+    // them; rows 2 and 3 add lane 31) and ONE readlane - round 3 read all four rows out (4 v_readlane + 3 adds through SGPRs + moves, and
+    // the s_nops a VALU write -> v_readlane needs); the pairing of the additions is the same, so the sum has the same bits.
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));  // row_bcast:15
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));  // row_bcast:31
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // Mish(x) = x*tanh(softplus(x)) (torch: softplus threshold 20).  tanh(log1p(e^x)) == n/(n+2), n = e^x(e^x+2).
@@ -137,6 +138,15 @@ __device__ __forceinline__ float mish(float x) {
     const float n = e * (e + 2.0f);
     const float r = x * (n * __builtin_amdgcn_rcpf(n + 2.0f));
     return x > 20.0f ? x : r;   // (x > 44: n overflows, r is NaN, the select takes x)
+}
+
+// The same without the select (fused programs, round 4: one v_min instead of v_cmp + v_cndmask per element): the exponent is clamped at
+// 2^30, where n / (n + 2) is 1 to the last bit (from x = 8.7 on), so x > 20.8 gives x * (n * rcp(n)) = x * (1 +- 1 ulp) instead of
+// exactly x - and never overflows.  Bit-identical to mish() for x <= 20; GroupNorm outputs (|v - mean| * rstd <= 16) do not reach 20.
+__device__ __forceinline__ float mish_nosel(float x) {
+    const float e = __builtin_amdgcn_exp2f(fminf(x * 1.4426950408889634f, 30.0f));
+    const float n = e * (e + 2.0f);
+    return x * (n * __builtin_amdgcn_rcpf(n + 2.0f));
 }
 
 // d/dv [ v * tanh(softplus(v)) ]   (training: GroupNorm + Mish backward)
@@ -492,7 +502,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
             for (int k = 0; k < NCH; ++k) {
                 f32x4 y;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = mish(v[k][e] * rstd * ga[k][e] + be[k][e]);
+                for (int e = 0; e < 4; ++e) y[e] = mish_nosel(v[k][e] * rstd * ga[k][e] + be[k][e]);
                 y += tb[k];
                 y += rs4[k];
                 if (b < a.B) *(f32x4*)(a.dst + o[k]) = y;
@@ -523,7 +533,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                 const float d = v - mean;
                 const float var = wave_sum(d * d) * inv_re;
                 const float rstd = gn_rstd(var);
-                float y = mish(d * rstd * a.gamma[co] + a.beta[co]);
+                float y = mish_nosel(d * rstd * a.gamma[co] + a.beta[co]);
                 y += tb;
                 y += rs1;
                 if (b < a.B) a.dst[o] = y;
@@ -649,7 +659,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                 const float rstd = gn_rstd(var);
                 f32x4 y;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = mish(d[e] * rstd * ga[e] + be[e]);
+                for (int e = 0; e < 4; ++e) y[e] = mish_nosel(d[e] * rstd * ga[e] + be[e]);
                 y += tb;
                 y += rs4;
                 if (b < a.B) *(f32x4*)(a.dst + o) = y;
@@ -674,7 +684,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                 const float rstd = gn_rstd(var);
                 f32x2 y;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) y[e] = mish(d[e] * rstd * ga[e] + be[e]);
+                for (int e = 0; e < 2; ++e) y[e] = mish_nosel(d[e] * rstd * ga[e] + be[e]);
                 y += tb;
                 y += rs2;
                 if (b < a.B) *(f32x2*)(a.dst + o) = y;

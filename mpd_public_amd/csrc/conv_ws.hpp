@@ -36,6 +36,13 @@ constexpr int kWsThreads = 512;
 // epilogue in a tile and the other two wait for them at the barrier.  NS = 2 (very large batches): 32 positions = FOUR regions, one duty
 // wave on EVERY SIMD (waves 0 .. 3), the A fragments feed two B fragments each, half as many barriers and hand-overs per position; the
 // K-partials then have ONE buffer (2 x 50 KB of windows + 37 KB) and a second barrier per tile in front of their writes.
+// The kernels are written for the inner levels' geometry - L = 8 positions per trajectory, row stride C_in + 8 floats (what
+// pick_row_stride finds for them), C_out = 8 GroupNorm groups of MT channels - as COMPILE-TIME constants (round 4: every LDS address of
+// the k-loop is `lane base + immediate`, the window addresses advance by one constant per tile; the round-3 form spent 91 VALU
+// instructions per wave and tile on runtime strides, 64-bit products and per-element bounds selects - tools/isa_census.py).
+constexpr int kWsL = 8;
+template <int NC16> constexpr int ws_row_stride() { return NC16 * 16 + 8; }
+
 template <int NC16, int MT, bool R1, int NS = 1>
 inline size_t conv_ws_lds_bytes(int L, int rs) {
     const size_t stage = (size_t)(16 * NS / L) * (L + 4) * rs * sizeof(float);
@@ -43,7 +50,9 @@ inline size_t conv_ws_lds_bytes(int L, int rs) {
     return 2 * stage + (NS == 1 ? 2 : 1) * red * (R1 ? 2 : 1);
 }
 
-template <int NC16, int MT, bool R1, int NS = 1>
+// TBRES: what the Conv1dBlock's epilogue adds behind Mish - 1: the time-bias row (blocks[0]), 2: a residual tensor (blocks[1]), 0: neither
+// (compile-time: the runtime form selected zeros per element, 8 v_cndmask + 2 packed adds on the duty wave's critical path)
+template <int NC16, int MT, bool R1, int NS = 1, int TBRES = 0>
 __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, const ConvArgs a2) {
     constexpr int KS = 5, PAD = 2, MS = MT / 16, NT = 16 * NS, WK = 8, NG = NC16 * KS, NIT = NG / WK, NIT2 = NC16 / WK;
     constexpr int NRED = NS == 1 ? 2 : 1;                  // K-partial buffers
@@ -57,13 +66,13 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
     const int tid = threadIdx.x, lane = tid & 63;
     const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = blockIdx.x / kWsGroups, p = blockIdx.x % kWsGroups;
-    const int L = a.L_out, LP = L + 2 * PAD, RS4 = a.rs >> 2;
-    const int spt = NT >> a.lg_Lout;                       // trajectories per tile (2 at L = 8)
-    const int stage4 = spt * LP * RS4;                     // float4 per window buffer
-    const int red4 = WK * NT * MTP4;                       // float4 per reduction buffer
-    const int red_off4 = 2 * stage4, red2_off4 = red_off4 + NRED * red4;
+    constexpr int L = kWsL, LP = L + 2 * PAD, RS4 = ws_row_stride<NC16>() / 4, C_OUT = 8 * MT;   // (the launcher checks a.L_out, a.rs, a.C_out)
+    constexpr int spt = NT / L;                            // trajectories per tile (2 or 4)
+    constexpr int stage4 = spt * LP * RS4;                 // float4 per window buffer
+    constexpr int red4 = WK * NT * MTP4;                   // float4 per reduction buffer
+    constexpr int red_off4 = 2 * stage4, red2_off4 = red_off4 + NRED * red4;
     const int n_tiles = a.n_tiles_n;
-    const int c4n = a.cin_pad >> 2;
+    constexpr int c4n = NC16 * 4;
 
     // ---- this wave's weights: k-groups wk, wk + 8, ...  (loaded once, kept for the whole launch)
     constexpr int nc16 = NC16;
@@ -85,46 +94,61 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
     }
     // ---- halo rows of both window buffers (never overwritten by the window writes)
     for (int idx = tid; idx < 2 * spt * 2 * PAD * c4n; idx += kWsThreads) {
-        const int c4 = idx & (c4n - 1), hr = idx >> a.lg_c4n;                 // hr over [buffer][trajectory][4 halo rows]
+        const int c4 = idx % c4n, hr = idx / c4n;                              // hr over [buffer][trajectory][4 halo rows]
         const int k = hr & 3, s = (hr >> 2) % spt, buf = (hr >> 2) / spt;
         const int lp = (k < PAD) ? k : (L + k);
         smem4[buf * stage4 + (s * LP + lp) * RS4 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    // window of a tile: NT positions x cin/4 float4 (1024 at C_in = 256, 2048 at 512)
+    // window of a tile: NT positions x cin/4 float4 (1024 at C_in = 256, 2048 at 512).  A lane's float4 sits at a fixed place of the
+    // window: its global address advances by ONE per-lane constant per tile (wstep: spt * L * channels of its source tensor); only a
+    // tile that reaches beyond the batch (the last one) takes the clamped / masked path (wave-uniform test).
     constexpr int SB = (NT * NC16 * 4) / kWsThreads;
     static_assert(SB >= 1 && (NT * NC16 * 4) % kWsThreads == 0, "window divides over the threads");
-    int wdst[SB], wrow[SB], wc[SB], ws_[SB];
+    int wdst[SB], ws_[SB];
+    const float* wsrc[SB];   // the lane's source address for tile 0
+    int wstep[SB], wtraj[SB];   // floats per tile / per trajectory of the lane's source tensor
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
         const int idx = tid + u * kWsThreads;
-        const int rowi = idx >> a.lg_c4n, c4 = idx & (c4n - 1);
-        const int s = rowi >> a.lg_Lin, li = rowi & (L - 1);
+        const int rowi = idx / c4n, c4 = idx % c4n;
+        const int s = rowi / L, li = rowi % L;
         wdst[u] = (s * LP + li + PAD) * RS4 + c4;
-        wrow[u] = li; wc[u] = c4 * 4; ws_[u] = s;
+        ws_[u] = s;
+        const int c = c4 * 4;
+        const bool first = c < a.c1;                        // channel concat (c1, c2 % 4 == 0)
+        const int cs = first ? a.c1 : a.c2;
+        wsrc[u] = (first ? a.src1 + c : a.src2 + (c - a.c1)) + (size_t)(s * L + li) * cs;
+        wtraj[u] = L * cs;
+        wstep[u] = spt * wtraj[u];
     }
     f32x4 wv[SB];
-    auto window_load = [&](int tile) {   // unconditional loads from clamped addresses (a conditional load serialises the queue)
-        const int s0 = tile * spt;
+    auto window_load = [&](int tile) {   // unconditional loads from valid addresses (a conditional load serialises the queue)
+        if ((tile + 1) * spt <= a.B) {
 #pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            int b = s0 + ws_[u];
-            b = b < a.B ? b : a.B - 1;
-            const size_t pos = (size_t)b * L + wrow[u];
-            const float* src = (wc[u] < a.c1) ? a.src1 + pos * a.c1 + wc[u] : a.src2 + pos * a.c2 + (wc[u] - a.c1);   // channel concat (c1, c2 % 4 == 0)
-            wv[u] = *(const f32x4*)src;
+            for (int u = 0; u < SB; ++u) wv[u] = *(const f32x4*)(wsrc[u] + (size_t)tile * wstep[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int over = tile * spt + ws_[u] - (a.B - 1);   // trajectories beyond the batch re-read the last one (masked at the write)
+                wv[u] = *(const f32x4*)(wsrc[u] + (size_t)tile * wstep[u] - (size_t)(over > 0 ? over : 0) * wtraj[u]);
+            }
         }
     };
     auto window_write = [&](int tile, int buf) {
-        const int s0 = tile * spt;
+        if ((tile + 1) * spt <= a.B) {
 #pragma unroll
-        for (int u = 0; u < SB; ++u) smem4[buf * stage4 + wdst[u]] = (s0 + ws_[u] < a.B) ? wv[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < SB; ++u) smem4[buf * stage4 + wdst[u]] = wv[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < SB; ++u) smem4[buf * stage4 + wdst[u]] = (tile * spt + ws_[u] < a.B) ? wv[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     };
 
     // lane's B row in a window (tile-local position n = j), and its column in the reduction buffer
     const int j = lane & 15, q = lane >> 4;
     int boff[NS];   // position sub-tile ns: tile-local position n = ns * 16 + j
 #pragma unroll
-    for (int ns = 0; ns < NS; ++ns) boff[ns] = (((ns * 16 + j) >> a.lg_Lout) * LP + (j & (L - 1))) * RS4 + q;
+    for (int ns = 0; ns < NS; ++ns) boff[ns] = (((ns * 16 + j) / L) * LP + (j & (L - 1))) * RS4 + q;
 
     // ---- epilogue operands of the region this lane would serve (channels are fixed per lane: loaded once)
     const int e0 = lane * EPL;
@@ -156,14 +180,13 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
         // duties go to waves 0 .. 3 only: the OLDER wave of each SIMD (see below); two regions per tile rotate over them, four take all
         const int r = NS == 1 ? (wk < 4 ? ((wk - 2 * i) & 3) : 7) : (wk <= 4 ? wk : 7);
         const int b_ep = tile * spt + r;
-        const size_t o_ep = ((size_t)(b_ep < a.B ? b_ep : 0) * L + el) * a.C_out + co;
+        const size_t o_ep = ((size_t)(b_ep < a.B ? b_ep : 0) * L + el) * C_OUT + co;
         // UNCONDITIONAL loads (every wave, from valid addresses; zeros are selected in the epilogue): as conditional loads into
         // zero-initialised registers they made hipcc put s_waitcnt vmcnt(0) HERE, at the top of every tile - every wave then sat out the
         // round trip of the window loads it had issued a moment ago, at the bottom of the previous tile, with the matrix pipes idle
         // (~1.5 k of the 7.3 k cycles of a tile: tools/ws_trace.py, the gap between `epilogue done` and the next `tile top`).
-        const float* const tb_p = a.tbias ? a.tbias + (size_t)(b_ep < a.B ? b_ep : 0) * a.tb_stride + co : a.bias + co;
-        const float* const rs_p = a.res ? a.res + o_ep : a.bias + co;
-        fvec tb = *(const fvec*)tb_p, rsv = *(const fvec*)rs_p;
+        const float* const tb_p = TBRES == 1 ? a.tbias + (size_t)(b_ep < a.B ? b_ep : 0) * a.tb_stride + co : (TBRES == 2 ? a.res + o_ep : a.bias + co);
+        fvec tb = *(const fvec*)tb_p;   // the ONE operand added behind Mish (TBRES == 0: a dummy load, never added)
         __builtin_amdgcn_sched_barrier(0);   // requested HERE (hipcc would sink them behind the k-loop, next to the barrier)
         // ---------------------------------------------------------------- k-loop of this tile (window buffer `cur`)
         f32x4 acc[NS][MS], acc2[NS][MS];
@@ -221,7 +244,7 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
         // (every wave "uses" the two operands here, where they have long arrived and nothing else is in flight: a load still pending on
         //  their registers at the loop's back edge - the six waves without a duty never read them - costs the same vmcnt(0) at the top
         //  of the next tile; behind the epilogue the wait would include the duty waves' store)
-        asm volatile("" :: "v"(tb), "v"(rsv));
+        asm volatile("" :: "v"(tb));
         // ---------------------------------------------------------------- epilogue: region r of this tile by duty wave (2 i + r) mod 8
         if (r < spt) {
             // raised issue priority for the duty: the tile's critical path is THIS wave (epilogue, then its k-loop), while its SIMD
@@ -246,10 +269,8 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
             const float rstd = gn_rstd(var);
             fvec y;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) y[e] = mish(d[e] * rstd * ga[e] + be[e]);
-            const fvec zv = 0.f;
-            y += a.tbias ? tb : zv;
-            y += a.res ? rsv : zv;
+            for (int e = 0; e < EPL; ++e) y[e] = mish_nosel(d[e] * rstd * ga[e] + be[e]);
+            if constexpr (TBRES != 0) y += tb;
             if (b_ep < a.B) *(fvec*)(a.dst + o_ep) = y;
             __builtin_amdgcn_s_setprio(0);
         }
@@ -259,12 +280,12 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
                 static_assert(64 % (MT / 4) == 0, "a lane keeps its channel chunk over the passes");
                 for (int idx = lane; idx < NT * (MT / 4); idx += 64) {
                     const int n = idx / (MT / 4), c = (idx - n * (MT / 4)) * 4;
-                    const int s = n >> a2.lg_Lout, l = n & (L - 1), b = tile * spt + s;
+                    const int s = n / L, l = n & (L - 1), b = tile * spt + s;
                     f32x4 v = *(const f32x4*)(red + (size_t)n * (MT + 4) + c);
 #pragma unroll
                     for (int k = 1; k < WK; ++k) v += *(const f32x4*)(red + (size_t)(k * NT + n) * (MT + 4) + c);
                     v += bias2;   // (c == (lane % (MT / 4)) * 4 in every pass)
-                    if (b < a2.B) *(f32x4*)(a2.dst + ((size_t)b * L + l) * a2.C_out + mt * MT + c) = v;
+                    if (b < a2.B) *(f32x4*)(a2.dst + ((size_t)b * L + l) * C_OUT + mt * MT + c) = v;
                 }
             }
         }

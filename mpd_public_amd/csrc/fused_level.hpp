@@ -39,6 +39,7 @@
 //     accumulate the block input into a second accumulator added after Mish (removes an op, a buffer and two barriers).
 #pragma once
 #include "conv_block.hpp"
+#include "fused_geom.hpp"
 
 namespace mpdx {
 
@@ -152,6 +153,47 @@ struct FusedArgs {
     long long* trace;    // dev tool: s_memtime stamps of workgroup 0, 128 slots per wave (null in production)
 };
 
+// The LDS layout scalars of a program as the kernels read them: compile-time constants for a static program with a geometry table
+// (fused_geom.hpp; everything folds into immediates), the argument block's fields otherwise.
+struct FusedLay {
+    int in_off4, in_rs4, in_rows, L0, gc1, gc2, c3, L3, s3_off4, s3_rs4, s3_col4, stat_off, par_off, par_floats, tt_off, tt_n, fpar_off, H, Cf, lg_c4n;
+};
+template <class GEOM>
+__device__ __forceinline__ FusedLay fused_lay(const FusedArgs& a) {
+    if constexpr (GEOM::has) {
+        constexpr FusedGeom g = GEOM::g;
+        constexpr int c4n = (g.gc1 + g.gc2 + 3) >> 2;
+        constexpr int lg = g.gc1 < 0 ? -2 : (c4n == 1 ? 0 : c4n == 2 ? 1 : c4n == 4 ? 2 : c4n == 8 ? 3 : c4n == 16 ? 4 : c4n == 32 ? 5 : c4n == 64 ? 6 : -1);
+        return FusedLay{g.in_off4, g.in_rs4, g.in_rows, g.L0, g.gc1 < 0 ? a.gc1 : g.gc1, g.gc1 < 0 ? a.gc2 : g.gc2, g.c3, g.L3, g.s3_off4, g.s3_rs4, g.s3_col4,
+                        g.stat_off, g.par_off, g.par_floats < 0 ? a.par_floats : g.par_floats, g.tt_off, g.tt_n, g.fpar_off, g.H, g.Cf,
+                        lg == -2 ? a.lg_c4n : lg};
+    } else {
+        return FusedLay{a.in_off4, a.in_rs4, a.in_rows, a.L0, a.gc1, a.gc2, a.c3, a.L3, a.s3_off4, a.s3_rs4, a.s3_col4, a.stat_off, a.par_off, a.par_floats,
+                        a.tt_off, a.tt_n, a.fpar_off, a.H, a.Cf, a.lg_c4n};
+    }
+}
+
+// host: does the geometry the host computed for a segment equal the table of the static program it matched?
+inline bool fused_geom_matches(const FusedArgs& a, const FusedGeom& g, int state_dim) {
+    if (a.nops != g.nops || a.in_off4 != g.in_off4 || a.in_rs4 != g.in_rs4 || a.in_rows != g.in_rows || a.L0 != g.L0) return false;
+    if (g.gc1 < 0) { if (a.gc1 != state_dim || a.gc2 != 0 || state_dim > 16) return false; }
+    else if (a.gc1 != g.gc1 || a.gc2 != g.gc2) return false;
+    if (a.c3 != g.c3 || (g.c3 && (a.L3 != g.L3 || a.s3_off4 != g.s3_off4 || a.s3_rs4 != g.s3_rs4 || a.s3_col4 != g.s3_col4))) return false;
+    if (a.stat_off != g.stat_off || a.par_off != g.par_off || a.tt_off != g.tt_off || a.tt_n != g.tt_n) return false;
+    if (g.par_floats >= 0 && a.par_floats != g.par_floats) return false;
+    if (g.H && (a.H != g.H || a.Cf != g.Cf || a.fpar_off != g.fpar_off || state_dim > 16)) return false;
+    for (int k = 0; k < g.nops; ++k) {
+        const FusedOp& o = a.ops[k];
+        const FusedGeomOp& t = g.ops[k];
+        if (o.shape != t.shape || o.src_off4 != t.src_off4 || o.src_rs4 != t.src_rs4) return false;
+        if (o.shape == kFusedShapeFinal) continue;
+        if (o.rsrc_off4 != t.rsrc_off4 || o.rsrc_rs4 != t.rsrc_rs4 || o.res_off4 != t.res_off4 || o.res_rs4 != t.res_rs4 || o.dst_off4 != t.dst_off4 ||
+            o.dst_rs4 != t.dst_rs4 || o.gdst != t.gdst || o.p_off != t.p_off || o.tb_off != t.tb_off)
+            return false;
+    }
+    return true;
+}
+
 // LDS-only workgroup barrier: waits for this wave's LDS traffic, NOT for its global loads (the weight ring stays in flight).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -184,7 +226,7 @@ __device__ __forceinline__ float row_sum16(float v) {
 // SAVE: the training forward's variant (every op also stores its output and its GroupNorm input through FusedArgs::save); the planning
 // kernels are instantiated without it (measured on one box: 22.54 vs 22.62 ms per cfg-2 plan with the stores merely compiled in)
 template <class S, bool SAVE = false>
-__device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp& op, f32x4 (&ring)[kFusedRing], float* smem, int wave, int lane, int b,
+__device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedLay& lay, const FusedOp& op, f32x4 (&ring)[kFusedRing], float* smem, int wave, int lane, int b,
                                               const float* __restrict__ nbase, int nmax, long long* tr_base, int& tr) {
     constexpr int P = kFusedRing, DB = MPDX_FUSED_DB, NTW = S::NTW, NJ = S::NJ;
     f32x4* const sm4 = (f32x4*)smem;
@@ -274,86 +316,107 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
     // priority until the op's closing barrier.  (Measured, same-box A/B: cfg 5 542.45 -> 542.1 ms, cfg 2 21.88 -> 21.82 ms - within
     // noise; kept because it is free.  At B = 100 there is one wave per SIMD and nothing to arbitrate.)
     __builtin_amdgcn_s_setprio(2);
-    const float* par_op = smem + a.par_off + op.p_off;   // [bias | gamma | beta | rbias] x COUT
+    const float* par_op = smem + lay.par_off + op.p_off;   // [bias | gamma | beta | rbias] x COUT
     // this lane's 4 output channels in tile t (M-passes: tile t is tile row ms + 4 t)
     int c0t[NTW], mst[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) { mst[t] = (S::MP > 1) ? ms + t * S::MSW : ms; c0t[t] = mst[t] * 16 + q * 4; }
     f32x4 y[NTW];
     if (S::GN) {
-        f32x4 v[NTW], add[NTW], gat[NTW], bet[NTW];
-        float* stat = smem + a.stat_off;
-        // A GroupNorm group = RB DPP rows of the NSn tiles of one tile row.  With four or more tile rows every wave owns ALL position
-        // tiles of its row(s), so the group's parts sit in this wave's registers: they are combined through readlane, with the same
-        // formula and order as the LDS exchange - and without its barrier.  (C_out = 32: two waves share a tile row -> exchange.)
+        // ---- GroupNorm statistics + affine + Mish, round-4 form (instruction diet: fp32 MFMA and VALU share the SIMD's issue port).
+        // A reduction runs over ALL of the wave's tiles that belong to one group at once (NJ tiles share their rows: one reduction;
+        // M-pass tiles are different tile rows: one each): one row_sum16 per pass instead of one per tile.
+        //   LOCAL (C_out >= 64: the wave owns every tile of its rows): plain TWO-PASS statistics of the whole group inside the wave - lane
+        //     sums -> DPP row sum -> the other rows of the group through the LDS crossbar (ds_swizzle lane ^ 16; groups of four rows:
+        //     ds_bpermute lane ^ 32 on top) -> mean; deviations -> the same for the sum of squares.  No per-row (mean, M2) parts, no
+        //     v_readlane -> v_mov -> v_cndmask selection of the parts, no Chan combination: ~60 VALU instructions fewer per op than round 3.
+        //   C_out = 32 (two waves share a tile row): the wave's own tiles are reduced two-pass as above (mean, M2 of 64 * NTW elements), ONE
+        //     8-byte exchange per (wave, row) through LDS + one barrier, Chan's formula for two equal parts.
+        // Normalisation re-uses the deviations: y = mish(d * (rstd * gamma) + beta).
         constexpr bool LOCAL = (S::MSW == kFusedWaves);
-        float rm[NTW][4], rM2[NTW][4];   // LOCAL: (mean, M2) of DPP row r of tile t, wave-uniform
+        constexpr int NG = (S::MP > 1) ? NTW : 1;   // independent reductions (groups) of this wave
+        constexpr int TPG = NTW / NG;               // tiles per reduction
+        f32x4 v[NTW], addv[NTW], gat[NTW], bet[NTW];
+        bool have_add = false;
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             const int c0 = c0t[t];
             const f32x4 bi = *(const f32x4*)(par_op + c0);
-            gat[t] = *(const f32x4*)(par_op + S::COUT + c0); bet[t] = *(const f32x4*)(par_op + 2 * S::COUT + c0);
-            f32x4 tb = {0.f, 0.f, 0.f, 0.f};
-            if (op.tb_off >= 0) tb = *(const f32x4*)(smem + a.tt_off + op.tb_off + c0);
-            add[t] = tb;
-            if (S::NCR > 0) add[t] += (racc[t][0] + racc[t][1]) + *(const f32x4*)(par_op + 3 * S::COUT + c0);
-            else if (op.res_off4 >= 0) add[t] += sm4[op.res_off4 + (npos[t] + 2) * op.res_rs4 + (c0 >> 2)];
-            v[t] = (acc[t][0] + acc[t][1]) + bi;
-            // local two-pass statistics of this DPP row (4 channels x 16 positions = 64 elements)
-            const float m_loc = row_sum16((v[t][0] + v[t][1]) + (v[t][2] + v[t][3])) * (1.0f / 64.0f);
-            const f32x4 dl = v[t] - m_loc;
-            const float m2_loc = row_sum16((dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]));
-            if constexpr (LOCAL) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    rm[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m_loc), 16 * r));
-                    rM2[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m2_loc), 16 * r));
-                }
-            } else {
-                if (j == 0) *(f32x2*)(stat + ((mst[t] * S::NSn + ns[t]) * 4 + q) * 2) = (f32x2){m_loc, m2_loc};
+            if (S::MP > 1 || t == 0) { gat[t] = *(const f32x4*)(par_op + S::COUT + c0); bet[t] = *(const f32x4*)(par_op + 2 * S::COUT + c0); }
+            else { gat[t] = gat[0]; bet[t] = bet[0]; }
+            if (op.tb_off >= 0) { addv[t] = *(const f32x4*)(smem + lay.tt_off + op.tb_off + c0); have_add = true; }
+            if (S::NCR > 0) {
+                const f32x4 r = (racc[t][0] + racc[t][1]) + *(const f32x4*)(par_op + 3 * S::COUT + c0);
+                addv[t] = (op.tb_off >= 0) ? addv[t] + r : r;
+                have_add = true;
+            } else if (op.res_off4 >= 0) {
+                const f32x4 r = sm4[op.res_off4 + (npos[t] + 2) * op.res_rs4 + (c0 >> 2)];
+                addv[t] = (op.tb_off >= 0) ? addv[t] + r : r;
+                have_add = true;
             }
+            v[t] = (acc[t][0] + acc[t][1]) + bi;
             if (SAVE && op.save_pre >= 0) *(f32x4*)(a.save + op.save_pre + ((size_t)b * S::LOUT + npos[t]) * S::COUT + c0) = v[t];
         }
-        if constexpr (!LOCAL) lds_barrier();
-        FOP_STAMP();   // statistics exchanged
-        // combine the parts of this lane's group: rows q0 .. q0+RB-1 of the tiles (row, 0..NSn-1); equal counts (64 each).
-        // Tiles that share their tile row (NJ > 1) share the group: one combination; M-pass tiles are different rows: one each.
-        const int q0 = q & ~(S::RB - 1);
-        float mean_t[NTW], rstd_t[NTW];
+        // sum over the rows of a lane's group that live in other DPP rows of this wave (LOCAL only)
+        auto rows_sum = [&](float x) -> float {
+            if constexpr (LOCAL && S::RB >= 2)
+                x += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));   // bit mode: lane ^ 16
+            if constexpr (LOCAL && S::RB == 4)
+                x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, x)));
+            return x;
+        };
+        constexpr int NLOC = 64 * TPG * (LOCAL ? S::RB : 1);   // elements one in-wave reduction covers
+        float mean_g[NG], rstd_g[NG];
+        f32x4 d[NTW];
+        float m2_g[NG];
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            if (S::MP == 1 && t > 0) { mean_t[t] = mean_t[0]; rstd_t[t] = rstd_t[0]; continue; }
-            float pm[S::NPARTS], pM2[S::NPARTS];
+        for (int g = 0; g < NG; ++g) {
+            float sl = 0.f;
 #pragma unroll
-            for (int k = 0; k < S::NPARTS; ++k) {
-                const int ns_k = k / S::RB, q_k = q0 + (k % S::RB);
-                if constexpr (LOCAL) {
-                    const int tk = (S::MP > 1) ? t : ns_k;   // the wave's tile holding position tile ns_k of this row
-                    pm[k] = q_k == 0 ? rm[tk][0] : (q_k == 1 ? rm[tk][1] : (q_k == 2 ? rm[tk][2] : rm[tk][3]));
-                    pM2[k] = q_k == 0 ? rM2[tk][0] : (q_k == 1 ? rM2[tk][1] : (q_k == 2 ? rM2[tk][2] : rM2[tk][3]));
-                } else {
-                    const f32x2 pv = *(const f32x2*)(stat + ((mst[t] * S::NSn + ns_k) * 4 + q_k) * 2);
-                    pm[k] = pv[0]; pM2[k] = pv[1];
-                }
+            for (int k = 0; k < TPG; ++k) {
+                const f32x4& x = v[g * TPG + k];
+                const float p = (x[0] + x[1]) + (x[2] + x[3]);
+                sl = (k == 0) ? p : sl + p;
             }
-            float mean, M2;
-            if constexpr (S::NPARTS == 4) {
-                mean = ((pm[0] + pm[1]) + (pm[2] + pm[3])) * 0.25f;
-                const float d0 = pm[0] - mean, d1 = pm[1] - mean, d2 = pm[2] - mean, d3 = pm[3] - mean;
-                M2 = ((pM2[0] + pM2[1]) + (pM2[2] + pM2[3])) + 64.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
-            } else {
-                mean = (pm[0] + pm[1]) * 0.5f;
-                const float d0 = pm[0] - mean, d1 = pm[1] - mean;
-                M2 = (pM2[0] + pM2[1]) + 64.0f * (d0 * d0 + d1 * d1);
+            mean_g[g] = rows_sum(row_sum16(sl)) * (1.0f / (float)NLOC);
+            float ql = 0.f;
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) {
+                const int t = g * TPG + k;
+                d[t] = v[t] - mean_g[g];
+                const float p = (d[t][0] * d[t][0] + d[t][1] * d[t][1]) + (d[t][2] * d[t][2] + d[t][3] * d[t][3]);
+                ql = (k == 0) ? p : ql + p;
             }
-            mean_t[t] = mean;
-            rstd_t[t] = gn_rstd(M2 * (1.0f / (64.0f * S::NPARTS)));
+            m2_g[g] = rows_sum(row_sum16(ql));
+        }
+        if constexpr (LOCAL) {
+            FOP_STAMP();   // statistics done (no exchange)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) rstd_g[g] = gn_rstd(m2_g[g] * (1.0f / (float)NLOC));
+        } else {
+            // two waves (nsg = 0, 1) share tile row ms: exchange (mean, M2) of 64 * NTW elements per DPP row q
+            float* stat = smem + lay.stat_off;
+            if (j == 0) *(f32x2*)(stat + ((nsg * S::MSW + ms) * 4 + q) * 2) = (f32x2){mean_g[0], m2_g[0]};
+            lds_barrier();
+            FOP_STAMP();   // statistics exchanged
+            const f32x2 o = *(const f32x2*)(stat + (((nsg ^ 1) * S::MSW + ms) * 4 + q) * 2);
+            // Chan, two parts of NLOC elements: mean = (m_a + m_b) / 2, M2 = M2_a + M2_b + NLOC / 2 * (m_b - m_a)^2; symmetric in (a, b),
+            // so both waves get the same bits
+            const float dm = o[0] - mean_g[0];
+            const float mean = 0.5f * (mean_g[0] + o[0]);
+            const float M2 = (m2_g[0] + o[1]) + (0.5f * (float)NLOC) * (dm * dm);
+            rstd_g[0] = gn_rstd(M2 * (1.0f / (float)(2 * NLOC)));
+            const float shift = mean_g[0] - mean;   // deviations from the group mean = deviations from the own mean + (own mean - group mean)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) d[t] = d[t] + shift;
         }
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
+            const int g = (S::MP > 1) ? t : 0;
+            const f32x4 sc = gat[t] * rstd_g[g];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[t][e] = mish((v[t][e] - mean_t[t]) * rstd_t[t] * gat[t][e] + bet[t][e]);
-            y[t] += add[t];
+            for (int e = 0; e < 4; ++e) y[t][e] = mish_nosel(d[t][e] * sc[e] + bet[t][e]);
+            if (have_add) y[t] += addv[t];
         }
     } else {  // bias only: Downsample1d / Upsample1d
 #pragma unroll
@@ -382,8 +445,11 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedOp&
 #undef FOP_STAMP
 }
 
-// ---- prologue of a fused program (shared by the generic and the static kernels)
-__device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, f32x4 (&ring)[kFusedRing], int tid, int lane, int wave, int b,
+// ---- prologue of a fused program (shared by the generic and the static kernels).  GEOM: the program's geometry table (fused_geom.hpp) -
+// the pass counts of the three staging copies, the index decomposition and every LDS address are then compile-time (round 3's generic
+// form: 1 177 VALU + 492 SALU + 151 branches per wave, tools/isa_census.py) - or GeomNone (runtime geometry, worst-case pass counts).
+template <class GEOM>
+__device__ __forceinline__ void fused_prologue(const FusedArgs& a, const FusedLay& lay, float* smem, f32x4 (&ring)[kFusedRing], int tid, int lane, int wave, int b,
                                                long long* tr_base, int& tr) {
     f32x4* const sm4 = (f32x4*)smem;
 #define FUSED_STAMP() do { if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter(); ++tr; } while (0)
@@ -391,14 +457,19 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, 
     //      zeros are written while they fly, and ONE barrier closes it.
     fused_ring_request(ring, a.packed + a.ops[0].sbase + (size_t)(wave & a.msmask[0]) * a.slen[0] * 256 + lane * 4, a.slen[0]);
 
-    const int cin = a.gc1 + a.gc2;
-    const int c4n = (cin + 3) >> 2;
-    const int n_in = a.L0 * c4n;
     constexpr int NT_ = kFusedThreads;
-    constexpr int IK = 2048 / NT_;   // input float4 per thread (<= 2048 float4 per trajectory window)
+    // float4 the three copies move at most (-> passes of 256 threads)
+    constexpr int kIn4 = !GEOM::has ? 2048 : (GEOM::g.gc1 < 0 ? GEOM::g.L0 * 4 : GEOM::g.L0 * ((GEOM::g.gc1 + GEOM::g.gc2 + 3) / 4));
+    constexpr int kS34 = !GEOM::has ? 1024 : GEOM::g.L3 * (GEOM::g.c3 / 4);
+    constexpr int kPar4 = !GEOM::has ? 2048
+                                     : ((GEOM::g.par_floats >= 0 ? GEOM::g.par_floats : GEOM::g.fpar_off + (16 * (GEOM::g.Cf + 4) + 16 + 3) / 4 * 4) + GEOM::g.tt_n) / 4;
+    const int cin = lay.gc1 + lay.gc2;
+    const int c4n = (cin + 3) >> 2;
+    const int n_in = lay.L0 * c4n;
+    constexpr int IK = (kIn4 + NT_ - 1) / NT_;   // input float4 per thread
     f32x4 iv[IK];
     int idst[IK], ck[IK];
-    const bool vec_ok = ((a.gc1 & 3) == 0) && ((a.gc2 & 3) == 0);
+    const bool vec_ok = ((lay.gc1 & 3) == 0) && ((lay.gc2 & 3) == 0);
     {
         // Unconditional loads from clamped addresses, zeros selected afterwards: a conditional load into a
         // zero-initialised register makes hipcc wait (vmcnt(0)) for the previous load before issuing the next one.
@@ -409,37 +480,37 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, 
             const int idx = tid + k * NT_;
             vk[k] = idx < n_in;
             const int idc = vk[k] ? idx : 0;
-            lk[k] = a.lg_c4n >= 0 ? (idc >> a.lg_c4n) : (idc / c4n);
+            lk[k] = lay.lg_c4n >= 0 ? (idc >> lay.lg_c4n) : (idc / c4n);
             ck[k] = (idc - lk[k] * c4n) << 2;
-            idst[k] = vk[k] ? a.in_off4 + (lk[k] + 2) * a.in_rs4 + (ck[k] >> 2) : -1;
+            idst[k] = vk[k] ? lay.in_off4 + (lk[k] + 2) * lay.in_rs4 + (ck[k] >> 2) : -1;
         }
         // (pass k is skipped as a whole - wave-uniform - when the window has fewer than k*256 float4: D=4 needs one pass of eight)
         if (vec_ok) {
 #pragma unroll
             for (int k = 0; k < IK; ++k) {
                 if (k * NT_ >= n_in) continue;   // iv[k] stays unset and is never stored (idst[k] < 0)
-                const size_t pos = (size_t)b * a.L0 + lk[k];
-                const float* src = (ck[k] < a.gc1) ? a.gsrc1 + pos * a.gc1 + ck[k] : a.gsrc2 + pos * a.gc2 + (ck[k] - a.gc1);
+                const size_t pos = (size_t)b * lay.L0 + lk[k];
+                const float* src = (ck[k] < lay.gc1) ? a.gsrc1 + pos * lay.gc1 + ck[k] : a.gsrc2 + pos * lay.gc2 + (ck[k] - lay.gc1);
                 iv[k] = *(const f32x4*)src;
             }
         } else {
 #pragma unroll
             for (int k = 0; k < IK; ++k) {   // channel padding (ce >= cin) is masked to zero at the LDS store below
                 if (k * NT_ >= n_in) continue;
-                const size_t pos = (size_t)b * a.L0 + lk[k];
+                const size_t pos = (size_t)b * lay.L0 + lk[k];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int ce = ck[k] + e;
-                    const float* src = (ce < a.gc1) ? a.gsrc1 + pos * a.gc1 + ce : (ce < cin) ? a.gsrc2 + pos * a.gc2 + (ce - a.gc1) : a.gsrc1 + pos * a.gc1;
+                    const float* src = (ce < lay.gc1) ? a.gsrc1 + pos * lay.gc1 + ce : (ce < cin) ? a.gsrc2 + pos * lay.gc2 + (ce - lay.gc1) : a.gsrc1 + pos * lay.gc1;
                     iv[k][e] = *src;
                 }
             }
         }
     }
     // second staged input (skip tensor of a later concat): <= 4 float4 per thread
-    constexpr int SK = 1024 / NT_;
-    f32x4 sv[SK];
-    const int s3c4 = a.c3 >> 2, n_s3 = a.L3 * s3c4;
+    constexpr int SK = (kS34 + NT_ - 1) / NT_;
+    f32x4 sv[SK > 0 ? SK : 1];
+    const int s3c4 = lay.c3 >> 2, n_s3 = lay.L3 * s3c4;
 #pragma unroll
     for (int k = 0; k < SK; ++k) {
         const int idx = tid + k * NT_;
@@ -448,9 +519,9 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, 
     }
     // parameters of every op ([bias | gamma | beta | rbias] blocks, contiguous in `packed` behind the weight streams) and the
     // slice of this timestep's conditioning row the segment's blocks use: two straight copies
-    constexpr int PK = 2048 / NT_;   // float4 per thread (<= 2048 float4 = 32 KB of parameters)
+    constexpr int PK = (kPar4 + NT_ - 1) / NT_;   // float4 per thread (<= 2048 float4 = 32 KB of parameters)
     f32x4 pv[PK];
-    const int npar4 = a.par_floats >> 2, ntt4 = a.tt_n >> 2;
+    const int npar4 = lay.par_floats >> 2, ntt4 = lay.tt_n >> 2;
 #pragma unroll
     for (int k = 0; k < PK; ++k) {
         const int idx = tid + k * NT_;
@@ -463,15 +534,15 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, 
     // staging writes below).  Every other buffer gets its halo rows zeroed by the op that writes it.
     {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < 2 * a.in_rs4; i += NT_) {
-            sm4[a.in_off4 + i] = z;
-            sm4[a.in_off4 + (a.in_rows - 2) * a.in_rs4 + i] = z;
+        for (int i = tid; i < 2 * lay.in_rs4; i += NT_) {
+            sm4[lay.in_off4 + i] = z;
+            sm4[lay.in_off4 + (lay.in_rows - 2) * lay.in_rs4 + i] = z;
         }
         if (a.in_clear) {
-            const int padw = a.in_rs4 - c4n;   // float4 columns beyond the staged channels
-            for (int i = tid; i < a.L0 * padw; i += NT_) {
+            const int padw = lay.in_rs4 - c4n;   // float4 columns beyond the staged channels
+            for (int i = tid; i < lay.L0 * padw; i += NT_) {
                 const int l = i / padw, cc = i - l * padw;
-                sm4[a.in_off4 + (l + 2) * a.in_rs4 + c4n + cc] = z;
+                sm4[lay.in_off4 + (l + 2) * lay.in_rs4 + c4n + cc] = z;
             }
         }
     }
@@ -489,14 +560,14 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, 
         const int idx = tid + k * NT_;
         if (idx < n_s3) {
             const int l = idx / s3c4, c = idx - l * s3c4;
-            sm4[a.s3_off4 + (l + 2) * a.s3_rs4 + a.s3_col4 + c] = sv[k];
+            sm4[lay.s3_off4 + (l + 2) * lay.s3_rs4 + lay.s3_col4 + c] = sv[k];
         }
     }
 #pragma unroll
     for (int k = 0; k < PK; ++k) {
         const int idx = tid + k * NT_;
-        if (idx < npar4) sm4[(a.par_off >> 2) + idx] = pv[k];
-        else if (idx - npar4 < ntt4) sm4[(a.tt_off >> 2) + idx - npar4] = pv[k];
+        if (idx < npar4) sm4[(lay.par_off >> 2) + idx] = pv[k];
+        else if (idx - npar4 < ntt4) sm4[(lay.tt_off >> 2) + idx - npar4] = pv[k];
     }
     lds_barrier();
     FUSED_STAMP();
@@ -510,9 +581,9 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, float* smem, 
 constexpr int kFinalPre = 4;   // elements per thread: H * D <= 1024
 struct FinalPre { float xv[kFinalPre], nz[kFinalPre], hc[kFinalPre]; };
 
-__device__ __forceinline__ void fused_final_prefetch(const FusedArgs& a, FinalPre& fp, int tid, int b) {
+__device__ __forceinline__ void fused_final_prefetch(const FusedArgs& a, const FusedLay& lay, FinalPre& fp, int tid, int b) {
     if (a.fmode == 0) return;
-    const int H = a.H, n = H * a.D;
+    const int H = lay.H, n = H * a.D;
 #pragma unroll
     for (int k = 0; k < kFinalPre; ++k) {
         const int idx = tid + k * kFusedThreads;
@@ -530,15 +601,15 @@ __device__ __forceinline__ void fused_final_prefetch(const FusedArgs& a, FinalPr
 // CF: the channel count of final_conv[0] when the program fixes it (static programs: the dot product unrolls, its 2 * CF / 4 LDS
 // reads are issued together), 0 = read it from the argument block.
 template <int CF = 0>
-__device__ __forceinline__ void fused_final_op(const FusedArgs& a, const FusedOp& op, const FinalPre& fp, float* smem, int tid, int lane, int b) {
+__device__ __forceinline__ void fused_final_op(const FusedArgs& a, const FusedLay& lay, const FusedOp& op, const FinalPre& fp, float* smem, int tid, int lane, int b) {
     f32x4* const sm4 = (f32x4*)smem;
     constexpr int NT_ = kFusedThreads;
     // ---- final_conv[1] (1x1, Cf -> D) + DDPM posterior step + hard conditioning (see final_step_kernel)
     float vmax = 0.f;
-    const int H = a.H, n = H * a.D;
-    const int Cf = CF ? CF : a.Cf;
+    const int H = lay.H, n = H * a.D;
+    const int Cf = CF ? CF : lay.Cf;
     const int wrs = Cf + 4;   // LDS row stride of the staged weights: rows d and d + 1 start 4 banks apart
-    const float* const fw = smem + a.par_off + a.fpar_off;
+    const float* const fw = smem + lay.par_off + lay.fpar_off;
 #pragma unroll
     for (int k = 0; k < kFinalPre; ++k) {
         const int idx = tid + k * NT_;
@@ -607,12 +678,13 @@ __global__ __launch_bounds__(kFusedThreads) void fused_level_kernel(const FusedA
     ++tr;
     f32x4 ring[kFusedRing];
     FinalPre fp;
-    fused_prologue(a, smem, ring, tid, lane, wave, b, tr_base, tr);
+    const FusedLay lay = fused_lay<GeomNone>(a);
+    fused_prologue<GeomNone>(a, lay, smem, ring, tid, lane, wave, b, tr_base, tr);
     for (int oi = 0; oi < a.nops; ++oi) {
         const FusedOp op = a.ops[oi];
-        if (oi + 1 < a.nops && a.ops[oi + 1].shape == kFusedShapeFinal) fused_final_prefetch(a, fp, tid, b);
+        if (oi + 1 < a.nops && a.ops[oi + 1].shape == kFusedShapeFinal) fused_final_prefetch(a, lay, fp, tid, b);
         if (op.shape == kFusedShapeFinal) {
-            fused_final_op(a, op, fp, smem, tid, lane, b);
+            fused_final_op(a, lay, op, fp, smem, tid, lane, b);
             if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter();
             ++tr;
             continue;
@@ -626,7 +698,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_level_kernel(const FusedA
         }
         switch (op.shape) {
 #define X(id, M, K, N, R, CO, LO, G) \
-    case id: fused_conv_op<FusedShape<M, K, N, R, CO, LO, G>, SAVE>(a, op, ring, smem, wave, lane, b, nbase, nmax, tr_base, tr); break;
+    case id: fused_conv_op<FusedShape<M, K, N, R, CO, LO, G>, SAVE>(a, lay, op, ring, smem, wave, lane, b, nbase, nmax, tr_base, tr); break;
             MPDX_FUSED_SHAPES(X)
 #undef X
             default: break;
@@ -643,12 +715,29 @@ template <int ID> struct FusedShapeOf;
 MPDX_FUSED_SHAPES(X)
 #undef X
 
-template <int SH, int I, int NEXT_SH, int PREV_COUT, bool SAVE>
-__device__ __forceinline__ void fused_static_op(const FusedArgs& a, f32x4 (&ring)[kFusedRing], FinalPre& fp, float* smem, int tid, int wave, int lane,
-                                                int b, long long* tr_base, int& tr) {
-    if constexpr (NEXT_SH == kFusedShapeFinal) fused_final_prefetch(a, fp, tid, b);
+// op I of a static program: the runtime descriptor (weight-stream base, training offsets) with every LDS geometry field replaced by the
+// program's compile-time table entry, when it has one
+template <class GEOM, int I, bool SAVE>
+__device__ __forceinline__ FusedOp fused_static_desc(const FusedArgs& a) {
+    FusedOp op = a.ops[I];
+    if constexpr (GEOM::has) {
+        constexpr FusedGeomOp g = GEOM::g.ops[I];
+        op.shape = g.shape;
+        op.src_off4 = g.src_off4; op.src_rs4 = g.src_rs4; op.rsrc_off4 = g.rsrc_off4; op.rsrc_rs4 = g.rsrc_rs4;
+        op.res_off4 = g.res_off4; op.res_rs4 = g.res_rs4; op.dst_off4 = g.dst_off4; op.dst_rs4 = g.dst_rs4;
+        op.p_off = g.p_off; op.tb_off = g.tb_off;
+        if constexpr (!SAVE) op.gdst = g.gdst;   // (the training forward switches the planning path's global outputs off at run time)
+    }
+    return op;
+}
+
+template <class GEOM, int SH, int I, int NEXT_SH, int PREV_COUT, bool SAVE>
+__device__ __forceinline__ void fused_static_op(const FusedArgs& a, const FusedLay& lay, f32x4 (&ring)[kFusedRing], FinalPre& fp, float* smem, int tid, int wave,
+                                                int lane, int b, long long* tr_base, int& tr) {
+    if constexpr (NEXT_SH == kFusedShapeFinal) fused_final_prefetch(a, lay, fp, tid, b);
+    const FusedOp op = fused_static_desc<GEOM, I, SAVE>(a);
     if constexpr (SH == kFusedShapeFinal) {
-        fused_final_op<PREV_COUT>(a, a.ops[I], fp, smem, tid, lane, b);
+        fused_final_op<PREV_COUT>(a, lay, op, fp, smem, tid, lane, b);
         if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter();
         ++tr;
     } else {
@@ -659,12 +748,13 @@ __device__ __forceinline__ void fused_static_op(const FusedArgs& a, f32x4 (&ring
             nbase = a.packed + a.ops[I + 1].sbase + (size_t)(wave & (N::MSn < kFusedWaves ? N::MSn - 1 : kFusedWaves - 1)) * (N::SLEN * 256) + lane * 4;
             nmax = N::SLEN - 1;
         }
-        fused_conv_op<typename FusedShapeOf<SH>::type, SAVE>(a, a.ops[I], ring, smem, wave, lane, b, nbase, nmax, tr_base, tr);
+        fused_conv_op<typename FusedShapeOf<SH>::type, SAVE>(a, lay, op, ring, smem, wave, lane, b, nbase, nmax, tr_base, tr);
     }
 }
 
-template <int... SH>
+template <class GEOM_, int... SH>
 struct FusedSeq {
+    using GEOM = GEOM_;
     static constexpr int N = sizeof...(SH);
     static constexpr int ids[sizeof...(SH)] = {SH...};
     template <int I>
@@ -673,11 +763,11 @@ struct FusedSeq {
         else return 0;
     }
     template <int I, bool SAVE>
-    __device__ static __forceinline__ void run_from(const FusedArgs& a, f32x4 (&ring)[kFusedRing], FinalPre& fp, float* smem, int tid, int wave, int lane,
-                                                    int b, long long* tr_base, int& tr) {
+    __device__ static __forceinline__ void run_from(const FusedArgs& a, const FusedLay& lay, f32x4 (&ring)[kFusedRing], FinalPre& fp, float* smem, int tid, int wave,
+                                                    int lane, int b, long long* tr_base, int& tr) {
         if constexpr (I < N) {
-            fused_static_op<ids[I], I, (I + 1 < N ? ids[I + 1 < N ? I + 1 : I] : -1), prev_cout<I>(), SAVE>(a, ring, fp, smem, tid, wave, lane, b, tr_base, tr);
-            run_from<I + 1, SAVE>(a, ring, fp, smem, tid, wave, lane, b, tr_base, tr);
+            fused_static_op<GEOM, ids[I], I, (I + 1 < N ? ids[I + 1 < N ? I + 1 : I] : -1), prev_cout<I>(), SAVE>(a, lay, ring, fp, smem, tid, wave, lane, b, tr_base, tr);
+            run_from<I + 1, SAVE>(a, lay, ring, fp, smem, tid, wave, lane, b, tr_base, tr);
         }
     }
 };
@@ -697,16 +787,17 @@ __global__ __launch_bounds__(kFusedThreads) void fused_program_kernel(const Fuse
     ++tr;
     f32x4 ring[kFusedRing];
     FinalPre fp;
-    fused_prologue(a, smem, ring, tid, lane, wave, b, tr_base, tr);
-    SEQ::template run_from<0, SAVE>(a, ring, fp, smem, tid, wave, lane, b, tr_base, tr);
+    const FusedLay lay = fused_lay<typename SEQ::GEOM>(a);
+    fused_prologue<typename SEQ::GEOM>(a, lay, smem, ring, tid, lane, wave, b, tr_base, tr);
+    SEQ::template run_from<0, SAVE>(a, lay, ring, fp, smem, tid, wave, lane, b, tr_base, tr);
 }
 
 // the programs of the standard networks
-using FusedSeqDown = FusedSeq<0, 1, 2, 2, 3, 4, 5, 6, 6, 7>;                       // downs.0 + downs.1
-using FusedSeqUpA = FusedSeq<8, 9, 10, 10, 11>;                                    // the up level at L = 16 (cat 256 -> 64)
-using FusedSeqUpB = FusedSeq<12, 13, 14, 14, 15, 2, kFusedShapeFinal>;             // the up level at L = 32 + final_conv + DDPM step
-using FusedSeqUpAB = FusedSeq<8, 9, 10, 10, 11, 12, 13, 14, 14, 15, 2, kFusedShapeFinal>;   // both up levels in one launch
-using FusedSeqDown3 = FusedSeq<0, 1, 2, 2, 3, 4, 5, 6, 6, 7, 16, 17, 18, 18, 19>;   // downs.0 + downs.1 + downs.2 in one launch
-using FusedSeqMid2 = FusedSeq<16, 17, 18, 18, 19>;                                 // downs.2 (C = 128, L = 16): two tile rows per wave
+using FusedSeqDown = FusedSeq<GeomDown, 0, 1, 2, 2, 3, 4, 5, 6, 6, 7>;                       // downs.0 + downs.1
+using FusedSeqUpA = FusedSeq<GeomNone, 8, 9, 10, 10, 11>;                                    // the up level at L = 16 (cat 256 -> 64)
+using FusedSeqUpB = FusedSeq<GeomNone, 12, 13, 14, 14, 15, 2, kFusedShapeFinal>;             // the up level at L = 32 + final_conv + DDPM step
+using FusedSeqUpAB = FusedSeq<GeomUpAB, 8, 9, 10, 10, 11, 12, 13, 14, 14, 15, 2, kFusedShapeFinal>;   // both up levels in one launch
+using FusedSeqDown3 = FusedSeq<GeomDown3, 0, 1, 2, 2, 3, 4, 5, 6, 6, 7, 16, 17, 18, 18, 19>;   // downs.0 + downs.1 + downs.2 in one launch
+using FusedSeqMid2 = FusedSeq<GeomNone, 16, 17, 18, 18, 19>;                                 // downs.2 (C = 128, L = 16): two tile rows per wave
 
 }  // namespace mpdx

@@ -124,6 +124,9 @@ struct mpdx_unet {
     int pack_version = 0, streams_version = -1;
     struct Unit { int fused; int layer; bool pair; };   // fused >= 0: fused[fused]; else layers[layer] (pair: + layers[layer+1] in one launch)
     std::vector<int> owner;                  // layer -> fused segment (-1: per-layer launch)
+    // mpdx_plan's second chain (small batches run as two concurrent half-batch chains): side stream + fork / join events, created on first use
+    struct PlanSide { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+    PlanSide side;
     // training (train_host.hpp)
     struct TrainLayer {
         int src1_l = -2, src2_l = -2, res_l = -2;   // layer that produced the tensor (-1: the network input, -2: none)

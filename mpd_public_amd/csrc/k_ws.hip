@@ -3,15 +3,26 @@
 
 namespace mpdx {
 
-template <int NC16, int MT, bool R1, int NS = 1>
-static int launch_ws(const Layer& l, ConvArgs& a, const ConvArgs& a2, int B, hipStream_t st) {
+template <int NC16, int MT, bool R1, int NS, int TBRES>
+static int launch_ws_t(const Layer& l, ConvArgs& a, const ConvArgs& a2, int B, hipStream_t st) {
+    if (l.L_out != kWsL || a.rs != ws_row_stride<NC16>() || l.cout != 8 * MT || l.cin_pad != NC16 * 16 || (R1 && (a2.C_out != l.cout || a2.L_out != kWsL)))
+        return fail(MPDX_E_STATE, "layer %s does not have the geometry the weight-stationary kernel is compiled for (L %d, row stride %d, C_out %d)",
+                    l.name.c_str(), l.L_out, a.rs, l.cout);
     a.n_tiles_n = (int)(((long)B * l.L_out + 16 * NS - 1) / (16 * NS));
     const size_t lds = conv_ws_lds_bytes<NC16, MT, R1, NS>(l.L_out, a.rs);
     if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "weight-stationary conv needs %zu B of LDS", lds);
-    auto kern = conv_ws_kernel<NC16, MT, R1, NS>;
+    auto kern = conv_ws_kernel<NC16, MT, R1, NS, TBRES>;
     if (int rc = raise_lds_limit((const void*)kern)) return rc;
     hipLaunchKernelGGL(kern, dim3((l.cout / MT) * kWsGroups), dim3(kWsThreads), lds, st, a, a2);
     return 0;
+}
+// what the block adds behind Mish: the time-bias row, a residual tensor, or nothing (never both: blocks[0] / blocks[1] of a ResidualTemporalBlock)
+template <int NC16, int MT, bool R1, int NS = 1>
+static int launch_ws(const Layer& l, ConvArgs& a, const ConvArgs& a2, int B, hipStream_t st) {
+    if (a.tbias && a.res) return fail(MPDX_E_STATE, "layer %s: time bias AND residual on one weight-stationary launch", l.name.c_str());
+    if (a.tbias) return launch_ws_t<NC16, MT, R1, NS, 1>(l, a, a2, B, st);
+    if (a.res) return launch_ws_t<NC16, MT, R1, NS, 2>(l, a, a2, B, st);
+    return launch_ws_t<NC16, MT, R1, NS, 0>(l, a, a2, B, st);
 }
 
 int launch_weight_stationary(int variant, const Layer& l, ConvArgs& a, const ConvArgs& a2, int B, hipStream_t st) {

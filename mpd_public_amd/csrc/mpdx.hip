@@ -37,6 +37,7 @@ int debug_level() {
 }
 
 static long long* g_conv_trace = nullptr;   // dev tool (mpdx_layer_trace)
+static thread_local int g_plan_chains = 1;  // > 1 while mpdx_plan enqueues a plan as that many concurrent sub-batch chains (tile choice)
 
 // ------------------------------------------------------------------------------------------------ small kernels
 
@@ -689,12 +690,15 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         for (int k = 0; k < (int)hops.size(); ++k)
             if (a.ops[k].tb_off >= 0) a.ops[k].tb_off -= tt_lo;
     }
+    // behind the activation buffers: GroupNorm exchange | time-table slice | parameter block.  The block whose size depends on the state
+    // dimension (final_conv[1]'s weights) comes LAST, so that every other LDS offset of a program is the same for every state_dim
+    // (fused_geom.hpp holds them as compile-time constants)
     a.stat_off = (int)off4 * 4;     // GroupNorm exchange: 8 tiles x 4 rows x (mean, M2)
     off4 += 16;
-    a.par_off = (int)off4 * 4;
-    off4 += (size_t)(poff + 3) / 4;
     a.tt_off = (int)off4 * 4;
     off4 += (size_t)a.tt_n / 4;
+    a.par_off = (int)off4 * 4;
+    off4 += (size_t)(poff + 3) / 4;
 
     if ((size_t)(poff / 4 + a.tt_n / 4) > 2048) return fuse_reject(__LINE__);   // prologue: 2048 float4 of parameters per workgroup
     {
@@ -721,7 +725,27 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
             else if (matches(FusedSeqUpAB::ids, FusedSeqUpAB::N)) f.program = 3;
             else if (matches(FusedSeqMid2::ids, FusedSeqMid2::N)) f.program = 4;
             else if (matches(FusedSeqDown3::ids, FusedSeqDown3::N)) f.program = 5;
+            // the static programs with a geometry table read their LDS layout as compile-time constants (fused_geom.hpp): the layout computed
+            // above must BE that table, otherwise the segment runs on the generic op-list kernel (runtime descriptors)
+            const int sdim = u->cfg.state_dim;
+            if ((f.program == 0 && !fused_geom_matches(a, GeomDown::g, sdim)) || (f.program == 3 && !fused_geom_matches(a, GeomUpAB::g, sdim)) ||
+                (f.program == 5 && !fused_geom_matches(a, GeomDown3::g, sdim))) {
+                if (getenv("MPDX_DEBUG_FUSE")) fprintf(stderr, "[mpdx] fused segment: geometry differs from the table of program %d -> generic kernel\n", f.program);
+                f.program = -1;
+            }
         }
+    }
+    if (getenv("MPDX_DEBUG_FUSE") && atoi(getenv("MPDX_DEBUG_FUSE")) >= 2) {   // dev: the segment's LDS geometry as a fused_geom.hpp initialiser
+        fprintf(stderr, "// program %d: layers [%d,%d) %s..%s, LDS %zu B\n{ %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, {\n", f.program, i0, i1,
+                u->layers[i0].name.c_str(), u->layers[i1 - 1].name.c_str(), f.lds_bytes, a.nops, a.in_off4, a.in_rs4, a.in_rows, a.L0,
+                (a.gc1 == u->cfg.state_dim && a.gc2 == 0) ? -1 : a.gc1, a.gc2, a.c3, a.L3, a.s3_off4, a.s3_rs4, a.s3_col4, a.stat_off, a.par_off, with_final ? -1 : a.par_floats, a.tt_off,
+                a.tt_n, a.fpar_off, with_final ? a.H : 0, with_final ? a.Cf : 0);
+        for (int k = 0; k < a.nops; ++k) {
+            const FusedOp& o = a.ops[k];
+            fprintf(stderr, "    {%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d},\n", o.shape, o.src_off4, o.src_rs4, o.rsrc_off4, o.rsrc_rs4, o.res_off4, o.res_rs4,
+                    o.dst_off4, o.dst_rs4, o.gdst, o.p_off, o.tb_off);
+        }
+        fprintf(stderr, "}},\n");
     }
     u->fused.push_back(f);
     if (getenv("MPDX_DEBUG_FUSE"))
@@ -814,7 +838,8 @@ void choose_tile(const Layer& l, int B, int& MT, int& NT) {
         MT = (min_mt <= 16 && l.cout % 16 == 0) ? 16 : 32;
         return;
     }
-    static const int target = getenv("MPDX_TARGET_WGS") ? atoi(getenv("MPDX_TARGET_WGS")) : 160;
+    static const int target_env = getenv("MPDX_TARGET_WGS") ? atoi(getenv("MPDX_TARGET_WGS")) : 160;
+    const int target = std::max(1, target_env / g_plan_chains);   // concurrent sub-batch chains of a plan share the CUs
     auto wgs = [&](int mt, int nt) { return (long)(l.cout / mt) * ((npos + nt - 1) / nt); };
     const int pad = (l.mode == CONV_S1) ? l.ks / 2 : 1;
     auto lds = [&](int mt, int nt) {  // max(staged windows, K-partial buffer), as conv_block_lds_bytes
@@ -1142,6 +1167,7 @@ void mpdx_unet_destroy(mpdx_unet* u) {
     if (u && u->pack_descs_dev) (void)hipFree(u->pack_descs_dev);
     if (u && u->pack_chunks_dev) (void)hipFree(u->pack_chunks_dev);
     if (u && u->jobs_dev) (void)hipFree(u->jobs_dev);
+    if (u && u->side.stream) { (void)hipStreamDestroy(u->side.stream); (void)hipEventDestroy(u->side.fork); (void)hipEventDestroy(u->side.join); }
     delete u;
 }
 
@@ -1262,6 +1288,37 @@ int mpdx_weighted_loss(const float* pred, const float* targ, const float* weight
 }
 
 
+// ---- sub-batch chains (MEASURED AND REJECTED, round 4; kept behind MPDX_PLAN_CHAINS=2 so that the measurement can be repeated).
+// Idea: a plan of a small batch (B = 100) is a chain of ~1 600 dependent launches whose kernels cannot fill 256 CUs and whose boundaries
+// (~2.3 us of every launch's rocprof duration lie outside the workgroups' own lifetimes) add up to a sixth of the step; trajectories are
+// independent, so the batch is cut into two halves that run as two independent chains on two HIP streams (side stream forked from / joined
+// into the caller's stream with events, no host synchronisation; the halves meet only at a guided step's guide iterations, whose
+// whole-tensor range test couples them).  Results are bit-identical to the single chain (tests/test_gpu_parity.py, test_gpu_guide.py pass
+// with the split on).  Measured on MI355X (profiles/r04_plan_chains.txt): cfg 2 24.8 vs 20.3 ms, cfg 3 27.3 vs 21.9, cfg 4 29.6 vs 24.1 -
+// SLOWER, and not because of the host: replayed as ONE hipGraph (tools/graph_probe_plan.py) the two-chain plan takes 25.2 ms against 20.15
+// for the single chain's graph.  Two half-batch kernels do not share the chip the way one full-batch kernel uses it: every launch pays its
+// fixed phases (staging, K-reduction, epilogue, boundary) for half the work, and the dispatcher does not interleave the two queues finely
+// enough to hide one chain's boundaries under the other's kernels.
+namespace mpdx {
+static int plan_side(mpdx_unet* u, mpdx_unet::PlanSide** out) {   // the handle's side stream + fork / join events (created on first use; one handle = one device)
+    mpdx_unet::PlanSide& s = u->side;
+    if (!s.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+    }
+    *out = &s;
+    return 0;
+}
+// trajectories of the first chain (0: one chain - the default).  MPDX_PLAN_CHAINS=2 switches the split on (development A/B).
+static int plan_split_point(int B, int npc, int n_ctx) {
+    static const int forced = getenv("MPDX_PLAN_CHAINS") ? atoi(getenv("MPDX_PLAN_CHAINS")) : 0;
+    if (forced != 2 || B < 16) return 0;
+    if (n_ctx >= 2) return (n_ctx / 2) * npc;     // whole contexts per chain: the range-test flags stay per chain
+    return std::min(B - 4, ((B / 2) + 3) & ~3);   // one context: both chains publish into its one flag (atomicMax)
+}
+}  // namespace mpdx
+
 int mpdx_plan(mpdx_unet* u, const float* packed, const float* timetab, int T, const mpdx_step_coefs* coefs, int n_without_noise,
               float* x, const float* noise, const float* hard_start, const float* hard_goal, float* chain, int B, float* ws,
               const mpdx_guide_params* guide, int n_guide_steps, int t_start_guide, uint32_t* guide_flags, int n_per_ctx,
@@ -1286,6 +1343,22 @@ int mpdx_plan(mpdx_unet* u, const float* packed, const float* timetab, int T, co
     // x_T with hard conditioning; chain[0]
     hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, x, (const float*)nullptr,
                        hard_start, hard_goal, 0.f, 0.f, chain, B, H, D);
+    // two concurrent sub-batch chains (see plan_split_point): chain c covers trajectories [b0[c], b0[c] + nb[c])
+    const int B0 = plan_split_point(B, npc, n_ctx);
+    const int nch = B0 > 0 ? 2 : 1;
+    mpdx_unet::PlanSide* side = nullptr;
+    if (nch == 2) {
+        if (int rc = plan_side(u, &side)) return rc;
+        if (int rc = ensure_fused_streams(u, packed, st)) return rc;   // (a one-off re-assembly of the weight streams stays ahead of the fork)
+        HIP_TRY(hipEventRecord(side->fork, st));
+        HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+    }
+    const int b0[2] = {0, B0}, nb[2] = {nch == 2 ? B0 : B, B - B0};
+    hipStream_t sts[2] = {st, side ? side->stream : st};
+    float* wss[2] = {ws, ws + u->slot_floats * (size_t)nb[0] * u->n_slots};   // two disjoint workspaces inside the caller's one
+    struct ChainsGuard { int* p; ~ChainsGuard() { *p = 1; } } guard{&g_plan_chains};
+    g_plan_chains = nch;
+    bool forked = nch == 2;
     int k = 0;
     for (int i = T - 1; i >= -n_without_noise; --i, ++k) {
         const int t = i < 0 ? 0 : i;
@@ -1297,19 +1370,36 @@ int mpdx_plan(mpdx_unet* u, const float* packed, const float* timetab, int T, co
         memset(&rng, 0, sizeof(rng));
         if (!noise && t != 0) { rng.on = 1; rng.seed = rng_seed; rng.offset = rng_offset; rng.elem0 = (unsigned long long)(k + 1) * n; }
         float* ch = chain ? chain + (size_t)(k + 1) * n : nullptr;
-        FinalArgs fa;
-        memset(&fa, 0, sizeof(fa));
-        fa.x_in = x; fa.out = x;
-        fa.k = coefs[t];
-        fa.n_per_ctx = npc;
-        if (!guided) fa.rng = rng;
-        if (!guided) {
-            fa.noise = nz; fa.hs = hard_start; fa.hg = hard_goal; fa.chain = ch; fa.mode = 1;
-            if (int rc = run_unet_and_final(u, packed, timetab, T, x, t, B, ws, fa, st)) return rc;
-        } else {
-            uint32_t* fl = guide_flags + (size_t)k * (n_guide_steps + 1) * n_ctx;
-            fa.mode = 2; fa.absmax = fl;  // posterior mean + its max|.| per context
-            if (int rc = run_unet_and_final(u, packed, timetab, T, x, t, B, ws, fa, st)) return rc;
+        uint32_t* fl = guided ? guide_flags + (size_t)k * (n_guide_steps + 1) * n_ctx : nullptr;
+        if (nch == 2 && !forked) {   // behind a guided step's joined guide iterations: fork again
+            HIP_TRY(hipEventRecord(side->fork, st));
+            HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+            forked = true;
+        }
+        for (int c = 0; c < nch; ++c) {
+            const size_t eo = (size_t)b0[c] * H * D;   // element offset of the chain's first trajectory
+            FinalArgs fa;
+            memset(&fa, 0, sizeof(fa));
+            fa.x_in = x + eo; fa.out = x + eo;
+            fa.k = coefs[t];
+            fa.n_per_ctx = npc;
+            if (!guided) {
+                fa.rng = rng;
+                fa.rng.elem0 += eo;
+                fa.noise = nz ? nz + eo : nullptr;
+                fa.hs = hard_start ? hard_start + (size_t)b0[c] * D : nullptr; fa.hg = hard_goal ? hard_goal + (size_t)b0[c] * D : nullptr;
+                fa.chain = ch ? ch + eo : nullptr; fa.mode = 1;
+            } else {
+                fa.mode = 2; fa.absmax = fl + b0[c] / npc;  // posterior mean + its max|.| per context
+            }
+            if (int rc = run_unet_and_final(u, packed, timetab, T, x + eo, t, nb[c], wss[c], fa, sts[c])) return rc;
+        }
+        if (guided) {
+            if (nch == 2) {   // the guide iterations couple the chains (whole-tensor range test of a context): joined stream, whole batch
+                HIP_TRY(hipEventRecord(side->join, side->stream));
+                HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
+                forked = false;
+            }
             for (int j = 0; j < n_guide_steps; ++j) {
                 const bool last = j == n_guide_steps - 1;  // the last iteration also adds the noise term and appends to the chain
                 if (int rc = launch_guide(guide, x, nullptr, hard_start, hard_goal, fl + (size_t)j * n_ctx, fl + (size_t)(j + 1) * n_ctx, npc, B, H,
@@ -1321,11 +1411,16 @@ int mpdx_plan(mpdx_unet* u, const float* packed, const float* timetab, int T, co
         if (dbg) {   // MPDX_DEBUG: attribute launch / execution errors to the loop iteration that caused them
             if (dbg >= 2) {
                 hipError_t e = hipStreamSynchronize(st);
+                if (e == hipSuccess && nch == 2) e = hipStreamSynchronize(side->stream);
                 if (e != hipSuccess) return fail((int)e, "mpdx_plan: loop iteration %d (t=%d%s) faulted: %s", k, t, guided ? ", guided" : "", hipGetErrorString(e));
             }
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail((int)e, "mpdx_plan: launch in loop iteration %d (t=%d%s) failed: %s", k, t, guided ? ", guided" : "", hipGetErrorString(e));
         }
+    }
+    if (nch == 2 && forked) {   // join: the caller's stream continues behind both chains
+        HIP_TRY(hipEventRecord(side->join, side->stream));
+        HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
     }
     HIP_TRY(hipGetLastError());
     return 0;
