@@ -104,9 +104,17 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
     // tile that reaches beyond the batch (the last one) takes the clamped / masked path (wave-uniform test).
     constexpr int SB = (NT * NC16 * 4) / kWsThreads;
     static_assert(SB >= 1 && (NT * NC16 * 4) % kWsThreads == 0, "window divides over the threads");
-    int wdst[SB], ws_[SB];
-    const float* wsrc[SB];   // the lane's source address for tile 0
-    int wstep[SB], wtraj[SB];   // floats per tile / per trajectory of the lane's source tensor
+    // The loads are BUFFER loads: resource = the source tensor (SGPR x4; with a channel concat the lane's float4 comes from src1 or src2 -
+    // the same for a whole wave, because c1 / 4 is a multiple of 64: the launcher checks it), voffset = the lane's byte offset inside a
+    // tile (one VGPR per float4, set up once), soffset = tile * bytes per tile (ONE scalar multiply per tile): no VALU instruction per load
+    // (round 3: 64-bit products and clamps per load, 32 VALU per wave and tile).
+    int wdst[SB], ws_[SB], wvoff[SB];
+    const int first_w = __builtin_amdgcn_readfirstlane((((tid % c4n) * 4) < a.c1) ? 1 : 0);   // wave-uniform (see above)
+    const float* const wsrc_t = first_w ? a.src1 : a.src2;   // this wave's source tensor
+    const int cs = first_w ? a.c1 : a.c2;                    // its channels
+    const int wtraj = L * cs;                                // floats per trajectory
+    const int wtile_bytes = spt * wtraj * 4;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wsrc_t, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
         const int idx = tid + u * kWsThreads;
@@ -115,22 +123,19 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
         wdst[u] = (s * LP + li + PAD) * RS4 + c4;
         ws_[u] = s;
         const int c = c4 * 4;
-        const bool first = c < a.c1;                        // channel concat (c1, c2 % 4 == 0)
-        const int cs = first ? a.c1 : a.c2;
-        wsrc[u] = (first ? a.src1 + c : a.src2 + (c - a.c1)) + (size_t)(s * L + li) * cs;
-        wtraj[u] = L * cs;
-        wstep[u] = spt * wtraj[u];
+        wvoff[u] = ((s * L + li) * cs + (first_w ? c : c - a.c1)) * 4;
     }
     f32x4 wv[SB];
     auto window_load = [&](int tile) {   // unconditional loads from valid addresses (a conditional load serialises the queue)
         if ((tile + 1) * spt <= a.B) {
+            const int soff = tile * wtile_bytes;
 #pragma unroll
-            for (int u = 0; u < SB; ++u) wv[u] = *(const f32x4*)(wsrc[u] + (size_t)tile * wstep[u]);
+            for (int u = 0; u < SB; ++u) wv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff[u], soff, 0));
         } else {
 #pragma unroll
             for (int u = 0; u < SB; ++u) {
                 const int over = tile * spt + ws_[u] - (a.B - 1);   // trajectories beyond the batch re-read the last one (masked at the write)
-                wv[u] = *(const f32x4*)(wsrc[u] + (size_t)tile * wstep[u] - (size_t)(over > 0 ? over : 0) * wtraj[u]);
+                wv[u] = *(const f32x4*)((const char*)wsrc_t + (size_t)tile * wtile_bytes + wvoff[u] - (size_t)(over > 0 ? over : 0) * wtraj * 4);
             }
         }
     };
@@ -149,6 +154,23 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
     int boff[NS];   // position sub-tile ns: tile-local position n = ns * 16 + j
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) boff[ns] = (((ns * 16 + j) / L) * LP + (j & (L - 1))) * RS4 + q;
+
+    // B-fragment addresses of this wave's k-groups in window buffer 0 (float4 units), computed ONCE: the k-group -> (channel chunk, tap)
+    // split depends on the wave, so inside the loop every read cost a VALU add (28 per wave and tile); the tile loop below is unrolled
+    // by two so that the window buffer is a compile-time constant and lands in the ds_read's immediate offset.
+    int baddr[NIT][NS], baddr2[R1 ? NIT2 : 1][NS];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int g = wk + it * WK, c16 = g / KS, ts = g - c16 * KS;
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) baddr[it][ns] = boff[ns] + ts * RS4 + c16 * 4;
+    }
+    if constexpr (R1) {
+#pragma unroll
+        for (int it = 0; it < NIT2; ++it)
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) baddr2[it][ns] = boff[ns] + PAD * RS4 + (wk + it * WK) * 4;
+    }
 
     // ---- epilogue operands of the region this lane would serve (channels are fixed per lane: loaded once)
     const int e0 = lane * EPL;
@@ -171,8 +193,8 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
     long long st_[4] = {0, 0, 0, 0};
 #define WS_STAMP(k) do { if (trp) { if (i == 8 && (k) == 0) st_[0] = (long long)__builtin_readcyclecounter(); if (i == 8 && (k) == 1) st_[1] = (long long)__builtin_readcyclecounter(); \
                                     if (i == 8 && (k) == 3) st_[2] = (long long)__builtin_readcyclecounter(); if (i == 9 && (k) == 0) st_[3] = (long long)__builtin_readcyclecounter(); } } while (0)
-    for (int i = 0; tile < n_tiles; ++i, tile += kWsGroups) {
-        const int cur = i & 1;
+    auto tile_body = [&](auto cur_c, const int i, const int tile) {
+        constexpr int cur = decltype(cur_c)::value;
         WS_STAMP(0);
         // this wave's epilogue duty for the tile (region r = trajectory r of the tile): its global operands are requested BEFORE the
         // k-loop - a duty wave that waits ~1 us for the residual after the barrier idles its SIMD's matrix pipe once its partner's
@@ -197,10 +219,9 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
         const f32x4* win = smem4 + cur * stage4;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int g = wk + it * WK, c16 = g / KS, ts = g - c16 * KS;
             f32x4 bf[NS];
 #pragma unroll
-            for (int ns = 0; ns < NS; ++ns) bf[ns] = win[boff[ns] + ts * RS4 + c16 * 4];
+            for (int ns = 0; ns < NS; ++ns) bf[ns] = win[baddr[it][ns]];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -216,7 +237,7 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
             for (int it = 0; it < NIT2; ++it) {
                 f32x4 bf[NS];
 #pragma unroll
-                for (int ns = 0; ns < NS; ++ns) bf[ns] = win[boff[ns] + PAD * RS4 + (wk + it * WK) * 4];
+                for (int ns = 0; ns < NS; ++ns) bf[ns] = win[baddr2[it][ns]];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -294,6 +315,13 @@ __global__ __launch_bounds__(kWsThreads) void conv_ws_kernel(const ConvArgs a, c
         // the prefetched residual - requested before the barrier, these loads put a ~1.5 us round trip in front of every epilogue:
         // stamps of tools/ws_trace.py, 3.5 k cycles per duty epilogue); they have the whole next k-loop to land
         if (nxt + kWsGroups < n_tiles) window_load(nxt + kWsGroups);
+    };
+    for (int i = 0; tile < n_tiles; i += 2) {   // two tiles per trip: window buffers 0 and 1 at compile time
+        tile_body(std::integral_constant<int, 0>{}, i, tile);
+        tile += kWsGroups;
+        if (tile >= n_tiles) break;
+        tile_body(std::integral_constant<int, 1>{}, i + 1, tile);
+        tile += kWsGroups;
     }
 #undef WS_STAMP
     if (trp) { trp[0] = st_[0]; trp[1] = st_[1]; trp[2] = st_[2]; trp[3] = st_[3]; }

@@ -200,10 +200,22 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // Request the first min(16, slen) blocks of a wave-stream (prologue only).  Slots beyond a short stream stay unset: the first
 // op's k-loop fills them with the next op's blocks.  (wave-uniform guards: no request is issued for a block nobody reads -
 // every request costs the CU's 64 B/clk vector-memory path 16 cycles.)
-__device__ __forceinline__ void fused_ring_request(f32x4 (&ring)[kFusedRing], const float* __restrict__ wbase, int slen) {
+// One 1-KiB A-fragment block of a wave-stream, as a BUFFER load: resource = the `packed` allocation (SGPR x4), voffset = lane * 16
+// (one VGPR for the whole kernel), soffset = byte offset of the block (wave-uniform: stream base + block * 1024, one SALU add).  No VALU
+// instruction per block: as per-lane 64-bit pointers the 472 block loads of the three-level down program cost 81 v_add_co / v_addc pairs
+// plus moves (a global load's immediate reaches 4 KB = four blocks) - tools/isa_census.py, round 4.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fused_weights_rsrc(const float* packed) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)packed, 0, 0x7fffffff, 0x00020000);   // raw buffer, no bounds in practice, DATA_FORMAT_32
+}
+__device__ __forceinline__ f32x4 fused_ld_block(__amdgpu_buffer_rsrc_t rs, int stream_bytes, int blk, unsigned lane_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_bytes, stream_bytes + blk * 1024, 0));
+}
+
+__device__ __forceinline__ void fused_ring_request(f32x4 (&ring)[kFusedRing], __amdgpu_buffer_rsrc_t rs, int wbase, int slen, unsigned lane_bytes) {
 #pragma unroll
     for (int p = 0; p < kFusedRing; ++p)   // (no zero-init: a load into a pre-initialised register makes hipcc drain vmcnt first)
-        if (p < slen) ring[p] = *(const f32x4*)(wbase + (size_t)p * 256);
+        if (p < slen) ring[p] = fused_ld_block(rs, wbase, p, lane_bytes);
     __builtin_amdgcn_sched_barrier(0);   // the requests go out HERE
 }
 
@@ -221,13 +233,13 @@ __device__ __forceinline__ float row_sum16(float v) {
 }
 
 // One conv op of static shape S: k-loop over this wave's tile(s) with the ring running on into the next op's stream, epilogue.
-//   nbase: the NEXT conv op's wave-stream (+ lane*4), nmax: its last block index (the ring's cross-over requests are clamped
+//   nbase: BYTE offset in `packed` of the NEXT conv op's wave-stream (wave-uniform), nmax: its last block index (the ring's cross-over requests are clamped
 //   to it; after the last conv op both describe any valid block)
 // SAVE: the training forward's variant (every op also stores its output and its GroupNorm input through FusedArgs::save); the planning
 // kernels are instantiated without it (measured on one box: 22.54 vs 22.62 ms per cfg-2 plan with the stores merely compiled in)
 template <class S, bool SAVE = false>
 __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedLay& lay, const FusedOp& op, f32x4 (&ring)[kFusedRing], float* smem, int wave, int lane, int b,
-                                              const float* __restrict__ nbase, int nmax, long long* tr_base, int& tr) {
+                                              int nbase, int nmax, long long* tr_base, int& tr) {
     constexpr int P = kFusedRing, DB = MPDX_FUSED_DB, NTW = S::NTW, NJ = S::NJ;
     f32x4* const sm4 = (f32x4*)smem;
     const int j = lane & 15, q = lane >> 4;
@@ -259,7 +271,9 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedLay
         rrow[t] = sm4 + (S::NCR > 0 ? op.rsrc_off4 + (ns[t] * 16 + j + 2) * op.rsrc_rs4 + q : 0);
     }
     const int rs4 = op.src_rs4;
-    const float* sbase = a.packed + op.sbase + (size_t)ms * (S::SLEN * 256) + lane * 4;
+    const __amdgpu_buffer_rsrc_t wrs = fused_weights_rsrc(a.packed);
+    const int sbase = (op.sbase + ms * (S::SLEN * 256)) * 4;   // BYTE offset of this wave's stream in `packed` (wave-uniform; nbase likewise)
+    const unsigned lane_bytes = (unsigned)lane * 16u;
     // B fragment of stream block r for joint tile t
     auto read_b = [&](int r, int t) -> f32x4 {
         const int rr = r % S::TOT, par = r / S::TOT;    // (ConvTranspose: second half of the stream = odd outputs)
@@ -299,12 +313,12 @@ __device__ __forceinline__ void fused_conv_op(const FusedArgs& a, const FusedLay
                 d = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bq[r % (DB + 1)][t][e], d, 0, 0, 0);
             }
         // refill slot r % P: the block P further down this op's stream, or (no such block) the next op's block of that slot
-        if (r + P < S::SLEN) ring[r % P] = *(const f32x4*)(sbase + (r + P) * 256);
-        else { const int k = r % P; ring[k] = *(const f32x4*)(nbase + (size_t)(k < nmax ? k : nmax) * 256); }
+        if (r + P < S::SLEN) ring[r % P] = fused_ld_block(wrs, sbase, r + P, lane_bytes);
+        else { const int k = r % P; ring[k] = fused_ld_block(wrs, nbase, k < nmax ? k : nmax, lane_bytes); }
         if (S::SLEN < P) {   // slots this op never used belong to the next op from the start
 #pragma unroll
             for (int k = S::SLEN; k < P; ++k)
-                if ((k - S::SLEN) % S::SLEN == r) ring[k] = *(const f32x4*)(nbase + (size_t)(k < nmax ? k : nmax) * 256);
+                if ((k - S::SLEN) % S::SLEN == r) ring[k] = fused_ld_block(wrs, nbase, k < nmax ? k : nmax, lane_bytes);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -455,7 +469,7 @@ __device__ __forceinline__ void fused_prologue(const FusedArgs& a, const FusedLa
 #define FUSED_STAMP() do { if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter(); ++tr; } while (0)
     // ---- prologue: every global load is issued first (weight ring of op 0, input window, parameters), the halo / padding
     //      zeros are written while they fly, and ONE barrier closes it.
-    fused_ring_request(ring, a.packed + a.ops[0].sbase + (size_t)(wave & a.msmask[0]) * a.slen[0] * 256 + lane * 4, a.slen[0]);
+    fused_ring_request(ring, fused_weights_rsrc(a.packed), (a.ops[0].sbase + (wave & a.msmask[0]) * a.slen[0] * 256) * 4, a.slen[0], (unsigned)lane * 16u);
 
     constexpr int NT_ = kFusedThreads;
     // float4 the three copies move at most (-> passes of 256 threads)
@@ -690,10 +704,10 @@ __global__ __launch_bounds__(kFusedThreads) void fused_level_kernel(const FusedA
             continue;
         }
         // the next conv op's wave-stream: this op's ring runs on into it (after the last conv op: any valid block, unused)
-        const float* nbase = a.packed + op.sbase + lane * 4;
+        int nbase = op.sbase * 4;
         int nmax = 0;
         if (oi + 1 < a.nops && a.ops[oi + 1].shape != kFusedShapeFinal) {
-            nbase = a.packed + a.ops[oi + 1].sbase + (size_t)(wave & a.msmask[oi + 1]) * a.slen[oi + 1] * 256 + lane * 4;
+            nbase = (a.ops[oi + 1].sbase + (wave & a.msmask[oi + 1]) * a.slen[oi + 1] * 256) * 4;
             nmax = a.slen[oi + 1] - 1;
         }
         switch (op.shape) {
@@ -741,11 +755,11 @@ __device__ __forceinline__ void fused_static_op(const FusedArgs& a, const FusedL
         if (tr_base) tr_base[tr] = (long long)__builtin_readcyclecounter();
         ++tr;
     } else {
-        const float* nbase = a.packed + a.ops[I].sbase + lane * 4;
+        int nbase = a.ops[I].sbase * 4;
         int nmax = 0;
         if constexpr (NEXT_SH >= 0 && NEXT_SH != kFusedShapeFinal) {
             using N = typename FusedShapeOf<NEXT_SH>::type;
-            nbase = a.packed + a.ops[I + 1].sbase + (size_t)(wave & (N::MSn < kFusedWaves ? N::MSn - 1 : kFusedWaves - 1)) * (N::SLEN * 256) + lane * 4;
+            nbase = (a.ops[I + 1].sbase + (wave & (N::MSn < kFusedWaves ? N::MSn - 1 : kFusedWaves - 1)) * (N::SLEN * 256)) * 4;
             nmax = N::SLEN - 1;
         }
         fused_conv_op<typename FusedShapeOf<SH>::type, SAVE>(a, lay, op, ring, smem, wave, lane, b, nbase, nmax, tr_base, tr);

@@ -8,6 +8,8 @@ static int launch_ws_t(const Layer& l, ConvArgs& a, const ConvArgs& a2, int B, h
     if (l.L_out != kWsL || a.rs != ws_row_stride<NC16>() || l.cout != 8 * MT || l.cin_pad != NC16 * 16 || (R1 && (a2.C_out != l.cout || a2.L_out != kWsL)))
         return fail(MPDX_E_STATE, "layer %s does not have the geometry the weight-stationary kernel is compiled for (L %d, row stride %d, C_out %d)",
                     l.name.c_str(), l.L_out, a.rs, l.cout);
+    if ((l.c2 > 0 && (l.c1 % 256 || l.c2 % 4)) || (l.c1 % 4) || (long)B * kWsL * std::max(l.c1, l.c2) * 4 > 0x7fffffffL)
+        return fail(MPDX_E_STATE, "layer %s: channel split %d + %d / batch %d outside what the weight-stationary kernel's window loads take", l.name.c_str(), l.c1, l.c2, B);
     a.n_tiles_n = (int)(((long)B * l.L_out + 16 * NS - 1) / (16 * NS));
     const size_t lds = conv_ws_lds_bytes<NC16, MT, R1, NS>(l.L_out, a.rs);
     if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "weight-stationary conv needs %zu B of LDS", lds);
