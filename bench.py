@@ -375,6 +375,9 @@ def _guided_oracle_check(dm, sd, g, gk, hc, D, T, n0, nb):
     def same3(a, b):   # identical to 3 significant figures (or both zero)
         return a == b or abs(a - b) <= 5e-3 * max(abs(a), abs(b))
     return {"trajectories": nb, "hip": {k: float(f"{v:.6g}") for k, v in hip.items()}, "oracle": {k: float(f"{v:.6g}") for k, v in orc.items()},
+            "colliding_waypoints": {"hip": int(m[:, 0].sum()), "oracle": int(hits.sum()), "checked": int(nb * 256),
+                                    "note": "a count over nb x 256 interpolated waypoints: one waypoint within fp32 rounding of a margin is 1 / checked of the "
+                                            "intensity, so on a slice this small the third significant figure of the intensity is a handful of waypoints"},
             "equal_to_3sf": {k: bool(same3(hip[k], orc[k])) for k in hip},
             "max_abs_diff_final_trajectories": float((chain[-1].cpu() - ref[-1]).abs().max()),
             "oracle_cpu_plan_s": round(cpu_s, 2), "weights": "synthetic (random-init): the figures are those of un-trained plans"}

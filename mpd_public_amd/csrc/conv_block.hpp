@@ -90,6 +90,11 @@ struct ConvArgs {
     float* bw_pg; float* bw_pb; float* bw_pbias; float* bw_dT; float* bw_gres;
     int bw_dT_stride;
     int bw_gres_store;   // this launch is the FIRST writer of bw_gres in the pass: store instead of +=
+    // Horizons that are not powers of two (H % 8 == 0: 24, 40, 48, 96 ...; temporal_unet.py:24,80-103 accepts them) run in a power-of-two
+    // CONTAINER [B][L_out][C] whose rows l >= Lv_out are kept ZERO by every producer - the zero rows double as the convolution's own
+    // padding, so the k-loop and the staging are untouched: only the epilogues mask (GroupNorm statistics over the valid rows,
+    // zeros stored beyond them).  Lv_out == L_out (or 0): nothing masked.  Honoured by EPI_GN_MISH_GEN and EPI_BIAS.
+    int Lv_out;
 };
 
 // wave64 all-reduce (sum) with DPP row operations + 4 readlanes instead of a 6-step ds_bpermute butterfly:
@@ -214,9 +219,22 @@ struct ConvGeom {
 //     odd  o=2m+1: k=2 (i=m),  k=0 (i=m+1)   -> slots 2,3
 __host__ __device__ inline int upt_slot_to_k(int slot) { return slot == 0 ? 1 : slot == 1 ? 3 : slot == 2 ? 2 : 0; }
 
-template <int MODE, int KS, int EPI, int MT, int NT, int WN, int WK>
+// Compile-time geometry of a launch (round 4).  GeoAny: every length / stride / channel count is read from the argument block (any
+// layer).  GeoL8<NC16>: the inner U-Net levels - CONV_S1 on L_in = L_out = 8 positions per trajectory, C_in = 16 * NC16 input channels
+// without padding (c1, c2 multiples of 4), LDS row stride C_in + 8 floats (what pick_row_stride finds for them): the twelve conv
+// launches of a B = 100 step that are not whole-trajectory programs.  With the geometry known the staging indices are constants and
+// shifts, the k-loop is straight-line code (round 3: ~40 SALU instructions of divisions / clamps per k-group between the MFMAs) and
+// every LDS address is `lane base + immediate`; tools/isa_census.py: 1 406 VALU + 574 SALU in the generic staging prologue.
+struct GeoAny { static constexpr int L = 0, NC16 = 0; };
+template <int NC16_> struct GeoL8 { static constexpr int L = 8, NC16 = NC16_; };
+constexpr int geo_ilog2(int v) { return v <= 1 ? 0 : 1 + geo_ilog2(v >> 1); }
+
+// TBRES: what a GroupNorm epilogue adds behind Mish, when known at compile time (-1: read the pointers; 0 nothing, 1 time bias, 2 residual)
+template <int MODE, int KS, int EPI, int MT, int NT, int WN, int WK, class GEO = GeoAny, int TBRES = -1>
 __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int block_id) {
     using G = ConvGeom<MODE, KS>;
+    constexpr bool GK = GEO::L > 0;   // geometry known at compile time
+    static_assert(!GK || MODE == CONV_S1, "GeoL8: stride-1 convolutions");
     constexpr int NWAVE = WN * WK, NTHR = 64 * NWAVE;
     constexpr int MS = MT / 16, NSUB = NT / 16, NSW = NSUB / WN;
     constexpr int PAD = G::PAD, NTAP = G::NTAP, NSLOT = G::NSLOT;
@@ -234,14 +252,15 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
 #define CB_STAMP() do { if (MPDX_TRACE_PTR(a.trace) && tid == 0 && (block_id == 0 || block_id == (int)gridDim.x - 1)) a.trace[(block_id ? 16 : 0) + tr_i] = (long long)__builtin_readcyclecounter(); ++tr_i; } while (0)
     const int n_mt = a.C_out / MT;   // MT is a compile-time power of two; one uniform division per workgroup
     const int mt = block_id % n_mt, nt = block_id / n_mt;
-    const int L_in = a.L_in, L_out = a.L_out;
-    const int spt = NT >> a.lg_Lout;  // trajectories per tile
+    const int L_in = GK ? GEO::L : a.L_in, L_out = GK ? GEO::L : a.L_out;
+    const int lg_Lin = GK ? geo_ilog2(GEO::L) : a.lg_Lin, lg_Lout = GK ? geo_ilog2(GEO::L) : a.lg_Lout, lg_c4n = GK ? geo_ilog2(GEO::NC16 * 4) : a.lg_c4n;
+    const int spt = NT >> lg_Lout;  // trajectories per tile
     const int s0 = nt * spt;
     const int LP = L_in + 2 * PAD;
-    const int RS4 = a.rs >> 2;  // LDS row stride in float4 units (all LDS indexing is in 16-B units: provably aligned)
+    const int RS4 = GK ? (GEO::NC16 * 16 + 8) / 4 : a.rs >> 2;  // LDS row stride in float4 units (all LDS indexing is in 16-B units: provably aligned)
     f32x4* const smem4 = (f32x4*)smem;
-    const int cin = a.c1 + a.c2;
-    const int c4n = a.cin_pad >> 2;
+    const int cin = GK ? GEO::NC16 * 16 : a.c1 + a.c2;
+    const int c4n = GK ? GEO::NC16 * 4 : a.cin_pad >> 2;
 
     CB_STAMP();  // 0: kernel entry
     // ------------------------------------------------------------------ weight prefetch (independent of LDS)
@@ -259,9 +278,13 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                             // monotonically WORSE: the 8 waves' up-front requests queue in the CU's 64 B/clk vector-memory path ahead
                             // of the activation staging loads (in-order return), and the clamped refills at the tail re-request the
                             // last k-group.  The mid-level launches are not bound by weight latency.
-    const int nc16 = a.cin_pad >> 4;
+    const int nc16 = GK ? GEO::NC16 : a.cin_pad >> 4;
     const int ngroups = nc16 * NTAP;
-    const float* wbase = a.wp + (size_t)(mt * MS) * nc16 * NSLOT * 256 + lane * 4;
+    // A fragments as BUFFER loads: resource = the layer's packed weights, voffset = lane * 16 (one VGPR), soffset = byte offset of the
+    // 1-KiB block (wave-uniform: SALU) - no VALU address arithmetic per load (round 3: a 64-bit add per block)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 0x7fffffff, 0x00020000);
+    const int wlane = lane * 16;
+    const int wtile = (mt * MS) * nc16 * NSLOT * 1024;
     f32x4 af[PF][MS][NCLS];
     auto load_a = [&](int g, f32x4 (&dst)[MS][NCLS]) {
         const int c16 = g / NTAP, ts = g - c16 * NTAP;
@@ -270,7 +293,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
 #pragma unroll
             for (int p = 0; p < NCLS; ++p) {
                 const int slot = (MODE == CONV_UPT) ? (p * 2 + ts) : ts;
-                dst[m][p] = *(const f32x4*)(wbase + ((size_t)(m * nc16 + c16) * NSLOT + slot) * 256);
+                dst[m][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane, wtile + ((m * nc16 + c16) * NSLOT + slot) * 1024, 0));
             }
     };
     const int niter = (ngroups + WK - 1) / WK;  // uniform over the workgroup's waves
@@ -291,8 +314,8 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
     // ------------------------------------------------------------------ stage the horizon windows (+halo) into LDS
     if (!MPDX_DBG(a, 1)) {
         // interior rows: idx -> (trajectory s, input position li, float4 column) by shifts; halo rows are zeroed separately
-        const int total = (spt << a.lg_Lin) << a.lg_c4n;
-        const bool vec_ok = ((a.c1 & 3) == 0) && ((a.c2 & 3) == 0);
+        const int total = (spt << lg_Lin) << lg_c4n;
+        const bool vec_ok = GK ? true : ((a.c1 & 3) == 0) && ((a.c2 & 3) == 0);
         constexpr int SB = 4;  // loads in flight per thread
         // The loads are UNCONDITIONAL (addresses clamped to something valid, zeros selected at the LDS store): a load inside
         // a branch into a zero-initialised register makes hipcc wait for ALL outstanding loads (vmcnt(0)) before it issues
@@ -314,8 +337,8 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                 const int idx = base + u * NTHR;
                 const bool in = idx < total;
                 const int idc = in ? idx : 0;
-                const int rowi = idc >> a.lg_c4n, c = (idc & (c4n - 1)) << 2;
-                const int s = rowi >> a.lg_Lin, li = rowi & (L_in - 1);
+                const int rowi = idc >> lg_c4n, c = (idc & (c4n - 1)) << 2;
+                const int s = rowi >> lg_Lin, li = rowi & (L_in - 1);
                 const int b = s0 + s;
                 dsto[u] = in ? (s * LP + li + PAD) * RS4 + (c >> 2) : -1;
                 ok[u] = in && b < a.B && c < cin;
@@ -358,9 +381,9 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
         // zero halo rows (conv padding): 2*PAD rows per trajectory
         if (PAD > 0) {
             constexpr int P2 = PAD > 0 ? 2 * PAD : 1;
-            const int htot = (spt * P2) << a.lg_c4n;
+            const int htot = (spt * P2) << lg_c4n;
             for (int idx = tid; idx < htot; idx += NTHR) {
-                const int hr = idx >> a.lg_c4n, c4 = idx & (c4n - 1);
+                const int hr = idx >> lg_c4n, c4 = idx & (c4n - 1);
                 const int s = hr / P2, k = hr - s * P2;                         // compile-time divisor
                 const int lp = (k < PAD) ? k : (L_in + k);                      // rows 0..PAD-1 and L_in+PAD..L_in+2PAD-1
                 smem4[(s * LP + lp) * RS4 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -383,12 +406,12 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
         const int ns = wn * NSW + i;
         if (MODE == CONV_UPT) {
             const int gm = (ns >> 1) * 16 + j;          // global input index within the tile
-            const int s = gm >> a.lg_Lin, m = gm & (L_in - 1);
+            const int s = gm >> lg_Lin, m = gm & (L_in - 1);
             boff[i] = (s * LP + m + PAD) * RS4 + q;  // row of input m (tap row offsets added below), float4 units
             npos[i] = s * L_out + 2 * m + (ns & 1);
         } else {
             const int n = ns * 16 + j;
-            const int s = n >> a.lg_Lout, l = n & (L_out - 1);
+            const int s = n >> lg_Lout, l = n & (L_out - 1);
             const int r0 = (MODE == CONV_DOWN) ? 2 * l : l;
             boff[i] = (s * LP + r0) * RS4 + q;
             npos[i] = n;
@@ -403,31 +426,46 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
 
     // (An explicit one-k-group-ahead register pipeline of the B fragments was measured 2.7 % SLOWER than letting hipcc
     //  interleave the ds_reads of this unrolled body - interleaved A/B, cfg 2: 30.2 vs 29.4 ms per plan.)
+    auto kgroup = [&](const int g, f32x4 (&afu)[MS][NCLS]) {   // the MFMAs of k-group g (wave-uniform) out of the staged window
+        const int c16 = g / NTAP, ts = g - c16 * NTAP;
+#pragma unroll
+        for (int i = 0; i < NSW; ++i) {
+            const int p = (MODE == CONV_UPT) ? (i & 1) : 0;
+            // row offset of this tap in the staged (zero-haloed) window:
+            //   conv/down: staged row (l*stride + tap) holds true index l*stride + tap - PAD;
+            //   convT:     boff already points at input m; even outputs use (m, m-1), odd outputs (m, m+1).
+            const int roff = (MODE == CONV_UPT) ? ((ts == 0) ? 0 : (p == 0 ? -1 : 1)) : ts;
+#ifdef MPDX_LOOP_ABLATION
+            const f32x4 bf = (a.dbg & 32) ? (f32x4){1.f, 2.f, 3.f, 4.f} : smem4[boff[i] + roff * RS4 + c16 * 4];
+#else
+            const f32x4 bf = smem4[boff[i] + roff * RS4 + c16 * 4];
+#endif
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int m = 0; m < MS; ++m)
+                    acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(afu[m][p][e], bf[e], acc[m][i], 0, 0, 0);
+        }
+    };
+    if constexpr (GK) {
+        // geometry known: the wave's k-groups wk, wk + WK, ... as straight-line code (their number is a constant; the (chunk, tap)
+        // of a k-group still depends on the wave: scalar arithmetic, once per k-group, nothing between the MFMAs of a k-group)
+        constexpr int NGR = GEO::NC16 * NTAP;
+        constexpr int NIT = (NGR + WK - 1) / WK;
+        static_assert(NGR % WK == 0, "GeoL8: the k-groups split evenly over the K-split waves");
+        if (!MPDX_DBG(a, 2)) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                kgroup(wk + it * WK, af[it % PF]);
+                if (it + PF < NIT) load_a(wk + (it + PF) * WK, af[it % PF]);   // refill this ring slot
+            }
+        }
+    } else
     for (int it0 = 0; it0 < niter && !MPDX_DBG(a, 2); it0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int g = wk + (it0 + u) * WK;
-            if (g < ngroups) {  // wave-uniform; only LDS reads + MFMAs are conditional
-                const int c16 = g / NTAP, ts = g - c16 * NTAP;
-#pragma unroll
-                for (int i = 0; i < NSW; ++i) {
-                    const int p = (MODE == CONV_UPT) ? (i & 1) : 0;
-                    // row offset of this tap in the staged (zero-haloed) window:
-                    //   conv/down: staged row (l*stride + tap) holds true index l*stride + tap - PAD;
-                    //   convT:     boff already points at input m; even outputs use (m, m-1), odd outputs (m, m+1).
-                    const int roff = (MODE == CONV_UPT) ? ((ts == 0) ? 0 : (p == 0 ? -1 : 1)) : ts;
-#ifdef MPDX_LOOP_ABLATION
-                    const f32x4 bf = (a.dbg & 32) ? (f32x4){1.f, 2.f, 3.f, 4.f} : smem4[boff[i] + roff * RS4 + c16 * 4];
-#else
-                    const f32x4 bf = smem4[boff[i] + roff * RS4 + c16 * 4];
-#endif
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int m = 0; m < MS; ++m)
-                            acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][m][p][e], bf[e], acc[m][i], 0, 0, 0);
-                }
-            }
+            if (g < ngroups) kgroup(g, af[u]);   // wave-uniform; only LDS reads + MFMAs are conditional
 #ifdef MPDX_LOOP_ABLATION   // a CONDITIONAL refill serialises the ring (hipcc waits vmcnt(0)): never in the production build
             if (!(a.dbg & 8)) load_a(ring_g(it0 + u + PF), af[u]);
 #else
@@ -464,79 +502,74 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
         const int gpt = 1 << lg_gpt;
         const int nreg = spt << lg_gpt;
         const int re = gs << a.lg_Lout;
-        const float inv_re = 1.0f / (float)re;   // power of two: exact
-        auto region4 = [&](auto nch_, int s, int gl, int b) {
-            constexpr int NCH = decltype(nch_)::value;
-            f32x4 v[NCH], tb[NCH], rs4[NCH], ga[NCH], be[NCH];
+        const int Lv = (a.Lv_out > 0 && a.Lv_out < L_out) ? a.Lv_out : L_out;   // valid rows of the container (see ConvArgs::Lv_out)
+        const float inv_re = 1.0f / (float)(gs * Lv);    // (a power of two - exact - when nothing is masked)
+        // a region of re = 64 * W * NCH elements: NCH chunks of W consecutive channels of one position per lane (W = 4: re = 256 NCH;
+        // W = 2: re = 128; W = 1: re = 64)
+        auto region = [&](auto w_, auto nch_, int s, int gl, int b) {
+            constexpr int W = decltype(w_)::value, NCH = decltype(nch_)::value;
+            float v[NCH][W], tb[NCH][W], rsd[NCH][W], ga[NCH][W], be[NCH][W];
             size_t o[NCH];
+            bool ok[NCH];
             float sum = 0.f;
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
-                const int e0 = (k * 64 + lane) * 4;
+                const int e0 = (k * 64 + lane) * W;
                 const int l = e0 >> a.lg_gs, c = gl * gs + (e0 & (gs - 1));
                 const int n = s * L_out + l, co = mt * MT + c;
+                ok[k] = l < Lv;
                 o[k] = ((size_t)(b < a.B ? b : 0) * L_out + l) * a.C_out + co;
-                const f32x4 bi = *(const f32x4*)(a.bias + co);
-                ga[k] = *(const f32x4*)(a.gamma + co); be[k] = *(const f32x4*)(a.beta + co);
-                tb[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; rs4[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (a.tbias) tb[k] = *(const f32x4*)(a.tbias + (size_t)(b < a.B ? b : 0) * a.tb_stride + co);
-                if (a.res) rs4[k] = *(const f32x4*)(a.res + o[k]);
-                const int ri = n * MTP4 + (c >> 2);
-                v[k] = smem4[ri];
 #pragma unroll
-                for (int kk = 1; kk < WK; ++kk) v[k] += smem4[ri + kk * NT * MTP4];
-                v[k] += bi;
-                if (a.pre && b < a.B) *(f32x4*)(a.pre + o[k]) = v[k];
-                sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+                for (int e = 0; e < W; ++e) {
+                    ga[k][e] = a.gamma[co + e]; be[k][e] = a.beta[co + e];
+                    tb[k][e] = a.tbias ? a.tbias[(size_t)(b < a.B ? b : 0) * a.tb_stride + co + e] : 0.f;
+                    rsd[k][e] = a.res ? a.res[o[k] + e] : 0.f;
+                    float x = red[(size_t)n * MTP + c + e];
+#pragma unroll
+                    for (int kk = 1; kk < WK; ++kk) x += red[((size_t)(kk * NT + n)) * MTP + c + e];
+                    x += a.bias[co + e];
+                    v[k][e] = x;
+                    if (a.pre && b < a.B) a.pre[o[k] + e] = x;
+                }
+                float p = v[k][0];
+#pragma unroll
+                for (int e = 1; e < W; ++e) p += v[k][e];   // (W == 4: ((v0 + v1) + v2) + v3)
+                sum += ok[k] ? p : 0.f;
             }
             const float mean = wave_sum(sum) * inv_re;
             float sq = 0.f;
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
-                v[k] = v[k] - mean;
-                sq += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
+                float p = 0.f;
+#pragma unroll
+                for (int e = 0; e < W; ++e) { v[k][e] -= mean; p += v[k][e] * v[k][e]; }
+                sq += ok[k] ? p : 0.f;
             }
             const float var = wave_sum(sq) * inv_re;
             const float rstd = gn_rstd(var);
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
-                f32x4 y;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = mish_nosel(v[k][e] * rstd * ga[k][e] + be[k][e]);
-                y += tb[k];
-                y += rs4[k];
-                if (b < a.B) *(f32x4*)(a.dst + o[k]) = y;
+                for (int e = 0; e < W; ++e) {
+                    float y = mish_nosel(v[k][e] * rstd * ga[k][e] + be[k][e]);
+                    y += tb[k][e];
+                    y += rsd[k][e];
+                    if (b < a.B) a.dst[o[k] + e] = ok[k] ? y : 0.f;
+                }
             }
         };
         for (int r = wave; r < nreg; r += NWAVE) {
             const int s = r >> lg_gpt, gl = r & (gpt - 1);
             const int b = s0 + s;
-            if (re >= 512) {
-                switch (re >> 8) {
-                    case 2: region4(std::integral_constant<int, 2>{}, s, gl, b); break;
-                    case 4: region4(std::integral_constant<int, 4>{}, s, gl, b); break;
-                    default: region4(std::integral_constant<int, 8>{}, s, gl, b); break;
-                }
-            } else {  // re == 64: one element per lane
-                const int l = lane >> a.lg_gs, c = gl * gs + (lane & (gs - 1));
-                const int n = s * L_out + l, co = mt * MT + c;
-                const size_t o = ((size_t)(b < a.B ? b : 0) * L_out + l) * a.C_out + co;
-                float tb = 0.f, rs1 = 0.f;
-                if (a.tbias) tb = a.tbias[(size_t)(b < a.B ? b : 0) * a.tb_stride + co];
-                if (a.res) rs1 = a.res[o];
-                float v = red[(size_t)n * MTP + c];
-#pragma unroll
-                for (int k = 1; k < WK; ++k) v += red[((size_t)(k * NT + n)) * MTP + c];
-                v += a.bias[co];
-                if (a.pre && b < a.B) a.pre[o] = v;
-                const float mean = wave_sum(v) * inv_re;
-                const float d = v - mean;
-                const float var = wave_sum(d * d) * inv_re;
-                const float rstd = gn_rstd(var);
-                float y = mish_nosel(d * rstd * a.gamma[co] + a.beta[co]);
-                y += tb;
-                y += rs1;
-                if (b < a.B) a.dst[o] = y;
+            using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
+            using I8 = std::integral_constant<int, 8>;
+            switch (re) {
+                case 64: region(I1{}, I1{}, s, gl, b); break;
+                case 128: region(I2{}, I1{}, s, gl, b); break;
+                case 256: region(I4{}, I1{}, s, gl, b); break;
+                case 512: region(I4{}, I2{}, s, gl, b); break;
+                case 1024: region(I4{}, I4{}, s, gl, b); break;
+                default: region(I4{}, I8{}, s, gl, b); break;
             }
         }
     } else
@@ -631,7 +664,8 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
         const int lg_gpt = (MT == 32 ? 5 : 4) - a.lg_gs;   // log2(groups per tile)
         const int gpt = 1 << lg_gpt;
         const int nreg = spt << lg_gpt;    // GroupNorm regions in the tile
-        const int re = gs << a.lg_Lout;    // elements per region: 256 (down/mid/final) or 128 (up path)
+        const int re = gs << lg_Lout;      // elements per region: 256 (down/mid/final) or 128 (up path)
+        const bool has_tb = TBRES < 0 ? a.tbias != nullptr : TBRES == 1, has_res = TBRES < 0 ? a.res != nullptr : TBRES == 2;
         const float inv_re = (re == 256) ? (1.0f / 256.0f) : (1.0f / 128.0f);
         for (int r = wave; r < nreg; r += NWAVE) {
             const int s = r >> lg_gpt, gl = r & (gpt - 1);
@@ -645,8 +679,8 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                 const f32x4 bi = *(const f32x4*)(a.bias + co);
                 const f32x4 ga = *(const f32x4*)(a.gamma + co), be = *(const f32x4*)(a.beta + co);
                 f32x4 tb = {0.f, 0.f, 0.f, 0.f}, rs4 = {0.f, 0.f, 0.f, 0.f};
-                if (a.tbias) tb = *(const f32x4*)(a.tbias + (size_t)(b < a.B ? b : 0) * a.tb_stride + co);
-                if (a.res) rs4 = *(const f32x4*)(a.res + o);
+                if (has_tb) tb = *(const f32x4*)(a.tbias + (size_t)(b < a.B ? b : 0) * a.tb_stride + co);
+                if (has_res) rs4 = *(const f32x4*)(a.res + o);
                 const int ri = n * MTP4 + (c >> 2);  // gs % 4 == 0 -> c % 4 == 0
                 f32x4 v = smem4[ri];
 #pragma unroll
@@ -660,8 +694,8 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                 f32x4 y;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = mish_nosel(d[e] * rstd * ga[e] + be[e]);
-                y += tb;
-                y += rs4;
+                if (TBRES < 0 || TBRES == 1) y += tb;
+                if (TBRES < 0 || TBRES == 2) y += rs4;
                 if (b < a.B) *(f32x4*)(a.dst + o) = y;
             } else {  // re == 128
                 const int e0 = lane * 2;
@@ -671,8 +705,8 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                 const f32x2 bi = *(const f32x2*)(a.bias + co);
                 const f32x2 ga = *(const f32x2*)(a.gamma + co), be = *(const f32x2*)(a.beta + co);
                 f32x2 tb = {0.f, 0.f}, rs2 = {0.f, 0.f};
-                if (a.tbias) tb = *(const f32x2*)(a.tbias + (size_t)(b < a.B ? b : 0) * a.tb_stride + co);
-                if (a.res) rs2 = *(const f32x2*)(a.res + o);
+                if (has_tb) tb = *(const f32x2*)(a.tbias + (size_t)(b < a.B ? b : 0) * a.tb_stride + co);
+                if (has_res) rs2 = *(const f32x2*)(a.res + o);
                 f32x2 v = *(const f32x2*)(red + (size_t)n * MTP + c);
 #pragma unroll
                 for (int k = 1; k < WK; ++k) v += *(const f32x2*)(red + ((size_t)(k * NT + n)) * MTP + c);
@@ -685,8 +719,8 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                 f32x2 y;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) y[e] = mish_nosel(d[e] * rstd * ga[e] + be[e]);
-                y += tb;
-                y += rs2;
+                if (TBRES < 0 || TBRES == 1) y += tb;
+                if (TBRES < 0 || TBRES == 2) y += rs2;
                 if (b < a.B) *(f32x2*)(a.dst + o) = y;
             }
         }
@@ -694,7 +728,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
         constexpr int M4 = MT / 4;
         for (int idx = tid; idx < NT * M4; idx += NTHR) {
             const int n = idx / M4, c = (idx - n * M4) * 4;   // M4 is a compile-time power of two
-            const int s = n >> a.lg_Lout, l = n & (L_out - 1), b = s0 + s;
+            const int s = n >> lg_Lout, l = n & (L_out - 1), b = s0 + s;
             const int co = mt * MT + c;
             const int ri = n * MTP4 + (c >> 2);
             f32x4 v = smem4[ri];
@@ -710,6 +744,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
             if (b < a.B && d) {
                 f32x4* q = (f32x4*)(d + ((size_t)b * L_out + l) * ld + cc);
                 if (a.accum & (d == a.dst2 ? 2 : 1)) v += *q;
+                if (a.Lv_out > 0 && l >= a.Lv_out) v = (f32x4){0.f, 0.f, 0.f, 0.f};   // rows beyond the valid horizon of the container stay zero
                 *q = v;
             }
         }
@@ -718,17 +753,17 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
 #undef CB_STAMP
 }
 
-template <int MODE, int KS, int EPI, int MT, int NT, int WN, int WK>
+template <int MODE, int KS, int EPI, int MT, int NT, int WN, int WK, class GEO = GeoAny, int TBRES = -1>
 __global__ __launch_bounds__(64 * WN * WK) void conv_block_kernel(const ConvArgs a) {
-    conv_block_body<MODE, KS, EPI, MT, NT, WN, WK>(a, blockIdx.x);
+    conv_block_body<MODE, KS, EPI, MT, NT, WN, WK, GEO, TBRES>(a, blockIdx.x);
 }
 
 // blocks[0] of a ResidualTemporalBlock (k5 conv + GroupNorm + Mish + time bias) and the block's residual 1x1 conv read the
 // same input and are independent: ONE launch, the first n_first workgroups run the former, the rest the latter.
-template <int MT, int NT>
+template <int MT, int NT, class GEO = GeoAny>
 __global__ __launch_bounds__(512) void conv_pair_kernel(const ConvArgs a1, const ConvArgs a2, const int n_first) {
-    if ((int)blockIdx.x < n_first) conv_block_body<CONV_S1, 5, EPI_GN_MISH, MT, NT, 1, 8>(a1, blockIdx.x);
-    else conv_block_body<CONV_S1, 1, EPI_BIAS, MT, NT, 1, 8>(a2, blockIdx.x - n_first);
+    if ((int)blockIdx.x < n_first) conv_block_body<CONV_S1, 5, EPI_GN_MISH, MT, NT, 1, 8, GEO, (GEO::L > 0 ? 1 : -1)>(a1, blockIdx.x);   // blocks[0]: + time bias
+    else conv_block_body<CONV_S1, 1, EPI_BIAS, MT, NT, 1, 8, GEO>(a2, blockIdx.x - n_first);
 }
 
 // LDS bytes a launch needs: max(staged windows, K-partial buffer)

@@ -54,6 +54,7 @@ struct FinalArgs {
     float* chain;        // optional second destination
     uint32_t* absmax;    // optional per-context max|out| (bit pattern)
     int B, H, D, C;
+    int Hc;              // rows per trajectory of h (the container; 0: H)
     int mode;            // 0: eps only; 1: full step; 2: posterior mean only (guide insertion point); 3: DDIM update
     int n_per_ctx;
     mpdx_step_coefs k;
@@ -81,6 +82,7 @@ enum { SRC_X = -1, SRC_NONE = -2 };
 struct Layer {
     int mode = CONV_S1, ks = 5, epi = EPI_GN_MISH;
     int c1 = 0, c2 = 0, cout = 0, L_in = 0, L_out = 0, gs = 0;
+    int Lv_out = 0;           // valid rows of the output when the horizon runs in a power-of-two container (0: all L_out rows; ConvArgs::Lv_out)
     int src1 = SRC_NONE, src2 = SRC_NONE, dst = 0, res = SRC_NONE;  // workspace slots
     int w = -1, b = -1, gamma = -1, beta = -1;                       // param indices
     int tb_off = -1;                                                 // offset in a time-table row
@@ -102,6 +104,10 @@ struct mpdx_unet {
     std::vector<int> tt_w, tt_b, tt_cout, tt_off;  // cond_mlp param indices per block
     int final_slot = 0;       // slot holding final_conv[0]'s output
     int n_done = 0;
+    // horizons that are not powers of two: the network runs in a container of Hc = next power of two rows per trajectory (ConvArgs::Lv_out);
+    // the network input is copied into workspace slot `xpad_slot` ([B][Hc][D], zero rows behind the H real ones) at the head of a pass
+    int Hc = 0, xpad_slot = -1;
+    bool masked() const { return Hc != cfg.n_support_points; }
     // launch units: fused whole-trajectory segments (fused_level.hpp) or single layers
     struct CopyJob { size_t src, dst; int n0, ss0, ds0, n1, ss1, ds1, n_inner; };   // strided copy inside `packed` (float units)
     struct Fused {

@@ -53,7 +53,7 @@ static int dispatch_tile_ksplit_only(const Layer& l, ConvArgs& a, int B, hipStre
 int launch_conv_layer(const Layer& l, ConvArgs& a, int B, hipStream_t st) {
     if (l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH) {
         const int re = l.gs * l.L_out;   // regions other than 128 / 256 elements (horizons other than 64): the general-region instantiations
-        if (re != 128 && re != 256) return dispatch_tile<CONV_S1, 5, EPI_GN_MISH_GEN>(l, a, B, st);
+        if ((re != 128 && re != 256) || (a.Lv_out > 0 && a.Lv_out < l.L_out)) return dispatch_tile<CONV_S1, 5, EPI_GN_MISH_GEN>(l, a, B, st);
         return dispatch_tile<CONV_S1, 5, EPI_GN_MISH>(l, a, B, st);
     }
     if (l.mode == CONV_S1 && l.ks == 1 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 1, EPI_BIAS>(l, a, B, st);

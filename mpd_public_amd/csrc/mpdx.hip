@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void final_step_kernel(const FinalArgs a) {
     const int b = live ? p / a.H : 0, l = live ? p - b * a.H : 0;
     float vmax = 0.f;
     if (live) {
-        const float* hp = a.h + (size_t)p * a.C;
+        const float* hp = a.h + ((size_t)b * (a.Hc > 0 ? a.Hc : a.H) + l) * a.C;
         for (int d = 0; d < a.D; ++d) {
             float s = bs[d];
             for (int c = 0; c < a.C; c += 4) {
@@ -238,6 +238,18 @@ __global__ __launch_bounds__(256) void randn_kernel(float* out, size_t n, uint64
     }
 }
 
+// network input [B][H][D] -> container [B][Hc][D] with zero rows behind the H real ones (horizons that are not powers of two)
+__global__ __launch_bounds__(256) void pad_input_kernel(const float* __restrict__ x, float* __restrict__ xc, int B, int H, int Hc, int D) {
+    const size_t n = (size_t)B * Hc * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const size_t p = i / D;
+        const int l = (int)(p % Hc);
+        const size_t b = p / Hc;
+        xc[i] = l < H ? x[(b * H + l) * D + d] : 0.f;
+    }
+}
+
 __global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
@@ -342,7 +354,11 @@ int pick_row_stride(int cin_pad, int mode, int L_in, int L_out, int LP) {
 
 static void build_model(mpdx_unet* u) {
     const mpdx_unet_cfg& c = u->cfg;
-    const int nl = c.n_levels, D = c.state_dim, H = c.n_support_points, te = c.time_emb_dim;
+    const int nl = c.n_levels, D = c.state_dim, te = c.time_emb_dim;
+    const int Hv = c.n_support_points;   // the horizon; H below = its power-of-two container (== Hv for 16 / 32 / 64 / 128)
+    int H = 1;
+    while (H < Hv) H <<= 1;
+    u->Hc = H;
     std::vector<int> dims(nl + 1);
     dims[0] = D;
     for (int i = 0; i < nl; ++i) dims[i + 1] = c.unet_input_dim * c.dim_mults[i];
@@ -362,6 +378,7 @@ static void build_model(mpdx_unet* u) {
         Layer l;
         l.name = wname; l.mode = mode; l.ks = ks; l.epi = epi;
         l.src1 = src1; l.c1 = c1; l.src2 = src2; l.c2 = c2; l.cout = cout; l.L_in = L_in; l.L_out = L_out; l.dst = dst;
+        l.Lv_out = (H != Hv) ? (int)((long)L_out * Hv / H) : 0;   // (levels halve container and horizon alike: Hv % 2^(levels-1) == 0)
         if (mode == CONV_UPT) l.w = add_param(u, wname, {c1 + c2, cout, ks}, PK_CONVT);
         else l.w = add_param(u, wname, {cout, c1 + c2, ks}, PK_CONV);
         l.b = add_param(u, bname, {cout});
@@ -439,6 +456,7 @@ static void build_model(mpdx_unet* u) {
     add_param(u, "final_conv.1.weight", {D, c.unet_input_dim, 1});
     add_param(u, "final_conv.1.bias", {D});
     u->slot_floats = std::max(slot, (size_t)c.unet_input_dim * H);
+    if (H != Hv) u->xpad_slot = u->n_slots++;   // one more workspace slot: the padded copy of the network input
 }
 
 // ------------------------------------------------------------------------------------------------ fused segments
@@ -765,6 +783,7 @@ static void build_units(mpdx_unet* u) {
         return i0 >= 0;
     };
     std::vector<int> owner(n, -1);
+    if (u->masked()) { u->owner = owner; return; }   // a horizon in a zero-padded container: every layer as its own (masking) launch
     auto try_seg = [&](const std::string& prefix, bool with_final) {
         int i0, i1;
         if (!range_of(prefix, i0, i1)) return;
@@ -888,6 +907,7 @@ static int make_conv_args(const mpdx_unet* u, const Layer& l, const float* packe
     a.dst = ws + slot * l.dst;
     a.B = B; a.L_in = l.L_in; a.L_out = l.L_out; a.C_out = l.cout;
     a.cin_pad = l.cin_pad; a.rs = l.rs; a.gs = l.gs; a.dbg = dbg;
+    a.Lv_out = l.Lv_out;
     a.trace = g_conv_trace;
     auto lg2 = [](int v) { int k = 0; while ((1 << k) < v) ++k; return k; };
     a.lg_c4n = lg2(l.cin_pad / 4); a.lg_Lin = lg2(l.L_in); a.lg_Lout = lg2(l.L_out); a.lg_gs = l.gs > 0 ? lg2(l.gs) : 0;
@@ -903,7 +923,7 @@ static int make_conv_args(const mpdx_unet* u, const Layer& l, const float* packe
 // weight-stationary vs per-layer kernels): 128 -> 128 <8,16>: 142.7 vs 95.9; 128 -> 256 + 1x1 <8,32,R1>: 268 vs 234 - with 5 k-groups per
 // wave a tile's 20-40 MFMAs per wave do not cover its barrier and window hand-over; kept: 256 -> 256: 319 vs 332, 512 -> 128 + 1x1: 387 vs 468.
 static int weight_stationary_variant(const Layer& l, const Layer* l2, const ConvArgs& a, int B, int dbg) {
-    if (!(l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH && l.L_out == 8 && l.L_in == 8)) return 0;
+    if (!(l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH && l.L_out == 8 && l.L_in == 8) || l.Lv_out) return 0;
     if (dbg || a.pre || (l.c1 & 3) || (l.c2 & 3) || l.cin_pad != l.c1 + l.c2) return 0;
     if ((long)B * l.L_out < 16L * kWsGroups * 8) return 0;
     const char* e = getenv("MPDX_WS");
@@ -932,7 +952,7 @@ static bool pair_tile(const Layer& l1, const Layer& l2, int B, int& MT, int& NT)
     static const bool off = getenv("MPDX_PAIR") && atoi(getenv("MPDX_PAIR")) == 0;
     if (off) return false;
     if (!(l1.mode == CONV_S1 && l1.ks == 5 && l1.epi == EPI_GN_MISH && l2.mode == CONV_S1 && l2.ks == 1 && l2.epi == EPI_BIAS)) return false;
-    if (l1.gs * l1.L_out != 128 && l1.gs * l1.L_out != 256) return false;   // general GroupNorm regions: no paired instantiations
+    if ((l1.gs * l1.L_out != 128 && l1.gs * l1.L_out != 256) || l1.Lv_out) return false;   // general / masked GroupNorm regions: no paired instantiations
     if (l1.src1 != l2.src1 || l1.src2 != l2.src2 || l1.cout != l2.cout || l1.L_out != l2.L_out || !layer_ksplit(l1)) return false;
     choose_tile(l1, B, MT, NT);   // the k5 block decides the tile; the 1x1 conv has no constraint beyond it
     if (l1.cout % MT) MT = 16;
@@ -1007,6 +1027,7 @@ static int run_final(mpdx_unet* u, const float* packed, FinalArgs& fa, int B, fl
     fa.w = packed + u->params[u->pidx.at("final_conv.1.weight")].off;
     fa.bias = packed + u->params[u->pidx.at("final_conv.1.bias")].off;
     fa.B = B; fa.H = c.n_support_points; fa.D = c.state_dim; fa.C = c.unet_input_dim;
+    fa.Hc = u->Hc;
     return launch_final_step(fa, st);
 }
 int launch_final_step(const FinalArgs& fa, hipStream_t st) {
@@ -1114,6 +1135,13 @@ static int run_unet_and_final(mpdx_unet* u, const float* packed, const float* ti
     const float* row = timetab + (size_t)t * u->tt_row;
     const auto units = current_units(u, B, nullptr);
     bool final_done = false;
+    if (u->masked()) {   // the network reads its input from the zero-padded container copy
+        float* xc = ws + u->slot_floats * (size_t)B * u->xpad_slot;
+        const size_t nx = (size_t)B * u->Hc * u->cfg.state_dim;
+        hipLaunchKernelGGL(pad_input_kernel, dim3((unsigned)std::min<size_t>((nx + 255) / 256, 2048)), dim3(256), 0, st, x, xc, B, u->cfg.n_support_points, u->Hc,
+                           u->cfg.state_dim);
+        x = xc;
+    }
     for (const auto& un : units) {
         if (int rc = run_unit(u, un, packed, row, x, ws, B, &fa, st)) return rc;
         if (un.fused >= 0) final_done |= u->fused[un.fused].has_final;
@@ -1140,8 +1168,12 @@ int mpdx_unet_create(const mpdx_unet_cfg* cfg, mpdx_unet** out) {
     if (cfg->time_emb_dim != 32) return fail(MPDX_E_INVALID, "time_emb_dim must be 32 (TimeEncoder(32, .), temporal_unet.py:66)");
     if (cfg->unet_input_dim % 16) return fail(MPDX_E_INVALID, "unet_input_dim must be a multiple of 16");
     const int H = cfg->n_support_points;
-    if (H < 16 || H > 128 || (H & (H - 1)) || (H >> (cfg->n_levels - 1)) < 2)
-        return fail(MPDX_E_INVALID, "n_support_points %d must be a power of two in [16, 128] with >= 2 points at the coarsest level", H);
+    // the reference's U-Net takes every horizon its stride-2 / transposed convolutions map back onto itself: H % 2^(levels - 1) == 0
+    // (temporal_unet.py:24,80-103).  Powers of two run natively; the others (24, 40, 48, 96 ...) in the next power-of-two container
+    // with zeroed, masked rows (ConvArgs::Lv_out), one launch per layer
+    if (H < 16 || H > 128 || (H % (1 << (cfg->n_levels - 1))) || (H >> (cfg->n_levels - 1)) < 2)
+        return fail(MPDX_E_INVALID, "n_support_points %d must be a multiple of 2^(levels-1) = %d in [16, 128] with >= 2 points at the coarsest level", H,
+                    1 << (cfg->n_levels - 1));
     mpdx_unet* u = new mpdx_unet();
     u->cfg = *cfg;
     build_model(u);

@@ -355,6 +355,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     if (!u || !flat || !packed || !packedT || !grads_flat || !x_start || !noise || !t_dev || !freqs16 || !loss_out || !ws || B <= 0)
         return fail(MPDX_E_INVALID, "bad argument");
     build_train_plan(u);
+    if (u->masked()) return fail(MPDX_E_INVALID, "the training kernels take power-of-two horizons (n_support_points %d runs in a padded container)", u->cfg.n_support_points);
     if (int rc = check_ready(u)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const mpdx_unet_cfg& c = u->cfg;

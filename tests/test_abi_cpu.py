@@ -67,16 +67,18 @@ def test_handle_parameter_table_matches_reference_tree(lib, D, mults):
 
 
 def test_invalid_configurations_are_rejected_with_messages(lib):
-    for kw in (dict(n_levels=1), dict(state_dim=0), dict(time_emb_dim=16), dict(unet_input_dim=24), dict(n_support_points=48),
-               dict(n_support_points=256), dict(n_support_points=8),
+    for kw in (dict(n_levels=1), dict(state_dim=0), dict(time_emb_dim=16), dict(unet_input_dim=24), dict(n_support_points=44),      # 44 % 2^(levels-1) != 0
+               dict(n_support_points=18, n_levels=3, dim_mults=(1, 2, 4)), dict(n_support_points=256), dict(n_support_points=8),
                dict(n_support_points=16),                                       # a 32-element GroupNorm region on the up path
                dict(n_support_points=16, n_levels=3, dim_mults=(1, 2, 4))):
         rc, _ = _create(lib, **kw)
         assert rc < 0, kw
         assert lib.mpdx_last_error()
     # horizons other than 64 that the kernels take (GroupNorm regions of 64 ... 2048 elements): created, parameter table as for H = 64
+    # ... and horizons that are multiples of 2^(levels-1) without being powers of two (temporal_unet.py:24,80-103): padded containers
     for kw in (dict(n_support_points=32), dict(n_support_points=128), dict(n_support_points=32, n_levels=3, dim_mults=(1, 2, 4)),
-               dict(n_support_points=128, n_levels=3, dim_mults=(1, 2, 4))):
+               dict(n_support_points=128, n_levels=3, dim_mults=(1, 2, 4)), dict(n_support_points=48), dict(n_support_points=96),
+               dict(n_support_points=24), dict(n_support_points=40), dict(n_support_points=36, n_levels=3, dim_mults=(1, 2, 4))):
         rc, h = _create(lib, **kw)
         assert rc == 0, (kw, lib.mpdx_last_error())
         assert lib.mpdx_unet_num_params(h) > 90

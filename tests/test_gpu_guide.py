@@ -41,7 +41,7 @@ def test_guide_increment_vs_oracle(env_id, robot_id, scale, weights):
 
 
 @pytest.mark.parametrize("env_id,robot_id", [("EnvDense2D", "RobotPointMass"), ("EnvSpheres3D", "RobotPanda")])
-@pytest.mark.parametrize("H", [32, 128])
+@pytest.mark.parametrize("H", [32, 128, 48, 96])
 def test_guide_increment_other_horizons_vs_oracle(env_id, robot_id, H):
     """Horizons other than 64: the support points of a trajectory map to the lanes of one (H <= 64) or two (H <= 128) waves; the GP
     prior's neighbours come from the LDS-staged state (no cross-lane traffic: the support index may cross the wave boundary).
@@ -215,7 +215,7 @@ def test_prior_then_guide_post_loop_vs_oracle(env_id, robot_id, opt):
             assert abs(a_ - b_) <= 5e-3 * abs(b_), (name, mname, a_, b_)   # 3 significant figures
 
 
-@pytest.mark.parametrize("H", [32, 128])
+@pytest.mark.parametrize("H", [32, 128, 48])
 def test_guided_plan_other_horizons_fused_equals_stepwise_and_tracks_oracle(H):
     """A full guided plan at H = 32 / 128 (Panda): mpdx_plan == the step-by-step protocol loop bit for bit, the un-guided part of the
     chain equals the oracle's, and the guided end result stays within the guided-chain tolerance class (isolated waypoints may take

@@ -83,11 +83,14 @@ def test_weight_stationary_inner_levels_are_bit_identical(B):
     assert torch.equal(small, y_ws[5:9])
 
 
-@pytest.mark.parametrize("H,mults,D", [(128, (1, 2, 4, 8), 4), (32, (1, 2, 4, 8), 4), (32, (1, 2, 4), 14)])
+@pytest.mark.parametrize("H,mults,D", [(128, (1, 2, 4, 8), 4), (32, (1, 2, 4, 8), 4), (32, (1, 2, 4), 14),
+                                       (48, (1, 2, 4, 8), 4), (96, (1, 2, 4, 8), 14), (24, (1, 2, 4, 8), 4), (40, (1, 2, 4), 14)])
 def test_other_horizons_unet_and_plan_vs_oracle(H, mults, D):
-    """n_support_points other than the shipped 64 (temporal_unet.py:24 takes any horizon the strided convs divide): powers of two from
-    16 to 128 run one launch per layer (the whole-trajectory programs exist for H = 64), GroupNorm regions of 64 ... 2048 elements on
-    the general-region instantiations (conv_block.hpp EPI_GN_MISH_GEN).  The U-Net output and a full unguided plan equal the oracle's."""
+    """n_support_points other than the shipped 64 (temporal_unet.py:24,80-103 takes any horizon the strided convs map back onto itself:
+    H % 2^(levels-1) == 0): one launch per layer (the whole-trajectory programs exist for H = 64).  Powers of two from 16 to 128 run on
+    GroupNorm regions of 64 ... 2048 elements (conv_block.hpp EPI_GN_MISH_GEN); the others (24, 40, 48, 96) in the next power-of-two
+    container whose rows beyond the horizon are kept zero and masked out of the statistics (ConvArgs::Lv_out).  The U-Net output and a
+    full unguided plan equal the oracle's."""
     import mpd_public_amd as m
     from mpd_public_amd import synthetic as syn
     from oracle.unet import unet_forward
