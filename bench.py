@@ -80,10 +80,15 @@ def _unit_classes(lib, hdl, B, names, flops, n):
             tile = buf.value.decode()
             kind = "conv_k5_gn_mish" if ".block.0." in nm else ("conv_k1" if "residual" in nm else ("down_k3s2" if "downs" in nm else "up_k4s2"))
             ws = tile.startswith("ws")   # weight-stationary persistent kernel (large batches)
+            # kernel name as rocprofv3 prints it, down to the tile arguments (the PMC traffic files are keyed by full kernel names)
+            mtnt = tile.replace("ws ", "").split("/")[0].split("x")
             if lib.mpdx_unet_unit_is_pair(hdl, B, i):
-                out.append((f"conv_k5_gn_mish+conv_k1 pair[{tile}] {flops[i]:.3e} flop", "conv_ws_kernel" if ws else "conv_pair_kernel"))
+                kn = "conv_ws_kernel<32, 16, true" if ws else f"conv_pair_kernel<{mtnt[0]}, {mtnt[1]}"
+                out.append((f"conv_k5_gn_mish+conv_k1 pair[{tile}] {flops[i]:.3e} flop", kn))
             else:
-                out.append((f"{kind}[{tile}] {flops[i]:.3e} flop", "conv_ws_kernel" if ws else "conv_block_kernel"))
+                mode = {"conv_k5_gn_mish": "0, 5, 1", "conv_k1": "0, 1, 0", "down_k3s2": "1, 3, 0", "up_k4s2": "2, 4, 0"}[kind]
+                kn = "conv_ws_kernel<16, 32, false" if ws else f"conv_block_kernel<{mode}, {mtnt[0]}, {mtnt[1]}, "
+                out.append((f"{kind}[{tile}] {flops[i]:.3e} flop", kn))
         elif nm.startswith("fused"):
             out.append(("fused level programs (fused_program_kernel<...>: whole-trajectory U-Net levels)", "fused_program_kernel"))
         else:
@@ -91,18 +96,30 @@ def _unit_classes(lib, hdl, B, names, flops, n):
     return out
 
 
+def csrc_fingerprint():
+    """sha256 (16 hex digits) over the kernel sources (mpd_public_amd/csrc/*): a PMC traffic file carries the fingerprint of the sources it
+    was measured on (tools/pmc_traffic.py), bench.py compares it with the sources it runs - a stale file is visible without git (the
+    GPU box gets a snapshot without .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "mpd_public_amd" / "csrc").glob("*")):
+        if f.suffix in (".hpp", ".hip"):
+            h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def _pmc_traffic(B, kernel):
     """HBM-side bytes per launch of `kernel` at batch B from the newest profiles/r*_pmc_traffic*.json that covers (batch, kernel):
     PMC counters cannot be read from inside this process; they are collected by tools/r04_evidence.sh (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate passes, gfx950 x2 fetch correction, MI355X_MICROARCH.md section HBM) on this same command and
-    committed under profiles/.  Returns (bytes or None, file name, age): age = how stale the file is - the commit that last touched it
-    and how many commits touching mpd_public_amd/csrc/ came after it (0 = measured on the kernels of HEAD)."""
+    committed under profiles/.  Returns (bytes or None, file name, age): age says whether the file was measured on the kernel sources
+    this run uses (fingerprints) - a stale file stays usable as an indication, and is labelled."""
     import re
 
     def _round_key(f):   # r02_ (a round's final evidence) after r02a_, r02b_ (mid-round states), rounds ascending
         m = re.match(r"r(\d+)([a-z]?)_", f.name)
         return (int(m.group(1)), m.group(2) or "~") if m else (-1, "")
-    pats = ("fused_program_kernel", "fused_level_kernel") if kernel.startswith("fused") else (kernel.split(" ")[0],)
+    pats = ("fused_program_kernel", "fused_level_kernel") if kernel.startswith("fused") else (kernel,)
     for f in sorted((ROOT / "profiles").glob("r*_pmc_traffic*.json"), key=_round_key, reverse=True):
         try:
             rec = json.loads(f.read_text())
@@ -111,22 +128,24 @@ def _pmc_traffic(B, kernel):
         if rec.get("batch") != B:
             continue
         hit = [v for k, v in rec.get("kernels", {}).items() if any(p in k for p in pats)]
+        if not hit and "<" in kernel:   # an older file of a build whose kernels had other template arguments: match the family
+            hit = [v for k, v in rec.get("kernels", {}).items() if kernel.split("<")[0] in k]
         if not hit:
             continue
         nl = sum(v["launches"] for v in hit)
         traffic = int(sum(v["traffic_bytes_per_launch"] * v["launches"] for v in hit) / nl)
-        age = None
-        try:
-            rel = str(f.relative_to(ROOT))
-            c = subprocess.run(["git", "-C", str(ROOT), "log", "-1", "--format=%h", "--", rel], capture_output=True, text=True, timeout=10).stdout.strip()
-            if c:
-                n = subprocess.run(["git", "-C", str(ROOT), "rev-list", "--count", f"{c}..HEAD", "--", "mpd_public_amd/csrc"],
-                                   capture_output=True, text=True, timeout=10).stdout.strip()
-                age = {"profile_commit": c, "kernel_commits_since": int(n) if n else None}
-        except Exception:
-            age = None   # no git on the box (the snapshot travels without .git): the file name carries the round
+        fp = rec.get("csrc_fingerprint")
+        age = {"profile_sources": fp, "current_sources": csrc_fingerprint(),
+               "measured_on_these_sources": (fp == csrc_fingerprint()) if fp else None}
         return traffic, f.name, age
     return None, None, None
+
+
+def _alg_bytes(c):
+    """algorithmic bytes of one launch of a class: its weights once + its input and output activations once.  Only the FLOP count is known
+    per class here, so this is derived for the record from it where the shape is regular: None otherwise (DESIGN.md section 3 gives the
+    per-kernel figures)."""
+    return c.get("algorithmic_bytes_per_launch")
 
 
 def roofline_leg(dm, B, T, reps=30):
@@ -166,7 +185,8 @@ def roofline_leg(dm, B, T, reps=30):
     for (a, b) in runs:
         _lib.check(lib.mpdx_unet_time_units(hdl, packed.data_ptr(), tab.data_ptr(), dm.model._timetab_T, x.data_ptr(), tt, B, ws.data_ptr(), st,
                                             a, b, reps, C.byref(out)), "mpdx_unet_time_units")
-        e = table.setdefault(cls[a][0], {"us": 0.0, "flop": 0.0, "launches": 0, "kernel": cls[a][1], "longest_run": 0})
+        e = table.setdefault(cls[a][0], {"us": 0.0, "flop": 0.0, "launches": 0, "kernel": cls[a][1], "longest_run": 0, "bytes": 0.0})
+        e["bytes"] += sum(float(lib.mpdx_unet_unit_bytes(hdl, B, k)) for k in range(a, b + 1))
         e["us"] += out.value * 1e3
         e["flop"] += sum(fl[k] for k in range(a, b + 1))
         e["launches"] += b - a + 1
@@ -177,24 +197,30 @@ def roofline_leg(dm, B, T, reps=30):
         tf = e["flop"] / (e["us"] * 1e-6) / 1e12 if e["us"] > 0 else 0.0
         classes.append({"class": k, "kernel": e["kernel"], "launches_per_pass": e["launches"], "us_per_pass": round(e["us"], 2),
                         "share": round(e["us"] / tot_us, 4), "avg_launch_us": round(e["us"] / e["launches"], 2),
-                        "flop_per_pass": e["flop"], "tflops": round(tf, 2), "frac": round(tf / FP32_PEAK_TFLOPS, 4)})
-    dom = classes[0]
+                        "flop_per_pass": e["flop"], "tflops": round(tf, 2), "frac": round(tf / FP32_PEAK_TFLOPS, 4),
+                        "algorithmic_bytes_per_launch": int(e["bytes"] / e["launches"])})
+    dom = dict(classes[0])
+    dom["kernel_pattern"] = dom["kernel"]
     # HBM-side traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process; they are
     # collected by tools/r02_evidence.sh (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, gfx950 x2 fetch
     # correction, MI355X_MICROARCH.md section HBM) on this same command and committed under profiles/.
-    traffic, traffic_src, traffic_age = _pmc_traffic(B, dom["kernel"])
+    traffic, traffic_src, traffic_age = _pmc_traffic(B, dom["kernel_pattern"])
     for c in classes:   # every class: HBM-side traffic per launch of ITS kernel at THIS batch (null when no PMC pass covers it)
         tr, src, _age = _pmc_traffic(B, c["kernel"])
         c["traffic"] = tr
+        c["traffic_source"] = src
+        c["traffic_over_algorithmic"] = round(tr / c["algorithmic_bytes_per_launch"], 2) if tr and c["algorithmic_bytes_per_launch"] else None
     roof = {"bound": "mfma", "achieved": dom["tflops"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
-            "traffic": traffic, "traffic_source": traffic_src, "traffic_age": traffic_age, "kernel": dom["kernel"], "class": dom["class"],
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_age": traffic_age,
+            "traffic_over_algorithmic": (round(traffic / _alg_bytes(dom), 2) if traffic and _alg_bytes(dom) else None),
+            "kernel": dom["kernel"].split("<")[0], "kernel_instance": dom["kernel"], "class": dom["class"],
             "launches_per_unet_pass": dom["launches_per_pass"], "avg_launch_us": dom["avg_launch_us"], "share_of_pass": dom["share"],
             "algorithmic_flop_per_launch": dom["flop_per_pass"] / dom["launches_per_pass"],
             "timed": f"in situ: one HIP-event pair per run of consecutive launches of the class inside {reps} real U-Net passes",
             "unet_pass_us": round(whole.value * 1e3, 1), "unet_pass_us_sum_of_classes": round(tot_us, 1),
             "unet_pass_tflops": round(sum(fl[k] for k in range(n)) / (whole.value * 1e-3) / 1e12, 3),
             "classes": classes}
-    if dom["kernel"].startswith("fused"):
+    if dom["kernel_pattern"].startswith("fused"):
         # one workgroup = one trajectory: a batch of B trajectories occupies min(B, 256) of the 256 CUs, so the fp32 MFMA rate these
         # programs can reach is that fraction of the chip peak (`frac` above stays achieved / CHIP peak)
         cus = min(B, 256)

@@ -308,6 +308,9 @@ int mpdx_unet_time_units(mpdx_unet* u, const float* packed_dev, const float* tim
                          float* ws, void* stream, int unit_first, int unit_last, int reps, float* ms_avg);
 /* layer index behind launch unit i of mpdx_unet_profile at batch B (-1: fused whole-trajectory segment or the final kernel) */
 int mpdx_unet_unit_layer(const mpdx_unet* u, int B, int i);
+/* measurement helper: ALGORITHMIC bytes of launch unit i of a U-Net pass at batch B - its weights / parameters once plus the activations
+ * that cross its boundary once (bench.py: roofline.traffic_over_algorithmic).  Replaces nothing in the reference. */
+double mpdx_unet_unit_bytes(const mpdx_unet* u, int B, int i);
 /* 1 when launch unit i is a paired launch (blocks[0] + the same block's residual 1x1 conv in one conv_pair_kernel) */
 int mpdx_unet_unit_is_pair(const mpdx_unet* u, int B, int i);
 /* `reps` back-to-back launches of layer `layer` between two events; dbg = ablation mask (1 skip staging, 2 skip

@@ -225,8 +225,10 @@ __host__ __device__ inline int upt_slot_to_k(int slot) { return slot == 0 ? 1 : 
 // launches of a B = 100 step that are not whole-trajectory programs.  With the geometry known the staging indices are constants and
 // shifts, the k-loop is straight-line code (round 3: ~40 SALU instructions of divisions / clamps per k-group between the MFMAs) and
 // every LDS address is `lane base + immediate`; tools/isa_census.py: 1 406 VALU + 574 SALU in the generic staging prologue.
-struct GeoAny { static constexpr int L = 0, NC16 = 0; };
-template <int NC16_> struct GeoL8 { static constexpr int L = 8, NC16 = NC16_; };
+struct GeoAny { static constexpr int L = 0, NC16 = 0, RSPAD = 0; };
+template <int NC16_> struct GeoL8 { static constexpr int L = 8, NC16 = NC16_, RSPAD = 8; };
+// the ConvTranspose1d(k4, s2, p1) of the innermost up level: 8 -> 16 positions (10 staged rows per trajectory: row stride C_in + 4)
+template <int NC16_> struct GeoUp8 { static constexpr int L = 8, NC16 = NC16_, RSPAD = 4; };
 constexpr int geo_ilog2(int v) { return v <= 1 ? 0 : 1 + geo_ilog2(v >> 1); }
 
 // TBRES: what a GroupNorm epilogue adds behind Mish, when known at compile time (-1: read the pointers; 0 nothing, 1 time bias, 2 residual)
@@ -234,7 +236,7 @@ template <int MODE, int KS, int EPI, int MT, int NT, int WN, int WK, class GEO =
 __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int block_id) {
     using G = ConvGeom<MODE, KS>;
     constexpr bool GK = GEO::L > 0;   // geometry known at compile time
-    static_assert(!GK || MODE == CONV_S1, "GeoL8: stride-1 convolutions");
+    static_assert(!GK || MODE == CONV_S1 || MODE == CONV_UPT, "compile-time geometry: stride-1 and transposed convolutions on 8 input positions");
     constexpr int NWAVE = WN * WK, NTHR = 64 * NWAVE;
     constexpr int MS = MT / 16, NSUB = NT / 16, NSW = NSUB / WN;
     constexpr int PAD = G::PAD, NTAP = G::NTAP, NSLOT = G::NSLOT;
@@ -252,12 +254,13 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
 #define CB_STAMP() do { if (MPDX_TRACE_PTR(a.trace) && tid == 0 && (block_id == 0 || block_id == (int)gridDim.x - 1)) a.trace[(block_id ? 16 : 0) + tr_i] = (long long)__builtin_readcyclecounter(); ++tr_i; } while (0)
     const int n_mt = a.C_out / MT;   // MT is a compile-time power of two; one uniform division per workgroup
     const int mt = block_id % n_mt, nt = block_id / n_mt;
-    const int L_in = GK ? GEO::L : a.L_in, L_out = GK ? GEO::L : a.L_out;
-    const int lg_Lin = GK ? geo_ilog2(GEO::L) : a.lg_Lin, lg_Lout = GK ? geo_ilog2(GEO::L) : a.lg_Lout, lg_c4n = GK ? geo_ilog2(GEO::NC16 * 4) : a.lg_c4n;
+    constexpr int GLO = (MODE == CONV_UPT) ? 2 * GEO::L : GEO::L;   // output positions per trajectory when the geometry is known
+    const int L_in = GK ? GEO::L : a.L_in, L_out = GK ? GLO : a.L_out;
+    const int lg_Lin = GK ? geo_ilog2(GEO::L) : a.lg_Lin, lg_Lout = GK ? geo_ilog2(GLO) : a.lg_Lout, lg_c4n = GK ? geo_ilog2(GEO::NC16 * 4) : a.lg_c4n;
     const int spt = NT >> lg_Lout;  // trajectories per tile
     const int s0 = nt * spt;
     const int LP = L_in + 2 * PAD;
-    const int RS4 = GK ? (GEO::NC16 * 16 + 8) / 4 : a.rs >> 2;  // LDS row stride in float4 units (all LDS indexing is in 16-B units: provably aligned)
+    const int RS4 = GK ? (GEO::NC16 * 16 + GEO::RSPAD) / 4 : a.rs >> 2;  // LDS row stride in float4 units (all LDS indexing is in 16-B units: provably aligned)
     f32x4* const smem4 = (f32x4*)smem;
     const int cin = GK ? GEO::NC16 * 16 : a.c1 + a.c2;
     const int c4n = GK ? GEO::NC16 * 4 : a.cin_pad >> 2;

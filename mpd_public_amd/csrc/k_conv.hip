@@ -19,7 +19,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
 // without padding, row stride C_in + 8, K split over the 8 waves, tiles of (16 | 32) channels x (16 | 32 | 64) positions
 static bool geo_l8(const Layer& l, const ConvArgs& a) {
     return l.mode == CONV_S1 && l.L_in == 8 && l.L_out == 8 && l.cin_pad == l.c1 + l.c2 && !(l.c1 & 3) && !(l.c2 & 3) && a.rs == l.cin_pad + 8 &&
-           (l.cin_pad == 128 || l.cin_pad == 256 || l.cin_pad == 512) && !a.pre && !a.dbg && !(a.Lv_out > 0 && a.Lv_out < l.L_out) &&
+           (l.cin_pad == 128 || l.cin_pad == 256 || l.cin_pad == 512) && !a.dbg && !(a.Lv_out > 0 && a.Lv_out < l.L_out) &&
            !(getenv("MPDX_GEO") && atoi(getenv("MPDX_GEO")) == 0);   // MPDX_GEO=0: the runtime-geometry kernels (development A/B)
 }
 template <int NC16, int MT, int NT, int TBRES>
@@ -98,7 +98,30 @@ int launch_conv_layer(const Layer& l, ConvArgs& a, int B, hipStream_t st) {
     }
     if (l.mode == CONV_S1 && l.ks == 1 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 1, EPI_BIAS>(l, a, B, st);
     if (l.mode == CONV_DOWN && l.ks == 3) return dispatch_tile_ksplit_only<CONV_DOWN, 3, EPI_BIAS>(l, a, B, st);
-    if (l.mode == CONV_UPT && l.ks == 4) return dispatch_tile_ksplit_only<CONV_UPT, 4, EPI_BIAS>(l, a, B, st);
+    if (l.mode == CONV_UPT && l.ks == 4) {
+        // Upsample1d of the innermost up level (C -> C, 8 -> 16 positions) with compile-time geometry, where instantiated
+        if (l.L_in == 8 && l.L_out == 16 && l.cin_pad == l.c1 && l.c2 == 0 && !(l.c1 & 3) && a.rs == l.cin_pad + 4 && !a.dbg && !a.pre && !a.accum && !a.dst2 &&
+            !(a.Lv_out > 0 && a.Lv_out < l.L_out) && !(getenv("MPDX_GEO") && atoi(getenv("MPDX_GEO")) == 0)) {
+            int MT, NT;
+            choose_tile(l, B, MT, NT);
+            if (l.cout % MT) MT = 16;
+            a.n_tiles_n = (int)(((long)B * l.L_out + NT - 1) / NT);
+#define MPDX_GEO_UP(nc, mt, nt)                                                                         \
+            if (l.cin_pad == nc * 16 && MT == mt && NT == nt) {                                          \
+                const size_t lds = conv_block_lds_bytes<CONV_UPT, 4, mt, nt, 8>(8, 16, nc * 16 + 4);     \
+                auto kern = conv_block_kernel<CONV_UPT, 4, EPI_BIAS, mt, nt, 1, 8, GeoUp8<nc>>;          \
+                if (lds <= 160 * 1024) {                                                                 \
+                    if (lds > 64 * 1024)                                                                 \
+                        if (int rc = raise_lds_limit((const void*)kern)) return rc;                      \
+                    hipLaunchKernelGGL(kern, dim3((a.C_out / mt) * a.n_tiles_n), dim3(512), lds, st, a); \
+                    return 0;                                                                            \
+                }                                                                                        \
+            }
+            MPDX_GEO_UP(8, 16, 64) MPDX_GEO_UP(8, 32, 64) MPDX_GEO_UP(8, 16, 32) MPDX_GEO_UP(8, 32, 32)
+#undef MPDX_GEO_UP
+        }
+        return dispatch_tile_ksplit_only<CONV_UPT, 4, EPI_BIAS>(l, a, B, st);
+    }
     // the input-gradient convolutions of the training step (train_host.hpp)
     if (l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 5, EPI_BIAS>(l, a, B, st);
     if (l.mode == CONV_S1 && l.ks == 3 && l.epi == EPI_BIAS) return dispatch_tile_ksplit_only<CONV_S1, 3, EPI_BIAS>(l, a, B, st);

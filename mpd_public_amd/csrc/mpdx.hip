@@ -1126,6 +1126,39 @@ static double unit_flops(const mpdx_unet* u, const mpdx_unet::Unit& un, int B) {
     return layer_flops(u->layers[un.layer], B) + (un.pair ? layer_flops(u->layers[un.layer + 1], B) : 0.0);
 }
 
+// ALGORITHMIC bytes of a launch unit: every weight / parameter it needs once + the activations that cross its boundary once (inputs,
+// residual, outputs; what stays in LDS inside a fused program does not count) - the denominator of bench.py's traffic_over_algorithmic
+static double layer_param_bytes(const mpdx_unet* u, const Layer& l) {
+    double n = (double)u->params[l.w].n + l.cout;
+    if (l.gamma >= 0) n += 2.0 * l.cout;
+    if (l.tb_off >= 0) n += l.cout;
+    return 4.0 * n;
+}
+static double unit_bytes(const mpdx_unet* u, const mpdx_unet::Unit& un, int B) {
+    auto act = [&](int L, int C) { return 4.0 * B * (double)L * C; };
+    if (un.fused >= 0) {
+        const auto& f = u->fused[un.fused];
+        const Layer& l0 = u->layers[f.first];
+        double b = act(l0.L_in, l0.c1 + l0.c2);
+        if (f.in3_consumer >= 0) b += act(u->layers[f.in3_consumer].L_in, u->layers[f.in3_consumer].c2);
+        for (int k = f.first; k < f.first + f.count; ++k) b += layer_param_bytes(u, u->layers[k]);
+        for (int k = 0; k < f.tmpl.nops; ++k)
+            if (f.tmpl.ops[k].shape != kFusedShapeFinal && f.tmpl.ops[k].gdst >= 0) {
+                const Layer& l = u->layers[f.op_layer[k]];
+                b += act(l.L_out, l.cout);
+            }
+        if (f.has_final) b += 3.0 * act(u->cfg.n_support_points, u->cfg.state_dim);   // x_t in, noise in, x_{t-1} out
+        return b;
+    }
+    double b = 0.0;
+    for (int k = un.layer; k < un.layer + (un.pair ? 2 : 1); ++k) {
+        const Layer& l = u->layers[k];
+        b += layer_param_bytes(u, l) + act(l.L_out, l.cout) + (l.res != SRC_NONE ? act(l.L_out, l.cout) : 0.0);
+        if (k == un.layer) b += act(l.L_in, l.c1 + l.c2);   // a paired launch reads its input once
+    }
+    return b;
+}
+
 // one U-Net pass + the final 1x1 conv / DDPM step described by `fa` (fa.mode 0: eps only)
 static int run_unet_and_final(mpdx_unet* u, const float* packed, const float* timetab, int T, const float* x, int t, int B,
                               float* ws, FinalArgs& fa, hipStream_t st) {
@@ -1613,6 +1646,14 @@ int mpdx_unet_unit_layer(const mpdx_unet* u, int B, int i) {
     const auto units = current_units(u, B, nullptr);
     if (i < 0 || i >= (int)units.size()) return -1;
     return units[i].fused >= 0 ? -1 : units[i].layer;
+}
+
+/* algorithmic bytes of launch unit i at batch B (weights once + boundary activations once); 0 for a bad index */
+double mpdx_unet_unit_bytes(const mpdx_unet* u, int B, int i) {
+    if (!u) return 0.0;
+    const auto units = current_units(u, B, nullptr);
+    if (i < 0 || i >= (int)units.size()) return 0.0;
+    return unit_bytes(u, units[i], B);
 }
 
 /* 1 when launch unit i is a paired launch (blocks[0] + the block's residual 1x1 conv in one conv_pair_kernel) */

@@ -23,10 +23,19 @@ def per_kernel(d, counter):
     return {k: (acc[k] / len(cnt[k]), len(cnt[k])) for k in acc}
 
 
+def csrc_fingerprint():   # as bench.csrc_fingerprint: which kernel sources this was measured on
+    import hashlib, pathlib
+    h = hashlib.sha256()
+    for f in sorted((pathlib.Path(__file__).resolve().parent.parent / "mpd_public_amd" / "csrc").glob("*")):
+        if f.suffix in (".hpp", ".hip"):
+            h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate passes) -- python bench.py --steps 1 "
                  "--warmup 1 --no-cpu-baseline --no-roofline --no-extras ; MI355X",
-       "batch": int(sys.argv[3]) if len(sys.argv) > 3 else None, "fetch_correction": 2.0,
+       "batch": int(sys.argv[3]) if len(sys.argv) > 3 else None, "fetch_correction": 2.0, "csrc_fingerprint": csrc_fingerprint(),
        "note": "traffic = FETCH_SIZE[KiB] x 1024 x 2 + WRITE_SIZE[KiB] x 1024 per launch; counts requests the L2 sends to the fabric "
                "(Infinity-Cache hits included): at B=100 everything is MALL-resident, so this is L2-miss traffic, an upper bound on HBM bytes",
        "kernels": {}}
