@@ -94,6 +94,7 @@ SIGNATURES = {
     "mpdx_unet_unit_layer": (_i, [_vp, _i, _i]),
     "mpdx_unet_unit_is_pair": (_i, [_vp, _i, _i]),
     "mpdx_unet_unit_bytes": (C.c_double, [_vp, _i, _i]),
+    "mpdx_unet_fused_program": (_i, [_vp, _i]),
     "mpdx_bench_layer": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, C.POINTER(C.c_float)]),
     "mpdx_unet_layer_tile": (_i, [_vp, _i, _i, C.c_char_p, _sz]),
     "mpdx_randn": (_i, [_vp, _sz, C.c_uint64, C.c_uint64, _vp]),

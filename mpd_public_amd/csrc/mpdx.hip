@@ -1648,6 +1648,13 @@ int mpdx_unet_unit_layer(const mpdx_unet* u, int B, int i) {
     return units[i].fused >= 0 ? -1 : units[i].layer;
 }
 
+/* which kernel runs fused segment `seg`: 0..5 = a static program (fused_program_kernel<FusedSeq...>; 0, 3, 5 read their LDS geometry from the
+ * compile-time tables of fused_geom.hpp), -1 = the generic op-list kernel (runtime descriptors), -2 = no such segment */
+int mpdx_unet_fused_program(const mpdx_unet* u, int seg) {
+    if (!u || seg < 0 || seg >= (int)u->fused.size()) return -2;
+    return u->fused[seg].program;
+}
+
 /* algorithmic bytes of launch unit i at batch B (weights once + boundary activations once); 0 for a bad index */
 double mpdx_unet_unit_bytes(const mpdx_unet* u, int B, int i) {
     if (!u) return 0.0;

@@ -119,3 +119,38 @@ def test_plan_diversity_and_cost_metrics_vs_oracle(robot_id, env_id):
     # best-trajectory selection of the entry (inference.py:319-322) on the same numbers
     cost = om.compute_path_length(ref, qd) + om.compute_smoothness(ref, qd)
     assert int(torch.argmin(compute_path_length(xu, ds.robot) + compute_smoothness(xu, ds.robot))) == int(np.argmin(cost))
+
+
+def test_measurement_helpers_guide_time_and_unit_bytes():
+    """bench.py's helpers behind the C ABI: mpdx_guide_time (gradient-only launches: x untouched, a positive time) and mpdx_unet_unit_bytes
+    (algorithmic bytes of a pass's launch units: every weight once + boundary activations)."""
+    import ctypes as C
+    import mpd_public_amd as m
+    from mpd_public_amd import _lib, synthetic as syn
+    from helpers import product_guide
+    lib = _lib.load()
+    ds = m.TrajectoryDataset("EnvDense2D", "RobotPointMass", tensor_args={"device": "cuda", "dtype": torch.float32})
+    g = product_guide(ds).cuda()
+    B, H, D = 16, 64, ds.state_dim
+    x = obstacle_hugging_trajs(ds, B, seed="gt", scale=0.9).cuda().contiguous()
+    x0 = x.clone()
+    gp = g.device_params(x.device)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.mpdx_absmax(x.data_ptr(), flag.data_ptr(), B, B, H, D, _lib.current_stream()))
+    out, ms = torch.empty_like(x), C.c_float()
+    _lib.check(lib.mpdx_guide_time(C.byref(gp), x.data_ptr(), out.data_ptr(), flag.data_ptr(), B, B, H, D, 20, _lib.current_stream(), C.byref(ms)))
+    assert ms.value > 0 and torch.equal(x, x0)
+    assert torch.equal(out, g(x))   # the timed launches computed the guide increment
+    net = m.TemporalUnet(n_support_points=64, state_dim=4, unet_input_dim=32, dim_mults=(1, 2, 4, 8))
+    net.load_state_dict(syn.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}), strict=True)
+    net = net.cuda()
+    hdl = net.engine(100, B)[0]
+    tot, i = 0.0, 0
+    while lib.mpdx_unet_unit_layer(hdl, B, i) >= 0 or lib.mpdx_unet_unit_bytes(hdl, B, i) > 0:
+        b = lib.mpdx_unet_unit_bytes(hdl, B, i)
+        assert b > 0
+        tot += b
+        i += 1
+    n_conv = sum(v.numel() for k, v in net.state_dict().items() if k.endswith("weight") and v.dim() == 3 and not k.startswith("final_conv.1"))
+    assert i == 15 and tot > 4.0 * n_conv   # two programs + thirteen per-layer / paired launches; at least every conv weight once
+    assert lib.mpdx_unet_unit_bytes(hdl, B, i) == 0.0
