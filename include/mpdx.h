@@ -264,6 +264,14 @@ typedef struct mpdx_rrt_opts {
 int mpdx_rrt_connect(const mpdx_guide_params* gp, const mpdx_rrt_opts* opts, const float* start, const float* goal, float* nodes,
                      int32_t* parent, int32_t* count, int32_t* link, int32_t* iters, int n, void* stream);
 
+/* RRT-Connect post-processing on the device: per problem the path start ... goal is extracted from the two trees mpdx_rrt_connect grew, shortcut
+ * greedily (`rounds` passes, edges checked on n_edge_checks interpolated configurations) and resampled uniformly in arc length to H support
+ * points with central-difference velocities -> trajs_out[n][H][2 q_dim]; path_len[n] (or NULL) = nodes of the shortcut path.  An unsolved problem
+ * becomes the straight line.  Replaces the path extraction / smoothing that MultiSampleBasedPlanner + HybridPlanner do between RRTConnect and GPMP2
+ * (scripts/generate_data/generate_trajectories.py:68-105; un-vendored: the published algorithms, parity unpinned). */
+int mpdx_rrt_paths(const mpdx_guide_params* gp, const float* start, const float* goal, const float* nodes, const int32_t* parent, const int32_t* link,
+                   float* trajs_out, int32_t* path_len, int n, int max_nodes, int H, float dt, int n_edge_checks, int rounds, void* stream);
+
 /* ---- the whole planning loop: replaces GaussianDiffusionModel.p_sample_loop driven by run_inference
  * (diffusion_model_base.py:157-182,285-316) with sample_fn=ddpm_sample_fn.  Everything is enqueued on `stream`
  * without a single host synchronisation: the t-dependent branches of the reference (`t_single < 0`,

@@ -677,6 +677,160 @@ __global__ __launch_bounds__(kRrtThreads) void rrt_connect_kernel(const RrtArgs 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// RRT-Connect post-processing on the device (round 4; round 3 did it in host loops over GPU edge checks: ~170 ms of the 200 ms a
+// 100-problem narrow-passage batch took): per problem ONE workgroup
+//   1. extracts the path start ... meeting node | other branch ... goal from the two trees (parent links staged in LDS and chased there),
+//   2. shortcuts it greedily (`rounds` passes: from node i jump to the LAST later node it sees - the host algorithm of
+//      generate_trajectories.shortcut_path, same result; edges checked on n_checks interpolated configurations with config_hit),
+//   3. resamples it uniformly in arc length to H support points, velocities by central differences, zero at both ends
+//      (generate_trajectories.resample_path), and writes the [H][2 QD] state trajectory.
+// An unsolved problem (link < 0) or a path longer than kPathMax nodes becomes the straight line start -> goal (the optimiser may repair it).
+constexpr int kPathMax = 1024;
+struct RrtPathArgs {
+    mpdx_guide_params gp;
+    const float* start;         // [n][QD]
+    const float* goal;          // [n][QD]
+    const float* nodes;         // [n][2][max_nodes][QD]
+    const int* parent;          // [n][2][max_nodes]
+    const int* link;            // [n][2]
+    float* out;                 // [n][H][2 QD]
+    int* path_len;              // [n] nodes of the shortcut path (2: straight line), or null
+    int max_nodes, H, n_checks, rounds;
+    float dt;
+};
+
+template <int QD, int DIM, int ROBOT>
+__global__ __launch_bounds__(kRrtThreads) void rrt_path_kernel(const RrtPathArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const mpdx_guide_params& gp = a.gp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int M = a.max_nodes, H = a.H;
+    float* pth = sm;                              // [kPathMax][QD] path nodes
+    float* pos = pth + kPathMax * QD;             // [H][QD] resampled positions
+    float* sarc = pos + H * QD;                   // [kPathMax] cumulative arc length
+    int* sidx = (int*)(sarc + kPathMax);          // [kPathMax] node indices / keep list
+    int* spar = sidx + kPathMax;                  // [2][M] parent links
+    int* sint = spar + 2 * M;                     // [16] scalars: 0 m, 1 n0, 4..7 per-wave hit flags
+    float* sprim = (float*)(sint + 16);
+    for (int i = tid; i < gp.n_prim_floats; i += kRrtThreads) sprim[i] = gp.prims[i];
+    const int* gpar = a.parent + (size_t)b * 2 * M;
+    for (int i = tid; i < 2 * M; i += kRrtThreads) spar[i] = gpar[i];
+    const int l0 = a.link[(size_t)b * 2], l1 = a.link[(size_t)b * 2 + 1];
+    __syncthreads();
+    // ---- 1. node index list: tree 0 from the meeting node back to the start (reversed below), then tree 1 from its meeting node to the goal
+    if (tid == 0) {
+        int n0 = 0, n1 = 0;
+        if (l0 >= 0 && l1 >= 0) {
+            for (int k = l0; k >= 0 && n0 <= kPathMax; k = spar[k]) ++n0;
+            for (int k = l1; k >= 0 && n1 <= kPathMax; k = spar[M + k]) ++n1;
+        }
+        if (n0 == 0 || n0 + n1 > kPathMax) { sint[0] = 0; sint[1] = 0; }
+        else {
+            int w = n0 - 1;
+            for (int k = l0; k >= 0; k = spar[k]) sidx[w--] = k;              // start ... meeting node
+            w = n0;
+            for (int k = l1; k >= 0; k = spar[M + k]) sidx[w++] = M + k;      // other tree's branch ... goal
+            sint[0] = n0 + n1; sint[1] = n0;
+        }
+    }
+    __syncthreads();
+    int m = sint[0];
+    const float* gnodes = a.nodes + (size_t)b * 2 * M * QD;
+    if (m == 0) {   // straight line
+        if (tid < QD) { pth[tid] = a.start[(size_t)b * QD + tid]; pth[QD + tid] = a.goal[(size_t)b * QD + tid]; }
+        m = 2;
+    } else {
+        for (int i = tid; i < m * QD; i += kRrtThreads) { const int nd = i / QD, j = i - nd * QD; pth[i] = gnodes[(size_t)sidx[nd] * QD + j]; }
+    }
+    __syncthreads();
+    // ---- 2. greedy shortcutting
+    const int nchk = a.n_checks;
+    const int nparts = (ROBOT == MPDX_ROBOT_PANDA) ? (kRrtThreads / nchk < 12 ? kRrtThreads / nchk : 12) : 1;
+    auto edge_free = [&](const float* qa, const float* qb) -> bool {   // workgroup-wide, as in rrt_connect_kernel
+        const int c = tid % nchk, part = tid / nchk;
+        bool hit = false;
+        if (part < nparts) {
+            const float w = nchk > 1 ? (float)c / (float)(nchk - 1) : 0.f;
+            float q[QD];
+#pragma unroll
+            for (int j = 0; j < QD; ++j) q[j] = (1.0f - w) * qa[j] + w * qb[j];
+            hit = config_hit<QD, DIM, ROBOT>(gp, sprim, q, part, nparts);
+        }
+        const bool wave_hit = __ballot(hit) != 0ull;
+        if (lane == 0) sint[4 + wave] = wave_hit ? 1 : 0;
+        __syncthreads();
+        const bool any = (sint[4] | sint[5] | sint[6] | sint[7]) != 0;
+        __syncthreads();
+        return !any;
+    };
+    for (int round = 0; round < a.rounds && m > 2; ++round) {
+        int nk = 1, i = 0;           // keep list in sidx (uniform control flow: every thread tracks i, nk)
+        if (tid == 0) sidx[0] = 0;
+        while (i < m - 1) {
+            int j = m - 1;
+            for (; j > i + 1; --j)
+                if (edge_free(pth + i * QD, pth + j * QD)) break;   // the LAST later node that i sees; none: the next node
+            if (tid == 0) sidx[nk] = j;
+            ++nk;
+            i = j;
+        }
+        __syncthreads();
+        if (nk == m) break;
+        // compact the path in place (ascending indices: node k moves to a position <= its own; one float per thread and pass)
+        for (int k = 1; k < nk; ++k) {
+            const int src = sidx[k];
+            float v = 0.f;
+            if (tid < QD) v = pth[src * QD + tid];
+            __syncthreads();
+            if (tid < QD) pth[k * QD + tid] = v;
+            __syncthreads();
+        }
+        m = nk;
+    }
+    if (tid == 0 && a.path_len) a.path_len[b] = m;
+    // ---- 3. arc-length resampling to H support points + central-difference velocities
+    if (tid == 0) {
+        float acc = 0.f;
+        sarc[0] = 0.f;
+        for (int k = 1; k < m; ++k) {
+            float d2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < QD; ++j) { const float d = pth[k * QD + j] - pth[(k - 1) * QD + j]; d2 += d * d; }
+            acc += sqrtf(d2);
+            sarc[k] = acc;
+        }
+    }
+    __syncthreads();
+    const float total = sarc[m - 1];
+    for (int h = tid; h < H; h += kRrtThreads) {
+        const float u = H > 1 ? total * (float)h / (float)(H - 1) : 0.f;
+        int k = 1;
+        while (k < m - 1 && sarc[k] <= u) ++k;     // first node with s[k] > u (searchsorted right), clamped to [1, m - 1]
+        const float den = fmaxf(sarc[k] - sarc[k - 1], 1e-12f);
+        const float w = fminf(fmaxf((u - sarc[k - 1]) / den, 0.f), 1.f);
+#pragma unroll
+        for (int j = 0; j < QD; ++j) {
+            float v = pth[(k - 1) * QD + j] * (1.0f - w) + pth[k * QD + j] * w;
+            if (h == 0) v = pth[j];
+            if (h == H - 1) v = pth[(m - 1) * QD + j];
+            pos[h * QD + j] = v;
+        }
+    }
+    __syncthreads();
+    float* o = a.out + (size_t)b * H * 2 * QD;
+    for (int i = tid; i < H * QD; i += kRrtThreads) {
+        const int h = i / QD, j = i - h * QD;
+        o[h * 2 * QD + j] = pos[i];
+        o[h * 2 * QD + QD + j] = (h > 0 && h < H - 1) ? (pos[(h + 1) * QD + j] - pos[(h - 1) * QD + j]) / (2.0f * a.dt) : 0.f;
+    }
+}
+
+template <int QD>
+inline size_t rrt_path_lds_bytes(int max_nodes, int H, int n_prim_floats) {
+    return (size_t)(kPathMax * QD + H * QD + kPathMax + kPathMax + 2 * max_nodes + 16 + n_prim_floats) * sizeof(float);
+}
+
 template <int QD>
 inline size_t rrt_lds_bytes(int max_nodes, int n_prim_floats) {
     return (size_t)(2 * max_nodes * QD + 3 * 8 + 8 + 8 + n_prim_floats) * sizeof(float);

@@ -84,4 +84,34 @@ int mpdx_rrt_connect(const mpdx_guide_params* gp, const mpdx_rrt_opts* o, const 
     return 0;
 }
 
+int mpdx_rrt_paths(const mpdx_guide_params* gp, const float* start, const float* goal, const float* nodes, const int32_t* parent, const int32_t* link,
+                   float* trajs_out, int32_t* path_len, int n, int max_nodes, int H, float dt, int n_edge_checks, int rounds, void* stream) {
+    using namespace mpdx;
+    if (!gp || !start || !goal || !nodes || !parent || !link || !trajs_out || n <= 0) return fail(MPDX_E_INVALID, "null argument");
+    if (max_nodes < 2 || H < 2 || H > 1024 || !(dt > 0.f) || n_edge_checks < 2 || n_edge_checks > kRrtThreads || rounds < 0)
+        return fail(MPDX_E_INVALID, "RRT paths: max_nodes %d, H %d, dt %g, n_edge_checks %d, rounds %d", max_nodes, H, (double)dt, n_edge_checks, rounds);
+    if (int rc = check_planner_params(gp, 0, 2 * gp->q_dim)) return rc;
+    RrtPathArgs a;
+    memset(&a, 0, sizeof(a));
+    a.gp = *gp; a.start = start; a.goal = goal; a.nodes = nodes; a.parent = parent; a.link = link; a.out = trajs_out; a.path_len = path_len;
+    a.max_nodes = max_nodes; a.H = H; a.n_checks = n_edge_checks; a.rounds = rounds; a.dt = dt;
+    hipStream_t st = (hipStream_t)stream;
+#define MPDX_RRTP(QD_, DIM_, ROBOT_)                                                                                     \
+    {                                                                                                                    \
+        const size_t lds = rrt_path_lds_bytes<QD_>(max_nodes, H, gp->n_prim_floats);                                     \
+        if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "RRT paths: %d nodes x %d dims need %zu B of LDS", max_nodes, QD_, lds); \
+        auto kern = rrt_path_kernel<QD_, DIM_, ROBOT_>;                                                                  \
+        if (lds > 64 * 1024)                                                                                             \
+            if (int rc = raise_lds_limit((const void*)kern)) return rc;                                                  \
+        hipLaunchKernelGGL(kern, dim3(n), dim3(kRrtThreads), lds, st, a);                                                \
+    }
+    if (gp->robot == MPDX_ROBOT_PANDA && gp->q_dim == 7) MPDX_RRTP(7, 3, MPDX_ROBOT_PANDA)
+    else if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 2) MPDX_RRTP(2, 2, MPDX_ROBOT_POINTMASS)
+    else if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 3) MPDX_RRTP(3, 3, MPDX_ROBOT_POINTMASS)
+    else return fail(MPDX_E_INVALID, "RRT paths: unsupported robot %d / q_dim %d", gp->robot, gp->q_dim);
+#undef MPDX_RRTP
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 }  // extern "C"

@@ -88,6 +88,19 @@ class RRTConnectBatch:
         self.done = self.link[:, 0] >= 0
         return int(self.iters.max())
 
+    def trajectories(self, n_support_points: int, dt: float, n_edge_checks: int = 32, rounds: int = 3, return_path_len: bool = False):
+        """The searches' results as [n, H, 2q] state trajectories, entirely on the device (`mpdx_rrt_paths`, csrc/planner.hpp rrt_path_kernel):
+        path extraction from the two trees, greedy shortcutting (`shortcut_path`'s algorithm) and arc-length resampling with
+        central-difference velocities (`resample_path`'s), one workgroup per problem; an unsolved problem becomes the straight line.
+        Round 3 ran these steps as host loops over GPU edge checks (~170 ms of the 200 ms of a 100-problem narrow-passage batch)."""
+        H = int(n_support_points)
+        out = torch.empty((self.n, H, 2 * self.q), dtype=torch.float32, device=self.nodes.device)
+        plen = torch.zeros(self.n, dtype=torch.int32, device=self.nodes.device)
+        _lib.check(_lib.load().mpdx_rrt_paths(C.byref(self._gp), self.start.data_ptr(), self.goal.data_ptr(), self.nodes.data_ptr(), self.parent.data_ptr(),
+                                              self.link.data_ptr(), out.data_ptr(), plen.data_ptr(), self.n, self.M, H, float(dt), int(n_edge_checks),
+                                              int(rounds), _lib.current_stream()), "mpdx_rrt_paths")
+        return (out, plen) if return_path_len else out
+
     def paths(self) -> List[Optional[torch.Tensor]]:
         """Per problem: [n_nodes, q] configurations from start to goal (None if the trees did not meet)."""
         nodes, parent, link, done = self.nodes.cpu(), self.parent.cpu().tolist(), self.link.cpu().tolist(), self.done.cpu().tolist()
@@ -255,13 +268,9 @@ def generate_collision_free_trajectories(env_id, robot_id, num_trajectories_per_
     rrt = RRTConnectBatch(task, start_state_pos.to(dev), goal_state_pos.to(dev), n, step_size=step, generator=gen)
     deadline_iters = 6000
     used = rrt.grow(max_iters=deadline_iters)
-    paths = rrt.paths()
-    line = torch.stack([start_state_pos.cpu(), goal_state_pos.cpu()])
-    init = []
-    for p in paths:   # an unsolved problem falls back to the straight line (the optimiser may still repair it; it is reported as colliding otherwise)
-        p = shortcut_path(task, p) if p is not None else line
-        init.append(resample_path(p, n_support_points, dt))
-    trajs0 = torch.stack(init).to(dev)
+    # path extraction + shortcutting + arc-length resampling on the device (an unsolved problem falls back to the straight line: the
+    # optimiser may still repair it; it is reported as colliding otherwise)
+    trajs0 = rrt.trajectories(n_support_points, dt)
     torch.cuda.synchronize()
     times["rrt_connect_s"] = time.perf_counter() - t0
     # -------------------------------- optimisation-based refinement (:92-120)

@@ -214,3 +214,42 @@ def test_gpmp2_descends_monotonically_and_repairs_collisions(env_id, robot_id):
         c.cutoff = ds.task.obstacle_cutoff_margin
     F0 = float(ogpmp.objective(x[0].cpu().double(), coll[0].robot, coll, dt, 1.0, opt.opts.sigma_obs, 128))
     assert abs(float(Fs[-1, 0]) - F0) <= 1e-3 * F0 + 1e-6, (float(Fs[-1, 0]), F0)
+
+
+@pytest.mark.parametrize("env_id,robot_id", [("EnvNarrowPassageDense2D", "RobotPointMass"), ("EnvSpheres3D", "RobotPanda")])
+def test_rrt_paths_on_device_match_the_host_algorithms_and_are_collision_free(env_id, robot_id):
+    """mpdx_rrt_paths (path extraction + greedy shortcutting + arc-length resampling in ONE launch) against the host restatements
+    shortcut_path / resample_path on the same trees: same shortcut nodes, same trajectories to fp32 rounding; every segment between
+    consecutive shortcut nodes is re-checked 4x finer; an unsolved problem becomes the straight line."""
+    import mpd_public_amd as m
+    from mpd_public_amd.generate_trajectories import RRTConnectBatch, edges_free, shortcut_path, resample_path
+    ds = m.TrajectoryDataset(env_id, robot_id, tensor_args={"device": "cuda", "dtype": torch.float32})
+    task = ds.task
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    q = task.random_coll_free_q(n_samples=2, device="cuda", generator=gen)
+    n, H, dt = 12, 64, 5.0 / 64
+    rrt = RRTConnectBatch(task, q[0], q[1], n, step_size=0.1 if ds.robot.q_dim <= 3 else 0.25, generator=gen)
+    rrt.grow(max_iters=6000)
+    assert int(rrt.done.sum()) >= n - 2
+    rrt.link[0] = -1; rrt.done[0] = False        # an "unsolved" problem
+    tr, plen = rrt.trajectories(H, dt, return_path_len=True)
+    tr, plen = tr.cpu(), plen.cpu()
+    assert tr.shape == (n, H, 2 * ds.robot.q_dim) and bool(torch.isfinite(tr).all())
+    qd = ds.robot.q_dim
+    line = torch.stack([q[0].cpu(), q[1].cpu()])
+    assert int(plen[0]) == 2
+    np.testing.assert_allclose(tr[0].numpy(), resample_path(line, H, dt).numpy(), rtol=0, atol=2e-5)
+    same = 0
+    for i, p in enumerate(rrt.paths()):
+        if p is None:
+            continue
+        sc = shortcut_path(task, p)
+        assert torch.equal(tr[i, 0, :qd], q[0].cpu()) and torch.equal(tr[i, -1, :qd], q[1].cpu())
+        assert not tr[i, 0, qd:].any() and not tr[i, -1, qd:].any()
+        if int(plen[i]) == sc.shape[0]:   # same greedy decisions (an edge within fp32 rounding of an obstacle may be judged differently)
+            same += 1
+            np.testing.assert_allclose(tr[i].numpy(), resample_path(sc, H, dt).numpy(), rtol=0, atol=5e-4)
+        # the device trajectory itself: its positions lie on collision-free segments (checked between consecutive support points, 8 checks each)
+        pts = tr[i, :, :qd].cuda().contiguous()
+        assert bool(edges_free(task, pts[:-1].contiguous(), pts[1:].contiguous(), n_edge_checks=8).all()), i
+    assert same >= n - 3, same
