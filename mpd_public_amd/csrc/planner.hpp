@@ -8,8 +8,8 @@
 //                       c = hinge obstacle / workspace / self-collision factors of every link sphere on the interpolated
 //                       trajectory (the SAME factors the guide differentiates: oracle/costs.py), start and goal states fixed.
 //                       The normal equations  (K^-1 + J^T J / sigma_obs^2 + lambda diag) delta = -grad  are BLOCK TRIDIAGONAL over the
-//                       H - 2 free support states (an interpolated point touches two neighbouring supports): assembled in LDS as a
-//                       banded matrix (half bandwidth 2d - 1, d = state dim) and solved by an in-LDS banded LDL^T - one workgroup
+//                       H - 2 free support states (an interpolated point touches two neighbouring supports): assembled in LDS as
+//                       d x d blocks (d = state dim) and solved there by block cyclic reduction (gpmp_bcr_solve) - one workgroup
 //                       per trajectory, no global traffic besides the trajectory itself.
 //   rrt_connect_kernel  RRT-Connect (Kuffner & LaValle 2000), one workgroup per problem, the WHOLE bidirectional search in one
 //                       launch: sampling (Philox), nearest neighbour over the tree (lanes over nodes + wave arg-min), steering,
@@ -182,14 +182,184 @@ constexpr int kGpmpThreads = 256;
 
 template <int QD>
 inline size_t gpmp_lds_bytes(int H, int N, int n_prim_floats) {
-    constexpr int D = 2 * QD, MSZ = QD * (QD + 1) / 2 + QD + 1, BW = 2 * D;
-    const size_t n = (size_t)(H - 2) * D;
-    return (size_t)(2 * H * D + 2 * N * MSZ + n * BW + n + 64 + n_prim_floats) * sizeof(float);
+    constexpr int D = 2 * QD, MSZ = QD * (QD + 1) / 2 + QD + 1, LSZ = D * (D + 1) / 2;
+    const size_t n = (size_t)(H - 2), terms = (size_t)2 * N * MSZ, pool = n * LSZ;   // the Cholesky pool overlays the per-point terms
+    return (size_t)(2 * H * D + (terms > pool ? terms : pool) + 2 * n * D * D + n * D + 64 + (H + 2) + n_prim_floats) * sizeof(float);
+}
+
+// ---- the Levenberg-Marquardt system: symmetric positive definite, block tridiagonal (n = H - 2 free supports, d x d blocks, d = 2 q_dim)
+//   Dm[i] = A[i][i] (row-major d x d, lower triangle used), Cm[i] = A[i+1][i] (row-major d x d), rhs[i] (d)
+// solved by BLOCK CYCLIC REDUCTION.  Rounds 3 / 4 first factorised the band column by column: 2 n d - 1 = 1 735 DEPENDENT steps for the Panda,
+// each at least one LDS round trip (tools/gpmp_phase_probe.py, s_memtime stamps: a workgroup-wide column update with one barrier per step
+// 750 cycles per step; one wave without barriers 900 cycles per factorisation step + 185 per substitution step = 393 us of a 528-us
+// iteration).  Cyclic reduction eliminates every other block of the current chain at once - ceil(log2 n) = 6 levels for n = 62 - and each
+// level is three workgroup-wide phases of d x d dense algebra:
+//   P1  L_e = chol(D_e)                                      one lane per eliminated block, the 105-entry triangle in registers
+//   P2  Y_lo = L^-1 A[e][a], Y_hi = L^-1 A[e][b], w = L^-1 r_e   one lane per column (in place; Y_hi is kept transposed, as A[b][e] was)
+//   P3  kept blocks: D_q -= Y^T Y (both eliminated neighbours), r_q -= Y^T w; new couplings A[q+2][q] = -Y_hi^T Y_lo (stored in the
+//       eliminated block's slot Dm[e]: its diagonal block was consumed by P1)
+// and the substitution walks the levels back: x_e = L^-T (w - Y_lo x_a - Y_hi x_b).  Positions p of level l (stride s = 2^l) are the
+// blocks (p + 1) s - 1; even positions are eliminated, odd ones kept.  The Cholesky factors (packed, reciprocal diagonal) of all n blocks
+// go to `Lp`, which overlays the per-point linearisation terms (dead once the system is assembled).
+template <int D>
+struct Bcr {
+    static constexpr int DD = D * D, LSZ = D * (D + 1) / 2;
+    static __device__ __forceinline__ int idx(int p, int s) { return (p + 1) * s - 1; }
+    // storage of the coupling between positions p and p + 1 of the level with stride s (rows: p + 1, columns: p)
+    static __device__ __forceinline__ float* coup(float* Dm, float* Cm, int s, int p) {
+        return s == 1 ? Cm + (size_t)p * DD : Dm + (size_t)(((2 * p + 3) * s) / 2 - 1) * DD;
+    }
+};
+
+template <int QD>
+__device__ __forceinline__ void gpmp_bcr_solve(float* Dm, float* Cm, float* rhs, float* Lp, const int n, const int tid) {
+    constexpr int D = 2 * QD, DD = D * D, LSZ = D * (D + 1) / 2, NTHR = 256;
+    using G = Bcr<D>;
+    int nlev = 0;
+    for (int nl = n, s = 1; nl >= 1; nl >>= 1, s <<= 1, ++nlev) {
+        const int ne = (nl + 1) >> 1, nk = nl >> 1;
+        // ---- P1: Cholesky of the eliminated diagonal blocks (registers; l_kk is stored as its reciprocal)
+        for (int t = tid; t < ne; t += NTHR) {
+            const int e = G::idx(2 * t, s);
+            const float* Dp = Dm + (size_t)e * DD;
+            float a[LSZ];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) a[i * (i + 1) / 2 + j] = Dp[i * D + j];
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const float rk = __builtin_amdgcn_rsqf(a[k * (k + 1) / 2 + k]);
+                a[k * (k + 1) / 2 + k] = rk;
+#pragma unroll
+                for (int i = k + 1; i < D; ++i) a[i * (i + 1) / 2 + k] *= rk;
+#pragma unroll
+                for (int j = k + 1; j < D; ++j)
+#pragma unroll
+                    for (int i = j; i < D; ++i) a[i * (i + 1) / 2 + j] = __builtin_fmaf(-a[i * (i + 1) / 2 + k], a[j * (j + 1) / 2 + k], a[i * (i + 1) / 2 + j]);
+            }
+            float* L = Lp + (size_t)e * LSZ;
+#pragma unroll
+            for (int i = 0; i < LSZ; ++i) L[i] = a[i];
+        }
+        __syncthreads();
+        // ---- P2: forward substitutions, one lane per right-hand-side column
+        for (int task = tid; task < ne * (2 * D + 1); task += NTHR) {
+            const int t = task / (2 * D + 1), c = task - t * (2 * D + 1), p = 2 * t, e = G::idx(p, s);
+            float* v;
+            int stride = 1;
+            if (c < D) {
+                if (p == 0) continue;
+                v = G::coup(Dm, Cm, s, p - 1) + c; stride = D;          // column c of A[e][a]
+            } else if (c < 2 * D) {
+                if (p + 1 >= nl) continue;
+                v = G::coup(Dm, Cm, s, p) + (c - D) * D;                // row c - D of A[b][e] = column of A[e][b]
+            } else v = rhs + (size_t)e * D;
+            const float* L = Lp + (size_t)e * LSZ;
+            float y[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) y[i] = v[i * stride];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                float acc = y[i];
+#pragma unroll
+                for (int j = 0; j < i; ++j) acc = __builtin_fmaf(-L[i * (i + 1) / 2 + j], y[j], acc);
+                y[i] = acc * L[i * (i + 1) / 2 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) v[i * stride] = y[i];
+        }
+        __syncthreads();
+        // ---- P3: Schur complements onto the kept blocks and the next level's couplings
+        for (int task = tid; task < nk * (LSZ + D); task += NTHR) {
+            const int u = task / (LSZ + D), r = task - u * (LSZ + D), q = 2 * u + 1, kb = G::idx(q, s);
+            const float* Y1 = G::coup(Dm, Cm, s, q - 1);                 // Y_hi^T of the eliminated block below: [i][k]
+            const bool up = q + 1 < nl;
+            const float* Y2 = up ? G::coup(Dm, Cm, s, q) : Y1;          // Y_lo of the eliminated block above: [k][j]
+            float acc = 0.f;
+            if (r < LSZ) {
+                int i = (int)((__builtin_amdgcn_sqrtf(8.0f * (float)r + 1.0f) - 1.0f) * 0.5f);
+                if ((i + 1) * (i + 2) / 2 <= r) ++i;
+                if (i * (i + 1) / 2 > r) --i;
+                const int j = r - i * (i + 1) / 2;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc = __builtin_fmaf(Y1[i * D + k], Y1[j * D + k], acc);
+                if (up) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) acc = __builtin_fmaf(Y2[k * D + i], Y2[k * D + j], acc);
+                }
+                Dm[(size_t)kb * DD + i * D + j] -= acc;
+            } else {
+                const int i = r - LSZ;
+                const float* w1 = rhs + (size_t)G::idx(q - 1, s) * D;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc = __builtin_fmaf(Y1[i * D + k], w1[k], acc);
+                if (up) {
+                    const float* w2 = rhs + (size_t)G::idx(q + 1, s) * D;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) acc = __builtin_fmaf(Y2[k * D + i], w2[k], acc);
+                }
+                rhs[(size_t)kb * D + i] -= acc;
+            }
+        }
+        // eliminated positions p = 2 t, t >= 1, with a neighbour on both sides: A[p+1][p-1] = -Y_hi^T Y_lo -> Dm[e]
+        const int nc = (nl - 1) >> 1;   // p = 2, 4, ... with p + 1 < nl
+        for (int task = tid; task < nc * DD; task += NTHR) {
+            const int t = task / DD + 1, r = task - (t - 1) * DD, i = r / D, j = r - i * D, p = 2 * t;
+            const float* Yh = G::coup(Dm, Cm, s, p);
+            const float* Yl = G::coup(Dm, Cm, s, p - 1);
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc = __builtin_fmaf(Yh[i * D + k], Yl[k * D + j], acc);
+            Dm[(size_t)G::idx(p, s) * DD + r] = -acc;
+        }
+        __syncthreads();
+    }
+    // ---- substitution, deepest level first
+    for (int lev = nlev - 1; lev >= 0; --lev) {
+        const int s = 1 << lev, nl = n >> lev, ne = (nl + 1) >> 1;
+        for (int task = tid; task < ne * D; task += NTHR) {
+            const int t = task / D, k = task - t * D, p = 2 * t, e = G::idx(p, s);
+            float acc = rhs[(size_t)e * D + k];
+            if (p > 0) {
+                const float* Yl = G::coup(Dm, Cm, s, p - 1) + k * D;
+                const float* xa = rhs + (size_t)G::idx(p - 1, s) * D;
+#pragma unroll
+                for (int j = 0; j < D; ++j) acc = __builtin_fmaf(-Yl[j], xa[j], acc);
+            }
+            if (p + 1 < nl) {
+                const float* Yh = G::coup(Dm, Cm, s, p) + k;
+                const float* xb = rhs + (size_t)G::idx(p + 1, s) * D;
+#pragma unroll
+                for (int i = 0; i < D; ++i) acc = __builtin_fmaf(-Yh[i * D], xb[i], acc);
+            }
+            rhs[(size_t)e * D + k] = acc;   // (every lane reads only its own component of w_e: in place)
+        }
+        __syncthreads();
+        for (int t = tid; t < ne; t += NTHR) {
+            const int e = G::idx(2 * t, s);
+            const float* L = Lp + (size_t)e * LSZ;
+            float* xe = rhs + (size_t)e * D;
+            float x[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) x[i] = xe[i];
+#pragma unroll
+            for (int k = D - 1; k >= 0; --k) {
+                float acc = x[k];
+#pragma unroll
+                for (int i = k + 1; i < D; ++i) acc = __builtin_fmaf(-L[i * (i + 1) / 2 + k], x[i], acc);
+                x[k] = acc * L[k * (k + 1) / 2 + k];
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) xe[i] = x[i];
+        }
+        __syncthreads();
+    }
 }
 
 template <int QD, int DIM, int ROBOT>
 __global__ __launch_bounds__(kGpmpThreads, 1) void gpmp_lm_kernel(const GpmpArgs a) {
-    constexpr int D = 2 * QD, NT = QD * (QD + 1) / 2, MSZ = NT + QD + 1, BW = 2 * D, NTHR = kGpmpThreads;
+    constexpr int D = 2 * QD, DD = D * D, LSZ = D * (D + 1) / 2, NT = QD * (QD + 1) / 2, MSZ = NT + QD + 1, NTHR = kGpmpThreads;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const mpdx_guide_params& gp = a.gp;
     const int tid = threadIdx.x, b = blockIdx.x, H = a.H;
@@ -198,10 +368,13 @@ __global__ __launch_bounds__(kGpmpThreads, 1) void gpmp_lm_kernel(const GpmpArgs
     float* sx = sm;                                  // [H][D] linearisation point
     float* sc = sx + H * D;                          // [H][D] candidate
     float* sM = sc + H * D;                          // [2][N][MSZ] per-point normal-equation terms
-    float* band = sM + 2 * N * MSZ;                  // [NR][BW]: band[r][c] = A[r][r - c]
-    float* rhs = band + (size_t)NR * BW;             // [NR]
+    const size_t n_terms = (size_t)2 * N * MSZ, n_pool = (size_t)n * LSZ;
+    float* Dm = sM + (n_terms > n_pool ? n_terms : n_pool);   // [n][D][D] diagonal blocks (lower triangles); the Cholesky pool of the solve overlays sM
+    float* Cm = Dm + (size_t)n * DD;                 // [n][D][D] Cm[i] = A[i+1][i]
+    float* rhs = Cm + (size_t)n * DD;                // [NR]
     float* red = rhs + NR;                           // [64] reduction scratch
-    float* sprim = red + 64;
+    int* ps = (int*)(red + 64);                      // [H + 1] first interpolation point of every support segment
+    float* sprim = (float*)(ps + H + 2);
     for (int i = tid; i < gp.n_prim_floats; i += NTHR) sprim[i] = gp.prims[i];
     const size_t base = (size_t)b * H * D;
     for (int i = tid; i < H * D; i += NTHR) {
@@ -211,6 +384,13 @@ __global__ __launch_bounds__(kGpmpThreads, 1) void gpmp_lm_kernel(const GpmpArgs
         sc[i] = (h > 0 && h < H - 1) ? xv + a.delta[base + i] : xv;
     }
     float F_cur = a.state[(size_t)b * 4 + 0], lam = a.state[(size_t)b * 4 + 1], n_acc = a.state[(size_t)b * 4 + 2];
+#ifdef MPDX_GPMP_STAMPS   // dev probe (tools/gpmp_phase_probe.py): s_memtime at the phase boundaries, written over the (unused) delta rows 0 / H-1 of trajectory 0
+    long long stamp[6];
+    stamp[0] = __builtin_amdgcn_s_memtime();
+#define GPMP_STAMP(i) stamp[i] = __builtin_amdgcn_s_memtime()
+#else
+#define GPMP_STAMP(i)
+#endif
     if (lam < 0.f) return;   // converged earlier (marked by a negative lambda): x is final, delta is zero - nothing left to do
     __syncthreads();
 
@@ -302,21 +482,29 @@ __global__ __launch_bounds__(kGpmpThreads, 1) void gpmp_lm_kernel(const GpmpArgs
         return;
     }
 
-    // ---- assemble the banded normal equations (every structural entry is written once; the rest of the band is zero)
-    for (int i = tid; i < NR * BW; i += NTHR) band[i] = 0.f;
+    GPMP_STAMP(1);
+    // ---- assemble the block-tridiagonal normal equations (every structural entry is written once; the rest is zero)
+    for (int i = tid; i < 2 * n * DD; i += NTHR) Dm[i] = 0.f;
+    // ps[h] = first point whose lower support is >= h (the points of segment [h, h + 1) are ps[h] .. ps[h + 1] - 1): the same float
+    // expression as point_w, so the table and the weights agree to the bit
+    for (int h = tid; h <= H; h += NTHR) {
+        int i = h;
+        if (gp.interpolate && scale > 0.f) {
+            i = (int)((float)h / scale);
+            if (i > N) i = N;
+            auto lo = [&](int k) { int v = (int)(scale * (float)k); return v > H - 1 ? H - 1 : v; };
+            while (i > 0 && lo(i - 1) >= h) --i;
+            while (i < N && lo(i) < h) ++i;
+        }
+        ps[h] = h >= H ? N : i;
+    }
     __syncthreads();
     constexpr int T0 = NT, T1 = T0 + QD, T2 = T1 + QD, T3 = T2 + QD, T4 = T3 + QD * QD, T5 = T4 + 3 * QD;
     for (int task = tid; task < n * T5; task += NTHR) {
         const int bi = task / T5, e = task - bi * T5;   // bi: free block (support h = bi + 1)
         const int h = bi + 1;
-        // points that touch support h: those with i0 in {h-1, h}
-        int plo = 0, phi = N - 1;
-        if (gp.interpolate && scale > 0.f) {
-            plo = (int)((float)(h - 1) / scale) - 1;
-            phi = (int)((float)(h + 1) / scale) + 1;
-            if (plo < 0) plo = 0;
-            if (phi > N - 1) phi = N - 1;
-        } else { plo = h; phi = h; }
+        // points that touch support h: those whose lower support is h - 1 or h
+        const int plo = ps[h - 1], phi = ps[h + 1] - 1;
         auto point_w = [&](int i, int& i0, int& i1, float& l0, float& l1) {
             i0 = i; i1 = i; l0 = 1.f; l1 = 0.f;
             if (gp.interpolate) {
@@ -344,10 +532,10 @@ __global__ __launch_bounds__(kGpmpThreads, 1) void gpmp_lm_kernel(const GpmpArgs
             }
             float val = s_ob * acc + (r == c ? s_gp * 2.0f * qa : 0.f);
             if (r == c) val *= (1.0f + lam);
-            band[(size_t)(bi * D + r) * BW + (r - c)] = val;
+            Dm[(size_t)bi * DD + r * D + c] = val;
         } else if (e < T1) {     // vel-vel diagonal (prior only: Q^-1 + Phi^T Q^-1 Phi = diag(24/dt^3, 8/dt))
             const int j = e - T0;
-            band[(size_t)(bi * D + QD + j) * BW] = s_gp * 2.0f * qc * (1.0f + lam);
+            Dm[(size_t)bi * DD + (QD + j) * (D + 1)] = s_gp * 2.0f * qc * (1.0f + lam);
         } else if (e < T3) {     // right-hand side = -gradient
             const bool vel = e >= T2;
             const int j = vel ? e - T2 : e - T1;
@@ -379,53 +567,20 @@ __global__ __launch_bounds__(kGpmpThreads, 1) void gpmp_lm_kernel(const GpmpArgs
                     point_w(i, i0, i1, l0, l1);
                     if (i0 == h && i1 == h + 1) acc += l0 * l1 * msum(i, tri);
                 }
-                band[(size_t)((bi + 1) * D + r) * BW + (D + r - c)] = s_ob * acc + (r == c ? -s_gp * qa : 0.f);
+                Cm[(size_t)bi * DD + r * D + c] = s_ob * acc + (r == c ? -s_gp * qa : 0.f);
             } else {             // -Q^-1 Phi = [[-12/dt^3, -6/dt^2], [6/dt^2, 2/dt]] per joint
                 const int k = (e - T4) / QD, j = (e - T4) - k * QD;
-                if (k == 0) band[(size_t)((bi + 1) * D + j) * BW + (D + j - (QD + j))] = s_gp * (-(qa * dt + qb));            // (pos_j of h+1, vel_j of h)
-                else if (k == 1) band[(size_t)((bi + 1) * D + QD + j) * BW + (D + QD + j - j)] = s_gp * (-qb);                 // (vel_j of h+1, pos_j of h)
-                else band[(size_t)((bi + 1) * D + QD + j) * BW + (D + QD + j - (QD + j))] = s_gp * (-(qb * dt + qc));           // (vel_j of h+1, vel_j of h)
+                if (k == 0) Cm[(size_t)bi * DD + j * D + (QD + j)] = s_gp * (-(qa * dt + qb));            // (pos_j of h+1, vel_j of h)
+                else if (k == 1) Cm[(size_t)bi * DD + (QD + j) * D + j] = s_gp * (-qb);                 // (vel_j of h+1, pos_j of h)
+                else Cm[(size_t)bi * DD + (QD + j) * D + (QD + j)] = s_gp * (-(qb * dt + qc));           // (vel_j of h+1, vel_j of h)
             }
         }
     }
     __syncthreads();
 
-    // ---- banded LDL^T with the forward substitution folded in (the right-hand side is one more row of every column update)
-    // column k: for 1 <= j <= i <= m:  A[k+i][k+j] -= A[k+i][k] A[k+j][k] / D_k ;  b[k+i] -= A[k+i][k] b[k] / D_k
-    // thread = (i, chunk of j): i in [1, BW-1], 4 j per chunk.  Rows beyond the next block are structurally zero: m <= 2d-1-(k mod d).
-    {
-        constexpr int JC = 4, NCH = (BW - 1 + JC - 1) / JC;
-        const int ti = tid / NCH + 1, tc = tid - (ti - 1) * NCH;   // ti in [1, ...], valid if ti <= BW-1
-        for (int k = 0; k < NR; ++k) {
-            int m = NR - 1 - k;
-            const int mb = 2 * D - 1 - (k % D);
-            if (m > mb) m = mb;
-            if (m > BW - 1) m = BW - 1;
-            if (ti <= m) {
-                const float dk = band[(size_t)k * BW];
-                const float lik = band[(size_t)(k + ti) * BW + ti] / dk;
-                if (tc == 0) rhs[k + ti] -= lik * rhs[k];
-#pragma unroll
-                for (int u = 0; u < JC; ++u) {
-                    const int j = tc * JC + u + 1;
-                    if (j <= ti) band[(size_t)(k + ti) * BW + (ti - j)] -= lik * band[(size_t)(k + j) * BW + j];
-                }
-            }
-            __syncthreads();
-        }
-        // z -> w = D^-1 z, then L^T x = w column by column from the bottom: x_i final, w_k -= L_ik x_i for the rows k above
-        for (int i = tid; i < NR; i += NTHR) rhs[i] /= band[(size_t)i * BW];
-        __syncthreads();
-        for (int i = NR - 1; i > 0; --i) {
-            const int c = tid + 1;   // column offset: k = i - c
-            if (c <= BW - 1 && i - c >= 0) {
-                const int k = i - c;
-                const float l = band[(size_t)i * BW + c];
-                if (l != 0.f) rhs[k] -= l / band[(size_t)k * BW] * rhs[i];
-            }
-            __syncthreads();
-        }
-    }
+    GPMP_STAMP(2);
+    gpmp_bcr_solve<QD>(Dm, Cm, rhs, sM, n, tid);
+    GPMP_STAMP(3);
     // ---- write back: the (possibly updated) current point, the new proposal, the state
     for (int i = tid; i < H * D; i += NTHR) {
         const int h = i / D;
@@ -433,6 +588,14 @@ __global__ __launch_bounds__(kGpmpThreads, 1) void gpmp_lm_kernel(const GpmpArgs
         a.delta[base + i] = (h > 0 && h < H - 1) ? a.step * rhs[(h - 1) * D + (i - h * D)] : 0.f;
     }
     if (tid == 0) { a.state[(size_t)b * 4 + 0] = F_cur; a.state[(size_t)b * 4 + 1] = lam; a.state[(size_t)b * 4 + 2] = n_acc; a.state[(size_t)b * 4 + 3] = F_cand; }
+#ifdef MPDX_GPMP_STAMPS
+    __syncthreads();
+    if (tid == 0 && b == 0) {
+        GPMP_STAMP(4);
+        // [linearise + judge, assemble, solve, write back] in s_memtime ticks (shader clock)
+        for (int i = 0; i < 4; ++i) a.delta[base + i] = (float)(stamp[i + 1] - stamp[i]);
+    }
+#endif
 }
 
 
