@@ -501,7 +501,7 @@ __global__ __launch_bounds__(kGpmpThreads, 1) void gpmp_lm_kernel(const GpmpArgs
     __syncthreads();
     constexpr int T0 = NT, T1 = T0 + QD, T2 = T1 + QD, T3 = T2 + QD, T4 = T3 + QD * QD, T5 = T4 + 3 * QD;
     for (int task = tid; task < n * T5; task += NTHR) {
-        const int bi = task / T5, e = task - bi * T5;   // bi: free block (support h = bi + 1)
+        const int e = task / n, bi = task - e * n;   // entry class e (slow index: a wave's lanes share the branch below), free block bi (support h = bi + 1)
         const int h = bi + 1;
         // points that touch support h: those whose lower support is h - 1 or h
         const int plo = ps[h - 1], phi = ps[h + 1] - 1;
