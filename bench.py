@@ -602,10 +602,10 @@ def training_leg(steps=40, B=32, T=25, D=4, opt=1, baseline=True):
                                          torch.cuda.current_stream().cuda_stream, cap, ms_, fl_, nm_, C.byref(n_)), "mpdx_unet_profile")
         fwd = float(sum(fl_[k] for k in range(n_.value)))
         tf = 3.0 * fwd / dt_native / 1e12
-        rec["roofline"] = {"bound": "launch latency (a chain of ~140 dependent 3-60 us kernels; fp32 MFMA for the convolutions)",
+        rec["roofline"] = {"bound": "launch latency (a chain of ~90 dependent 3-50 us kernels; fp32 MFMA for the convolutions)",
                            "algorithmic_flop_per_iteration": 3.0 * fwd, "forward_flop": fwd, "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 4),
-                           "launches_per_iteration": "see profiles/r03_train_kernel_stats.csv (rocprofv3 of this loop)"}
+                           "launches_per_iteration": "see profiles/r04_train_kernel_stats.csv (rocprofv3 of this loop)"}
     except Exception as e:   # the record must survive a failing helper
         rec["roofline"] = {"error": f"{type(e).__name__}: {e}"}
     if not baseline:

@@ -2,6 +2,7 @@
 //
 // gfx950 only.  No CUDA shims, no dual paths.  All device memory is caller-owned; nothing here synchronises.
 #include "host.hpp"
+#include "loss.hpp"
 
 namespace mpdx {
 
@@ -200,29 +201,7 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const float* x0, const fl
 __global__ __launch_bounds__(1024) void weighted_loss_kernel(const float* pred, const float* targ, const float* weights, const float* hs,
                                                              const float* hg, int l1, float* out, int B, int H, int D) {
     __shared__ double part[16];
-    const size_t n = (size_t)B * H * D;
-    double acc = 0.0;
-#pragma unroll 4
-    for (unsigned i = threadIdx.x; i < (unsigned)n; i += 1024u) {   // (32-bit index arithmetic; n = B * H * D is far below 2^32 here)
-        const unsigned d = i % (unsigned)D, p = i / (unsigned)D;
-        const unsigned l = p % (unsigned)H, b = p / (unsigned)H;
-        float v = pred[i];
-        if (hs && l == 0) v = hs[b * D + d];
-        if (hg && l == (unsigned)(H - 1)) v = hg[b * D + d];
-        const float e = __fsub_rn(v, targ[i]);
-        float q = l1 ? fabsf(e) : __fmul_rn(e, e);
-        if (weights) q = __fmul_rn(q, weights[(size_t)l * D + d]);
-        acc += (double)q;
-    }
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double tot = 0.0;
-        for (int k = 0; k < 16; ++k) tot += part[k];
-        out[0] = (float)(tot / (double)n);
-    }
+    weighted_loss_body(pred, targ, weights, hs, hg, l1, out, B, H, D, part);
 }
 
 // standard-normal generator (Philox4x32-10 + Box-Muller, conv_block.hpp): 4 normals per counter.

@@ -28,6 +28,7 @@
 #pragma once
 #include "conv_block.hpp"
 #include "train_types.hpp"
+#include "loss.hpp"
 
 namespace mpdx {
 
@@ -471,6 +472,12 @@ struct TimeTrainArgs {
     int row, nblk;
     unsigned long long woff[40], boff[40];
     int cout[40], toff[40];
+    // q_sample (diffusion_model_base.py:320-330) + apply_hard_conditioning (:335) of the same sample, and the pass's zero words: this is the
+    // first launch of a training pass, and both are per-sample work with no dependence on the time MLP (round 4: were a memset + a launch)
+    const float* x0; const float* noise; const float* sqrt_ac; const float* sqrt_1mac; const float* hs; const float* hg;
+    float* xn;                  // [B][H][D]
+    float* zero_words;          // block 0 clears n_zero floats (the dgrad convolutions' zero bias + the time backward's ticket)
+    int H, D, T, n_zero;
 };
 
 // one block of 512 threads per sample; every stage spreads its dot products over all threads it can use and keeps its loads in flight
@@ -481,6 +488,22 @@ __global__ __launch_bounds__(512) void time_train_fwd_kernel(const TimeTrainArgs
     const int b = blockIdx.x, tid = threadIdx.x;
     if (tid < a.nblk) s_toff[tid] = a.toff[tid];
     if (tid == 0) s_toff[a.nblk] = a.row;
+    if (a.xn) {   // x_t = sqrt(acp[t_b]) x0 + sqrt(1 - acp[t_b]) noise, hard conditions: q_sample_kernel's arithmetic (mpdx.hip)
+        long long tb = a.t[b];
+        tb = tb < 0 ? 0 : (tb >= a.T ? a.T - 1 : tb);
+        const float ca = a.sqrt_ac[tb], cb = a.sqrt_1mac[tb];
+        const int HD = a.H * a.D;
+        for (int i = tid; i < HD; i += 512) {
+            const int l = i / a.D, d = i - l * a.D;
+            const size_t g = (size_t)b * HD + i;
+            float r = __fadd_rn(__fmul_rn(ca, a.x0[g]), __fmul_rn(cb, a.noise[g]));
+            if (a.hs && l == 0) r = a.hs[b * a.D + d];
+            if (a.hg && l == a.H - 1) r = a.hg[b * a.D + d];
+            a.xn[g] = r;
+        }
+    }
+    if (b == 0 && a.zero_words)
+        for (int i = tid; i < a.n_zero; i += 512) a.zero_words[i] = 0.f;
     if (tid < 16) {
         const float arg = (float)a.t[b] * a.freqs[tid];
         emb[tid] = sinf(arg);
@@ -720,6 +743,41 @@ __global__ __launch_bounds__(256) void final_dgrad_kernel(const float* __restric
     }
 }
 
+// The loss value, its gradient and the gradient's way back through final_conv[1] in ONE launch (round 4: were three).  Blocks [0, gridDim.x - 1):
+// gH[r][c] = sum_d dE[r][d] W[d][c] with dE computed on the fly (loss_grad_kernel's arithmetic; the lane with c == d also stores dE[r][d], which
+// the weight / bias gradients of final_conv[1] read) - needs C >= D.  The LAST block: the loss value, weighted_loss_kernel's summation order.
+__global__ __launch_bounds__(1024) void train_loss_kernel(const float* __restrict__ pred, const float* __restrict__ targ, const float* __restrict__ weights_hd,
+                                                          const float* __restrict__ hs, const float* __restrict__ hg, int l1, float scale, float* __restrict__ dE,
+                                                          const float* __restrict__ w, float* __restrict__ gH, int B, int H, int D, int C, float* __restrict__ loss_out) {
+    __shared__ double part[16];
+    const unsigned nb = gridDim.x - 1;
+    if (blockIdx.x == nb) {
+        weighted_loss_body(pred, targ, weights_hd, hs, hg, l1, loss_out, B, H, D, part);
+        return;
+    }
+    const size_t rows = (size_t)B * H, total = rows * C;
+    const float inv = scale / (float)(rows * D);
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < total; i += (size_t)nb * 1024) {
+        const int c = (int)(i % C);
+        const size_t r = i / C;
+        const int h = (int)(r % H);
+        const bool hard = (hs && h == 0) || (hg && h == H - 1);
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) {
+            float g = 0.f;
+            if (!hard) {
+                const float e = pred[r * D + d] - targ[r * D + d];
+                g = l1 ? (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) : 2.0f * e;
+                if (weights_hd) g *= weights_hd[h * D + d];
+                g *= inv;
+            }
+            if (c == d) dE[r * D + d] = g;
+            s = fmaf(g, w[(size_t)d * C + c], s);
+        }
+        gH[i] = s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Optimiser.  sumsq_kernel + adam_kernel = torch.nn.utils.clip_grad_norm_(params, max_norm) (trainer.py:268-272) followed by
 // torch.optim.Adam.step() with the defaults the reference uses (betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad):
@@ -747,9 +805,23 @@ __global__ __launch_bounds__(256) void norm_finish_kernel(const float* __restric
         norm[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (nrm + 1e-6f)) : 1.0f;
     }
 }
+// `part` (n_part sumsq_kernel partial sums; null: no clipping): every block adds them up in norm_finish_kernel's order (same bits) instead of
+// waiting for a one-block launch in between; block 0 publishes norm[0] = |g|, norm[1] = the clip coefficient.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
-                                                   float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, const float* __restrict__ clip) {
-    const float coef = clip ? clip[1] : 1.0f;
+                                                   float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, const float* __restrict__ part, int n_part,
+                                                   float max_norm, float* __restrict__ norm) {
+    float coef = 1.0f;
+    if (part) {
+        __shared__ float red[4];
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n_part; i += 256) s += part[i];
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        const float nrm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        coef = max_norm > 0.f ? fminf(1.0f, max_norm / (nrm + 1e-6f)) : 1.0f;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { norm[0] = nrm; norm[1] = coef; }
+    }
     const float step = lr / bc1;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float gi = g[i] * coef;

@@ -372,13 +372,9 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
 
     // ---- forward, every layer's output (and GroupNorm input) kept
     // (no memset of the gradient buffers: the first writer of each in the backward pass stores, the later ones add - `first_write`)
-    HIP_TRY(hipMemsetAsync(ws + w.zeros, 0, (1024 + 4) * sizeof(float), st));   // the zero bias of the dgrad convolutions + the time backward's ticket
-    {
-        const size_t ne = (size_t)B * H * D;
-        (void)ne;
-        if (int rc = mpdx_q_sample(x_start, noise, t_dev, sqrt_alphas_cumprod_dev, sqrt_one_minus_alphas_cumprod_dev, hard_start, hard_goal, xn, B, H, D, T, st))
-            return rc;
-    }
+    // (q_sample with its hard conditions and the pass's zero words - the zero bias of the dgrad convolutions + the time backward's ticket - are
+    //  per-sample side jobs of the first launch, time_train_fwd_kernel: round 3 spent a memset and a launch on them)
+    if (!sqrt_alphas_cumprod_dev || !sqrt_one_minus_alphas_cumprod_dev) return fail(MPDX_E_INVALID, "schedule tables missing");
     TimeTrainArgs ta;
     memset(&ta, 0, sizeof(ta));
     TimeBwdArgs tb;
@@ -395,6 +391,9 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             ta.woff[i] = u->params[u->tt_w[i]].foff; ta.boff[i] = u->params[u->tt_b[i]].foff;
             ta.cout[i] = u->tt_cout[i]; ta.toff[i] = u->tt_off[i];
         }
+        ta.x0 = x_start; ta.noise = noise; ta.sqrt_ac = sqrt_alphas_cumprod_dev; ta.sqrt_1mac = sqrt_one_minus_alphas_cumprod_dev;
+        ta.hs = hard_start; ta.hg = hard_goal; ta.xn = xn; ta.zero_words = ws + w.zeros; ta.n_zero = 1024 + 4;
+        ta.H = H; ta.D = D; ta.T = T;
         hipLaunchKernelGGL(time_train_fwd_kernel, dim3(B), dim3(512), 0, st, ta);
         tb.flat = flat; tb.grad = grads_flat; tb.dT = ws + w.dT; tb.emb = ta.emb; tb.h1 = ta.h1; tb.temb = ta.temb; tb.tm = ta.tm; tb.h1m = ta.h1m;
         tb.dtm = ws + w.dtm; tb.dh1 = ws + w.dh1; tb.ticket = (unsigned*)(ws + w.ticket);
@@ -464,10 +463,12 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         fa.B = B; fa.H = H; fa.D = D; fa.C = c.unet_input_dim;
         if (!eps_done) launch_final_step(fa, st);
         const float* target = predict_epsilon ? noise : x_start;
-        if (int rc = mpdx_weighted_loss((const float*)eps, target, weights_hd, hard_start, hard_goal, l1, loss_out, B, H, D, st)) return rc;
-        const size_t ne = (size_t)B * H * D;
-        hipLaunchKernelGGL(loss_grad_kernel, dim3((unsigned)std::min<size_t>((ne + 255) / 256, 1024)), dim3(256), 0, st, (const float*)eps, target, weights_hd,
-                           hard_start ? 1 : 0, hard_goal ? 1 : 0, l1, loss_scale, dE, B, H, D);
+        // loss value + dE + the gradient wrt final_conv[0]'s output (back through final_conv[1]) in one launch
+        if (fa.C < D) return fail(MPDX_E_INVALID, "training: unet_input_dim %d < state_dim %d", fa.C, D);
+        const size_t tot = (size_t)B * H * fa.C;
+        hipLaunchKernelGGL(train_loss_kernel, dim3((unsigned)std::min<size_t>((tot + 1023) / 1024, 1024) + 1), dim3(1024), 0, st, (const float*)eps, target, weights_hd,
+                           hard_start, hard_goal, l1, loss_scale, dE, flat + u->params[u->pidx.at("final_conv.1.weight")].foff, ws + w.grad0 + (size_t)(n - 1) * w.slotB,
+                           B, H, D, fa.C, loss_out);
     }
     HIP_TRY(hipGetLastError());
 
@@ -482,8 +483,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         const int C = c.unet_input_dim;
         const int wi = u->pidx.at("final_conv.1.weight"), bi = u->pidx.at("final_conv.1.bias");
         const size_t rows = (size_t)B * H;
-        hipLaunchKernelGGL(final_dgrad_kernel, dim3((unsigned)std::min<size_t>((rows * C + 255) / 256, 2048)), dim3(256), 0, st, (const float*)dE,
-                           flat + u->params[wi].foff, grd(n - 1), rows, D, C);
+        // (grd(n - 1) = dE W was written by train_loss_kernel)
         WgradJob fj;
         if (int rc = make_wgrad(dE, H, D, 0, D, out(n - 1), H, C, 0, C, 1, 0, 1, B, part, gflat(wi), C, 0, &df, fj)) return rc;
         const bool fb = attach_bias(fj, &df, gflat(bi), false);
@@ -501,7 +501,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     static const bool gnfuse_off = getenv("MPDX_TRAIN_GN_FUSE") && atoi(getenv("MPDX_TRAIN_GN_FUSE")) == 0;   // dev A/B switch
     std::vector<char> du_ready(n, 0);   // grd(j) already holds the gradient wrt layer j's CONVOLUTION output
     std::vector<char> written(n, 0);    // grd(j) has been written in this pass (launches execute in the order they are enqueued here)
-    written[n - 1] = 1;                 // final_dgrad_kernel above
+    written[n - 1] = 1;                 // train_loss_kernel above
     auto first_write = [&](int j) { const bool f = !written[j]; written[j] = 1; return f; };
     for (int i = n - 1; i >= 0; --i) {
         const Layer& l = u->layers[i];
@@ -651,15 +651,16 @@ int mpdx_adam_step(float* params, const float* grads, float* exp_avg, float* exp
     if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch || n == 0 || step < 1) return fail(MPDX_E_INVALID, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     const float* clip = nullptr;
+    int n_part = 0;
     if (max_norm > 0.f) {
         const int nb = (int)std::min<size_t>((n + 255) / 256, 1024);
         hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, grads, n, scratch + 8);
-        hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)(scratch + 8), nb, max_norm, scratch);
-        clip = scratch;
+        clip = scratch + 8;   // the partial sums; adam_kernel finishes the norm itself (norm_finish_kernel's order) and publishes scratch[0..1]
+        n_part = nb;
     }
     const float bc1 = 1.0f - (float)pow((double)beta1, step), bc2 = 1.0f - (float)pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, lr,
-                       beta1, beta2, eps, bc1, sqrtf(bc2), clip);
+                       beta1, beta2, eps, bc1, sqrtf(bc2), clip, n_part, max_norm, scratch);
     HIP_TRY(hipGetLastError());
     return 0;
 }
