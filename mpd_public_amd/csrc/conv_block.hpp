@@ -95,6 +95,12 @@ struct ConvArgs {
     // padding, so the k-loop and the staging are untouched: only the epilogues mask (GroupNorm statistics over the valid rows,
     // zeros stored beyond them).  Lv_out == L_out (or 0): nothing masked.  Honoured by EPI_GN_MISH_GEN and EPI_BIAS.
     int Lv_out;
+    // training, EPI_BIAS input-gradient convolutions of the resampling layers (round 4: were a zero_stuff_kernel / acc_slice_kernel launch each):
+    //   stuff: src1 is [B][L_in / 2][c1] and is read ZERO-STUFFED (row li of the window = source row li / 2 for even li, zero for odd li): the
+    //          input gradient of a stride-2 convolution is a stride-1 convolution of the stuffed output gradient;
+    //   decim: only the even output rows are stored, at row l / 2 of a [B][L_out / 2][.] destination: the input gradient of ConvTranspose1d(4, 2, 1)
+    //          is every second output of a stride-1 5-tap convolution of the output gradient.
+    int stuff, decim;
 };
 
 // wave64 all-reduce (sum) with DPP row operations + 4 readlanes instead of a 6-step ds_bpermute butterfly:
@@ -347,6 +353,7 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                 ok[u] = in && b < a.B && c < cin;
                 cc[u] = c < cin ? c : 0;
                 pos[u] = (size_t)(b < a.B ? b : a.B - 1) * L_in + li;
+                if (a.stuff) { ok[u] = ok[u] && !(li & 1); pos[u] = (size_t)(b < a.B ? b : a.B - 1) * (L_in >> 1) + (li >> 1); }
             }
 #pragma unroll
             for (int u = 0; u < SB; ++u) {
@@ -744,8 +751,9 @@ __device__ __forceinline__ void conv_block_body(const ConvArgs& a, const int blo
                 if (co >= a.c_split) { d = a.dst2; cc = co - a.c_split; ld = a.C_out - a.c_split; }
                 else ld = a.c_split;
             }
+            if (a.decim && (l & 1)) continue;
             if (b < a.B && d) {
-                f32x4* q = (f32x4*)(d + ((size_t)b * L_out + l) * ld + cc);
+                f32x4* q = a.decim ? (f32x4*)(d + ((size_t)b * (L_out >> 1) + (l >> 1)) * ld + cc) : (f32x4*)(d + ((size_t)b * L_out + l) * ld + cc);
                 if (a.accum & (d == a.dst2 ? 2 : 1)) v += *q;
                 if (a.Lv_out > 0 && l >= a.Lv_out) v = (f32x4){0.f, 0.f, 0.f, 0.f};   // rows beyond the valid horizon of the container stay zero
                 *q = v;

@@ -571,7 +571,9 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         if (t.need_dgrad) {
             const Layer& dgl = t.dg;
             const float* din = dy;
-            if (l.mode == CONV_DOWN) {
+            static const bool resamp_fold_off = getenv("MPDX_TRAIN_RESAMPLE_FOLD") && atoi(getenv("MPDX_TRAIN_RESAMPLE_FOLD")) == 0;   // dev A/B switch
+            const bool fold = !resamp_fold_off;
+            if (l.mode == CONV_DOWN && !fold) {
                 const size_t tot = (size_t)B * 2 * l.L_out * l.cout;
                 hipLaunchKernelGGL(zero_stuff_kernel, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, st, dy, ws + w.zst, B, l.L_out, l.cout);
                 din = ws + w.zst;
@@ -580,9 +582,13 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             memset(&a, 0, sizeof(a));
             if (int rc = fill_geom(dgl, B, a)) return rc;
             a.src1 = din;
+            if (l.mode == CONV_DOWN && fold) a.stuff = 1;   // the staging reads dy zero-stuffed (ConvArgs::stuff)
             a.wp = packedT + t.dgrad_woff;
             a.bias = ws + w.zeros;
-            if (l.mode == CONV_UPT) a.dst = ws + w.tmpX;   // full-resolution result, every second position is the gradient
+            if (l.mode == CONV_UPT && fold && t.src1_l >= 0) {   // even output rows straight into the gradient of the layer's input (ConvArgs::decim)
+                a.dst = grd(t.src1_l); a.decim = 1;
+                if (!first_write(t.src1_l)) a.accum |= 1;
+            } else if (l.mode == CONV_UPT) a.dst = ws + w.tmpX;   // full-resolution result, every second position is the gradient
             else {   // added straight into the gradient buffer(s) of the layer's input(s)
                 a.dst = t.src1_l >= 0 ? grd(t.src1_l) : nullptr;
                 if (t.src1_l >= 0 && !first_write(t.src1_l)) a.accum |= 1;
@@ -627,7 +633,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
                 else rc = launch_bwd_pair<1>(dgl, a, B, jobs, njobs, st);
                 if (rc) return rc;
             } else if (int rc = launch_layer(dgl, a, B, st)) return rc;
-            if (l.mode == CONV_UPT && t.src1_l >= 0) launch_acc(grd(t.src1_l), ws + w.tmpX, B, l.L_in, l.c1, dgl.L_out, Cin, 0, 2, first_write(t.src1_l) ? 1 : 0, st);
+            if (l.mode == CONV_UPT && t.src1_l >= 0 && !a.decim) launch_acc(grd(t.src1_l), ws + w.tmpX, B, l.L_in, l.c1, dgl.L_out, Cin, 0, 2, first_write(t.src1_l) ? 1 : 0, st);
         }
     }
     if (df.red.n) {
