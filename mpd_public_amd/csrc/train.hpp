@@ -600,24 +600,58 @@ __device__ __forceinline__ void time_bwd_all_body(const TimeBwdArgs& a, const in
     __shared__ unsigned s_woff[40];
     __shared__ unsigned s_ticket;
     const int tid = threadIdx.x;
+#ifdef MPDX_TB_STAMPS   // dev probe: s_memtime differences printed by thread 0 of a few blocks
+    long long tbs[8]; int tbn = 0;
+#define TB_STAMP() do { tbs[tbn++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TB_DUMP(tag) do { if (tid == 0) printf("time_bwd %s blk %d: %lld %lld %lld %lld %lld %lld\n", tag, block_id, tbs[1]-tbs[0], tbs[2]-tbs[0], tbs[3]-tbs[0], tbs[4]-tbs[0], tbs[5]-tbs[0], tbs[6]-tbs[0]); } while (0)
+    for (int i = 0; i < 8; ++i) tbs[i] = 0;
+    TB_STAMP();
+#else
+#define TB_STAMP()
+#define TB_DUMP(tag)
+#endif
     if (tid < a.nblk) { s_toff[tid] = a.toff[tid]; s_woff[tid] = (unsigned)a.woff[tid]; }
     if (tid == 0) s_toff[a.nblk] = a.row;
     __syncthreads();
     auto block_of = [&](int r) { int blk = 0; while (blk + 1 < a.nblk && r >= s_toff[blk + 1]) ++blk; return blk; };   // toff ascending
     if (block_id >= a.B) {   // ---------------------------------------------- cond_mlp gradients of 32 table rows
-        const int rr = (block_id - a.B) * 32 + (tid >> 5), e = tid & 31;
-        if (rr >= a.row) return;
-        const int blk = block_of(rr);
-        const int c = rr - s_toff[blk];
+        // dT[b][rr0 .. rr0 + 32) and mish(temb)[b][0 .. 32) of 128 samples at a time through LDS: ONE global round trip per chunk (round 3 read
+        // both straight from global memory inside the b loop, eight deep)
+        const int rr0 = (block_id - a.B) * 32, rloc = tid >> 5, e = tid & 31, rr = rr0 + rloc;
+        constexpr int CH = 128;
+        float* const dS = sh;              // [CH][32]
+        float* const tS = sh + CH * 32;    // [CH][32]
         float sw = 0.f, sb = 0.f;
+        for (int b0 = 0; b0 < a.B; b0 += CH) {
+            const int nb = a.B - b0 < CH ? a.B - b0 : CH;
+            float vd[4], vt[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {   // (unconditional loads, clamped indices)
+                const int idx = tid + k * 1024, bb = idx >> 5, c = idx & 31;
+                const int bs = b0 + (bb < nb ? bb : nb - 1), rc = rr0 + c < a.row ? rr0 + c : a.row - 1;
+                vd[k] = a.dT[(size_t)bs * a.row + rc];
+                vt[k] = a.tm[(size_t)bs * 32 + c];
+            }
+            __syncthreads();   // the previous chunk's reads are done
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { dS[tid + k * 1024] = vd[k]; tS[tid + k * 1024] = vt[k]; }
+            __syncthreads();
 #pragma unroll 8
-        for (int b = 0; b < a.B; ++b) {
-            const float d = a.dT[(size_t)b * a.row + rr];
-            sw = fmaf(d, a.tm[(size_t)b * 32 + e], sw);
-            sb += d;
+            for (int b = 0; b < nb; ++b) {
+                const float d = dS[b * 32 + rloc];
+                sw = fmaf(d, tS[b * 32 + e], sw);
+                sb += d;
+            }
         }
-        a.grad[a.woff[blk] + (size_t)c * 32 + e] = sw;
-        if (e == 0) a.grad[a.boff[blk] + c] = sb;
+        TB_STAMP();
+        if (rr < a.row) {
+            const int blk = block_of(rr);
+            const int c = rr - s_toff[blk];
+            a.grad[a.woff[blk] + (size_t)c * 32 + e] = sw;
+            if (e == 0) a.grad[a.boff[blk] + c] = sb;
+        }
+        TB_STAMP();
+        if (block_id == a.B || block_id == a.B + 30) TB_DUMP("cond");
         return;
     }
     // ------------------------------------------------------------------------------- sample b: gradient wrt temb
@@ -631,78 +665,119 @@ __device__ __forceinline__ void time_bwd_all_body(const TimeBwdArgs& a, const in
         roff[r] = s_woff[blk] + (unsigned)(r - s_toff[blk]) * 32u;
     }
     __syncthreads();
+    TB_STAMP();   // 1: staged
     {
+        // rows part, part + 32, ... in ascending order; their weight loads are issued sixteen at a time, unconditionally (clamped row): as a plain
+        // loop (even with an unroll pragma) hipcc issued one load per trip and waited for it - 75-85 k cycles for the 60 trips of a 1 920-row table
         float s = 0.f;
-#pragma unroll 8
-        for (int r = part; r < a.row; r += 32) s = fmaf(dTs[r], a.flat[roff[r] + e], s);
+        for (int r0 = part; r0 < a.row; r0 += 32 * 16) {
+            float wv[16], dv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = r0 + 32 * u, rc = r < a.row ? r : part;
+                wv[u] = a.flat[roff[rc] + e];
+                dv[u] = dTs[rc];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (r0 + 32 * u < a.row) s = fmaf(dv[u], wv[u], s);
+        }
         red[part * 32 + e] = s;
     }
     __syncthreads();
     if (part == 0) {
         float t = 0.f;
         for (int p = 0; p < 32; ++p) t += red[p * 32 + e];
-        a.dtm[(size_t)b * 32 + e] = t * mish_grad(a.temb[(size_t)b * 32 + e]);
+        // WRITE-THROUGH store (agent-scope atomic = sc1): the row is at the device's coherence point once vmcnt drains.  Round 3 made the rows visible
+        // with __threadfence() - a release fence at agent scope writes back the WHOLE L2 of the XCD (buffer_wbl2), dirty with the megabytes of
+        // gradient partials the reductions before this launch left there: 70 k cycles per sample block, 35 k more for the acquire side of the
+        // last block (s_memtime stamps, -DMPDX_TB_STAMPS): two thirds of the launch.
+        __hip_atomic_store(a.dtm + (size_t)b * 32 + e, t * mish_grad(a.temb[(size_t)b * 32 + e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __threadfence();   // this block's dtm row is visible device-wide before its ticket
-    __syncthreads();
+    TB_STAMP();
+    __syncthreads();   // every store of the row has drained (above) before the ticket is taken
     if (tid == 0) s_ticket = atomicAdd(a.ticket, 1u);
     __syncthreads();
-    if (s_ticket != (unsigned)a.B - 1u) return;
-    __threadfence();   // the last block: every other sample's dtm row is visible to the loads below
+    TB_STAMP();   // 3: ticket
+    if (s_ticket != (unsigned)a.B - 1u) { if (block_id == 0 || block_id == 77) TB_DUMP("sample"); return; }
     // ------------------------------------------------------------------------------- tail (one block): encoder.3 and encoder.1
+    // (the other samples' dtm rows are read with agent-scope atomic loads below: they bypass this XCD's L2, no acquire fence)
     float* const dtmS = sh;            // [32][32]
     float* const h1mS = sh + 1024;     // [32][128]
     float* const dh1S = sh + 5120;     // [32][128]
     float* const embS = sh + 9216;     // [32][32]
-    const int k = tid & 127, q8 = tid >> 7;     // encoder.3: this thread's column k; rows e = q8 + 8 i (dW3), samples bb = q8 + 8 i (dh1)
-    const int j = tid & 31, k0 = tid >> 5;      // encoder.1: this thread's column j; rows k = k0 + 32 i
+    // Output mapping (round 4): a thread's four outputs are CONSECUTIVE rows, so that one 16-byte LDS read feeds four FMAs and the operand shared by
+    // the four is read once per sample - 2 LDS reads per 4 FMAs instead of 8 (the loops were LDS-issue bound: 25 k cycles per chunk of 32 samples).
+    // Every output still adds its samples in ascending order: same bits.
+    const int k = tid & 127, q8 = tid >> 7;     // encoder.3: column k; rows e = 4 q8 + i (dW3), samples bb = q8 + 8 i (dh1)
+    const int j = tid & 31, k0 = tid >> 5;      // encoder.1: column j; rows kk = 4 k0 + i
     float w3g[4] = {0.f, 0.f, 0.f, 0.f}, b3g[4] = {0.f, 0.f, 0.f, 0.f}, w1g[4] = {0.f, 0.f, 0.f, 0.f}, b1g[4] = {0.f, 0.f, 0.f, 0.f};
     float w3c[32];   // W3[e][k], e = 0..31 (this thread's column)
 #pragma unroll
     for (int ee = 0; ee < 32; ++ee) w3c[ee] = a.flat[a.w3 + (size_t)ee * 128 + k];
+    TB_STAMP();   // 4: tail entered
+    // a chunk's operands are fetched while the chunk before it is worked on; samples beyond the batch are staged as ZEROS: fmaf(0, x, acc) == acc
+    // and acc + 0 == acc exactly, so the loops below run full 32 trips
+    float z0, z1, z2[4], zh[4];
+    auto fetch = [&](int b0) {
+        const int nb = a.B - b0 < 32 ? a.B - b0 : 32;   // (<= 0 behind the last chunk: everything zero, nothing loaded)
+        z0 = tid < nb * 32 ? __hip_atomic_load(a.dtm + (size_t)b0 * 32 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        z1 = tid < nb * 32 ? a.emb[(size_t)b0 * 32 + tid] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) z2[q] = tid + q * 1024 < nb * 128 ? a.h1m[(size_t)b0 * 128 + tid + q * 1024] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) zh[i] = q8 + 8 * i < nb ? a.h1[(size_t)(b0 + q8 + 8 * i) * 128 + k] : 0.f;
+    };
+    fetch(0);
     for (int b0 = 0; b0 < a.B; b0 += 32) {
         const int nb = a.B - b0 < 32 ? a.B - b0 : 32;
+        float hcur[4];
         __syncthreads();
-        for (int i = tid; i < nb * 32; i += 1024) { dtmS[i] = a.dtm[(size_t)b0 * 32 + i]; embS[i] = a.emb[(size_t)b0 * 32 + i]; }
-        for (int i = tid; i < nb * 128; i += 1024) h1mS[i] = a.h1m[(size_t)b0 * 128 + i];
-        __syncthreads();
+        dtmS[tid] = z0; embS[tid] = z1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {   // dW3[e][k] += sum_b dtemb[b][e] mish(h1[b][k]);  db3[e] += sum_b dtemb[b][e]
-            const int ee = q8 + 8 * i;
-            for (int bb = 0; bb < nb; ++bb) {
-                const float d = dtmS[bb * 32 + ee];
-                w3g[i] = fmaf(d, h1mS[bb * 128 + k], w3g[i]);
-                b3g[i] += d;
-            }
+        for (int q = 0; q < 4; ++q) h1mS[tid + q * 1024] = z2[q];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hcur[i] = zh[i];
+        __syncthreads();
+        fetch(b0 + 32);
+#pragma unroll 8
+        for (int bb = 0; bb < 32; ++bb) {   // dW3[e][k] += sum_b dtemb[b][e] mish(h1[b][k]);  db3[e] += sum_b dtemb[b][e]
+            const f32x4 d = *(const f32x4*)(dtmS + bb * 32 + 4 * q8);
+            const float h = h1mS[bb * 128 + k];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { w3g[i] = fmaf(d[i], h, w3g[i]); b3g[i] += d[i]; }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {   // dh1[b][k] = mish'(h1[b][k]) sum_e dtemb[b][e] W3[e][k]
             const int bb = q8 + 8 * i;
-            if (bb < nb) {
-                float s = 0.f;
+            const float hv = hcur[i];
+            float s = 0.f;
 #pragma unroll
-                for (int ee = 0; ee < 32; ++ee) s = fmaf(dtmS[bb * 32 + ee], w3c[ee], s);
-                dh1S[bb * 128 + k] = s * mish_grad(a.h1[(size_t)(b0 + bb) * 128 + k]);
+            for (int e4 = 0; e4 < 8; ++e4) {
+                const f32x4 d = *(const f32x4*)(dtmS + bb * 32 + 4 * e4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s = fmaf(d[u], w3c[4 * e4 + u], s);
             }
+            dh1S[bb * 128 + k] = bb < nb ? s * mish_grad(hv) : 0.f;   // (zero rows behind the batch: see above)
         }
         __syncthreads();
+#pragma unroll 8
+        for (int bb = 0; bb < 32; ++bb) {   // dW1[k][j] += sum_b dh1[b][k] emb[b][j];  db1[k] += sum_b dh1[b][k]
+            const f32x4 d = *(const f32x4*)(dh1S + bb * 128 + 4 * k0);
+            const float em = embS[bb * 32 + j];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {   // dW1[k][j] += sum_b dh1[b][k] emb[b][j];  db1[k] += sum_b dh1[b][k]
-            const int kk = k0 + 32 * i;
-            for (int bb = 0; bb < nb; ++bb) {
-                const float d = dh1S[bb * 128 + kk];
-                w1g[i] = fmaf(d, embS[bb * 32 + j], w1g[i]);
-                b1g[i] += d;
-            }
+            for (int i = 0; i < 4; ++i) { w1g[i] = fmaf(d[i], em, w1g[i]); b1g[i] += d[i]; }
         }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int ee = q8 + 8 * i, kk = k0 + 32 * i;
+        const int ee = 4 * q8 + i, kk = 4 * k0 + i;
         a.grad[a.w3 + (size_t)ee * 128 + k] = w3g[i];
         if (k == 0) a.grad[a.b3 + ee] = b3g[i];
         a.grad[a.w1 + (size_t)kk * 32 + j] = w1g[i];
         if (j == 0) a.grad[a.b1 + kk] = b1g[i];
+        if (i == 3) { TB_STAMP(); TB_STAMP(); TB_DUMP("tail"); }
     }
 }
 
@@ -762,17 +837,29 @@ __global__ __launch_bounds__(1024) void train_loss_kernel(const float* __restric
         const size_t r = i / C;
         const int h = (int)(r % H);
         const bool hard = (hs && h == 0) || (hg && h == H - 1);
+        // D <= 16 (checked on the host): the row's operands are loaded up front, unconditionally - with the loads inside a loop of runtime length
+        // every element was a dependent round trip (48 us per launch at batch 128 x D = 14)
+        float pv[16], tv[16], wv[16], ww[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            const int dc = d < D ? d : D - 1;
+            pv[d] = pred[r * D + dc]; tv[d] = targ[r * D + dc];
+            wv[d] = weights_hd ? weights_hd[h * D + dc] : 1.0f;
+            ww[d] = w[(size_t)dc * C + c];
+        }
         float s = 0.f;
-        for (int d = 0; d < D; ++d) {
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            if (d >= D) break;
             float g = 0.f;
             if (!hard) {
-                const float e = pred[r * D + d] - targ[r * D + d];
+                const float e = pv[d] - tv[d];
                 g = l1 ? (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) : 2.0f * e;
-                if (weights_hd) g *= weights_hd[h * D + d];
+                if (weights_hd) g *= wv[d];
                 g *= inv;
             }
             if (c == d) dE[r * D + d] = g;
-            s = fmaf(g, w[(size_t)d * C + c], s);
+            s = fmaf(g, ww[d], s);
         }
         gH[i] = s;
     }
