@@ -28,8 +28,13 @@ import sys; sys.path.insert(0, '$GRAFT_REPO_ROOT')
 import bench
 print(bench.planner_baseline_leg())
 " > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_train128 -- python -c "
+import sys; sys.path.insert(0, '$GRAFT_REPO_ROOT')
+import bench
+print(bench.training_leg(steps=40, B=128, D=14, baseline=False))
+" > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
-for n in cfg5 train planner; do cp $(find $O/prof_$n -name "*kernel_stats.csv" | head -1) $O/${n}_kernel_stats.csv; rm -rf $O/prof_$n; done
+for n in cfg5 train train128 planner; do cp $(find $O/prof_$n -name "*kernel_stats.csv" | head -1) $O/${n}_kernel_stats.csv; rm -rf $O/prof_$n; done
 timeout 900 python -c "
 import json, bench
 print(json.dumps({'batch32_D4': bench.training_leg(), 'batch128_D14': bench.training_leg(B=128, D=14)}, indent=1))
@@ -49,6 +54,12 @@ if [ -f build_ab/libmpdx_dev.so ]; then
 fi
 MPDX_BENCH_TABLE=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras 2>&1 >/dev/null | grep "^#" > $O/launch_table.txt
 MPDX_BENCH_TABLE=1 timeout 300 python bench.py --config cfg5 --steps 2 --warmup 1 --no-cpu-baseline --no-extras 2>&1 >/dev/null | grep "^#" > $O/launch_table_cfg5.txt
+timeout 600 python -c "
+import json, bench
+print(json.dumps(bench.planner_baseline_leg(), indent=1))
+" 2>/dev/null > $O/planner_baseline.json
+timeout 300 python tools/gpmp_phase_probe.py 2>&1 | grep "solve=\|sigma_obs" > $O/gpmp_probe.txt
+(python tools/train_enqueue_probe.py; python tools/graph_probe_train.py 32; python tools/graph_probe_train.py 128) 2>&1 | grep -v "amdgpu.ids\|Warn" > $O/train_host_vs_gpu.txt
 # multi-GPU dry run on the single-GPU rig (8 ranks share the GPU over gloo): record shape + sharding / gather / checksum code, no fabric
 timeout 1200 python bench.py --gpus 8 --steps 2 --warmup 1 > $O/bench_rig8_single_gpu.json 2> $O/bench_rig8.err; tail -1 $O/bench_rig8_single_gpu.json | cut -c1-200
 head -4 $O/cfg2_kernel_stats.csv | cut -c1-160
