@@ -575,9 +575,8 @@ def training_leg(steps=40, B=32, T=25, D=4, opt=1, baseline=True):
     hc = {0: x0[:, 0, :].contiguous(), 63: x0[:, -1, :].contiguous()}
     ts, ema = TrainStep(dm), EMA(0.995)
 
-    def native(k):
-        ts.loss_backward(x0, hc)
-        ts.adam_step(1e-4, max_norm=1.0)
+    def native(k):   # what trainer.train() runs per step with the native optimiser: TrainStep.step (one hipGraph replay from the third call on)
+        ts.step(x0, hc, 1e-4, max_norm=1.0)
         if k % 10 == 0:
             ema.update_model_average(ema_model, dm)
     for k in range(5):
@@ -589,6 +588,7 @@ def training_leg(steps=40, B=32, T=25, D=4, opt=1, baseline=True):
     torch.cuda.synchronize()
     dt_native = (time.perf_counter() - t0) / steps
     rec = {"workload": f"p_losses + backward + clip_grad_norm_ + Adam + EMA/10, batch {B} x H=64 x D={D}, T={T}, dim_mults option {opt}, fp32",
+           "launch_mode": "TrainStep.step: " + ("the iteration's launches replayed as one hipGraph (batch <= 64: host-bound; MPDX_TRAIN_GRAPH=0: eager)" if B <= 64 and os.environ.get("MPDX_TRAIN_GRAPH") != "0" else "eager launches (GPU-bound batch)"),
            "train_steps_per_s": round(1.0 / dt_native, 1), "ms_per_train_step": round(dt_native * 1e3, 3)}
     # roofline of the iteration: algorithmic FLOPs = 3 x the forward pass (forward + input gradients + weight gradients of every
     # convolution; GroupNorm / Mish / Adam are O(activations + parameters)), the forward count from the library's own layer table

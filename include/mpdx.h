@@ -140,7 +140,9 @@ int    mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* pa
                                 const float* hard_goal, const float* weights_hd, int T, int B, int predict_epsilon, int l1, float loss_scale,
                                 float* loss_out, float* ws, void* stream);
 /* torch.nn.utils.clip_grad_norm_(max_norm) if max_norm > 0, then torch.optim.Adam.step() (no weight decay, no amsgrad);
- * step counts from 1; scratch: >= 1032 floats (scratch[0] <- the gradient norm before clipping, scratch[1] <- the clip factor) */
+ * step counts from 1; scratch: >= 1032 floats (scratch[0] <- the gradient norm before clipping, scratch[1] <- the clip factor).
+ * step < 0: the count lives on the device - the int at scratch + 4 holds the number of steps taken so far and this call advances it (the form a
+ * training step captured into a hipGraph needs: kernel arguments are frozen at capture, trainer.TrainStep.step) */
 int    mpdx_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
                       float eps, int step, float max_norm, float* scratch, void* stream);
 /* EMA.update_model_average (trainer.py:67-85): ema = beta * ema + (1 - beta) * params */

@@ -304,11 +304,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 // behind them: 4 of the 8 waves work, the others leave at once - a finished wave does not take part in the workgroup's barriers).
 struct BwdPairArgs {
     ConvArgs cd;
-    WgradArgs w[2];
-    int n_dgrad;
-    int nw[2];           // blocks of each weight-gradient GEMM (nw[1] == 0: one source)
-    int gx[2], gy[2];    // their grids: x = N tiles, y = M tiles, z = batch splits
-    int ks_w;            // taps of the weight gradient (1, 3, 4 or 5)
+    WgradArgs w[3];
+    int n_dgrad;         // 0: weight-gradient GEMMs only (the layers whose input needs no gradient + final_conv[1], collected into ONE launch)
+    int nw[3];           // blocks of each weight-gradient GEMM (0: unused slot)
+    int gx[3], gy[3];    // their grids: x = N tiles, y = M tiles, z = batch splits
+    int ks_w[3];         // taps of each weight gradient (1, 3, 4 or 5)
 };
 // EPI_D = EPI_GN_BWD: the dgrad blocks also take their result through the Mish + GroupNorm backward of the Conv1dBlock below (conv_block.hpp)
 template <int KS_D, int MT, int NT, int EPI_D = EPI_BIAS>
@@ -319,12 +319,12 @@ __global__ __launch_bounds__(512) void bwd_pair_kernel(const BwdPairArgs a) {
     }
     if (threadIdx.x >= 256) return;
     int idx = (int)blockIdx.x - a.n_dgrad;
-    const int which = idx >= a.nw[0] ? 1 : 0;
-    if (which) idx -= a.nw[0];
+    int which = 0;
+    while (which < 2 && idx >= a.nw[which]) { idx -= a.nw[which]; ++which; }
     const WgradArgs& w = a.w[which];
     const int bx = idx % a.gx[which], r = idx / a.gx[which];
     const int by = r % a.gy[which], bz = r / a.gy[which];
-    switch (a.ks_w) {
+    switch (a.ks_w[which]) {
         case 1: wgrad_body<1>(w, bx, by, bz); break;
         case 3: wgrad_body<3>(w, bx, by, bz); break;
         case 4: wgrad_body<4>(w, bx, by, bz); break;
@@ -869,8 +869,11 @@ __global__ __launch_bounds__(1024) void train_loss_kernel(const float* __restric
 // Optimiser.  sumsq_kernel + adam_kernel = torch.nn.utils.clip_grad_norm_(params, max_norm) (trainer.py:268-272) followed by
 // torch.optim.Adam.step() with the defaults the reference uses (betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad):
 //   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
+// `cnt` (or null): the device-resident optimiser step counter of a step replayed as a hipGraph (mpdx_adam_step with step < 0): block 0 advances it
+// here, the Adam kernel behind this launch reads the new value - the step-dependent bias corrections cannot be kernel arguments of a replayed graph.
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part, int* __restrict__ cnt) {
     __shared__ float red[4];
+    if (cnt && blockIdx.x == 0 && threadIdx.x == 0) cnt[0] += 1;
     float s = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s = fmaf(g[i], g[i], s);
     s = wave_sum(s);
@@ -896,10 +899,20 @@ __global__ __launch_bounds__(256) void norm_finish_kernel(const float* __restric
 // waiting for a one-block launch in between; block 0 publishes norm[0] = |g|, norm[1] = the clip coefficient.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
                                                    float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, const float* __restrict__ part, int n_part,
-                                                   float max_norm, float* __restrict__ norm) {
+                                                   float max_norm, float* __restrict__ norm, const int* __restrict__ cnt) {
     float coef = 1.0f;
+    __shared__ float red[4];
+    if (cnt) {   // graph replay: 1-based step count from device memory; the corrections as mpdx_adam_step computes them on the host (double pow, float result)
+        __shared__ float s_bc[2];
+        if (threadIdx.x == 0) {
+            const double st = (double)cnt[0];
+            s_bc[0] = 1.0f - (float)pow((double)b1, st);
+            s_bc[1] = sqrtf(1.0f - (float)pow((double)b2, st));
+        }
+        __syncthreads();
+        bc1 = s_bc[0]; bc2_sqrt = s_bc[1];
+    }
     if (part) {
-        __shared__ float red[4];
         float s = 0.f;
         for (int i = threadIdx.x; i < n_part; i += 256) s += part[i];
         s = wave_sum(s);

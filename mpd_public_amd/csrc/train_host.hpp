@@ -251,11 +251,10 @@ static int launch_bwd_pair(const Layer& dgl, ConvArgs& cd, int B, const WgradJob
     memset(&a, 0, sizeof(a));
     a.cd = cd;
     a.n_dgrad = (dgl.cout / MT) * cd.n_tiles_n;
-    a.ks_w = jobs[0].KS;
     size_t lds = 0;
     int total = a.n_dgrad;
     for (int k = 0; k < njobs; ++k) {
-        a.w[k] = jobs[k].a;
+        a.w[k] = jobs[k].a; a.ks_w[k] = jobs[k].KS;
         a.gx[k] = jobs[k].grid.x; a.gy[k] = jobs[k].grid.y;
         a.nw[k] = jobs[k].grid.x * jobs[k].grid.y * jobs[k].grid.z;
         total += a.nw[k];
@@ -275,6 +274,30 @@ static int launch_bwd_pair(const Layer& dgl, ConvArgs& cd, int B, const WgradJob
     MPDX_BP_TILE(32, 64) MPDX_BP_TILE(32, 32) MPDX_BP_TILE(16, 64) MPDX_BP_TILE(16, 32) MPDX_BP_TILE(32, 16) MPDX_BP_TILE(16, 16)
 #undef MPDX_BP_TILE
     return fail(MPDX_E_INVALID, "no backward-pair instantiation for tile %dx%d", MT, NT);
+}
+
+// up to three weight-gradient GEMMs that have no input-gradient convolution to ride on (layers whose input needs no gradient, final_conv[1]) in ONE
+// launch: bwd_pair_kernel with n_dgrad = 0 (any instantiation: the dgrad body is never entered)
+static int launch_lone_wgrads(const WgradJob* jobs, int njobs, hipStream_t st) {
+    if (njobs <= 0) return 0;
+    BwdPairArgs a;
+    memset(&a, 0, sizeof(a));
+    size_t lds = 0;
+    int total = 0;
+    for (int k = 0; k < njobs; ++k) {
+        a.w[k] = jobs[k].a; a.ks_w[k] = jobs[k].KS;
+        a.gx[k] = jobs[k].grid.x; a.gy[k] = jobs[k].grid.y;
+        a.nw[k] = jobs[k].grid.x * jobs[k].grid.y * jobs[k].grid.z;
+        total += a.nw[k];
+        lds = std::max(lds, jobs[k].lds);
+    }
+    auto kern = bwd_pair_kernel<1, 16, 16, EPI_BIAS>;
+    if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "weight-gradient launch needs %zu B of LDS", lds);
+    if (lds > 64 * 1024)
+        if (int rc = raise_lds_limit((const void*)kern)) return rc;
+    hipLaunchKernelGGL(kern, dim3(total), dim3(512), lds, st, a);
+    for (int k = 0; k < njobs; ++k) finish_wgrad(jobs[k], st);
+    return 0;
 }
 
 // channel sums of a dense [rows][C] tensor -> out[C]
@@ -479,6 +502,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     df.on = w.deferred; df.ws = ws; df.grads = grads_flat; df.wcur = w.wparts; df.pcur = w.pvecs;
     df.red.ws = ws; df.red.grad = grads_flat; df.red.n = 0;
     df.col.ws = ws; df.col.grad = grads_flat; df.col.n = 0;
+    std::vector<WgradJob> lone;   // deferred weight-gradient GEMMs without a dgrad convolution: launched together, three per launch
     {   // final_conv[1]
         const int C = c.unet_input_dim;
         const int wi = u->pidx.at("final_conv.1.weight"), bi = u->pidx.at("final_conv.1.bias");
@@ -487,7 +511,8 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         WgradJob fj;
         if (int rc = make_wgrad(dE, H, D, 0, D, out(n - 1), H, C, 0, C, 1, 0, 1, B, part, gflat(wi), C, 0, &df, fj)) return rc;
         const bool fb = attach_bias(fj, &df, gflat(bi), false);
-        run_wgrad(fj, st);
+        if (fj.deferred) lone.push_back(fj);   // rides with the other GEMMs that have no dgrad convolution (one launch behind the loop)
+        else run_wgrad(fj, st);
         if (!fb) launch_rowsum(dE, rows, D, rpart, gflat(bi), st, &df);
     }
     // A Conv1dBlock j whose output feeds exactly one k5 convolution i (blocks[0] -> blocks[1] of a ResidualTemporalBlock) gets its
@@ -567,7 +592,10 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         // one launch for all of them needs every job on its own partial buffer (the deferred mode)
         const bool paired = t.need_dgrad && !pair_off && jobs[0].deferred && (njobs == 1 || jobs[1].deferred);
         if (!paired)
-            for (int k = 0; k < njobs; ++k) run_wgrad(jobs[k], st);
+            for (int k = 0; k < njobs; ++k) {
+                if (!t.need_dgrad && !pair_off && jobs[k].deferred) lone.push_back(jobs[k]);
+                else run_wgrad(jobs[k], st);
+            }
         if (t.need_dgrad) {
             const Layer& dgl = t.dg;
             const float* din = dy;
@@ -636,6 +664,8 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             if (l.mode == CONV_UPT && t.src1_l >= 0 && !a.decim) launch_acc(grd(t.src1_l), ws + w.tmpX, B, l.L_in, l.c1, dgl.L_out, Cin, 0, 2, first_write(t.src1_l) ? 1 : 0, st);
         }
     }
+    for (size_t k = 0; k < lone.size(); k += 3)
+        if (int rc = launch_lone_wgrads(lone.data() + k, (int)std::min<size_t>(3, lone.size() - k), st)) return rc;
     if (df.red.n) {
         int blocks = 0;
         for (int k = 0; k < df.red.n; ++k) {
@@ -651,22 +681,26 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     return 0;
 }
 
-/* clip_grad_norm_ (max_norm > 0) + Adam step on flat vectors; scratch: >= 1032 floats; step: 1-based step count */
+/* clip_grad_norm_ (max_norm > 0) + Adam step on flat vectors; scratch: >= 1032 floats; step: 1-based step count, or < 0: the count lives on the device
+ * (int at scratch + 4, the number of steps taken so far; this call advances it) - the form a step replayed as a hipGraph needs, its kernel arguments being frozen */
 int mpdx_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2, float eps,
                    int step, float max_norm, float* scratch, void* stream) {
-    if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch || n == 0 || step < 1) return fail(MPDX_E_INVALID, "bad argument");
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch || n == 0 || step == 0) return fail(MPDX_E_INVALID, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     const float* clip = nullptr;
     int n_part = 0;
-    if (max_norm > 0.f) {
+    int* cnt = step < 0 ? (int*)(scratch + 4) : nullptr;
+    if (max_norm > 0.f || cnt) {   // (device-counter mode: the launch also advances the counter, clipping or not)
         const int nb = (int)std::min<size_t>((n + 255) / 256, 1024);
-        hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, grads, n, scratch + 8);
-        clip = scratch + 8;   // the partial sums; adam_kernel finishes the norm itself (norm_finish_kernel's order) and publishes scratch[0..1]
-        n_part = nb;
+        hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, grads, n, scratch + 8, cnt);
+        if (max_norm > 0.f) {
+            clip = scratch + 8;   // the partial sums; adam_kernel finishes the norm itself (norm_finish_kernel's order) and publishes scratch[0..1]
+            n_part = nb;
+        }
     }
-    const float bc1 = 1.0f - (float)pow((double)beta1, step), bc2 = 1.0f - (float)pow((double)beta2, step);
+    const float bc1 = step > 0 ? 1.0f - (float)pow((double)beta1, step) : 1.0f, bc2 = step > 0 ? 1.0f - (float)pow((double)beta2, step) : 1.0f;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, lr,
-                       beta1, beta2, eps, bc1, sqrtf(bc2), clip, n_part, max_norm, scratch);
+                       beta1, beta2, eps, bc1, sqrtf(bc2), clip, n_part, max_norm, scratch, (const int*)cnt);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -218,6 +218,79 @@ class TrainStep:
         self.unet._stamp = None   # the inference engine's pack of these weights is stale until the next pack()
         return self.scratch[0] if mn > 0 else None
 
+    # ------------------------------------------------------------------------------------------------ one iteration as a hipGraph
+    def step(self, x_start, hard_conds=None, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=None, t=None, noise=None, use_graph=None):
+        """One training iteration of trainer.py:186-283 - p_losses + backward (loss_backward) and clip + Adam (adam_step) - returning the loss.
+
+        From the third call with the same shapes and hyper-parameters on, the iteration is REPLAYED AS ONE hipGraph (torch.cuda.CUDAGraph over the
+        same native launches): at the reference's batch of 32 the ~85 launches of an iteration take the host as long to enqueue (0.70-0.80 ms,
+        box dependent) as the GPU to run (0.71 ms), and a slower host is then what a step costs; the replay is one host call.  What a captured
+        graph freezes is kept out of its kernel arguments: the batch and the hard conditions are copied into static buffers, t and the noise
+        are drawn by torch's graph-safe generator inside the graph (`torch.randint`, `torch.randn_like`, as diffusion_model_base.py:356 / :337 draw
+        them; pass `t` / `noise` to supply them instead), and Adam's step count lives on the device (mpdx_adam_step with step < 0).
+        `use_graph=False` (or MPDX_TRAIN_GRAPH=0) runs the two eager calls; by default batches of more than 64 trajectories do (GPU-bound)."""
+        import os
+        if use_graph is None:   # default: replay where the HOST is the bound - small batches (measured: batch 32 0.77 -> 0.73 ms, batch 128 x D=14 1.255 -> 1.274 ms:
+            # there the GPU is the bound and the replay only adds the copies into the static buffers); MPDX_TRAIN_GRAPH=1 / 0 forces either
+            env = os.environ.get("MPDX_TRAIN_GRAPH")
+            use_graph = (env != "0") if env is not None else x_start.shape[0] <= 64
+        hard_conds = hard_conds or {}
+        mn = float(max_norm) if max_norm else 0.0
+        key = (tuple(x_start.shape), tuple(sorted((int(k), tuple(v.shape)) for k, v in hard_conds.items())), float(lr), tuple(betas), float(eps), mn,
+               t is not None, noise is not None)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        g = graphs.get(key) if use_graph else None
+        if g is None:
+            warm = self.__dict__.setdefault("_graph_warm", {})
+            warm[key] = warm.get(key, 0) + 1
+            if not use_graph or warm[key] < 3:   # eager (also the warm-up of everything a capture must not do: allocations, one-off attribute calls)
+                loss, _ = self.loss_backward(x_start, hard_conds, t=t, noise=noise)
+                self.adam_step(lr, betas, eps, max_norm)
+                return loss
+            g = graphs[key] = self._capture(x_start, hard_conds, lr, betas, eps, mn, t, noise)
+        g["x"].copy_(x_start, non_blocking=True)
+        for k, v in hard_conds.items():
+            g["hc"][k].copy_(v, non_blocking=True)
+        if t is not None:
+            g["t"].copy_(t, non_blocking=True)
+        if noise is not None:
+            g["noise"].copy_(noise, non_blocking=True)
+        if self.__dict__.get("_dev_steps") != self.step_count:   # eager adam_step calls in between moved the host's count: re-seed the device's
+            self.scratch.view(torch.int32)[4] = self.step_count
+        if not self.fp.aliased():
+            raise RuntimeError("the model's parameters no longer alias the flat training vector (was the model moved or re-created?) - build a new TrainStep")
+        g["graph"].replay()
+        self.step_count += 1
+        self._dev_steps = self.step_count
+        self.unet._stamp = None
+        self.unet._timetab, self.unet._timetab_T = None, 0
+        if not self.fp.grads_bound():
+            self.fp.bind_grads()
+        return g["loss"]
+
+    def _capture(self, x_start, hard_conds, lr, betas, eps, mn, t, noise):
+        m, dev = self.model, x_start.device
+        B = x_start.shape[0]
+        st = {"x": x_start.to(torch.float32).contiguous().clone(), "hc": {k: v.to(device=dev, dtype=torch.float32).contiguous().clone() for k, v in hard_conds.items()},
+              "t": None if t is None else t.to(device=dev, dtype=torch.long).reshape(-1).contiguous().clone(),
+              "noise": None if noise is None else noise.to(torch.float32).contiguous().clone()}
+        self.scratch.view(torch.int32)[4] = self.step_count
+        self._dev_steps = self.step_count
+        lib = _lib.load()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            tt = st["t"] if st["t"] is not None else torch.randint(0, m.n_diffusion_steps, (B,), device=dev).long()
+            nz = st["noise"] if st["noise"] is not None else torch.randn_like(st["x"])
+            loss, _ = self.loss_backward(st["x"], st["hc"], t=tt, noise=nz)
+            _lib.check(lib.mpdx_adam_step(self.fp.flat.data_ptr(), self.fp.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                          self.fp.n, float(lr), float(betas[0]), float(betas[1]), float(eps), -1, mn,
+                                          self.scratch.data_ptr(), _lib.current_stream()), "mpdx_adam_step")
+        torch.cuda.current_stream(dev).wait_stream(side)
+        st["graph"], st["loss"] = graph, loss
+        return st
+
 
 class _PLossesFn(torch.autograd.Function):
     """autograd bridge: forward = TrainStep.loss_backward (loss AND gradients in one native pass), backward hands each parameter its
@@ -375,6 +448,7 @@ def train(model=None, train_dataloader=None, epochs=None, lr=None, steps_til_sum
     for epoch in range(epochs):
         model.train()
         for step, batch in enumerate(train_dataloader):
+            fused_step = False
             if custom_loss:   # the reference's generic path (trainer.py:186-197, 262-266)
                 bd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
                 if "hard_conds" in bd:
@@ -388,7 +462,13 @@ def train(model=None, train_dataloader=None, epochs=None, lr=None, steps_til_sum
             else:
                 x = batch[f"{field}_normalized"].to(dev)
                 hard_conds = {k: v.to(dev) for k, v in batch.get("hard_conds", {}).items()}
-                loss, info = step_fn.loss_backward(x, hard_conds)
+                # the native optimiser: loss + backward + clip + Adam as ONE call (replayed as a hipGraph, TrainStep.step); on summary steps the two
+                # halves run apart, because the summary / validation below look at the model BEFORE the optimiser step (trainer.py:199-266)
+                fused_step = optimizers is None and not (steps_til_summary and train_steps_current % steps_til_summary == 0)
+                if fused_step:
+                    loss, info = step_fn.step(x, hard_conds, lr, max_norm=max_norm), {}
+                else:
+                    loss, info = step_fn.loss_backward(x, hard_conds)
             if steps_til_summary and train_steps_current % steps_til_summary == 0:
                 lv = float(loss)   # the only host synchronisation of a step, on summary steps
                 train_losses_l.append((train_steps_current, {"diffusion_loss": lv}))
@@ -418,7 +498,8 @@ def train(model=None, train_dataloader=None, epochs=None, lr=None, steps_til_sum
                 print(f"Early stopped training at {train_steps_current} steps.")
                 stop_training = True
             if optimizers is None:
-                step_fn.adam_step(lr, max_norm=max_norm)
+                if not fused_step:
+                    step_fn.adam_step(lr, max_norm=max_norm)
             else:   # torch optimisers over the same (aliased) parameters, as the reference runs them
                 if not custom_loss:
                     # the native pass wrote the flat gradient; an earlier model.loss() with autograd or zero_grad(set_to_none=True)

@@ -416,3 +416,45 @@ def test_gn_backward_epilogue_matches_the_separate_kernel():
     assert out.returncode == 0, out.stderr[-2000:]
     there = [ln.split()[1] for ln in out.stdout.splitlines() if ln.startswith("GRADHASH")][0]
     assert here == there
+
+
+def test_graph_replayed_steps_equal_eager_steps():
+    """TrainStep.step replays an iteration (loss + backward + clip + Adam) as ONE hipGraph from the third call on (the first two run eagerly
+    and warm everything a capture must not do).  With t and the noise supplied, six steps through step() leave the parameters, both Adam
+    moments and the loss of every step where six eager loss_backward + adam_step pairs leave them: the launches are the same; what the
+    graph cannot take as (frozen) kernel arguments - Adam's bias corrections - is computed on the device from a device-resident step count
+    (double pow, float result, as the host computes it: allowed to differ in the last bit of the correction, 1e-6 relative here)."""
+    from mpd_public_amd.trainer import TrainStep
+    x0, noise, hc = _batch(4)
+    x0, noise, hc = x0.cuda(), noise.cuda(), {k: v.cuda() for k, v in hc.items()}
+    dm_e, dm_g = _model(4, 1), _model(4, 1)
+    ts_e, ts_g = TrainStep(dm_e), TrainStep(dm_g)
+    losses_e, losses_g = [], []
+    for k in range(6):
+        tt = TTS[k % 2].cuda()
+        nz = noise * (1.0 + 0.1 * k)
+        xb = x0 * (1.0 - 0.05 * k)   # the batch changes from step to step: the replay must read the copies, not the captured tensors' first contents
+        le, _ = ts_e.loss_backward(xb, hc, t=tt, noise=nz)
+        ts_e.adam_step(1e-3, max_norm=1.0)
+        losses_e.append(float(le))
+        losses_g.append(float(ts_g.step(xb, hc, 1e-3, max_norm=1.0, t=tt, noise=nz)))
+    assert "_graphs" in ts_g.__dict__ and len(ts_g._graphs) == 1, "the third step was meant to capture"
+    assert ts_g.step_count == ts_e.step_count == 6
+    np.testing.assert_allclose(losses_g, losses_e, rtol=1e-6)
+    for name in ("flat",):
+        a, b = getattr(ts_g.fp, name).cpu(), getattr(ts_e.fp, name).cpu()
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()), name
+    for a, b in ((ts_g.exp_avg, ts_e.exp_avg), (ts_g.exp_avg_sq, ts_e.exp_avg_sq)):
+        assert float((a - b).abs().max().cpu()) <= 1e-6 * float(b.abs().max().cpu())
+    # an eager optimiser step in between moves the host's count; the next replay re-seeds the device's
+    ts_e.loss_backward(x0, hc, t=TTS[0].cuda(), noise=noise); ts_e.adam_step(1e-3, max_norm=1.0)
+    ts_g.loss_backward(x0, hc, t=TTS[0].cuda(), noise=noise); ts_g.adam_step(1e-3, max_norm=1.0)
+    le, _ = ts_e.loss_backward(x0, hc, t=TTS[1].cuda(), noise=noise); ts_e.adam_step(1e-3, max_norm=1.0)
+    lg = ts_g.step(x0, hc, 1e-3, max_norm=1.0, t=TTS[1].cuda(), noise=noise)
+    assert ts_g.step_count == ts_e.step_count == 8
+    assert float((ts_g.fp.flat - ts_e.fp.flat).abs().max().cpu()) <= 1e-6 * float(ts_e.fp.flat.abs().max().cpu())
+    # without t / noise the graph draws them itself (torch's graph-safe generator): the loss differs from replay to replay
+    dm_r = _model(4, 1)
+    ts_r = TrainStep(dm_r)
+    ls = [float(ts_r.step(x0, hc, 1e-3, max_norm=1.0)) for _ in range(6)]
+    assert len(set(ls[2:])) > 1 and all(np.isfinite(ls))
