@@ -162,7 +162,7 @@ class TrainStep:
         self.unet._stamp = self.unet._param_stamp() if sync_engine else None
         self.unet._timetab, self.unet._timetab_T = None, 0
 
-    def loss_backward(self, x_start, hard_conds=None, t=None, noise=None, loss_scale=1.0, bind_grads=True):
+    def loss_backward(self, x_start, hard_conds=None, t=None, noise=None, loss_scale=1.0, bind_grads=True, _static_loss=False):
         """(loss, info) as model.loss(x, None, hard_conds) returns them, with d loss / d parameters left in every p.grad
         (overwritten, not accumulated - the reference zeroes the gradients before every backward, trainer.py:262-263)."""
         m = self.model
@@ -194,7 +194,7 @@ class TrainStep:
             self.loss_buf.data_ptr(), self._ws.data_ptr(), _lib.current_stream()), "mpdx_train_loss_backward")
         if bind_grads and not self.fp.grads_bound():   # the docstring's promise: the gradients ARE in p.grad after this call
             self.fp.bind_grads()
-        return self.loss_buf[0].clone(), {}
+        return (self.loss_buf[0] if _static_loss else self.loss_buf[0].clone()), {}   # (_static_loss: the graph's own output tensor, TrainStep.step)
 
     def _snapshot_pending(self):
         """The flat gradient buffer is shared by every native pass.  An autograd loss (_PLossesFn) normally reads it in place in its
@@ -248,13 +248,16 @@ class TrainStep:
                 self.adam_step(lr, betas, eps, max_norm)
                 return loss
             g = graphs[key] = self._capture(x_start, hard_conds, lr, betas, eps, mn, t, noise)
-        g["x"].copy_(x_start, non_blocking=True)
-        for k, v in hard_conds.items():
-            g["hc"][k].copy_(v, non_blocking=True)
+        dsts, srcs = [g["x"]] + [g["hc"][k] for k in hard_conds], [x_start] + [hard_conds[k] for k in hard_conds]
+        if noise is not None:
+            dsts.append(g["noise"]); srcs.append(noise)
+        if all(a.dtype == b.dtype and a.device == b.device and a.shape == b.shape for a, b in zip(dsts, srcs)):
+            torch._foreach_copy_(dsts, srcs)   # ONE launch for the batch and its hard conditions
+        else:
+            for a, b in zip(dsts, srcs):
+                a.copy_(b, non_blocking=True)
         if t is not None:
             g["t"].copy_(t, non_blocking=True)
-        if noise is not None:
-            g["noise"].copy_(noise, non_blocking=True)
         if self.__dict__.get("_dev_steps") != self.step_count:   # eager adam_step calls in between moved the host's count: re-seed the device's
             self.scratch.view(torch.int32)[4] = self.step_count
         if not self.fp.aliased():
@@ -283,7 +286,7 @@ class TrainStep:
         with torch.cuda.graph(graph, stream=side):
             tt = st["t"] if st["t"] is not None else torch.randint(0, m.n_diffusion_steps, (B,), device=dev).long()
             nz = st["noise"] if st["noise"] is not None else torch.randn_like(st["x"])
-            loss, _ = self.loss_backward(st["x"], st["hc"], t=tt, noise=nz)
+            loss, _ = self.loss_backward(st["x"], st["hc"], t=tt, noise=nz, _static_loss=True)
             _lib.check(lib.mpdx_adam_step(self.fp.flat.data_ptr(), self.fp.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                           self.fp.n, float(lr), float(betas[0]), float(betas[1]), float(eps), -1, mn,
                                           self.scratch.data_ptr(), _lib.current_stream()), "mpdx_adam_step")
