@@ -93,6 +93,11 @@ struct TrainWs {
 static size_t wgrad_splits(int M, int N, int B) {
     const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
     int S = (256 + tiles - 1) / tiles;   // about one workgroup per CU
+    // A block walks its trajectories one staging round trip after the other: with few splits a large batch makes that chain the launch's long pole
+    // (batch 128, the 256-channel layers: 32 trajectories per block).  Up to twice the splits keep it at <= 16 trajectories per block - measured at
+    // batch 128 x D=14: 1.247 -> 1.177 ms per iteration; four times the splits: 1.81 ms (the partial sums' traffic takes over), and at batch 32 (8
+    // trajectories per block already) twice the splits cost 0.73 -> 0.77 ms (gpurun_out/r04y/wgrad_split.txt).
+    if (tiles >= 16) S = std::min(std::max(S, B / 16), 2 * S);
     S = std::max(1, std::min(S, B));
     const int per = (B + S - 1) / S;
     return (size_t)((B + per - 1) / per);
