@@ -1,58 +1,99 @@
-// loss.hpp - the weighted loss value (helpers.py:71-99) as a device function shared by the stand-alone kernel (mpdx.hip, validation
-// p_losses) and the training step's fused loss kernel (train.hpp): ONE workgroup of 1024 threads, fixed summation order.
+// loss.hpp - the weighted loss value (helpers.py:71-99) as device functions shared by the stand-alone kernel (mpdx.hip, validation p_losses)
+// and the training step's fused loss kernel (train.hpp).
+//
+// The VALUE of the sum is defined by its order: 1024 "threads", thread t adds its elements i = t, t + 1024, ... in ascending order (double), the 64
+// threads of a wave are combined by an xor-shuffle tree, the 16 wave sums are added in wave order.  weighted_loss_kernel runs that as ONE workgroup
+// of 1024 threads; the training step runs the 16 waves as 16 one-wave workgroups on 16 CUs (same bits, a sixteenth of the time: round 4 found the
+// one-workgroup form VALU-bound on its index arithmetic - two 32-bit divisions per element, 48 us per launch at batch 128 x D = 14 - the indices are
+// now advanced incrementally).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace mpdx {
 
-// mean over all B*H*D elements of |e| or e^2 (optionally times weights[H*D]) of apply_hard_conditioning(pred) against targ.
-// Call with 1024 threads; `part` is 16 doubles of LDS.
-__device__ __forceinline__ void weighted_loss_body(const float* pred, const float* targ, const float* weights, const float* hs, const float* hg, int l1,
-                                                   float* out, int B, int H, int D, double* part) {
-    const size_t n = (size_t)B * H * D;
+// the elements of thread `tid` (0 .. 1023), ascending:  |e| or e^2 (optionally times weights[H*D]) of apply_hard_conditioning(pred) against targ
+__device__ __forceinline__ double weighted_loss_thread_sum(const float* pred, const float* targ, const float* weights, const float* hs, const float* hg,
+                                                           int l1, int B, int H, int D, unsigned tid) {
+    const unsigned nn = (unsigned)((size_t)B * H * D);   // (32-bit index arithmetic; n = B * H * D is far below 2^32 here)
     double acc = 0.0;
-    // A thread's elements i = tid, tid + 1024, ... are added in ascending order (the value of the sum is defined by that order); their loads are
-    // issued U at a time, UNCONDITIONALLY (clamped indices, selects afterwards): with the loads inside the element loop and behind the hard-condition
-    // branches this one-workgroup reduction was a chain of n / 4096 dependent round trips - 54 us at batch 128 x D = 14 (round 4 profile).
-    constexpr unsigned U = 16;
-    const unsigned nn = (unsigned)n;   // (32-bit index arithmetic; n = B * H * D is far below 2^32 here)
-    for (unsigned i0 = threadIdx.x; i0 < nn; i0 += 1024u * U) {
+    if (tid >= nn) return acc;
+    // (d, l, b) of element i, advanced by 1024 elements without a division: i += 1024 -> d += 1024 % D with a carry into the row index p = i / D,
+    // p += 1024 / D (+ carry) -> l += that % H with a carry into b
+    const unsigned uD = (unsigned)D, uH = (unsigned)H;
+    unsigned i = tid, d = i % uD, p = i / uD, l = p % uH, b = p / uH;
+    const unsigned sd = 1024u % uD, sp = 1024u / uD, spl = sp % uH, spb = sp / uH;
+    constexpr unsigned U = 8;   // loads in flight per thread (issued unconditionally, clamped: a load behind a branch waits for everything before it)
+    while (i < nn) {
         float pv[U], tv[U], wv[U], sv[U], gv[U];
-        unsigned li[U];
+        unsigned ll[U];
         bool in[U];
 #pragma unroll
         for (unsigned u = 0; u < U; ++u) {
-            const unsigned i = i0 + u * 1024u;
             in[u] = i < nn;
-            const unsigned ic = in[u] ? i : 0u;
-            const unsigned d = ic % (unsigned)D, p = ic / (unsigned)D;
-            const unsigned l = p % (unsigned)H, b = p / (unsigned)H;
-            li[u] = l;
+            const unsigned ic = in[u] ? i : tid, dc = in[u] ? d : 0u, lc = in[u] ? l : 1u, bc = in[u] ? b : 0u;
+            ll[u] = lc;
             pv[u] = pred[ic]; tv[u] = targ[ic];
-            wv[u] = weights ? weights[(size_t)l * D + d] : 1.0f;
-            sv[u] = hs ? hs[b * D + d] : 0.f;
-            gv[u] = hg ? hg[b * D + d] : 0.f;
+            wv[u] = weights ? weights[(size_t)lc * uD + dc] : 1.0f;
+            sv[u] = hs ? hs[bc * uD + dc] : 0.f;
+            gv[u] = hg ? hg[bc * uD + dc] : 0.f;
+            i += 1024u;
+            d += sd;
+            const unsigned carry = d >= uD ? 1u : 0u;
+            d -= carry * uD;
+            l += spl + carry; b += spb;
+            if (l >= uH) { l -= uH; ++b; }
         }
 #pragma unroll
         for (unsigned u = 0; u < U; ++u) {
             if (!in[u]) continue;
             float v = pv[u];
-            if (hs && li[u] == 0) v = sv[u];
-            if (hg && li[u] == (unsigned)(H - 1)) v = gv[u];
+            if (hs && ll[u] == 0) v = sv[u];
+            if (hg && ll[u] == uH - 1u) v = gv[u];
             const float e = __fsub_rn(v, tv[u]);
             float q = l1 ? fabsf(e) : __fmul_rn(e, e);
             if (weights) q = __fmul_rn(q, wv[u]);
             acc += (double)q;
         }
     }
+    return acc;
+}
+
+__device__ __forceinline__ double weighted_loss_wave_sum(double acc) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
+    return acc;
+}
+
+// ONE workgroup of 1024 threads; `part`: 16 doubles of LDS
+__device__ __forceinline__ void weighted_loss_body(const float* pred, const float* targ, const float* weights, const float* hs, const float* hg, int l1,
+                                                   float* out, int B, int H, int D, double* part) {
+    const double acc = weighted_loss_wave_sum(weighted_loss_thread_sum(pred, targ, weights, hs, hg, l1, B, H, D, threadIdx.x));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
         double tot = 0.0;
         for (int k = 0; k < 16; ++k) tot += part[k];
-        out[0] = (float)(tot / (double)n);
+        out[0] = (float)(tot / (double)((size_t)B * H * D));
+    }
+}
+
+// wave `w` (0 .. 15) of the same sum as its own one-wave workgroup: partial sums through `gpart` (16 doubles of global memory, agent-scope atomic
+// stores / loads: no L2-flushing fence), the workgroup that takes the last ticket (`ticket`: zero at launch) adds them in wave order.  Call with the
+// 64 threads of one wave.
+__device__ __forceinline__ void weighted_loss_wave_block(const float* pred, const float* targ, const float* weights, const float* hs, const float* hg, int l1,
+                                                         float* out, int B, int H, int D, int w, double* gpart, unsigned* ticket) {
+    const unsigned lane = threadIdx.x & 63;
+    const double acc = weighted_loss_wave_sum(weighted_loss_thread_sum(pred, targ, weights, hs, hg, l1, B, H, D, (unsigned)w * 64u + lane));
+    unsigned last = 0;
+    if (lane == 0) {
+        __hip_atomic_store(gpart + w, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = atomicAdd(ticket, 1u) == 15u ? 1u : 0u;
+        if (last) {
+            double tot = 0.0;
+            for (int k = 0; k < 16; ++k) tot += __hip_atomic_load(gpart + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out[0] = (float)(tot / (double)((size_t)B * H * D));
+        }
     }
 }
 

@@ -820,14 +820,14 @@ __global__ __launch_bounds__(256) void final_dgrad_kernel(const float* __restric
 
 // The loss value, its gradient and the gradient's way back through final_conv[1] in ONE launch (round 4: were three).  Blocks [0, gridDim.x - 1):
 // gH[r][c] = sum_d dE[r][d] W[d][c] with dE computed on the fly (loss_grad_kernel's arithmetic; the lane with c == d also stores dE[r][d], which
-// the weight / bias gradients of final_conv[1] read) - needs C >= D.  The LAST block: the loss value, weighted_loss_kernel's summation order.
+// the weight / bias gradients of final_conv[1] read) - needs C >= D.  The LAST 16 blocks: the loss value, weighted_loss_kernel's summation order.
 __global__ __launch_bounds__(1024) void train_loss_kernel(const float* __restrict__ pred, const float* __restrict__ targ, const float* __restrict__ weights_hd,
                                                           const float* __restrict__ hs, const float* __restrict__ hg, int l1, float scale, float* __restrict__ dE,
-                                                          const float* __restrict__ w, float* __restrict__ gH, int B, int H, int D, int C, float* __restrict__ loss_out) {
-    __shared__ double part[16];
-    const unsigned nb = gridDim.x - 1;
-    if (blockIdx.x == nb) {
-        weighted_loss_body(pred, targ, weights_hd, hs, hg, l1, loss_out, B, H, D, part);
+                                                          const float* __restrict__ w, float* __restrict__ gH, int B, int H, int D, int C, float* __restrict__ loss_out,
+                                                          double* __restrict__ loss_part, unsigned* __restrict__ loss_ticket) {
+    const unsigned nb = gridDim.x - 16;
+    if (blockIdx.x >= nb) {   // the loss value: wave w of weighted_loss_kernel's sum as its own one-wave workgroup (loss.hpp)
+        if (threadIdx.x < 64) weighted_loss_wave_block(pred, targ, weights_hd, hs, hg, l1, loss_out, B, H, D, (int)(blockIdx.x - nb), loss_part, loss_ticket);
         return;
     }
     const size_t rows = (size_t)B * H, total = rows * C;

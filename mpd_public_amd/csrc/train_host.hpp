@@ -83,7 +83,7 @@ static int ensure_pack_descs(mpdx_unet* u) {
 
 // workspace layout for a batch of B (float offsets)
 struct TrainWs {
-    size_t xn, eps, dE, out0, pre0, grad0, tmpX, dU, zst, pvec, wpart, rpart, emb, h1, temb, tm, h1m, tb, dT, dtm, dh1, zeros, ticket, norm, total;
+    size_t xn, eps, dE, out0, pre0, grad0, tmpX, dU, zst, pvec, wpart, rpart, emb, h1, temb, tm, h1m, tb, dT, dtm, dh1, zeros, ticket, norm, lossp, total;
     size_t slotB;          // floats of one activation slot for the batch
     size_t wpart_floats;
     // deferred reductions (one launch each at the end of the backward pass): every layer keeps its own partial sums
@@ -152,6 +152,7 @@ static TrainWs train_ws(const mpdx_unet* u, int B) {
     w.zeros = take(1024);
     w.ticket = take(4);      // directly behind `zeros`: one memset clears both
     w.norm = take(1024 + 8);
+    w.lossp = take(32);       // 16 doubles: the loss value's wave sums (train_loss_kernel); offsets are multiples of 4 floats: 8-byte aligned
     w.total = o;
     return w;
 }
@@ -494,9 +495,9 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         // loss value + dE + the gradient wrt final_conv[0]'s output (back through final_conv[1]) in one launch
         if (fa.C < D || D > 16) return fail(MPDX_E_INVALID, "training: unet_input_dim %d / state_dim %d (the loss kernel takes state_dim <= 16 <= unet_input_dim)", fa.C, D);
         const size_t tot = (size_t)B * H * fa.C;
-        hipLaunchKernelGGL(train_loss_kernel, dim3((unsigned)std::min<size_t>((tot + 1023) / 1024, 1024) + 1), dim3(1024), 0, st, (const float*)eps, target, weights_hd,
+        hipLaunchKernelGGL(train_loss_kernel, dim3((unsigned)std::min<size_t>((tot + 1023) / 1024, 1024) + 16), dim3(1024), 0, st, (const float*)eps, target, weights_hd,
                            hard_start, hard_goal, l1, loss_scale, dE, flat + u->params[u->pidx.at("final_conv.1.weight")].foff, ws + w.grad0 + (size_t)(n - 1) * w.slotB,
-                           B, H, D, fa.C, loss_out);
+                           B, H, D, fa.C, loss_out, (double*)(ws + w.lossp), (unsigned*)(ws + w.ticket) + 1);   // (ticket word 1: zeroed by the pass's first launch)
     }
     HIP_TRY(hipGetLastError());
 
