@@ -365,21 +365,35 @@ __device__ __forceinline__ void wgrad_reduce_all_body(const ReduceAllArgs& a, co
     const unsigned per = (unsigned)e.M * e.N * e.KS, KS = (unsigned)e.KS, N = (unsigned)e.N;   // (32-bit index arithmetic, as pack_train_kernel)
     const unsigned base = (unsigned)(block_id - a.cstart[lo]) * 1024u + (unsigned)tid;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int z = 0; z < e.S; ++z) {
+    unsigned ic[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned i = base + k * 256u;
-            s[k] += part[(size_t)z * per + (i < per ? i : 0u)];
+    for (int k = 0; k < 4; ++k) { const unsigned i = base + k * 256u; ic[k] = i < per ? i : 0u; }
+    // splits z ascending (the sum's order); eight splits' loads (32 per thread) are issued together
+    for (int z0 = 0; z0 < e.S; z0 += 8) {
+        float v[8][4];
+#pragma unroll
+        for (int zz = 0; zz < 8; ++zz) {
+            const int z = z0 + zz < e.S ? z0 + zz : e.S - 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[zz][k] = part[(size_t)z * per + ic[k]];
         }
+#pragma unroll
+        for (int zz = 0; zz < 8; ++zz)
+            if (z0 + zz < e.S) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] += v[zz][k];
+            }
     }
+    // g[(m * n_tot + n_off + n) * KS + kk] for i = (m * N + n) * KS + kk: the same index when the layer has one source (n_tot == N), else one division
+    const unsigned NK = N * KS;
+    const bool dense = (unsigned)e.n_tot == N;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const unsigned i = base + k * 256u;
         if (i >= per) continue;
-        const unsigned kk = i % KS, mn = i / KS;
-        const unsigned n = mn % N, m = mn / N;
-        g[((size_t)m * e.n_tot + e.n_off + n) * KS + kk] = s[k];
+        size_t o = i;
+        if (!dense) { const unsigned m = i / NK, r = i - m * NK; o = ((size_t)m * e.n_tot + e.n_off) * KS + r; }
+        g[o] = s[k];
     }
 }
 
