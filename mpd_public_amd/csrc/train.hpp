@@ -226,6 +226,59 @@ struct WgradArgs {
 
 constexpr int kWgRS = 48;   // LDS row stride: 4 consecutive rows start 16 banks apart
 
+// The trajectory loop of wgrad_body for LA = 8 NR rows of A and LB = LA (Conv1d k5 / k1) or 2 LA (stride-2 layers: KS = 3 / 4) rows of B, round 4:
+// the NEXT trajectory's operand rows are fetched into registers (unconditional loads, clamped columns, zeros selected at the LDS store) while the
+// current one's MFMAs run, and the barriers are LDS-only (lds_barrier: __syncthreads() also drains vmcnt and would wait for the prefetch).  The
+// generic loop below issues its loads inside column-guard branches - one dependent round trip per row - and a block walks 8-32 trajectories: that
+// chain, not the MFMAs, was the length of every backward launch.  Same MFMA order per trajectory, trajectories ascending: same bits.
+template <int KS, int NR>
+__device__ __forceinline__ void wgrad_loop_prefetch(const WgradArgs& a, float* As, float* Bs, const int b0, const int b1, const int m0, const int n0, const int mi,
+                                                    const int ni, const int i16, const int kq, const int col, const int row0, const bool do_bias, float& bsum,
+                                                    f32x4 (&acc)[KS]) {
+    constexpr int NRB = (KS == 3 || KS == 4) ? 2 * NR : NR, LA = 8 * NR, LB = 8 * NRB;
+    const bool okA = m0 + col < a.M, okB = n0 + col < a.N;
+    const float* pA = a.A + a.a_off + (okA ? m0 + col : a.M - 1) + (size_t)row0 * a.lda;
+    const float* pB = a.Bm + a.b_off + (okB ? n0 + col : a.N - 1) + (size_t)row0 * a.ldb;
+    float ra[NR], rb[NRB];
+    auto fetch = [&](int b) {
+        const float* qa = pA + (size_t)b * LA * a.lda;
+        const float* qb = pB + (size_t)b * LB * a.ldb;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) ra[u] = qa[(size_t)(8 * u) * a.lda];
+#pragma unroll
+        for (int u = 0; u < NRB; ++u) rb[u] = qb[(size_t)(8 * u) * a.ldb];
+    };
+    fetch(b0);
+    for (int b = b0; b < b1; ++b) {
+        lds_barrier();   // the previous trajectory's fragments are read
+#pragma unroll
+        for (int u = 0; u < NR; ++u) As[(size_t)(row0 + 8 * u) * kWgRS + col] = okA ? ra[u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < NRB; ++u) Bs[(size_t)(row0 + 8 * u + 2) * kWgRS + col] = okB ? rb[u] : 0.f;
+        fetch(b + 1 < b1 ? b + 1 : b);   // (the last trip re-reads its own rows: no branch around the loads)
+        lds_barrier();
+        if (do_bias) {   // fixed order: this thread's rows ascending, trajectories ascending; the 8 row phases are combined at the end
+            if (a.bias_from_b) {
+#pragma unroll
+                for (int u = 0; u < NRB; ++u) bsum += Bs[(size_t)(row0 + 8 * u + 2) * kWgRS + col];
+            } else {
+#pragma unroll
+                for (int u = 0; u < NR; ++u) bsum += As[(size_t)(row0 + 8 * u) * kWgRS + col];
+            }
+        }
+#pragma unroll
+        for (int t0 = 0; t0 < LA; t0 += 4) {
+            const float av = As[(size_t)(t0 + kq) * kWgRS + mi + i16];
+            const int pr = a.sb * (t0 + kq) + a.ob + 2;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                const float bv = Bs[(size_t)(pr + k) * kWgRS + ni + i16];
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[k], 0, 0, 0);
+            }
+        }
+    }
+}
+
 template <int KS>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -247,6 +300,15 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
     const int col = tid & 31, row0 = tid >> 5;   // 8 rows per pass
     const bool do_bias = a.bias_part && (a.bias_from_b ? by == 0 : bx == 0);   // all 256 threads: (column, row phase of 8)
     float bsum = 0.f;
+    const int nr = a.LA >> 3;
+    const bool fast = (a.LA & 7) == 0 && a.LB == ((KS == 3 || KS == 4) ? 2 * a.LA : a.LA) && (nr == 1 || nr == 2 || nr == 4 || nr == 8) && b1 > b0;
+    if (fast) {
+        __syncthreads();   // the halo rows
+        if (nr == 1) wgrad_loop_prefetch<KS, 1>(a, As, Bs, b0, b1, m0, n0, mi, ni, i16, kq, col, row0, do_bias, bsum, acc);
+        else if (nr == 2) wgrad_loop_prefetch<KS, 2>(a, As, Bs, b0, b1, m0, n0, mi, ni, i16, kq, col, row0, do_bias, bsum, acc);
+        else if (nr == 4) wgrad_loop_prefetch<KS, 4>(a, As, Bs, b0, b1, m0, n0, mi, ni, i16, kq, col, row0, do_bias, bsum, acc);
+        else wgrad_loop_prefetch<KS, 8>(a, As, Bs, b0, b1, m0, n0, mi, ni, i16, kq, col, row0, do_bias, bsum, acc);
+    } else
     for (int b = b0; b < b1; ++b) {
         __syncthreads();   // the previous trajectory's fragments are read
         for (int r = row0; r < a.LA; r += 8)
