@@ -93,11 +93,14 @@ struct TrainWs {
 static size_t wgrad_splits(int M, int N, int B) {
     const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
     int S = (256 + tiles - 1) / tiles;   // about one workgroup per CU
-    // A block walks its trajectories one staging round trip after the other: with few splits a large batch makes that chain the launch's long pole
-    // (batch 128, the 256-channel layers: 32 trajectories per block).  Up to twice the splits keep it at <= 16 trajectories per block - measured at
-    // batch 128 x D=14: 1.247 -> 1.177 ms per iteration; four times the splits: 1.81 ms (the partial sums' traffic takes over), and at batch 32 (8
-    // trajectories per block already) twice the splits cost 0.73 -> 0.77 ms (gpurun_out/r04y/wgrad_split.txt).
-    if (tiles >= 16) S = std::min(std::max(S, B / 16), 2 * S);
+    // How many batch splits: more splits = shorter trajectory chains per block but more partial sums to write and re-read (wgrad_reduce_all).  With the
+    // prefetching trajectory loop the measured optimum of the 256 x 256 layers (64 tiles, 4 splits by the rule above) is 2 / 2 / 4 / 8 splits at batch
+    // 32 / 64 / 128 / 512 (gpurun_out/r04za/wgrad_rule*.txt: batch 32 0.68 -> 0.63 ms with half the splits, batch 512 2.42 -> 2.37 with twice) - the
+    // rule's count times sqrt(B / 128), within [1/2, 2]; fewer splits for every layer, more only for the layers with many tiles.
+    {
+        const float f = std::min(2.0f, std::max(0.5f, sqrtf((float)B / 128.0f)));
+        if (f < 1.0f || tiles >= 16) S = std::max(1, (int)lroundf((float)S * f));
+    }
     S = std::max(1, std::min(S, B));
     const int per = (B + S - 1) / S;
     return (size_t)((B + per - 1) / per);
