@@ -77,19 +77,47 @@ __device__ __forceinline__ void weighted_loss_body(const float* pred, const floa
     }
 }
 
-// wave `w` (0 .. 15) of the same sum as its own one-wave workgroup: partial sums through `gpart` (16 doubles of global memory, agent-scope atomic
-// stores / loads: no L2-flushing fence), the workgroup that takes the last ticket (`ticket`: zero at launch) adds them in wave order.  Call with the
-// 64 threads of one wave.
+// wave `w` (0 .. 15) of the same sum as its own workgroup: ALL 1024 threads of the workgroup fetch the wave's elements (coalesced, every load in
+// flight at once) and leave each element's term q in LDS; the workgroup's first wave then adds its threads' terms in the sum's order (thread t: elements
+// t, t + 1024, ... ascending, in double; xor-shuffle tree).  (A first version let the one wave fetch its own 112 elements per thread, eight at a time:
+// fourteen dependent round trips, 20 us at batch 128 x D = 14.)  Partial sums go through `gpart` (16 doubles of global memory, agent-scope atomic
+// stores / loads: no L2-flushing fence); the workgroup that takes the last ticket (`ticket`: zero at launch) adds them in wave order.
+constexpr int kLossChunk = 128;   // elements per thread and LDS round: 64 x 128 floats = 32 KB
 __device__ __forceinline__ void weighted_loss_wave_block(const float* pred, const float* targ, const float* weights, const float* hs, const float* hg, int l1,
-                                                         float* out, int B, int H, int D, int w, double* gpart, unsigned* ticket) {
-    const unsigned lane = threadIdx.x & 63;
-    const double acc = weighted_loss_wave_sum(weighted_loss_thread_sum(pred, targ, weights, hs, hg, l1, B, H, D, (unsigned)w * 64u + lane));
-    unsigned last = 0;
-    if (lane == 0) {
+                                                         float* out, int B, int H, int D, int w, double* gpart, unsigned* ticket, float* q) {
+    const unsigned nn = (unsigned)((size_t)B * H * D), uD = (unsigned)D, uH = (unsigned)H;
+    const unsigned K = (nn + 1023u) / 1024u;   // elements per thread of the sum
+    const unsigned tid = threadIdx.x;
+    double acc = 0.0;
+    for (unsigned k0 = 0; k0 < K; k0 += kLossChunk) {
+        const unsigned cnt = K - k0 < (unsigned)kLossChunk ? K - k0 : (unsigned)kLossChunk;
+        for (unsigned j = tid; j < 64u * cnt; j += 1024u) {
+            const unsigned t = j & 63u, k = k0 + (j >> 6);
+            const unsigned i = (unsigned)w * 64u + t + 1024u * k;
+            float term = 0.f;   // (elements behind the end add +0.0: the double sum is unchanged)
+            if (i < nn) {
+                const unsigned d = i % uD, p = i / uD, l = p % uH, b = p / uH;
+                float v = pred[i];
+                if (hs && l == 0) v = hs[b * uD + d];
+                if (hg && l == uH - 1u) v = hg[b * uD + d];
+                const float e = __fsub_rn(v, targ[i]);
+                term = l1 ? fabsf(e) : __fmul_rn(e, e);
+                if (weights) term = __fmul_rn(term, weights[(size_t)l * uD + d]);
+            }
+            q[j] = term;
+        }
+        __syncthreads();
+        if (tid < 64u)
+            for (unsigned kk = 0; kk < cnt; ++kk)
+                if ((unsigned)w * 64u + tid + 1024u * (k0 + kk) < nn) acc += (double)q[tid + 64u * kk];
+        __syncthreads();
+    }
+    if (tid >= 64u) return;
+    acc = weighted_loss_wave_sum(acc);
+    if (tid == 0) {
         __hip_atomic_store(gpart + w, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        last = atomicAdd(ticket, 1u) == 15u ? 1u : 0u;
-        if (last) {
+        if (atomicAdd(ticket, 1u) == 15u) {
             double tot = 0.0;
             for (int k = 0; k < 16; ++k) tot += __hip_atomic_load(gpart + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out[0] = (float)(tot / (double)((size_t)B * H * D));

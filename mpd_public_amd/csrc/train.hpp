@@ -903,7 +903,8 @@ __global__ __launch_bounds__(1024) void train_loss_kernel(const float* __restric
                                                           double* __restrict__ loss_part, unsigned* __restrict__ loss_ticket) {
     const unsigned nb = gridDim.x - 16;
     if (blockIdx.x >= nb) {   // the loss value: wave w of weighted_loss_kernel's sum as its own one-wave workgroup (loss.hpp)
-        if (threadIdx.x < 64) weighted_loss_wave_block(pred, targ, weights_hd, hs, hg, l1, loss_out, B, H, D, (int)(blockIdx.x - nb), loss_part, loss_ticket);
+        __shared__ float lq[64 * kLossChunk];
+        weighted_loss_wave_block(pred, targ, weights_hd, hs, hg, l1, loss_out, B, H, D, (int)(blockIdx.x - nb), loss_part, loss_ticket, lq);
         return;
     }
     const size_t rows = (size_t)B * H, total = rows * C;
