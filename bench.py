@@ -352,6 +352,8 @@ def guided_leg(device, plans=5, reps=200):
         table_bytes = int(gp.n_prim_floats) * 4
         abytes = 2 * B * 64 * D * 4 + table_bytes
         flop = guide_flop_estimate(g.dataset, g, B)
+        gname = "guide_step_panda_kernel" if robot == "RobotPanda" else "guide_step_kernel"
+        g_traffic, g_src, g_age = _pmc_traffic(B, gname)   # rocprofv3 --pmc passes of `bench.py --config cfg3 / cfg4` (tools/r04_evidence.sh), None without a file
         rec = {"workload": f"{cfg}: {env_id}-{robot} shape, {B} trajectories x H=64 x D={D}, T={T} (+{n0}), guided: {n_guided} guided steps x "
                            f"{gk['n_guide_steps']} guide iterations = {launches} guide launches per plan",
                "plan_ms": round(plan_s * 1e3, 3), "denoising_steps_per_s": round((T + n0) / plan_s, 1),
@@ -361,7 +363,8 @@ def guided_leg(device, plans=5, reps=200):
                                 "timed": f"{reps} back-to-back launches between one HIP-event pair on the launch stream (mpdx_guide_time)",
                                 "roofline": {"bound": "hbm", "achieved": round(abytes / (us * 1e-6) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": round(abytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
-                                             "algorithmic_bytes_per_launch": abytes, "table_bytes": table_bytes, "traffic": None,
+                                             "algorithmic_bytes_per_launch": abytes, "table_bytes": table_bytes, "traffic": g_traffic,
+                                             "traffic_source": g_src, "traffic_age": g_age,
                                              "note": "latency-bound by construction: 2 * B*H*D*4 bytes + the primitive table per launch; FK / SDF "
                                                      "arithmetic on one workgroup per trajectory"},
                                 "flop_estimate_per_launch": flop, "GFLOPs_estimate": round(flop / (us * 1e-6) / 1e9, 1),

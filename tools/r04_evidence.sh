@@ -12,6 +12,11 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_fetch -- $BENCH1 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_write -- $BENCH1 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_sq -- $BENCH1 > /dev/null 2>&1
+# the guide kernels at B = 100 (cfg 3: point mass, cfg 4: Panda): the two counter passes each
+for c in cfg3 cfg4; do
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_${c}_fetch -- $BENCH1 --config $c > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_${c}_write -- $BENCH1 --config $c > /dev/null 2>&1
+done
 # the batch that fills the GPU (cfg 5 shard, B = 6400): kernel stats + the same three counter passes
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_cfg5 -- $BENCH --config cfg5 --steps 2 > /dev/null 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc5_fetch -- $BENCH1 --config cfg5 > /dev/null 2>&1
@@ -42,6 +47,7 @@ print(json.dumps({'batch32_D4': bench.training_leg(), 'batch128_D14': bench.trai
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/cfg2_kernel_stats.csv
 cp $(find $O/prof_default -name "*kernel_stats.csv" | head -1) $O/default_cmd_kernel_stats.csv
 python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write 100 > $O/pmc_traffic.json
+for c in cfg3 cfg4; do python tools/pmc_traffic.py $O/pmc_${c}_fetch $O/pmc_${c}_write 100 > $O/pmc_traffic_$c.json; rm -rf $O/pmc_${c}_fetch $O/pmc_${c}_write; done
 python tools/pmc_summary.py $O/pmc_sq > $O/pmc_sq_summary.json
 python tools/pmc_traffic.py $O/pmc5_fetch $O/pmc5_write 6400 > $O/pmc_traffic_B6400.json
 python tools/pmc_summary.py $O/pmc5_sq > $O/pmc_sq_summary_B6400.json
