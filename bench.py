@@ -108,7 +108,7 @@ def csrc_fingerprint():
     return h.hexdigest()[:16]
 
 
-def _pmc_traffic(B, kernel):
+def _pmc_traffic(B, kernel, pattern="r*_pmc_traffic*.json"):
     """HBM-side bytes per launch of `kernel` at batch B from the newest profiles/r*_pmc_traffic*.json that covers (batch, kernel):
     PMC counters cannot be read from inside this process; they are collected by tools/r04_evidence.sh (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate passes, gfx950 x2 fetch correction, MI355X_MICROARCH.md section HBM) on this same command and
@@ -120,7 +120,7 @@ def _pmc_traffic(B, kernel):
         m = re.match(r"r(\d+)([a-z]?)_", f.name)
         return (int(m.group(1)), m.group(2) or "~") if m else (-1, "")
     pats = ("fused_program_kernel", "fused_level_kernel") if kernel.startswith("fused") else (kernel,)
-    for f in sorted((ROOT / "profiles").glob("r*_pmc_traffic*.json"), key=_round_key, reverse=True):
+    for f in sorted((ROOT / "profiles").glob(pattern), key=_round_key, reverse=True):
         try:
             rec = json.loads(f.read_text())
         except Exception:
@@ -353,7 +353,8 @@ def guided_leg(device, plans=5, reps=200):
         abytes = 2 * B * 64 * D * 4 + table_bytes
         flop = guide_flop_estimate(g.dataset, g, B)
         gname = "guide_step_panda_kernel" if robot == "RobotPanda" else "guide_step_kernel"
-        g_traffic, g_src, g_age = _pmc_traffic(B, gname)   # rocprofv3 --pmc passes of `bench.py --config cfg3 / cfg4` (tools/r04_evidence.sh), None without a file
+        g_traffic, g_src, g_age = _pmc_traffic(B, gname, "r*_guide_pmc_traffic*.json")   # (own file family: the headline's lookup must not meet the D = 14 network's kernels)
+        # rocprofv3 --pmc passes of `bench.py --config cfg3 / cfg4` (tools/r04_evidence.sh), None without a file
         rec = {"workload": f"{cfg}: {env_id}-{robot} shape, {B} trajectories x H=64 x D={D}, T={T} (+{n0}), guided: {n_guided} guided steps x "
                            f"{gk['n_guide_steps']} guide iterations = {launches} guide launches per plan",
                "plan_ms": round(plan_s * 1e3, 3), "denoising_steps_per_s": round((T + n0) / plan_s, 1),
