@@ -353,7 +353,7 @@ def guided_leg(device, plans=5, reps=200):
         abytes = 2 * B * 64 * D * 4 + table_bytes
         flop = guide_flop_estimate(g.dataset, g, B)
         gname = "guide_step_panda_kernel" if robot == "RobotPanda" else "guide_step_kernel"
-        g_traffic, g_src, g_age = _pmc_traffic(B, gname, "r*_guide_pmc_traffic*.json")   # (own file family: the headline's lookup must not meet the D = 14 network's kernels)
+        g_traffic, g_src, g_age = _pmc_traffic(B, gname, "r*_guidepmc_*.json")   # (own file family: the headline's lookup must not meet the D = 14 network's kernels)
         # rocprofv3 --pmc passes of `bench.py --config cfg3 / cfg4` (tools/r04_evidence.sh), None without a file
         rec = {"workload": f"{cfg}: {env_id}-{robot} shape, {B} trajectories x H=64 x D={D}, T={T} (+{n0}), guided: {n_guided} guided steps x "
                            f"{gk['n_guide_steps']} guide iterations = {launches} guide launches per plan",

@@ -47,7 +47,7 @@ print(json.dumps({'batch32_D4': bench.training_leg(), 'batch128_D14': bench.trai
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/cfg2_kernel_stats.csv
 cp $(find $O/prof_default -name "*kernel_stats.csv" | head -1) $O/default_cmd_kernel_stats.csv
 python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write 100 > $O/pmc_traffic.json
-for c in cfg3 cfg4; do python tools/pmc_traffic.py $O/pmc_${c}_fetch $O/pmc_${c}_write 100 > $O/guide_pmc_traffic_$c.json; rm -rf $O/pmc_${c}_fetch $O/pmc_${c}_write; done
+for c in cfg3 cfg4; do python tools/pmc_traffic.py $O/pmc_${c}_fetch $O/pmc_${c}_write 100 > $O/guidepmc_$c.json; rm -rf $O/pmc_${c}_fetch $O/pmc_${c}_write; done
 python tools/pmc_summary.py $O/pmc_sq > $O/pmc_sq_summary.json
 python tools/pmc_traffic.py $O/pmc5_fetch $O/pmc5_write 6400 > $O/pmc_traffic_B6400.json
 python tools/pmc_summary.py $O/pmc5_sq > $O/pmc_sq_summary_B6400.json
