@@ -458,3 +458,21 @@ def test_graph_replayed_steps_equal_eager_steps():
     ts_r = TrainStep(dm_r)
     ls = [float(ts_r.step(x0, hc, 1e-3, max_norm=1.0)) for _ in range(6)]
     assert len(set(ls[2:])) > 1 and all(np.isfinite(ls))
+
+
+@pytest.mark.parametrize("H", [32, 128])
+def test_training_at_other_horizons_is_refused_loudly(H):
+    """The backward kernels take GroupNorm regions (channels per group x level horizon) of 128 or 256 elements - what every level of the
+    reference's H = 64 networks has.  At H = 32 / 128 some level has 64 / 512: the pass is REFUSED with a message that names the layer,
+    not computed wrongly (the planning path runs these horizons: test_other_horizons_unet_and_plan_vs_oracle)."""
+    import mpd_public_amd as m
+    from mpd_public_amd.trainer import TrainStep
+    D, opt, B = 4, 1, 5
+    net = m.TemporalUnet(n_support_points=H, state_dim=D, unet_input_dim=32, dim_mults=DIM_MULTS[opt])
+    net.load_state_dict(synth_sd(D, opt), strict=True)
+    dm = m.GaussianDiffusionModel(model=net, n_diffusion_steps=25, predict_epsilon=True, loss_type="l2").cuda()
+    x0, noise = t(f"lossH{H}_x0", (B, H, D), "uniform", 0.8), t(f"lossH{H}_noise", (B, H, D))
+    hc = {0: t(f"lossH{H}_hc0", (B, D), "uniform", 0.7), H - 1: t(f"lossH{H}_hc1", (B, D), "uniform", 0.7)}
+    ts = TrainStep(dm)
+    with pytest.raises(RuntimeError, match="GroupNorm region"):
+        ts.loss_backward(x0.cuda(), {k: v.cuda() for k, v in hc.items()}, t=torch.tensor([3, 24, 0, 12, 7]).cuda(), noise=noise.cuda())
