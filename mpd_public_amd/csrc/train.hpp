@@ -480,55 +480,52 @@ __global__ __launch_bounds__(256) void pack_train_kernel(const PackDesc* __restr
     const float* src = flat + d.src;
     const unsigned n = (unsigned)d.n;
     const unsigned cin = (unsigned)d.cin, cout = (unsigned)d.cout, ks = (unsigned)d.ks;
-    unsigned idx[4], sa[4];
-    bool in[4], ok[4];
-    float v[4];
+    // A thread takes the four CONSECUTIVE outputs i0 .. i0 + 3 of one lane of one 256-float fragment block (round 4; before: outputs i, i + 256, i + 512,
+    // i + 768 - four decompositions of the block index per thread, and the kernel was VALU-bound on their 32-bit divisions: 22 us for 47 MB): one
+    // decomposition, the four sources a constant stride apart.
+    const unsigned i0 = c.first + 4u * threadIdx.x;
+    const unsigned lane = (i0 >> 2) & 63;
+    unsigned r = i0 >> 8;
+    unsigned sa0 = i0, sstep = 1, lim_ci = 0, ci0 = 0;   // source of element e: sa0 + e * sstep, valid while ci0 + e < lim_ci (vectors: i0 + e < n)
+    bool okq = true;
+    float* dst;
+    unsigned total;
     if (c.which == 0) {
-        const unsigned pn = (unsigned)d.pn, nc16 = (unsigned)d.cin_pad >> 4, nslot = (unsigned)d.nslot;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned i = c.first + k * 256u + threadIdx.x;
-            idx[k] = i; in[k] = i < pn;
-            if (d.kind == 0) { ok[k] = i < n; sa[k] = i; }   // PK_VEC
-            else {   // forward layout [m16][c16][slot][lane][4]
-                const unsigned e = i & 3, lane = (i >> 2) & 63;
-                unsigned r = i >> 8;
-                const unsigned slot = r % nslot; r /= nslot;
-                const unsigned c16 = r % nc16, m16 = r / nc16;
-                const unsigned co = m16 * 16 + (lane & 15), ci = c16 * 16 + (lane >> 4) * 4 + e;
-                ok[k] = ci < cin;
-                sa[k] = d.kind == 2 ? (ci * cout + co) * ks + (unsigned)upt_slot_to_k((int)slot) : (co * cin + ci) * ks + slot;
-            }
-            ok[k] = ok[k] && in[k];
+        total = (unsigned)d.pn;
+        dst = packed + d.dst;
+        if (d.kind == 0) { ci0 = i0; lim_ci = n; }   // PK_VEC: a copy
+        else {   // forward layout [m16][c16][slot][lane][4]
+            const unsigned nc16 = (unsigned)d.cin_pad >> 4, nslot = (unsigned)d.nslot;
+            const unsigned slot = r % nslot; r /= nslot;
+            const unsigned c16 = r % nc16, m16 = r / nc16;
+            const unsigned co = m16 * 16 + (lane & 15);
+            ci0 = c16 * 16 + (lane >> 4) * 4; lim_ci = cin;
+            if (d.kind == 2) { sa0 = (ci0 * cout + co) * ks + (unsigned)upt_slot_to_k((int)slot); sstep = cout * ks; }
+            else { sa0 = (co * cin + ci0) * ks + slot; sstep = ks; }
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = src[ok[k] ? sa[k] : 0u];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (in[k]) packed[d.dst + idx[k]] = ok[k] ? v[k] : 0.f;
     } else {   // dgrad layout: a CONV_S1 weight [t_cout][t_cin][t_ks]
         if (!packedT) return;
-        const unsigned tnc16 = (unsigned)d.t_cin_pad >> 4, tks = (unsigned)d.t_ks, tcin = (unsigned)d.t_cin, tcout = (unsigned)d.t_cout, pnT = (unsigned)d.pnT;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned i = c.first + k * 256u + threadIdx.x;
-            idx[k] = i; in[k] = i < pnT;
-            const unsigned e = i & 3, lane = (i >> 2) & 63;
-            unsigned r = i >> 8;
-            const unsigned slot = r % tks; r /= tks;
-            const unsigned c16 = r % tnc16, m16 = r / tnc16;
-            const unsigned o = m16 * 16 + (lane & 15);            // output channel of the dgrad conv = input channel of the layer
-            const unsigned ii = c16 * 16 + (lane >> 4) * 4 + e;   // input channel of the dgrad conv = output channel of the layer
-            ok[k] = in[k] && ii < tcin && o < tcout && (d.t_mode == 0 || slot > 0);
-            sa[k] = d.t_mode == 0 ? (ii * cin + o) * ks + (ks - 1 - slot)      // W[co = ii][ci = o][k - 1 - k']
-                                  : (o * cout + ii) * ks + (slot - 1);          // W[ci = o][co = ii][k' - 1]
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = src[ok[k] ? sa[k] : 0u];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (in[k]) packedT[d.dstT + idx[k]] = ok[k] ? v[k] : 0.f;
+        total = (unsigned)d.pnT;
+        dst = packedT + d.dstT;
+        const unsigned tnc16 = (unsigned)d.t_cin_pad >> 4, tks = (unsigned)d.t_ks, tcin = (unsigned)d.t_cin, tcout = (unsigned)d.t_cout;
+        const unsigned slot = r % tks; r /= tks;
+        const unsigned c16 = r % tnc16, m16 = r / tnc16;
+        const unsigned o = m16 * 16 + (lane & 15);     // output channel of the dgrad conv = input channel of the layer
+        ci0 = c16 * 16 + (lane >> 4) * 4;               // input channel of the dgrad conv = output channel of the layer
+        lim_ci = tcin;
+        okq = o < tcout && (d.t_mode == 0 || slot > 0);
+        if (d.t_mode == 0) { sa0 = (ci0 * cin + o) * ks + (ks - 1 - slot); sstep = cin * ks; }   // W[co = ii][ci = o][k - 1 - k']
+        else { sa0 = (o * cout + ci0) * ks + (slot - 1); sstep = ks; }                             // W[ci = o][co = ii][k' - 1]
     }
+    bool ok[4];
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ok[e] = okq && i0 + e < total && ci0 + e < lim_ci;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = src[ok[e] ? sa0 + e * sstep : 0u];   // (unconditional loads from clamped addresses; zeros selected afterwards)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (i0 + e < total) dst[i0 + e] = ok[e] ? v[e] : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -788,7 +785,8 @@ __device__ __forceinline__ void time_bwd_all_body(const TimeBwdArgs& a, const in
     // Every output still adds its samples in ascending order: same bits.
     const int k = tid & 127, q8 = tid >> 7;     // encoder.3: column k; rows e = 4 q8 + i (dW3), samples bb = q8 + 8 i (dh1)
     const int j = tid & 31, k0 = tid >> 5;      // encoder.1: column j; rows kk = 4 k0 + i
-    float w3g[4] = {0.f, 0.f, 0.f, 0.f}, b3g[4] = {0.f, 0.f, 0.f, 0.f}, w1g[4] = {0.f, 0.f, 0.f, 0.f}, b1g[4] = {0.f, 0.f, 0.f, 0.f};
+    float w3g[4] = {0.f, 0.f, 0.f, 0.f}, w1g[4] = {0.f, 0.f, 0.f, 0.f};
+    float b3s = 0.f, b1s = 0.f;   // bias gradients: thread e < 32 sums dtemb[.][e], thread kk < 128 sums dh1[.][kk] (samples ascending) - not every thread of the GEMM loops
     float w3c[32];   // W3[e][k], e = 0..31 (this thread's column)
 #pragma unroll
     for (int ee = 0; ee < 32; ++ee) w3c[ee] = a.flat[a.w3 + (size_t)ee * 128 + k];
@@ -822,7 +820,11 @@ __device__ __forceinline__ void time_bwd_all_body(const TimeBwdArgs& a, const in
             const f32x4 d = *(const f32x4*)(dtmS + bb * 32 + 4 * q8);
             const float h = h1mS[bb * 128 + k];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { w3g[i] = fmaf(d[i], h, w3g[i]); b3g[i] += d[i]; }
+            for (int i = 0; i < 4; ++i) w3g[i] = fmaf(d[i], h, w3g[i]);
+        }
+        if (tid < 32) {
+#pragma unroll 8
+            for (int bb = 0; bb < 32; ++bb) b3s += dtmS[bb * 32 + tid];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {   // dh1[b][k] = mish'(h1[b][k]) sum_e dtemb[b][e] W3[e][k]
@@ -843,16 +845,20 @@ __device__ __forceinline__ void time_bwd_all_body(const TimeBwdArgs& a, const in
             const f32x4 d = *(const f32x4*)(dh1S + bb * 128 + 4 * k0);
             const float em = embS[bb * 32 + j];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { w1g[i] = fmaf(d[i], em, w1g[i]); b1g[i] += d[i]; }
+            for (int i = 0; i < 4; ++i) w1g[i] = fmaf(d[i], em, w1g[i]);
+        }
+        if (tid < 128) {
+#pragma unroll 8
+            for (int bb = 0; bb < 32; ++bb) b1s += dh1S[bb * 128 + tid];
         }
     }
+    if (tid < 32) a.grad[a.b3 + tid] = b3s;
+    if (tid < 128) a.grad[a.b1 + tid] = b1s;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int ee = 4 * q8 + i, kk = 4 * k0 + i;
         a.grad[a.w3 + (size_t)ee * 128 + k] = w3g[i];
-        if (k == 0) a.grad[a.b3 + ee] = b3g[i];
         a.grad[a.w1 + (size_t)kk * 32 + j] = w1g[i];
-        if (j == 0) a.grad[a.b1 + kk] = b1g[i];
         if (i == 3) { TB_STAMP(); TB_STAMP(); TB_DUMP("tail"); }
     }
 }
