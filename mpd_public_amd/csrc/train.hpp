@@ -958,7 +958,15 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     __shared__ float red[4];
     if (cnt && blockIdx.x == 0 && threadIdx.x == 0) cnt[0] += 1;
     float s = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s = fmaf(g[i], g[i], s);
+    // a thread's elements in ascending order (the sum's order), their loads eight at a time (unconditional, clamped: fmaf(0, 0, s) == s)
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += 8 * stride) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const size_t k = i + u * stride; v[u] = g[k < n ? k : i]; if (k >= n) v[u] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = fmaf(v[u], v[u], s);
+    }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
