@@ -796,6 +796,12 @@ def main():
                 out["planner_baseline"] = {"error": f"{type(e).__name__}: {e}"}
             try:
                 out["training"] = training_leg()
+                # the larger shapes of the same iteration (no torch-autograd leg): where the step stops being launch-bound
+                for nm, (tb, td, tsteps) in {"batch128_D14": (128, 14, 40), "batch512_D14": (512, 14, 15)}.items():
+                    r = training_leg(steps=tsteps, B=tb, D=td, baseline=False)
+                    out["training"][nm] = {"ms_per_train_step": r["ms_per_train_step"], "train_steps_per_s": r["train_steps_per_s"],
+                                           "fp32_TFLOPs": r.get("roofline", {}).get("achieved"), "fp32_peak_frac": r.get("roofline", {}).get("frac"),
+                                           "launch_mode": r.get("launch_mode")}
             except Exception as e:
                 out["training"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
