@@ -184,6 +184,9 @@ class TrainStep:
         if self._ws is None or self._ws_B < B:
             self._ws = torch.empty(int(lib.mpdx_train_workspace_floats(h, B)), dtype=torch.float32, device=dev)
             self._ws_B = B
+            # graphs captured by step() hold the OLD workspace's address: drop them (they are re-captured after their next two eager calls)
+            self.__dict__.pop("_graphs", None)
+            self.__dict__.pop("_graph_warm", None)
         self.pack(sync_engine=False)
         self._snapshot_pending()   # an autograd loss whose backward() has not run yet still needs the gradients about to be overwritten
         _lib.check(lib.mpdx_train_loss_backward(

@@ -453,6 +453,17 @@ def test_graph_replayed_steps_equal_eager_steps():
     lg = ts_g.step(x0, hc, 1e-3, max_norm=1.0, t=TTS[1].cuda(), noise=noise)
     assert ts_g.step_count == ts_e.step_count == 8
     assert float((ts_g.fp.flat - ts_e.fp.flat).abs().max().cpu()) <= 1e-6 * float(ts_e.fp.flat.abs().max().cpu())
+    # a larger batch re-allocates the workspace the captured graph points into: the graphs are dropped and re-captured, results stay those of eager steps
+    xb, nb, hb = torch.cat([x0, x0 * 0.5]), torch.cat([noise, noise * 0.7]), {k: torch.cat([v, v * 0.9]) for k, v in hc.items()}
+    tb = torch.cat([TTS[0], TTS[1]]).cuda()
+    for ts_ in (ts_e, ts_g):
+        ts_.loss_backward(xb, hb, t=tb, noise=nb); ts_.adam_step(1e-3, max_norm=1.0)
+    assert "_graphs" not in ts_g.__dict__, "the workspace moved: the captured graphs had to go"
+    for k in range(4):
+        ts_e.loss_backward(x0, hc, t=TTS[k % 2].cuda(), noise=noise); ts_e.adam_step(1e-3, max_norm=1.0)
+        ts_g.step(x0, hc, 1e-3, max_norm=1.0, t=TTS[k % 2].cuda(), noise=noise)
+    assert len(ts_g._graphs) == 1 and ts_g.step_count == ts_e.step_count
+    assert float((ts_g.fp.flat - ts_e.fp.flat).abs().max().cpu()) <= 1e-6 * float(ts_e.fp.flat.abs().max().cpu())
     # without t / noise the graph draws them itself (torch's graph-safe generator): the loss differs from replay to replay
     dm_r = _model(4, 1)
     ts_r = TrainStep(dm_r)
