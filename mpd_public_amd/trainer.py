@@ -243,6 +243,12 @@ class TrainStep:
                t is not None, noise is not None)
         graphs = self.__dict__.setdefault("_graphs", {})
         g = graphs.get(key) if use_graph else None
+        if g is not None and g["ptrs"] != self._static_ptrs():
+            # a buffer the graph reads or writes has moved since the capture (e.g. the TemporalUnet's inference engine re-created its weight pack after
+            # a summary / validation pass): the graph is stale - drop it; it is re-captured after two eager steps
+            del graphs[key]
+            self.__dict__.setdefault("_graph_warm", {})[key] = 0
+            g = None
         if g is None:
             warm = self.__dict__.setdefault("_graph_warm", {})
             warm[key] = warm.get(key, 0) + 1
@@ -274,6 +280,11 @@ class TrainStep:
             self.fp.bind_grads()
         return g["loss"]
 
+    def _static_ptrs(self):
+        """addresses of every persistent buffer a captured iteration touches"""
+        return (self._packed().data_ptr(), self.fp.packedT.data_ptr(), self.fp.flat.data_ptr(), self.fp.grad.data_ptr(), self.exp_avg.data_ptr(),
+                self.exp_avg_sq.data_ptr(), self.scratch.data_ptr(), self.loss_buf.data_ptr(), 0 if self._ws is None else self._ws.data_ptr())
+
     def _capture(self, x_start, hard_conds, lr, betas, eps, mn, t, noise):
         m, dev = self.model, x_start.device
         B = x_start.shape[0]
@@ -294,7 +305,7 @@ class TrainStep:
                                           self.fp.n, float(lr), float(betas[0]), float(betas[1]), float(eps), -1, mn,
                                           self.scratch.data_ptr(), _lib.current_stream()), "mpdx_adam_step")
         torch.cuda.current_stream(dev).wait_stream(side)
-        st["graph"], st["loss"] = graph, loss
+        st["graph"], st["loss"], st["ptrs"] = graph, loss, self._static_ptrs()
         return st
 
 

@@ -464,6 +464,14 @@ def test_graph_replayed_steps_equal_eager_steps():
         ts_g.step(x0, hc, 1e-3, max_norm=1.0, t=TTS[k % 2].cuda(), noise=noise)
     assert len(ts_g._graphs) == 1 and ts_g.step_count == ts_e.step_count
     assert float((ts_g.fp.flat - ts_e.fp.flat).abs().max().cpu()) <= 1e-6 * float(ts_e.fp.flat.abs().max().cpu())
+    # the inference engine re-creates the TemporalUnet's weight pack after a training step (a summary pass that plans with the model): the captured
+    # graph points at the old one and must not be replayed
+    for dm_ in (dm_e, dm_g):
+        dm_.model.engine(25, 4)
+    for k in range(3):
+        ts_e.loss_backward(x0, hc, t=TTS[k % 2].cuda(), noise=noise); ts_e.adam_step(1e-3, max_norm=1.0)
+        ts_g.step(x0, hc, 1e-3, max_norm=1.0, t=TTS[k % 2].cuda(), noise=noise)
+    assert float((ts_g.fp.flat - ts_e.fp.flat).abs().max().cpu()) <= 1e-6 * float(ts_e.fp.flat.abs().max().cpu())
     # without t / noise the graph draws them itself (torch's graph-safe generator): the loss differs from replay to replay
     dm_r = _model(4, 1)
     ts_r = TrainStep(dm_r)
