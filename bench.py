@@ -96,6 +96,9 @@ def _unit_classes(lib, hdl, B, names, flops, n):
     return out
 
 
+_NOT_PLANNING = ("train", "k_train", "k_fused_train", "planner", "k_planner", "loss")
+
+
 def csrc_fingerprint():
     """sha256 (16 hex digits) over the kernel sources (mpd_public_amd/csrc/*): a PMC traffic file carries the fingerprint of the sources it
     was measured on (tools/pmc_traffic.py), bench.py compares it with the sources it runs - a stale file is visible without git (the
@@ -103,7 +106,7 @@ def csrc_fingerprint():
     import hashlib
     h = hashlib.sha256()
     for f in sorted((ROOT / "mpd_public_amd" / "csrc").glob("*")):
-        if f.suffix in (".hpp", ".hip"):
+        if f.suffix in (".hpp", ".hip") and not f.name.startswith(_NOT_PLANNING):   # the planning path's kernels: the training / planner families have no PMC records
             h.update(f.name.encode()); h.update(f.read_bytes())
     return h.hexdigest()[:16]
 

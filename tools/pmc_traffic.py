@@ -27,7 +27,7 @@ def csrc_fingerprint():   # as bench.csrc_fingerprint: which kernel sources this
     import hashlib, pathlib
     h = hashlib.sha256()
     for f in sorted((pathlib.Path(__file__).resolve().parent.parent / "mpd_public_amd" / "csrc").glob("*")):
-        if f.suffix in (".hpp", ".hip"):
+        if f.suffix in (".hpp", ".hip") and not f.name.startswith(("train", "k_train", "k_fused_train", "planner", "k_planner", "loss")):
             h.update(f.name.encode()); h.update(f.read_bytes())
     return h.hexdigest()[:16]
 
