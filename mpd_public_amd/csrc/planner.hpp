@@ -271,6 +271,61 @@ __device__ __forceinline__ void gpmp_bcr_solve(float* Dm, float* Cm, float* rhs,
         }
         __syncthreads();
         // ---- P3: Schur complements onto the kept blocks and the next level's couplings
+        if constexpr (D > 8 && D < 16) {
+            // d x d x d products on the matrix cores: one wave = one product, four v_mfma_f32_16x16x4_f32 (d padded to 16 by zero operands; exact fp32
+            // FMAs).  A kept block's two products share one accumulator; column d of the B operand (free: d < 16) carries the eliminated block's
+            // right-hand side, so that  r_q -= Y^T w  falls out of the same instructions as column d of the result.  (The scalar form below - two LDS
+            // loads per FMA - was ~40 % of the solve for the Panda.)
+            const int lane = tid & 63, wave = tid >> 6;
+            const int c16 = lane & 15, kq = lane >> 4;   // operand row / column index, k sub-index; result: rows 4 kq + r, column c16
+            const int nc = (nl - 1) >> 1;
+            for (int task = wave; task < nk + nc; task += NTHR / 64) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (task < nk) {
+                    const int q = 2 * task + 1, kb = G::idx(q, s);
+                    const float* Y1 = G::coup(Dm, Cm, s, q - 1);      // Y_hi^T of the eliminated block below: [i][k]
+                    const float* w1 = rhs + (size_t)G::idx(q - 1, s) * D;
+                    const bool up = q + 1 < nl;
+                    const float* Y2 = up ? G::coup(Dm, Cm, s, q) : Y1;   // Y_lo of the eliminated block above: [k][j]
+                    const float* w2 = up ? rhs + (size_t)G::idx(q + 1, s) * D : w1;
+                    const int cc = c16 < D ? c16 : 0;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int k = 4 * kk + kq, kc = k < D ? k : 0;
+                        const bool kin = k < D;
+                        const float y1 = Y1[cc * D + kc], y2 = Y2[kc * D + cc], v1 = w1[kc], v2 = w2[kc];
+                        const float a1 = (kin && c16 < D) ? y1 : 0.f, b1 = kin ? (c16 < D ? y1 : (c16 == D ? v1 : 0.f)) : 0.f;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+                        const float a2 = (kin && c16 < D && up) ? y2 : 0.f, b2 = (kin && up) ? (c16 < D ? y2 : (c16 == D ? v2 : 0.f)) : 0.f;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * kq + r;
+                        if (i < D && c16 <= i) Dm[(size_t)kb * DD + i * D + c16] -= acc[r];          // lower triangle of D_q
+                        else if (i < D && c16 == D) rhs[(size_t)kb * D + i] -= acc[r];                // r_q
+                    }
+                } else {   // eliminated position p = 2 t (t >= 1) with a neighbour on both sides: A[p+1][p-1] = -Y_hi^T Y_lo -> Dm[e]
+                    const int p = 2 * (task - nk + 1);
+                    const float* Yh = G::coup(Dm, Cm, s, p);
+                    const float* Yl = G::coup(Dm, Cm, s, p - 1);
+                    const int cc = c16 < D ? c16 : 0;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int k = 4 * kk + kq, kc = k < D ? k : 0;
+                        const bool ok = k < D && c16 < D;
+                        const float av = Yh[cc * D + kc], bv = Yl[kc * D + cc];
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? av : 0.f, ok ? bv : 0.f, acc, 0, 0, 0);
+                    }
+                    float* dst = Dm + (size_t)G::idx(p, s) * DD;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * kq + r;
+                        if (i < D && c16 < D) dst[i * D + c16] = -acc[r];
+                    }
+                }
+            }
+        } else {
         for (int task = tid; task < nk * (LSZ + D); task += NTHR) {
             const int u = task / (LSZ + D), r = task - u * (LSZ + D), q = 2 * u + 1, kb = G::idx(q, s);
             const float* Y1 = G::coup(Dm, Cm, s, q - 1);                 // Y_hi^T of the eliminated block below: [i][k]
@@ -312,6 +367,7 @@ __device__ __forceinline__ void gpmp_bcr_solve(float* Dm, float* Cm, float* rhs,
 #pragma unroll
             for (int k = 0; k < D; ++k) acc = __builtin_fmaf(Yh[i * D + k], Yl[k * D + j], acc);
             Dm[(size_t)G::idx(p, s) * DD + r] = -acc;
+        }
         }
         __syncthreads();
     }
