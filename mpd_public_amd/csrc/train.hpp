@@ -228,7 +228,7 @@ constexpr int kWgRS = 48;   // LDS row stride: 4 consecutive rows start 16 banks
 
 // The trajectory loop of wgrad_body for LA = 8 NR rows of A and LB = LA (Conv1d k5 / k1) or 2 LA (stride-2 layers: KS = 3 / 4) rows of B, round 4:
 // the NEXT trajectory's operand rows are fetched into registers (unconditional loads, clamped columns, zeros selected at the LDS store) while the
-// current one's MFMAs run, and the barriers are LDS-only (lds_barrier: __syncthreads() also drains vmcnt and would wait for the prefetch).  The
+// current one's MFMAs run; the barriers wait for LDS traffic only (lds_barrier; hipcc's __syncthreads() does the same here: checked in the ISA).  The
 // generic loop below issues its loads inside column-guard branches - one dependent round trip per row - and a block walks 8-32 trajectories: that
 // chain, not the MFMAs, was the length of every backward launch.  Same MFMA order per trajectory, trajectories ascending: same bits.
 template <int KS, int NR>
