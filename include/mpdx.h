@@ -146,6 +146,10 @@ int    mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* pa
 int    mpdx_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
                       float eps, int step, float max_norm, float* scratch, void* stream);
 /* EMA.update_model_average (trainer.py:67-85): ema = beta * ema + (1 - beta) * params */
+/* draw mode of mpdx_train_loss_backward (replaces `t = torch.randint(...)`, `noise = torch.randn_like(x)` of diffusion_model_base.py:356 / :337 when an
+ * iteration is replayed as a hipGraph): with a non-null step_counter_dev - the device int mpdx_adam_step(step < 0) advances - the following loss passes
+ * treat t_dev and noise as OUTPUTS drawn on the device (Philox4x32-10 keyed by seed, stream position step * B + sample); NULL disarms */
+int    mpdx_train_draw(mpdx_unet* u, unsigned long long seed, const int* step_counter_dev);
 int    mpdx_ema_update(float* ema, const float* params, size_t n, float beta, void* stream);
 
 /* standard-normal generator for the production path (Philox4x32-10 + Box-Muller); replaces torch.randn /

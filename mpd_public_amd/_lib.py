@@ -105,6 +105,7 @@ SIGNATURES = {
     "mpdx_train_pack": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mpdx_train_loss_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "mpdx_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _f, _vp, _vp]),
+    "mpdx_train_draw": (_i, [_vp, C.c_uint64, _vp]),
     "mpdx_ema_update": (_i, [_vp, _vp, _sz, _f, _vp]),
     "mpdx_gpmp_step": (_i, [C.POINTER(GuideParams), C.POINTER(GpmpOpts), _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mpdx_rrt_paths": (_i, [C.POINTER(GuideParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp]),

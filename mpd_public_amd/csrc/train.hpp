@@ -551,7 +551,26 @@ struct TimeTrainArgs {
     float* xn;                  // [B][H][D]
     float* zero_words;          // block 0 clears n_zero floats (the dgrad convolutions' zero bias + the time backward's ticket)
     int H, D, T, n_zero;
+    // draw mode (mpdx_train_draw: an iteration replayed as a hipGraph): the timestep and the noise of sample b are DRAWN here - Philox4x32-10 keyed
+    // by rng_seed, stream position (*rng_counter) * B + b: the device-resident optimiser step count, so every replay draws afresh - and written to
+    // t_out / noise_out (what torch.randint / torch.randn_like were two launches for)
+    unsigned long long rng_seed;
+    const int* rng_counter;     // null: t and noise are inputs
+    long long* t_out;
+    float* noise_out;
 };
+
+// uniform integer in [0, T) from one Philox counter (multiply-shift of 32 random bits)
+__device__ __forceinline__ int philox_randint(uint64_t seed, uint64_t ctr, int T) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return (int)(((uint64_t)c0 * (uint64_t)(uint32_t)T) >> 32);
+}
 
 // one block of 512 threads per sample; every stage spreads its dot products over all threads it can use and keeps its loads in flight
 // together (the first version ran encoder.3 on 32 threads x 32 dependent loads and the table on 128 threads: 17 us per call)
@@ -561,8 +580,30 @@ __global__ __launch_bounds__(512) void time_train_fwd_kernel(const TimeTrainArgs
     const int b = blockIdx.x, tid = threadIdx.x;
     if (tid < a.nblk) s_toff[tid] = a.toff[tid];
     if (tid == 0) s_toff[a.nblk] = a.row;
-    if (a.xn) {   // x_t = sqrt(acp[t_b]) x0 + sqrt(1 - acp[t_b]) noise, hard conditions: q_sample_kernel's arithmetic (mpdx.hip)
-        long long tb = a.t[b];
+    const bool draw = a.rng_counter != nullptr;
+    const unsigned long long rng_pos = draw ? (unsigned long long)(unsigned)(*a.rng_counter) * gridDim.x + (unsigned)b : 0ull;
+    const long long t_b = draw ? (long long)philox_randint(a.rng_seed ^ 0x74696D6573746570ull, rng_pos, a.T) : a.t[b];
+    if (draw && tid == 0) a.t_out[b] = t_b;
+    if (a.xn && draw) {   // the sample's noise drawn in place (HD % 4 == 0: checked on the host), then q_sample's arithmetic
+        const long long tb = t_b < 0 ? 0 : (t_b >= a.T ? a.T - 1 : t_b);
+        const float ca = a.sqrt_ac[tb], cb = a.sqrt_1mac[tb];
+        const int HD = a.H * a.D, nq = HD >> 2;
+        for (int q4 = tid; q4 < nq; q4 += 512) {
+            float z[4];
+            philox_normal4(a.rng_seed, rng_pos * (unsigned long long)nq + (unsigned)q4, z);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * q4 + e, l = i / a.D, d = i - l * a.D;
+                const size_t g = (size_t)b * HD + i;
+                a.noise_out[g] = z[e];
+                float r = __fadd_rn(__fmul_rn(ca, a.x0[g]), __fmul_rn(cb, z[e]));
+                if (a.hs && l == 0) r = a.hs[b * a.D + d];
+                if (a.hg && l == a.H - 1) r = a.hg[b * a.D + d];
+                a.xn[g] = r;
+            }
+        }
+    } else if (a.xn) {   // x_t = sqrt(acp[t_b]) x0 + sqrt(1 - acp[t_b]) noise, hard conditions: q_sample_kernel's arithmetic (mpdx.hip)
+        long long tb = t_b;
         tb = tb < 0 ? 0 : (tb >= a.T ? a.T - 1 : tb);
         const float ca = a.sqrt_ac[tb], cb = a.sqrt_1mac[tb];
         const int HD = a.H * a.D;
@@ -578,7 +619,7 @@ __global__ __launch_bounds__(512) void time_train_fwd_kernel(const TimeTrainArgs
     if (b == 0 && a.zero_words)
         for (int i = tid; i < a.n_zero; i += 512) a.zero_words[i] = 0.f;
     if (tid < 16) {
-        const float arg = (float)a.t[b] * a.freqs[tid];
+        const float arg = (float)t_b * a.freqs[tid];
         emb[tid] = sinf(arg);
         emb[tid + 16] = cosf(arg);
         a.emb[(size_t)b * 32 + tid] = emb[tid];

@@ -375,6 +375,22 @@ int mpdx_train_pack(mpdx_unet* u, const float* flat, float* packed, float* packe
     return 0;
 }
 
+/* Draw mode of the training pass (an iteration captured into a hipGraph, trainer.TrainStep.step): with a non-null `step_counter_dev` (a device int
+ * that counts the optimiser steps taken: mpdx_adam_step(step < 0) advances it) the NEXT mpdx_train_loss_backward calls treat `t_dev` and `noise` as
+ * OUTPUTS and draw them on the device (Philox4x32-10 keyed by `seed`, stream position step * B + sample); null disarms. */
+namespace mpdx {
+struct TrainRng { unsigned long long seed; const int* counter; };
+static std::mutex g_train_rng_mu;
+static std::unordered_map<const mpdx_unet*, TrainRng> g_train_rng;
+}  // namespace mpdx
+int mpdx_train_draw(mpdx_unet* u, unsigned long long seed, const int* step_counter_dev) {
+    if (!u) return fail(MPDX_E_INVALID, "null handle");
+    std::lock_guard<std::mutex> lk(g_train_rng_mu);
+    if (step_counter_dev) g_train_rng[u] = TrainRng{seed, step_counter_dev};
+    else g_train_rng.erase(u);
+    return 0;
+}
+
 /* One p_losses evaluation WITH its gradient (diffusion_model_base.py:331-352 + loss.backward()):
  *   x_noisy = q_sample(x_start, t, noise) with hard conditions; x_recon = unet(x_noisy, t) with hard conditions;
  *   loss = mean(|x_recon - target|^p [* weights]);  grads_flat = d loss * loss_scale / d parameters  (every entry written).
@@ -426,6 +442,15 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         ta.x0 = x_start; ta.noise = noise; ta.sqrt_ac = sqrt_alphas_cumprod_dev; ta.sqrt_1mac = sqrt_one_minus_alphas_cumprod_dev;
         ta.hs = hard_start; ta.hg = hard_goal; ta.xn = xn; ta.zero_words = ws + w.zeros; ta.n_zero = 1024 + 4;
         ta.H = H; ta.D = D; ta.T = T;
+        {
+            std::lock_guard<std::mutex> lk(g_train_rng_mu);
+            auto it = g_train_rng.find(u);
+            if (it != g_train_rng.end()) {
+                if ((H * D) & 3) return fail(MPDX_E_INVALID, "draw mode: H * D = %d is not a multiple of 4", H * D);
+                ta.rng_seed = it->second.seed; ta.rng_counter = it->second.counter;
+                ta.t_out = const_cast<long long*>(t_dev); ta.noise_out = const_cast<float*>(noise);
+            }
+        }
         hipLaunchKernelGGL(time_train_fwd_kernel, dim3(B), dim3(512), 0, st, ta);
         tb.flat = flat; tb.grad = grads_flat; tb.dT = ws + w.dT; tb.emb = ta.emb; tb.h1 = ta.h1; tb.temb = ta.temb; tb.tm = ta.tm; tb.h1m = ta.h1m;
         tb.dtm = ws + w.dtm; tb.dh1 = ws + w.dh1; tb.ticket = (unsigned*)(ws + w.ticket);

@@ -229,8 +229,9 @@ class TrainStep:
         same native launches): at the reference's batch of 32 the ~85 launches of an iteration take the host as long to enqueue (0.70-0.80 ms,
         box dependent) as the GPU to run (0.71 ms), and a slower host is then what a step costs; the replay is one host call.  What a captured
         graph freezes is kept out of its kernel arguments: the batch and the hard conditions are copied into static buffers, t and the noise
-        are drawn by torch's graph-safe generator inside the graph (`torch.randint`, `torch.randn_like`, as diffusion_model_base.py:356 / :337 draw
-        them; pass `t` / `noise` to supply them instead), and Adam's step count lives on the device (mpdx_adam_step with step < 0).
+        are drawn ON THE DEVICE by the pass's first launch (mpdx_train_draw: Philox keyed by the model's seed and the device-resident step count -
+        what diffusion_model_base.py:356 / :337 draw with torch.randint / torch.randn_like; pass `t` / `noise` to supply them instead), and Adam's
+        step count lives on the device (mpdx_adam_step with step < 0).
         `use_graph=False` (or MPDX_TRAIN_GRAPH=0) runs the two eager calls; by default batches of more than 64 trajectories do (GPU-bound)."""
         import os
         if use_graph is None:   # default: replay where the HOST is the bound - small batches (measured: batch 32 0.77 -> 0.73 ms, batch 128 x D=14 1.255 -> 1.274 ms:
@@ -297,10 +298,19 @@ class TrainStep:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         graph = torch.cuda.CUDAGraph()
+        draw = st["t"] is None and st["noise"] is None   # both drawn: on the device, inside the pass's first launch (mpdx_train_draw)
+        if draw:
+            st["t"], st["noise"] = torch.zeros(B, dtype=torch.long, device=dev), torch.empty_like(st["x"])
         with torch.cuda.graph(graph, stream=side):
             tt = st["t"] if st["t"] is not None else torch.randint(0, m.n_diffusion_steps, (B,), device=dev).long()
             nz = st["noise"] if st["noise"] is not None else torch.randn_like(st["x"])
-            loss, _ = self.loss_backward(st["x"], st["hc"], t=tt, noise=nz, _static_loss=True)
+            if draw:
+                _lib.check(lib.mpdx_train_draw(self.unet._handle(), int(m._rng_seed) & (2 ** 64 - 1), self.scratch.data_ptr() + 16), "mpdx_train_draw")
+            try:
+                loss, _ = self.loss_backward(st["x"], st["hc"], t=tt, noise=nz, _static_loss=True)
+            finally:
+                if draw:
+                    lib.mpdx_train_draw(self.unet._handle(), 0, None)
             _lib.check(lib.mpdx_adam_step(self.fp.flat.data_ptr(), self.fp.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                           self.fp.n, float(lr), float(betas[0]), float(betas[1]), float(eps), -1, mn,
                                           self.scratch.data_ptr(), _lib.current_stream()), "mpdx_adam_step")

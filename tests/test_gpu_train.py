@@ -475,8 +475,19 @@ def test_graph_replayed_steps_equal_eager_steps():
     # without t / noise the graph draws them itself (torch's graph-safe generator): the loss differs from replay to replay
     dm_r = _model(4, 1)
     ts_r = TrainStep(dm_r)
-    ls = [float(ts_r.step(x0, hc, 1e-3, max_norm=1.0)) for _ in range(6)]
+    ls, tts, nzs = [], [], []
+    for _ in range(8):
+        ls.append(float(ts_r.step(x0, hc, 1e-3, max_norm=1.0)))
+        if getattr(ts_r, "_graphs", None):
+            g = next(iter(ts_r._graphs.values()))
+            tts.append(g["t"].cpu().clone()); nzs.append(g["noise"].cpu().clone())
     assert len(set(ls[2:])) > 1 and all(np.isfinite(ls))
+    # the replays draw t and the noise on the device (mpdx_train_draw): timesteps in [0, T), different from replay to replay, noise ~ N(0, 1)
+    assert len(tts) >= 5 and all(int(v.min()) >= 0 and int(v.max()) < 25 for v in tts)
+    assert any(not torch.equal(tts[0], v) for v in tts[1:]) and not torch.equal(nzs[0], nzs[1])
+    allz = torch.cat([v.flatten() for v in nzs])
+    assert abs(float(allz.mean())) < 0.05 and abs(float(allz.std()) - 1.0) < 0.05
+    assert len(torch.unique(torch.cat(tts))) >= 10   # 6 samples x >= 5 replays over 25 timesteps
 
 
 @pytest.mark.parametrize("H", [32, 128])
