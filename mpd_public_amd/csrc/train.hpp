@@ -232,7 +232,10 @@ constexpr int kWgRS = 48;   // LDS row stride: 4 consecutive rows start 16 banks
 // generic loop below issues its loads inside column-guard branches - one dependent round trip per row - and a block walks 8-32 trajectories: that
 // chain, not the MFMAs, was the length of every backward launch.  Same MFMA order per trajectory, trajectories ascending: same bits.
 template <int KS, int NR>
-__device__ __forceinline__ void wgrad_loop_prefetch(const WgradArgs& a, float* As, float* Bs, const int b0, const int b1, const int m0, const int n0, const int mi,
+// (bs, be): this wave group's trajectories; `trips` >= be - bs: the trip count every wave group of the workgroup runs (the barriers are workgroup-wide);
+// (lo, hi): the batch split's whole range, for the clamped prefetch of a trip without a trajectory
+__device__ __forceinline__ void wgrad_loop_prefetch(const WgradArgs& a, float* As, float* Bs, const int bs, const int be, const int trips, const int lo, const int hi,
+                                                    const int m0, const int n0, const int mi,
                                                     const int ni, const int i16, const int kq, const int col, const int row0, const bool do_bias, float& bsum,
                                                     f32x4 (&acc)[KS]) {
     constexpr int NRB = (KS == 3 || KS == 4) ? 2 * NR : NR, LA = 8 * NR, LB = 8 * NRB;
@@ -248,15 +251,19 @@ __device__ __forceinline__ void wgrad_loop_prefetch(const WgradArgs& a, float* A
 #pragma unroll
         for (int u = 0; u < NRB; ++u) rb[u] = qb[(size_t)(8 * u) * a.ldb];
     };
-    fetch(b0);
-    for (int b = b0; b < b1; ++b) {
+    auto clampb = [&](int b) { return b < lo ? lo : (b > hi - 1 ? hi - 1 : b); };
+    fetch(clampb(bs));
+    for (int it = 0; it < trips; ++it) {
+        const int b = bs + it;
+        const bool live = b < be;
         lds_barrier();   // the previous trajectory's fragments are read
 #pragma unroll
-        for (int u = 0; u < NR; ++u) As[(size_t)(row0 + 8 * u) * kWgRS + col] = okA ? ra[u] : 0.f;
+        for (int u = 0; u < NR; ++u) As[(size_t)(row0 + 8 * u) * kWgRS + col] = (okA && live) ? ra[u] : 0.f;
 #pragma unroll
-        for (int u = 0; u < NRB; ++u) Bs[(size_t)(row0 + 8 * u + 2) * kWgRS + col] = okB ? rb[u] : 0.f;
-        fetch(b + 1 < b1 ? b + 1 : b);   // (the last trip re-reads its own rows: no branch around the loads)
+        for (int u = 0; u < NRB; ++u) Bs[(size_t)(row0 + 8 * u + 2) * kWgRS + col] = (okB && live) ? rb[u] : 0.f;
+        fetch(clampb(b + 1));   // (a trip without a successor re-reads a valid trajectory: no branch around the loads)
         lds_barrier();
+        if (!live) continue;
         if (do_bias) {   // fixed order: this thread's rows ascending, trajectories ascending; the 8 row phases are combined at the end
             if (a.bias_from_b) {
 #pragma unroll
@@ -279,12 +286,16 @@ __device__ __forceinline__ void wgrad_loop_prefetch(const WgradArgs& a, float* A
     }
 }
 
+// ngrp = 2 (inside bwd_pair_kernel's 512-thread workgroups, prefetching loop only): the block's trajectories are walked by TWO groups of four waves,
+// each on its own LDS slot and half of the range (a block's launch-long chain of trajectories halves); group 1's accumulators are added to group 0's
+// through LDS at the end (sum = first half + second half: fixed order, deterministic).
 template <int KS>
-__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, const int by, const int bz) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, const int by, const int bz, const int ngrp = 1) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                               // [LA][48]
-    float* Bs = smem + (size_t)a.LA * kWgRS;        // [LB + 4][48], row r holds position r - 2
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = ngrp == 2 ? (int)(threadIdx.x >> 8) : 0;
+    float* As = smem + (size_t)grp * (a.LA + a.LB + 4) * kWgRS;   // [LA][48]
+    float* Bs = As + (size_t)a.LA * kWgRS;                        // [LB + 4][48], row r holds position r - 2
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int n0 = bx * 32, m0 = by * 32;
     const int b0 = bz * a.b_per_split, b1 = min(a.B, b0 + a.b_per_split);
     const int mi = (wave & 1) * 16, ni = (wave >> 1) * 16;
@@ -302,12 +313,17 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
     float bsum = 0.f;
     const int nr = a.LA >> 3;
     const bool fast = (a.LA & 7) == 0 && a.LB == ((KS == 3 || KS == 4) ? 2 * a.LA : a.LA) && (nr == 1 || nr == 2 || nr == 4 || nr == 8) && b1 > b0;
+    if (ngrp == 2 && !fast) {   // (the host pairs wave groups only with shapes the prefetching loop takes; an empty split: nothing to add)
+        if (grp == 1) return;
+    }
+    const int nb_all = b1 - b0, trips = (ngrp == 2 && fast) ? (nb_all + 1) / 2 : nb_all;
+    const int bs = b0 + grp * trips, be = min(b1, bs + trips);
     if (fast) {
         __syncthreads();   // the halo rows
-        if (nr == 1) wgrad_loop_prefetch<KS, 1>(a, As, Bs, b0, b1, m0, n0, mi, ni, i16, kq, col, row0, do_bias, bsum, acc);
-        else if (nr == 2) wgrad_loop_prefetch<KS, 2>(a, As, Bs, b0, b1, m0, n0, mi, ni, i16, kq, col, row0, do_bias, bsum, acc);
-        else if (nr == 4) wgrad_loop_prefetch<KS, 4>(a, As, Bs, b0, b1, m0, n0, mi, ni, i16, kq, col, row0, do_bias, bsum, acc);
-        else wgrad_loop_prefetch<KS, 8>(a, As, Bs, b0, b1, m0, n0, mi, ni, i16, kq, col, row0, do_bias, bsum, acc);
+        if (nr == 1) wgrad_loop_prefetch<KS, 1>(a, As, Bs, bs, be, trips, b0, b1, m0, n0, mi, ni, i16, kq, col, row0, do_bias, bsum, acc);
+        else if (nr == 2) wgrad_loop_prefetch<KS, 2>(a, As, Bs, bs, be, trips, b0, b1, m0, n0, mi, ni, i16, kq, col, row0, do_bias, bsum, acc);
+        else if (nr == 4) wgrad_loop_prefetch<KS, 4>(a, As, Bs, bs, be, trips, b0, b1, m0, n0, mi, ni, i16, kq, col, row0, do_bias, bsum, acc);
+        else wgrad_loop_prefetch<KS, 8>(a, As, Bs, bs, be, trips, b0, b1, m0, n0, mi, ni, i16, kq, col, row0, do_bias, bsum, acc);
     } else
     for (int b = b0; b < b1; ++b) {
         __syncthreads();   // the previous trajectory's fragments are read
@@ -329,6 +345,21 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
                 acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[k], 0, 0, 0);
             }
         }
+    }
+    if (ngrp == 2 && fast) {   // group 1 -> LDS -> group 0
+        __syncthreads();   // every fragment is read: the slots are free
+        float* X = smem;   // [256 lanes][KS][4] accumulators | [256] bias sums
+        if (grp == 1) {
+#pragma unroll
+            for (int k = 0; k < KS; ++k) *(f32x4*)(X + ((size_t)tid * KS + k) * 4) = acc[k];
+            X[256 * KS * 4 + tid] = bsum;
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) acc[k] += *(const f32x4*)(X + ((size_t)tid * KS + k) * 4);
+        bsum += X[256 * KS * 4 + tid];
+        As = smem;   // (group 0's slot: the bias reduction below)
     }
     if (do_bias) {
         __syncthreads();   // the last trajectory's fragments are read: As is free
@@ -371,6 +402,7 @@ struct BwdPairArgs {
     int nw[3];           // blocks of each weight-gradient GEMM (0: unused slot)
     int gx[3], gy[3];    // their grids: x = N tiles, y = M tiles, z = batch splits
     int ks_w[3];         // taps of each weight gradient (1, 3, 4 or 5)
+    int two[3];          // the job's blocks run two wave groups (wgrad_body ngrp = 2: all 512 threads work)
 };
 // EPI_D = EPI_GN_BWD: the dgrad blocks also take their result through the Mish + GroupNorm backward of the Conv1dBlock below (conv_block.hpp)
 template <int KS_D, int MT, int NT, int EPI_D = EPI_BIAS>
@@ -379,18 +411,19 @@ __global__ __launch_bounds__(512) void bwd_pair_kernel(const BwdPairArgs a) {
         conv_block_body<CONV_S1, KS_D, EPI_D, MT, NT, 1, 8>(a.cd, blockIdx.x);
         return;
     }
-    if (threadIdx.x >= 256) return;
     int idx = (int)blockIdx.x - a.n_dgrad;
     int which = 0;
     while (which < 2 && idx >= a.nw[which]) { idx -= a.nw[which]; ++which; }
+    const int ngrp = a.two[which] ? 2 : 1;
+    if (threadIdx.x >= 256 && ngrp == 1) return;
     const WgradArgs& w = a.w[which];
     const int bx = idx % a.gx[which], r = idx / a.gx[which];
     const int by = r % a.gy[which], bz = r / a.gy[which];
     switch (a.ks_w[which]) {
-        case 1: wgrad_body<1>(w, bx, by, bz); break;
-        case 3: wgrad_body<3>(w, bx, by, bz); break;
-        case 4: wgrad_body<4>(w, bx, by, bz); break;
-        default: wgrad_body<5>(w, bx, by, bz); break;
+        case 1: wgrad_body<1>(w, bx, by, bz, ngrp); break;
+        case 3: wgrad_body<3>(w, bx, by, bz, ngrp); break;
+        case 4: wgrad_body<4>(w, bx, by, bz, ngrp); break;
+        default: wgrad_body<5>(w, bx, by, bz, ngrp); break;
     }
 }
 

@@ -246,6 +246,14 @@ static int launch_wgrad(const float* A, int LA, int lda, int a_off, int M, const
     return 0;
 }
 
+// two wave groups per weight-gradient block inside bwd_pair_kernel's 512-thread workgroups (train.hpp wgrad_body, ngrp = 2): shapes of the prefetching loop
+static bool wgrad_two_groups(const WgradJob& j) {
+    static const bool off = getenv("MPDX_WGRAD_TWO") && atoi(getenv("MPDX_WGRAD_TWO")) == 0;   // dev A/B switch
+    if (off) return false;
+    const int LA = j.a.LA, LB = j.a.LB, nr = LA >> 3;
+    return (LA & 7) == 0 && LB == ((j.KS == 3 || j.KS == 4) ? 2 * LA : LA) && (nr == 1 || nr == 2 || nr == 4 || nr == 8);
+}
+
 // dgrad convolution + the layer's weight-gradient GEMM(s) in ONE launch (bwd_pair_kernel); the jobs must use distinct partial buffers
 // GN_BWD: the dgrad blocks run the EPI_GN_BWD epilogue (cd carries its operands; `dgl` then has epi = EPI_GN_MISH and the group size
 // of the Conv1dBlock below, so that the tile holds whole GroupNorm regions)
@@ -267,7 +275,8 @@ static int launch_bwd_pair(const Layer& dgl, ConvArgs& cd, int B, const WgradJob
         a.gx[k] = jobs[k].grid.x; a.gy[k] = jobs[k].grid.y;
         a.nw[k] = jobs[k].grid.x * jobs[k].grid.y * jobs[k].grid.z;
         total += a.nw[k];
-        lds = std::max(lds, jobs[k].lds);
+        a.two[k] = wgrad_two_groups(jobs[k]) ? 1 : 0;
+        lds = std::max(lds, a.two[k] ? std::max(2 * jobs[k].lds, (size_t)(256 * jobs[k].KS * 4 + 256) * sizeof(float)) : jobs[k].lds);
     }
 #define MPDX_BP_TILE(mt, nt)                                                                              \
     if (MT == mt && NT == nt) {                                                                           \
@@ -298,7 +307,8 @@ static int launch_lone_wgrads(const WgradJob* jobs, int njobs, hipStream_t st) {
         a.gx[k] = jobs[k].grid.x; a.gy[k] = jobs[k].grid.y;
         a.nw[k] = jobs[k].grid.x * jobs[k].grid.y * jobs[k].grid.z;
         total += a.nw[k];
-        lds = std::max(lds, jobs[k].lds);
+        a.two[k] = wgrad_two_groups(jobs[k]) ? 1 : 0;
+        lds = std::max(lds, a.two[k] ? std::max(2 * jobs[k].lds, (size_t)(256 * jobs[k].KS * 4 + 256) * sizeof(float)) : jobs[k].lds);
     }
     auto kern = bwd_pair_kernel<1, 16, 16, EPI_BIAS>;
     if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "weight-gradient launch needs %zu B of LDS", lds);
