@@ -563,7 +563,7 @@ def planner_baseline_leg(n=100, opt_iters=500):
     return out
 
 
-def training_leg(steps=40, B=32, T=25, D=4, opt=1, baseline=True):
+def training_leg(steps=100, B=32, T=25, D=4, opt=1, baseline=True):
     """training iterations per second at the reference's training configuration (train.py: batch 32, T = 25, dim_mults
     option 1, Adam 1e-4, clip_grad_norm 1.0, EMA every 10 steps) - the native step (HIP forward + backward + Adam + EMA) next to
     the same iteration written with torch autograd over the functional U-Net (ATen / MIOpen kernels) on the same GPU, which is
