@@ -316,7 +316,7 @@ def guided_leg(device, plans=5, reps=200):
     """BASELINE configs[2] and [3] - the GUIDED sampler north_star names (inference.py:188-258 is the timed region): plan wall-clock and
     denoising-steps/s, the guide kernel's time per launch (mpdx_guide_time: `reps` back-to-back launches between one HIP-event pair on
     the launch stream) against its algorithmic bytes (2 * B*H*D*4 + tables) and a FLOP estimate, and - checker leg - the
-    four plan figures of an <= 8-trajectory slice planned with the SAME noise by the HIP path and by the CPU oracle."""
+    plan figures of an <= 8-trajectory slice planned with the SAME noise by the HIP path and by the CPU oracle (fp32 and fp64): _guided_oracle_check."""
     import torch
     from mpd_public_amd import _lib, synthetic as syn
     lib = _lib.load()
@@ -382,38 +382,14 @@ def guided_leg(device, plans=5, reps=200):
 
 
 def _guided_oracle_check(dm, sd, g, gk, hc, D, T, n0, nb):
-    """Checker leg: `nb` trajectories planned with the SAME pre-generated noise by the HIP path and by the CPU oracle (oracle/: U-Net,
-    DDPM step and the autograd guide of oracle/costs.py); the four plan figures north_star names, side by side."""
-    import torch
-    from helpers import oracle_guide, oracle_plan_metrics
-    from oracle import diffusion as odiff
-    ds = g.dataset
-    noise = torch.randn((T + n0 + 1, nb, 64, D), generator=torch.Generator().manual_seed(31))
-    kw = dict(n_guide_steps=gk["n_guide_steps"], t_start_guide=gk["t_start_guide"], n_diffusion_steps_without_noise=n0)
-    chain = dm.run_inference(None, hc, n_samples=nb, horizon=64, return_chain=True, guide=g, noise_std_extra_schedule_fn=lambda t: 0.5,
-                             noise=noise.cuda(), **kw)
-    xu = ds.unnormalize_trajectories(chain[-1])
-    m = ds.task.trajectory_metrics(xu, n_check=256).cpu()
-    og, _ = oracle_guide(ds, 1e-2, 1e-7, dtype=torch.float32)
-    t0 = time.perf_counter()
-    ref = odiff.run_inference(sd, {k: v.cpu() for k, v in hc.items()}, noise, T, noise_std=0.5, guide=og, **kw)
-    cpu_s = time.perf_counter() - t0
-    xr = og.normalizer.unnormalize(ref[-1])
-    hits, plen, smooth = oracle_plan_metrics(ds, xr, n_check=256)
-    hip = {"collision_free_rate": float((m[:, 0] == 0).float().mean()), "collision_intensity": float((m[:, 0] / m[:, 3]).mean()),
-           "path_length": float(m[:, 1].mean()), "smoothness": float(m[:, 2].mean())}
-    orc = {"collision_free_rate": float((hits == 0).float().mean()), "collision_intensity": float((hits.float() / 256.0).mean()),
-           "path_length": float(plen.mean()), "smoothness": float(smooth.mean())}
-
-    def same3(a, b):   # identical to 3 significant figures (or both zero)
-        return a == b or abs(a - b) <= 5e-3 * max(abs(a), abs(b))
-    return {"trajectories": nb, "hip": {k: float(f"{v:.6g}") for k, v in hip.items()}, "oracle": {k: float(f"{v:.6g}") for k, v in orc.items()},
-            "colliding_waypoints": {"hip": int(m[:, 0].sum()), "oracle": int(hits.sum()), "checked": int(nb * 256),
-                                    "note": "a count over nb x 256 interpolated waypoints: one waypoint within fp32 rounding of a margin is 1 / checked of the "
-                                            "intensity, so on a slice this small the third significant figure of the intensity is a handful of waypoints"},
-            "equal_to_3sf": {k: bool(same3(hip[k], orc[k])) for k in hip},
-            "max_abs_diff_final_trajectories": float((chain[-1].cpu() - ref[-1]).abs().max()),
-            "oracle_cpu_plan_s": round(cpu_s, 2), "weights": "synthetic (random-init): the figures are those of un-trained plans"}
+    """Checker leg: `nb` trajectories planned with the SAME pre-generated noise by the HIP path and by the CPU oracle in fp32 AND fp64
+    (oracle/: U-Net, DDPM step and the autograd guide of oracle/costs.py).  The record is tests/helpers.py::guided_parity_record - the
+    decidable form of north_star's "identical to 3 s.f." for a discontinuous (hinge / arg-min / norm-clip) chain: `equal_to_3sf` compares
+    the HIP metrics kernel with an fp64 evaluation of the SAME plan over the waypoints whose fp64 hinge slack is not within 1e-5 of a
+    margin (`ambiguous_waypoints` excluded), `chain_class` bounds the HIP chain's hinge flips against the fp64 chain by the fp32 CPU
+    oracle's own (inference.py:288-297, 311-316)."""
+    from helpers import guided_parity_record
+    return guided_parity_record(dm, sd, g, gk, hc, T, n0, nb)
 
 
 def _all_ranks(dist, vals, device):

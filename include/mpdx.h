@@ -231,6 +231,11 @@ int mpdx_absmax(const float* x, uint32_t* absmax_out, int n_per_ctx, int B, int 
  * smoothness, #waypoints checked}; n_check = interpolated waypoints per trajectory used for collision checking. */
 int mpdx_traj_metrics(const mpdx_guide_params* gp, const float* x_unnormalised, float* out4, int n_check, int B, int H, int D,
                       void* stream);
+/* the same, plus the per-waypoint collision flags the count is made of: mask [B, n_check] bytes (1 = the interpolated waypoint
+ * collides), or NULL.  compute_collision_intensity_trajs (inference.py:295-297) is the mean of these flags; the parity tests use them to
+ * compare the kernel's decisions with an fp64 evaluation waypoint by waypoint. */
+int mpdx_traj_metrics_mask(const mpdx_guide_params* gp, const float* x_unnormalised, float* out4, uint8_t* mask, int n_check, int B,
+                           int H, int D, void* stream);
 
 /* ---- baseline planners of the dataset-generation script: replaces `HybridPlanner(RRTConnect x n via
  * MultiSampleBasedPlanner, GPMP2).optimize()` of scripts/generate_data/generate_trajectories.py:68-120.  The planners are

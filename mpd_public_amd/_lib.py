@@ -84,6 +84,7 @@ SIGNATURES = {
     "mpdx_guide_step_scaled": (_i, [C.POINTER(GuideParams), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mpdx_guide_time": (_i, [C.POINTER(GuideParams), _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.POINTER(C.c_float)]),
     "mpdx_traj_metrics": (_i, [C.POINTER(GuideParams), _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mpdx_traj_metrics_mask": (_i, [C.POINTER(GuideParams), _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mpdx_guide_trace": (_i, [C.POINTER(GuideParams), _vp, _vp, _i, _i, _i, _vp, C.POINTER(C.c_longlong)]),
     "mpdx_absmax": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "mpdx_unet_profile": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(C.c_double),

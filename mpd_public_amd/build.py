@@ -18,8 +18,16 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
-LIB = PKG / "libmpdx.so"
-OBJ = PKG.parent / "build" / "obj"
+def _extra() -> list:
+    # dev builds: -DMPDX_DEV_HOOKS (tools/*_trace.py, ablate_layers.py), -DMPDX_LOOP_ABLATION (tools/ablate_loop.py), kernel A/B knobs
+    return os.environ.get("MPDX_BUILD_DEFS", "").split()
+
+
+# A build with extra definitions is a DIFFERENT library: it gets its own object directory and must name its own output
+# (MPDX_BUILD_OUT=build_ab/libmpdx_<tag>.so), so that a dev / A-B build can neither clobber nor be mistaken for the shipped one.
+_TAG = hashlib.sha256(" ".join(_extra()).encode()).hexdigest()[:8] if _extra() else ""
+LIB = Path(os.environ["MPDX_BUILD_OUT"]).resolve() if os.environ.get("MPDX_BUILD_OUT") else PKG / "libmpdx.so"
+OBJ = PKG.parent / "build" / ("obj" + ("_" + _TAG if _TAG else ""))
 SOURCES = [CSRC / "mpdx.hip"] + sorted(CSRC.glob("k_*.hip"))
 HEADERS = sorted(CSRC.glob("*.hpp")) + [PKG.parent / "include" / "mpdx.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function"]
@@ -45,11 +53,6 @@ def deps(src: Path) -> list:
         for inc in _INC.findall(p.read_text(errors="replace")):
             todo.append((p.parent / inc).resolve())
     return sorted(seen)
-
-
-def _extra() -> list:
-    # dev builds: -DMPDX_DEV_HOOKS (tools/*_trace.py, ablate_layers.py), -DMPDX_LOOP_ABLATION (tools/ablate_loop.py)
-    return os.environ.get("MPDX_BUILD_DEFS", "").split()
 
 
 def _stamp(src: Path) -> str:
@@ -91,9 +94,13 @@ def _compile(src: Path, verbose: bool) -> None:
 
 
 def build(force: bool = False, verbose: bool = True, only: list | None = None) -> Path:
-    if not force and not needs_build():
+    if _extra() and not os.environ.get("MPDX_BUILD_OUT"):
+        raise RuntimeError("MPDX_BUILD_DEFS is set: name the output with MPDX_BUILD_OUT=build_ab/libmpdx_<tag>.so (a build with extra "
+                           "definitions never replaces mpd_public_amd/libmpdx.so)")
+    if not force and not only and not needs_build():   # `only` rebuilds the named TUs whatever their stamps say
         return LIB
     OBJ.mkdir(parents=True, exist_ok=True)
+    LIB.parent.mkdir(parents=True, exist_ok=True)
     todo = [s for s in SOURCES if force or stale(s)]
     if only:   # dev: python -m mpd_public_amd.build k_fused  (rebuild these TUs whatever their stamps say)
         todo = sorted(set(todo) | {s for s in SOURCES if s.stem in only})

@@ -151,6 +151,102 @@ __device__ __forceinline__ float objects_force(const float* __restrict__ prims, 
     return 0.f;
 }
 
+// objects_force for NP points at once (the 2-3 link spheres of a Panda sphere group): ONE scan of the primitive table - a batch's LDS
+// reads are shared by the points, whose distance chains are independent (3 x the instruction-level parallelism of one point's scan,
+// which is a serial min / arg-min chain).  Per point exactly the arithmetic of objects_force: same bits.
+template <int DIM, int NPT, int UB = 2>
+__device__ __forceinline__ void objects_force_n(const float* __restrict__ prims, const mpdx_field& f, const float (&p)[NPT][DIM], const float (&margin)[NPT],
+                                                float (&force)[NPT][DIM]) {
+    float best[NPT];
+    int bi[NPT];
+#pragma unroll
+    for (int n = 0; n < NPT; ++n) { best[n] = 3.0e38f; bi[n] = -1; }
+    const float* sp = prims + f.sphere_off;
+    for (int s0 = 0; s0 < f.n_spheres; s0 += UB) {
+        float c[UB][4];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int si = (s0 + u < f.n_spheres) ? s0 + u : f.n_spheres - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[u][j] = sp[si * 4 + j];
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+#pragma unroll
+            for (int n = 0; n < NPT; ++n) {
+                float n2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < DIM; ++j) { const float d = p[n][j] - c[u][j]; n2 += d * d; }
+                const float sd = (s0 + u < f.n_spheres) ? __builtin_amdgcn_sqrtf(n2) - c[u][3] : 3.0e38f;
+                const bool better = sd < best[n];
+                best[n] = better ? sd : best[n];
+                bi[n] = better ? s0 + u : bi[n];
+            }
+        }
+    }
+    const float* bp = prims + f.box_off;
+    for (int s0 = 0; s0 < f.n_boxes; s0 += 2) {
+        float c[2][6];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int si = (s0 + u < f.n_boxes) ? s0 + u : f.n_boxes - 1;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) c[u][j] = bp[si * 6 + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int n = 0; n < NPT; ++n) {
+                float mx = -3.0e38f, n2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < DIM; ++j) {
+                    const float d = fabsf(p[n][j] - c[u][j]) - c[u][3 + j];
+                    mx = fmaxf(mx, d);
+                    const float r = fmaxf(d, 0.f);
+                    n2 += r * r;
+                }
+                const float sd = (s0 + u < f.n_boxes) ? fminf(mx, 0.f) + __builtin_amdgcn_sqrtf(n2) : 3.0e38f;
+                const bool better = sd < best[n];
+                best[n] = better ? sd : best[n];
+                bi[n] = better ? f.n_spheres + s0 + u : bi[n];
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NPT; ++n) {
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) force[n][j] = 0.f;
+        if ((margin[n] - best[n]) > 0.f && bi[n] >= 0) {
+            if (bi[n] < f.n_spheres) {
+                float d[DIM], n2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < DIM; ++j) { d[j] = p[n][j] - sp[bi[n] * 4 + j]; n2 += d[j] * d[j]; }
+                const float inv = n2 > 0.f ? __builtin_amdgcn_rsqf(n2) : 0.f;
+#pragma unroll
+                for (int j = 0; j < DIM; ++j) force[n][j] = -d[j] * inv;
+            } else {
+                const int bb = bi[n] - f.n_spheres;
+                float d[DIM], sg[DIM], mx = -3.0e38f, n2 = 0.f;
+                int jm = 0;
+#pragma unroll
+                for (int j = 0; j < DIM; ++j) {
+                    const float cc = p[n][j] - bp[bb * 6 + j];
+                    sg[j] = cc > 0.f ? 1.f : (cc < 0.f ? -1.f : 0.f);
+                    d[j] = fabsf(cc) - bp[bb * 6 + 3 + j];
+                    jm = d[j] > mx ? j : jm;
+                    mx = fmaxf(mx, d[j]);
+                    const float r = fmaxf(d[j], 0.f);
+                    n2 += r * r;
+                }
+                const bool outside = mx > 0.f;
+                const float inv = outside ? __builtin_amdgcn_rsqf(n2) : 0.f;
+#pragma unroll
+                for (int j = 0; j < DIM; ++j) force[n][j] = -(outside ? sg[j] * fmaxf(d[j], 0.f) * inv : (j == jm ? sg[j] : 0.f));
+            }
+        }
+    }
+}
+
 template <int DIM>
 __device__ __forceinline__ void workspace_force(const mpdx_field& f, const float (&p)[DIM], float margin, float (&force)[DIM]) {
 #pragma unroll
@@ -161,11 +257,12 @@ __device__ __forceinline__ void workspace_force(const mpdx_field& f, const float
 }
 
 // Panda forward kinematics (modified DH): frame origins O_k and z axes Z_k in the world frame
-template <int QD>
+// NJ < 7: only the first NJ frames (a sphere group whose spheres sit on frames <= NJ needs no more; rows k >= NJ are left untouched)
+template <int QD, int NJ = 7>
 __device__ __forceinline__ void panda_fk(const float (&q)[QD], float (&O)[7][3], float (&Z)[7][3]) {
     float R[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}, T[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < NJ; ++k) {
         float st, ct;
         __sincosf(q[k < QD ? k : 0], &st, &ct);  // |q| <= pi (joint limits): the hardware sin/cos is accurate to ~1e-6 here
         const float ca = kPandaCA[k], sa = kPandaSA[k], aa = kPandaA[k], dd = kPandaD[k];
@@ -222,10 +319,11 @@ __device__ __forceinline__ float objects_sdf(const float* __restrict__ prims, co
 //               workspace, or self-collides; margin = link radius, no cutoff margin)
 //   out[b][1] = path length  sum_h |q_{h+1} - q_h|      out[b][2] = smoothness  sum_h |v_{h+1} - v_h|
 //   out[b][3] = number of interpolated waypoints checked
+//   mask[b][i] (optional) = 1 if interpolated waypoint i collides (what out[b][0] counts)
 // x is UNNORMALISED [B,H,D] (inference.py:285 un-normalises before computing metrics).
 template <int QD, int DIM, int ROBOT>
 __global__ __launch_bounds__(64) void traj_metrics_kernel(const mpdx_guide_params gp, const float* __restrict__ x, float* __restrict__ out,
-                                                          int B, int H, int n_check) {
+                                                          int B, int H, int n_check, uint8_t* __restrict__ mask) {
     constexpr int D = 2 * QD;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x, b = blockIdx.x;
@@ -299,6 +397,7 @@ __global__ __launch_bounds__(64) void traj_metrics_kernel(const mpdx_guide_param
             }
         }
         ncoll += hit ? 1.f : 0.f;
+        if (mask) mask[(size_t)b * N + i] = hit ? 1 : 0;   // per-waypoint collision flags (mpdx_traj_metrics_mask)
     }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
@@ -580,7 +679,17 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
 //            order), clips by norm, weights
 //   phase 4  wave 0: sum over fields, GP prior, apply (guide_gp_apply)
 constexpr int kPandaFKS = 75;   // floats per interpolated point in LDS: O[7][3] | Z[7][3] | P[11][3]  (odd stride: no bank conflicts)
-constexpr int kPandaParts = 4;  // sphere groups {0-2, 3-5, 6-8, 9-10}; pair groups of 3
+// Sphere groups (round 5).  The kernel is VALU-issue bound once two workgroups share a CU (stamps + ISA census, profiles/r05_guide_*):
+// what counts is the number of instructions, so the split follows the kinematic chain - a group's joint gradients and (in the dense
+// variant) its forward kinematics stop at the highest frame its spheres sit on:
+//     group 0: spheres 0-3  (frames 1,1,3,3) -> joints 0-2      group 2: spheres 7-9 (frames 5,7,7) -> all 7 joints
+//     group 1: spheres 4-6  (frames 4,5,5)   -> joints 0-4      group 3: sphere 10 (frame 7) + ALL 12 self-collision pairs
+// (round 4: {0-2, 3-5, 6-8, 9-10} with 3 pairs each: every group touched frame 7 through its pairs, i.e. 4 x the full FK and 4 x a
+// 7-joint fold for the self field).  Entries of sG that are zero by construction are neither written nor read.
+constexpr int kPandaParts = 4;
+constexpr int panda_group_first(int part) { return part == 0 ? 0 : part == 1 ? 4 : part == 2 ? 7 : part == 3 ? 10 : 11; }
+constexpr int panda_group_joints(int part) { return part == 0 ? 3 : part == 1 ? 5 : 7; }      // joints that move the group's spheres
+// (the self field lives in part 3 alone, with all 7 joints)
 
 // phase 2 of guide_step_panda_kernel for sphere / pair group PART and point half `half`
 // FKREG: the forward kinematics of the point are evaluated HERE from the LDS-staged state (sx, H, D, scale) instead of being read from
@@ -589,8 +698,9 @@ template <int PART, bool FKREG>
 __device__ __forceinline__ void panda_group_forces(const mpdx_guide_params& gp, const float* sprim, const float* sfk, float* sG, int half, int lane, int N,
                                                    long long* tr, const float* sx = nullptr, int H = 0, float scale = 0.f) {
     constexpr int QD = 7, NP = kPandaParts, D = 14;
-    constexpr int s_beg = PART * 3, s_end = (s_beg + 3 < kPandaNS) ? s_beg + 3 : kPandaNS;
-    constexpr int p_beg = PART * 3, p_end = (p_beg + 3 < kPandaNP) ? p_beg + 3 : kPandaNP;
+    constexpr int s_beg = panda_group_first(PART), s_end = panda_group_first(PART + 1), NG = s_end - s_beg;
+    constexpr int NJ = panda_group_joints(PART);
+    constexpr bool SELF = PART == NP - 1;   // this group also carries the self-collision pairs
     for (int i = half * 64 + lane; i < N; i += 128) {
         float O[7][3], Z[7][3], P[kPandaNS][3];
         if constexpr (FKREG) {
@@ -607,16 +717,17 @@ __device__ __forceinline__ void panda_group_forces(const mpdx_guide_params& gp, 
             float q[QD];
 #pragma unroll
             for (int j = 0; j < QD; ++j) q[j] = l0 * sx[i0 * D + j] + l1 * sx[i1 * D + j];
-            panda_fk(q, O, Z);
+            panda_fk<QD, NJ>(q, O, Z);
 #pragma unroll
             for (int s = 0; s < kPandaNS; ++s) {
+                if (kPandaSF[s] > NJ) continue;   // (compile time after unrolling: frames beyond the group's chain are never read)
 #pragma unroll
                 for (int r = 0; r < 3; ++r) P[s][r] = O[kPandaSF[s] - 1][r] + kPandaSO[s] * Z[kPandaSF[s] - 1][r];
             }
         } else {
             const float* fk = sfk + i * kPandaFKS;
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
+            for (int k = 0; k < NJ; ++k) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) { O[k][r] = fk[k * 3 + r]; Z[k][r] = fk[21 + k * 3 + r]; }
             }
@@ -626,25 +737,25 @@ __device__ __forceinline__ void panda_group_forces(const mpdx_guide_params& gp, 
                 for (int r = 0; r < 3; ++r) P[s][r] = fk[42 + s * 3 + r];
             }
         }
-        for (int f = 0; f < gp.n_fields; ++f) {
-            float FF[7][3], FM[7][3];  // per frame: force on its spheres, their moment about the world origin
+        // fold of per-frame forces / moments into joint gradients, stored as sG[(f, PART)][i][0 .. NJ)
+        auto fold_store = [&](int f, const float (&FF)[7][3], const float (&FM)[7][3]) {
+            float Ft[3] = {0.f, 0.f, 0.f}, Mt[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 7; ++k) { FF[k][0] = FF[k][1] = FF[k][2] = 0.f; FM[k][0] = FM[k][1] = FM[k][2] = 0.f; }
-            const int kind = gp.fields[f].kind;
-            if (kind == MPDX_FIELD_OBJECTS || kind == MPDX_FIELD_WORKSPACE) {
+            for (int k = NJ - 1; k >= 0; --k) {  // joint k moves every sphere on frames >= k  (joints >= NJ move none of this group's)
 #pragma unroll
-                for (int s = s_beg; s < s_end; ++s) {
-                    const int fr = kPandaSF[s] - 1;
-                    const float margin = kPandaSR[s] + gp.cutoff_margin;
-                    float p3[3] = {P[s][0], P[s][1], P[s][2]}, fo[3];
-                    if (kind == MPDX_FIELD_OBJECTS) objects_force<3>(sprim, gp.fields[f], p3, margin, fo);
-                    else workspace_force<3>(gp.fields[f], p3, margin, fo);
-                    FF[fr][0] += fo[0]; FF[fr][1] += fo[1]; FF[fr][2] += fo[2];
-                    FM[fr][0] += p3[1] * fo[2] - p3[2] * fo[1]; FM[fr][1] += p3[2] * fo[0] - p3[0] * fo[2]; FM[fr][2] += p3[0] * fo[1] - p3[1] * fo[0];
-                }
-            } else if (kind == MPDX_FIELD_SELF) {
+                for (int r = 0; r < 3; ++r) { Ft[r] += FF[k][r]; Mt[r] += FM[k][r]; }
+                const float cx = O[k][1] * Ft[2] - O[k][2] * Ft[1], cy = O[k][2] * Ft[0] - O[k][0] * Ft[2], cz = O[k][0] * Ft[1] - O[k][1] * Ft[0];
+                sG[((f * NP + PART) * N + i) * QD + k] = Z[k][0] * (Mt[0] - cx) + Z[k][1] * (Mt[1] - cy) + Z[k][2] * (Mt[2] - cz);
+            }
+        };
+        if constexpr (SELF) {   // the self-collision field(s) first, in a loop of their own: the eight sphere centres the pairs touch die here
+            for (int f = 0; f < gp.n_fields; ++f) {
+                if (gp.fields[f].kind != MPDX_FIELD_SELF) continue;
+                float FF[7][3], FM[7][3];
 #pragma unroll
-                for (int pr = p_beg; pr < p_end; ++pr) {
+                for (int k = 0; k < 7; ++k) { FF[k][0] = FF[k][1] = FF[k][2] = 0.f; FM[k][0] = FM[k][1] = FM[k][2] = 0.f; }
+#pragma unroll
+                for (int pr = 0; pr < kPandaNP; ++pr) {
                     const int sa_ = kPandaPA[pr], sb_ = kPandaPB[pr];
                     const int fa = kPandaSF[sa_] - 1, fb = kPandaSF[sb_] - 1;
                     const float dx = P[sa_][0] - P[sb_][0], dy = P[sa_][1] - P[sb_][1], dz = P[sa_][2] - P[sb_][2];
@@ -657,15 +768,37 @@ __device__ __forceinline__ void panda_group_forces(const mpdx_guide_params& gp, 
                     FM[fa][0] -= P[sa_][1] * fz - P[sa_][2] * fy; FM[fa][1] -= P[sa_][2] * fx - P[sa_][0] * fz; FM[fa][2] -= P[sa_][0] * fy - P[sa_][1] * fx;
                     FM[fb][0] += P[sb_][1] * fz - P[sb_][2] * fy; FM[fb][1] += P[sb_][2] * fx - P[sb_][0] * fz; FM[fb][2] += P[sb_][0] * fy - P[sb_][1] * fx;
                 }
+                fold_store(f, FF, FM);
+                if (tr) tr[f] = (long long)__builtin_readcyclecounter();
             }
-            float Ft[3] = {0.f, 0.f, 0.f}, Mt[3] = {0.f, 0.f, 0.f};
+        }
+        for (int f = 0; f < gp.n_fields; ++f) {
+            const int kind = gp.fields[f].kind;
+            if (kind != MPDX_FIELD_OBJECTS && kind != MPDX_FIELD_WORKSPACE) continue;   // (self: above, group 3 only; sG of the other parts is never read)
+            float FF[7][3], FM[7][3];  // per frame: force on its spheres, their moment about the world origin
 #pragma unroll
-            for (int k = 6; k >= 0; --k) {  // joint k moves every sphere on frames >= k
+            for (int k = 0; k < 7; ++k) { FF[k][0] = FF[k][1] = FF[k][2] = 0.f; FM[k][0] = FM[k][1] = FM[k][2] = 0.f; }
+            // the group's link spheres: one scan of the primitive table for all of them
+            float pg[NG][3], mg[NG], fg[NG][3];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) { Ft[r] += FF[k][r]; Mt[r] += FM[k][r]; }
-                const float cx = O[k][1] * Ft[2] - O[k][2] * Ft[1], cy = O[k][2] * Ft[0] - O[k][0] * Ft[2], cz = O[k][0] * Ft[1] - O[k][1] * Ft[0];
-                sG[((f * NP + PART) * N + i) * QD + k] = Z[k][0] * (Mt[0] - cx) + Z[k][1] * (Mt[1] - cy) + Z[k][2] * (Mt[2] - cz);
+            for (int n = 0; n < NG; ++n) {
+                pg[n][0] = P[s_beg + n][0]; pg[n][1] = P[s_beg + n][1]; pg[n][2] = P[s_beg + n][2];
+                mg[n] = kPandaSR[s_beg + n] + gp.cutoff_margin;
             }
+            if (kind == MPDX_FIELD_OBJECTS) objects_force_n<3, NG>(sprim, gp.fields[f], pg, mg, fg);
+            else {
+#pragma unroll
+                for (int n = 0; n < NG; ++n) workspace_force<3>(gp.fields[f], pg[n], mg[n], fg[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < NG; ++n) {
+                const int fr = kPandaSF[s_beg + n] - 1;
+                const float(&p3)[3] = pg[n];
+                const float(&fo)[3] = fg[n];
+                FF[fr][0] += fo[0]; FF[fr][1] += fo[1]; FF[fr][2] += fo[2];
+                FM[fr][0] += p3[1] * fo[2] - p3[2] * fo[1]; FM[fr][1] += p3[2] * fo[0] - p3[0] * fo[2]; FM[fr][2] += p3[0] * fo[1] - p3[1] * fo[0];
+            }
+            fold_store(f, FF, FM);
             if (tr) tr[f] = (long long)__builtin_readcyclecounter();
         }
     }
@@ -698,18 +831,21 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void guide_step_panda_kernel(co
     float* sprim = sC + MAXF * H * QD;
     for (int i = threadIdx.x; i < gp.n_prim_floats; i += 64 * WPT) sprim[i] = gp.prims[i];
 
-    // ---- load + unnormalise (normalization.py:156-167)
+    // ---- load + unnormalise (normalization.py:156-167): the support wave(s) only; the state is NOT kept in registers across the force
+    //      phases (28 VGPRs that every one of the 8 waves held - and, in the 128-register dense variant, spilled to scratch: 112 B per
+    //      lane, 148 MB written per launch at B = 6400); phase 4 reads x again (L2) and the unnormalised state from LDS
     const int ctx = b / a.n_per_ctx;
-    const bool clipall = __uint_as_float(a.amax_in[ctx]) > 1.0001f;
-    float xn[D], xu[D];
-    const size_t base = ((size_t)b * H + (live ? hs_ : 0)) * D;
+    if (wv < nsw) {
+        const size_t base = ((size_t)b * H + (live ? hs_ : 0)) * D;
+        const bool clipall = __uint_as_float(a.amax_in[ctx]) > 1.0001f;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        xn[d] = live ? a.x[base + d] : 0.f;
-        const float c = clipall ? fminf(fmaxf(xn[d], -1.f), 1.f) : xn[d];
-        const float u01 = __fadd_rn(c, 1.0f) * 0.5f;
-        xu[d] = gp.identity_normalizer ? xn[d] : __fadd_rn(__fmul_rn(u01, __fsub_rn(gp.maxs[d], gp.mins[d])), gp.mins[d]);
-        if (live && wv < nsw) sx[hs_ * D + d] = xu[d];
+        for (int d = 0; d < D; ++d) {
+            const float xnd = live ? a.x[base + d] : 0.f;
+            const float c = clipall ? fminf(fmaxf(xnd, -1.f), 1.f) : xnd;
+            const float u01 = __fadd_rn(c, 1.0f) * 0.5f;
+            const float xud = gp.identity_normalizer ? xnd : __fadd_rn(__fmul_rn(u01, __fsub_rn(gp.maxs[d], gp.mins[d])), gp.mins[d]);
+            if (live) sx[hs_ * D + d] = xud;
+        }
     }
     __syncthreads();
     G_STAMP();  // 1 state unnormalised + staged
@@ -762,60 +898,81 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void guide_step_panda_kernel(co
     __syncthreads();
     G_STAMP();  // 4 all waves done
 
+    // the support wave(s) request x again HERE: the round trip hides under the gather (requested in phase 4 it sat on the critical path of
+    // the one wave that finishes the trajectory: 1.8 k cycles, tools/guide_trace.py)
+    float xn[D];
+    int hs_o = hs_;
+    asm volatile("" : "+v"(hs_o));   // the 64-bit element address is re-derived here, not carried (as a spilled register pair) through the force phases
+    const size_t base = ((size_t)b * H + (live ? hs_o : 0)) * D;
+    if (wv < nsw) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) xn[d] = live ? a.x[base + d] : 0.f;   // same floats as the prologue read (nothing has written x since)
+    }
+
     // ---- phase 3: wave f gathers field f to the support points (one or two blocks of 64), clips, weights
     if (wv < gp.n_fields) {
         const int f = wv;
-        for (int sb = 0; sb < nsw; ++sb) {
-            const int hg_ = sb * 64 + lane;
-            if (hg_ >= H) continue;
-            int ilo = hg_, ihi = hg_;
-            if (gp.interpolate && scale > 0.f) {
-                ilo = (int)((float)(hg_ - 1) / scale) - 1;   // points of the segments (hg-1, hg) and (hg, hg+1): any number per segment
-                ihi = (int)((float)(hg_ + 1) / scale) + 1;
-                if (ilo < 0) ilo = 0;
-                if (ihi > N - 1) ihi = N - 1;
-            }
-            float g[QD];
-#pragma unroll
-            for (int j = 0; j < QD; ++j) g[j] = 0.f;
-            for (int i = ilo; i <= ihi; ++i) {
-                int i0 = i, i1 = i;
-                float l0 = 1.f, l1 = 0.f;
-                if (gp.interpolate) {
-                    const float u = scale * (float)i;
-                    i0 = (int)u;
-                    if (i0 > H - 1) i0 = H - 1;
-                    i1 = i0 + 1 < H ? i0 + 1 : H - 1;
-                    l1 = u - (float)i0;
-                    l0 = 1.0f - l1;
+        // the parts of sG[(f, .)] that hold data are known per field kind (panda_part_joints): two straight-line variants of the gather,
+        // chosen once per wave (a per-element test inside the loop doubled this phase: 6.3 k -> 12 k cycles, tools/guide_trace.py)
+        auto gather = [&](auto self_c) {
+            constexpr bool SELFK = decltype(self_c)::value;
+            for (int sb = 0; sb < nsw; ++sb) {
+                const int hg_ = sb * 64 + lane;
+                if (hg_ >= H) continue;
+                int ilo = hg_, ihi = hg_;
+                if (gp.interpolate && scale > 0.f) {
+                    ilo = (int)((float)(hg_ - 1) / scale) - 1;   // points of the segments (hg-1, hg) and (hg, hg+1): any number per segment
+                    ihi = (int)((float)(hg_ + 1) / scale) + 1;
+                    if (ilo < 0) ilo = 0;
+                    if (ihi > N - 1) ihi = N - 1;
                 }
-                const bool m0 = i0 == hg_, m1 = i1 == hg_ && gp.interpolate;
-                if (m0 || m1) {
+                float g[QD];
 #pragma unroll
-                    for (int j = 0; j < QD; ++j) {
-                        float v = 0.f;
+                for (int j = 0; j < QD; ++j) g[j] = 0.f;
+                for (int i = ilo; i <= ihi; ++i) {
+                    int i0 = i, i1 = i;
+                    float l0 = 1.f, l1 = 0.f;
+                    if (gp.interpolate) {
+                        const float u = scale * (float)i;
+                        i0 = (int)u;
+                        if (i0 > H - 1) i0 = H - 1;
+                        i1 = i0 + 1 < H ? i0 + 1 : H - 1;
+                        l1 = u - (float)i0;
+                        l0 = 1.0f - l1;
+                    }
+                    const bool m0 = i0 == hg_, m1 = i1 == hg_ && gp.interpolate;
+                    if (m0 || m1) {
 #pragma unroll
-                        for (int pt = 0; pt < NP; ++pt) v += sG[((f * NP + pt) * N + i) * QD + j];
-                        if (m0) g[j] += l0 * v;
-                        if (m1) g[j] += l1 * v;
+                        for (int j = 0; j < QD; ++j) {
+                            float v = 0.f;
+#pragma unroll
+                            for (int pt = 0; pt < NP; ++pt)
+                                if (SELFK ? pt == NP - 1 : j < panda_group_joints(pt)) v += sG[((f * NP + pt) * N + i) * QD + j];   // (compile time)
+                            if (m0) g[j] += l0 * v;
+                            if (m1) g[j] += l1 * v;
+                        }
                     }
                 }
-            }
-            // clip over ALL D dims of (g + 1e-6): the velocity dims of a collision gradient are 0
-            clip_waypoint_grad<QD>(gp, g, QD);
-            const bool interior = hg_ > 0 && hg_ < H - 1;
+                // clip over ALL D dims of (g + 1e-6): the velocity dims of a collision gradient are 0
+                clip_waypoint_grad<QD>(gp, g, QD);
+                const bool interior = hg_ > 0 && hg_ < H - 1;
 #pragma unroll
-            for (int j = 0; j < QD; ++j) sC[(f * H + hg_) * QD + j] = interior ? gp.fields[f].weight * g[j] : 0.f;
-        }
+                for (int j = 0; j < QD; ++j) sC[(f * H + hg_) * QD + j] = interior ? gp.fields[f].weight * g[j] : 0.f;
+            }
+        };
+        if (gp.fields[f].kind == MPDX_FIELD_SELF) gather(std::true_type{}); else gather(std::false_type{});
     }
     __syncthreads();
     G_STAMP();  // 5 gathered + clipped
     if (wv >= nsw) return;
 
     // ---- phase 4 (the support wave(s)): sum over fields, GP prior, apply
-    float total[D];
+    float total[D], xu[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) total[d] = 0.f;
+    for (int d = 0; d < D; ++d) {
+        total[d] = 0.f;
+        xu[d] = live ? sx[hs_ * D + d] : 0.f;        // = the unnormalised state the prologue staged
+    }
     if (live) {
         for (int f = 0; f < gp.n_fields; ++f) {
 #pragma unroll

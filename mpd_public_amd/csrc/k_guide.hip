@@ -81,6 +81,11 @@ int mpdx_guide_step_scaled(const mpdx_guide_params* gp, float* x, float* grad_ou
 }
 
 int mpdx_traj_metrics(const mpdx_guide_params* gp, const float* x_unnormalised, float* out4, int n_check, int B, int H, int D, void* stream) {
+    return mpdx_traj_metrics_mask(gp, x_unnormalised, out4, nullptr, n_check, B, H, D, stream);
+}
+
+int mpdx_traj_metrics_mask(const mpdx_guide_params* gp, const float* x_unnormalised, float* out4, uint8_t* mask, int n_check, int B, int H, int D,
+                           void* stream) {
     if (!gp || !x_unnormalised || !out4 || B <= 0) return fail(MPDX_E_INVALID, "bad argument");
     if (H > 128 || H < 2) return fail(MPDX_E_INVALID, "H=%d unsupported (max 128)", H);
     if (D != 2 * gp->q_dim || D > 16) return fail(MPDX_E_INVALID, "state dim %d != 2*q_dim (%d)", D, gp->q_dim);
@@ -88,11 +93,11 @@ int mpdx_traj_metrics(const mpdx_guide_params* gp, const float* x_unnormalised, 
     const size_t lds = (size_t)(H * D + gp->n_prim_floats) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 2 && gp->ws_dim == 2)
-        hipLaunchKernelGGL((traj_metrics_kernel<2, 2, MPDX_ROBOT_POINTMASS>), dim3(B), dim3(64), lds, st, *gp, x_unnormalised, out4, B, H, n_check);
+        hipLaunchKernelGGL((traj_metrics_kernel<2, 2, MPDX_ROBOT_POINTMASS>), dim3(B), dim3(64), lds, st, *gp, x_unnormalised, out4, B, H, n_check, mask);
     else if (gp->robot == MPDX_ROBOT_POINTMASS && gp->q_dim == 3 && gp->ws_dim == 3)
-        hipLaunchKernelGGL((traj_metrics_kernel<3, 3, MPDX_ROBOT_POINTMASS>), dim3(B), dim3(64), lds, st, *gp, x_unnormalised, out4, B, H, n_check);
+        hipLaunchKernelGGL((traj_metrics_kernel<3, 3, MPDX_ROBOT_POINTMASS>), dim3(B), dim3(64), lds, st, *gp, x_unnormalised, out4, B, H, n_check, mask);
     else if (gp->robot == MPDX_ROBOT_PANDA && gp->q_dim == 7 && gp->ws_dim == 3)
-        hipLaunchKernelGGL((traj_metrics_kernel<7, 3, MPDX_ROBOT_PANDA>), dim3(B), dim3(64), lds, st, *gp, x_unnormalised, out4, B, H, n_check);
+        hipLaunchKernelGGL((traj_metrics_kernel<7, 3, MPDX_ROBOT_PANDA>), dim3(B), dim3(64), lds, st, *gp, x_unnormalised, out4, B, H, n_check, mask);
     else
         return fail(MPDX_E_INVALID, "unsupported robot %d / q_dim %d / ws_dim %d", gp->robot, gp->q_dim, gp->ws_dim);
     HIP_TRY(hipGetLastError());

@@ -1,5 +1,6 @@
 // k_ws.hip - the weight-stationary persistent conv kernels (conv_ws.hpp).
 #include "host.hpp"
+#include "conv_wsn.hpp"
 
 namespace mpdx {
 
@@ -27,8 +28,27 @@ static int launch_ws(const Layer& l, ConvArgs& a, const ConvArgs& a2, int B, hip
     return launch_ws_t<NC16, MT, R1, NS, 0>(l, a, a2, B, st);
 }
 
+// the 128-channel layers of the innermost up level without a K split (conv_wsn.hpp): one wave = one (GroupNorm group, trajectory pair) tile
+template <int MODE, int TBRES>
+static int launch_wsn_t(const Layer& l, ConvArgs& a, int B, hipStream_t st) {
+    if (l.L_in != 8 || l.c1 != kWsnC || l.c2 != 0 || l.cin_pad != kWsnC || l.cout != kWsnC || (MODE == CONV_S1 ? (l.L_out != 8 || l.gs != 16) : l.L_out != 16) ||
+        a.pre || a.accum || a.dst2 || a.c_split || a.decim || a.stuff || (a.tbias && a.tb_stride) || (a.Lv_out > 0 && a.Lv_out < l.L_out) || (long)B * 8 * kWsnC * 4 > 0x7fffffffL)
+        return fail(MPDX_E_STATE, "layer %s does not have the geometry conv_wsn_kernel is compiled for", l.name.c_str());
+    const size_t lds = conv_wsn_lds_bytes<MODE>();
+    auto kern = conv_wsn_kernel<MODE, TBRES>;
+    if (int rc = raise_lds_limit((const void*)kern)) return rc;
+    hipLaunchKernelGGL(kern, dim3((kWsnC / 16) * kWsnGroups), dim3(kWsnThreads), lds, st, a);
+    return 0;
+}
+
 int launch_weight_stationary(int variant, const Layer& l, ConvArgs& a, const ConvArgs& a2, int B, hipStream_t st) {
     switch (variant) {
+        case 4:
+            if (a.tbias && a.res) return fail(MPDX_E_STATE, "layer %s: time bias AND residual on one weight-stationary launch", l.name.c_str());
+            if (a.tbias) return launch_wsn_t<CONV_S1, 1>(l, a, B, st);
+            if (a.res) return launch_wsn_t<CONV_S1, 2>(l, a, B, st);
+            return launch_wsn_t<CONV_S1, 0>(l, a, B, st);
+        case 5: return launch_wsn_t<CONV_UPT, 0>(l, a, B, st);
         case 1: {   // 32-position tiles (one duty wave on every SIMD) from 16 tiles per workgroup on
             static const int ns_env = getenv("MPDX_WS_NS") ? atoi(getenv("MPDX_WS_NS")) : 0;   // dev A/B: 1 / 2 force the tile
             const bool big = ns_env ? ns_env == 2 : (long)B * l.L_out >= 32L * kWsGroups * 16;

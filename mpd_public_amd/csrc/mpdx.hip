@@ -902,6 +902,12 @@ static int make_conv_args(const mpdx_unet* u, const Layer& l, const float* packe
 // weight-stationary vs per-layer kernels): 128 -> 128 <8,16>: 142.7 vs 95.9; 128 -> 256 + 1x1 <8,32,R1>: 268 vs 234 - with 5 k-groups per
 // wave a tile's 20-40 MFMAs per wave do not cover its barrier and window hand-over; kept: 256 -> 256: 319 vs 332, 512 -> 128 + 1x1: 387 vs 468.
 static int weight_stationary_variant(const Layer& l, const Layer* l2, const ConvArgs& a, int B, int dbg) {
+    const char* wsn = getenv("MPDX_WSN");   // dev A/B: 0 = the 128-channel layers stay on the per-layer kernels
+    const bool wsn_on = !(wsn && atoi(wsn) == 0) && !(getenv("MPDX_WS") && atoi(getenv("MPDX_WS")) == 0);
+    // Upsample1d(128) of the innermost up level, 8 -> 16 positions: conv_wsn_kernel<CONV_UPT> (round 5)
+    if (l.mode == CONV_UPT && l.ks == 4 && l.epi == EPI_BIAS && !l2 && l.L_in == 8 && l.L_out == 16 && !l.Lv_out && l.c1 == 128 && l.c2 == 0 &&
+        l.cin_pad == 128 && l.cout == 128 && !dbg && !a.pre && !a.accum && !a.dst2 && wsn_on && (long)B * 8 >= 16L * kWsGroups * 8)
+        return 5;
     if (!(l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH && l.L_out == 8 && l.L_in == 8) || l.Lv_out) return 0;
     if (dbg || a.pre || (l.c1 & 3) || (l.c2 & 3) || l.cin_pad != l.c1 + l.c2) return 0;
     if ((long)B * l.L_out < 16L * kWsGroups * 8) return 0;
@@ -914,6 +920,7 @@ static int weight_stationary_variant(const Layer& l, const Layer* l2, const Conv
         return 0;
     }
     if (l.cout == 256 && l.gs == 32 && l.cin_pad == 256) return 1;
+    if (l.cout == 128 && l.gs == 16 && l.cin_pad == 128 && l.c2 == 0 && wsn_on) return 4;   // conv_wsn_kernel<CONV_S1>: no K split (round 5)
     return 0;
 }
 
@@ -1704,7 +1711,8 @@ int mpdx_unet_layer_tile(const mpdx_unet* u, int i, int B, char* buf, size_t buf
     memset(&dummy, 0, sizeof(dummy));
     const Layer* l2 = (i + 1 < (int)u->layers.size() && pair_tile(l, u->layers[i + 1], B, MT, NT)) ? &u->layers[i + 1] : nullptr;
     if (const int v = weight_stationary_variant(l, l2, dummy, B, 0)) {   // "ws": the weight-stationary persistent kernel (conv_ws.hpp)
-        snprintf(buf, buflen, "ws %dx16/1x8%s", v == 1 ? 32 : 16, v == 3 ? "+1x1" : "");
+        if (v >= 4) snprintf(buf, buflen, "wsn 16x16/8x1");   // conv_wsn_kernel: 8 waves = 8 position tiles, whole K per wave
+        else snprintf(buf, buflen, "ws %dx16/1x8%s", v == 1 ? 32 : 16, v == 3 ? "+1x1" : "");
         return 0;
     }
     choose_tile(l, B, MT, NT);

@@ -173,19 +173,21 @@ class PlanningTask:
                                                            [1.0] * len(costs), True, 128, True, 1.0, device)
         return self._gp
 
-    def trajectory_metrics(self, trajs, n_check=None):
+    def trajectory_metrics(self, trajs, n_check=None, return_mask=False):
         """trajs: UNNORMALISED [B,H,D] on the GPU -> float tensor [B,4]: (#colliding waypoints, path length, smoothness,
-        #waypoints checked)."""
+        #waypoints checked); with return_mask also the per-waypoint collision flags [B, n_check] (bool) the count is made of."""
         import ctypes as C
         trajs = trajs.to(torch.float32).contiguous()
         if not trajs.is_cuda:
             raise RuntimeError("trajectory metrics run on the GPU (libmpdx); there is no CPU fallback")
         B, H, D = trajs.shape
+        n_check = int(n_check or 4 * H)
         out = torch.empty((B, 4), dtype=torch.float32, device=trajs.device)
+        mask = torch.empty((B, n_check), dtype=torch.uint8, device=trajs.device) if return_mask else None
         gp = self._params(trajs.device)
-        _lib.check(_lib.load().mpdx_traj_metrics(C.byref(gp), trajs.data_ptr(), out.data_ptr(), int(n_check or 4 * H), B, H, D,
-                                                 _lib.current_stream()), "mpdx_traj_metrics")
-        return out
+        _lib.check(_lib.load().mpdx_traj_metrics_mask(C.byref(gp), trajs.data_ptr(), out.data_ptr(), mask.data_ptr() if return_mask else None,
+                                                      n_check, B, H, D, _lib.current_stream()), "mpdx_traj_metrics_mask")
+        return (out, mask.bool()) if return_mask else out
 
     def get_trajs_collision_and_free(self, trajs, return_indices=False, **kw):
         m = self.trajectory_metrics(trajs)

@@ -163,3 +163,137 @@ def kernel_path(fused: bool):
             os.environ.pop("MPDX_FUSED", None)
         else:
             os.environ["MPDX_FUSED"] = old
+
+
+# ---------------------------------------------------------------------------------------------- decidable plan figures (guided plans)
+def oracle_hinge_slack(dataset, xu, n_check=256, dtype=torch.float64):
+    """Per interpolated waypoint of the UNNORMALISED trajectories xu [B,H,D] (CPU): slack[b,i] = max over EVERY collision hinge of the
+    waypoint (link sphere x field: objects / workspace faces / self-collision pairs) of (margin - signed distance), margin = link
+    radius (no cutoff margin) - the quantity whose sign IS the collision flag of inference.py:288-297 (a waypoint collides iff
+    slack > 0), evaluated in `dtype`.  |slack| < eps marks a waypoint whose flag no fp32 evaluation can decide."""
+    from oracle import costs as oc
+    from oracle.guide import interpolate_points_v1
+    _, comp = oracle_guide(dataset, dtype=dtype)
+    xi = interpolate_points_v1(xu.to(dtype), n_check)
+    slack = torch.full(xi.shape[:2], -float("inf"), dtype=dtype)
+    for term in comp.cost_l:
+        if not isinstance(term, oc.CostCollision):
+            continue
+        rob, f = term.robot, term.field
+        pts = rob.link_points(xi[..., : rob.q_dim])          # [B, N, K, dim]
+        radii = rob.radii.to(dtype)
+        if f.kind == "objects":
+            s = radii - f.sdf(pts)
+        elif f.kind == "workspace":
+            m = radii.unsqueeze(-1)
+            s = torch.cat([m - (pts - f.ws_min.to(dtype)), m - (f.ws_max.to(dtype) - pts)], dim=-1).flatten(-2)
+        else:
+            a, b = pts[..., f.pairs[:, 0], :], pts[..., f.pairs[:, 1], :]
+            s = radii[f.pairs[:, 0]] + radii[f.pairs[:, 1]] - torch.linalg.norm(a - b, dim=-1)
+        slack = torch.maximum(slack, s.amax(-1))
+    return slack
+
+
+def guided_parity_record(dm, sd, guide, gk, hc, T, n0, nb, n_check=256, eps=1e-5, seed=31, threads=16, weights=(1e-2, 1e-7)):
+    """The DECIDABLE form of north_star's "collision-free rate and smoothness identical to 3 s.f." for guided plans (checker leg; used by
+    tests/test_gpu_guided_class.py and by bench.py's guided.oracle_check).
+
+    A guided chain is discontinuous: a waypoint within fp32 rounding of a hinge margin takes a clipped increment (w = 1e-2) in one
+    evaluation and not in another, and 150 guide iterations + the U-Net spread the flip - so two CORRECT fp32 evaluations of one plan end
+    ~1e-2 apart on every trajectory (measured: the fp32 CPU oracle against its own fp64 run), and the count of colliding waypoints of a
+    small slice differs in the third figure between any two of them.  What can be decided, and is:
+      (1) same plan - the HIP metrics kernel's per-waypoint collision flags on the HIP plan against an fp64 evaluation of the SAME
+          trajectories: a waypoint is `ambiguous` iff its fp64 hinge slack max_h(margin_h - sdf_h) lies within +-eps of zero; every
+          other waypoint must carry the same flag, so the figures over the unambiguous waypoints / trajectories agree EXACTLY
+          (path length and smoothness: to fp32 rounding);
+      (2) chain class - flags of the HIP plan, of the fp32 CPU oracle's plan and of the fp64 oracle's plan (same injected noise):
+          flips(HIP vs fp64) <= 2 * flips(fp32 oracle vs fp64) + 2, i.e. the HIP chain is as close to the rounding-free chain as the
+          oracle's own fp32 arithmetic is (the guided analogue of test_chain_error_is_fp32_rounding_class).
+    Returns a JSON-able dict; `equal_to_3sf` is (1) per figure, `chain_class.within_fp32_class` is (2)."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    from oracle import diffusion as odiff
+    from oracle import metrics as omet
+    ds = guide.dataset
+    D = ds.state_dim
+    qd = D // 2
+    noise = torch.randn((T + n0 + 1, nb, 64, D), generator=torch.Generator().manual_seed(seed))
+    kw = dict(n_guide_steps=gk["n_guide_steps"], t_start_guide=gk["t_start_guide"], n_diffusion_steps_without_noise=n0)
+    chain = dm.run_inference(None, hc, n_samples=nb, horizon=64, return_chain=True, guide=guide, noise_std_extra_schedule_fn=lambda t: 0.5,
+                             noise=noise.cuda(), **kw)
+    xu_hip_dev = ds.unnormalize_trajectories(chain[-1])
+    m, mask_hip = ds.task.trajectory_metrics(xu_hip_dev, n_check=n_check, return_mask=True)
+    m, mask_hip, x_hip, xu_hip = m.cpu(), mask_hip.cpu(), chain[-1].cpu(), xu_hip_dev.cpu()
+    hcc = {k: v.cpu() for k, v in hc.items()}
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(threads, old_threads)))   # (more threads are slower on this ATen loop: bench.py's cpu_baseline probe)
+
+    def oracle_chain(dtype):
+        og, _ = oracle_guide(ds, *weights, dtype=dtype)
+        t0 = time.perf_counter()
+        r = odiff.run_inference({k: v.to(dtype) for k, v in sd.items()}, {k: v.to(dtype) for k, v in hcc.items()}, noise.to(dtype), T,
+                                noise_std=0.5, guide=og, dtype=dtype, **kw)
+        return r[-1], og.normalizer.unnormalize(r[-1]), time.perf_counter() - t0
+    try:
+        with ThreadPoolExecutor(2) as ex:
+            f32, f64 = ex.submit(oracle_chain, torch.float32), ex.submit(oracle_chain, torch.float64)
+            (x32, xu32, s32), (x64, xu64, s64) = f32.result(), f64.result()
+    finally:
+        torch.set_num_threads(old_threads)
+
+    def figures(hit, xu):      # per-plan figures from per-waypoint flags [nb, n_check] + fp64 path metrics
+        z = xu.double().numpy()
+        return {"collision_free_rate": float((hit.sum(1) == 0).float().mean()), "collision_intensity": float(hit.float().mean(1).mean()),
+                "path_length": float(omet.compute_path_length(z, qd).mean()), "smoothness": float(omet.compute_smoothness(z, qd).mean())}
+
+    def same3(a, b):           # identical to 3 significant figures (or both zero)
+        return a == b or abs(a - b) <= 5e-3 * max(abs(a), abs(b))
+
+    # ---- (1) same plan: HIP kernel vs fp64 evaluation of the HIP trajectories
+    slack = oracle_hinge_slack(ds, xu_hip, n_check)
+    hit64, amb = slack > 0, slack.abs() < eps
+    dec = ~amb
+    disagree = int(((mask_hip != hit64) & dec).sum())
+    traj_dec = ~((amb & ~((mask_hip & dec).any(1, keepdim=True))).any(1))   # a trajectory whose only possible hits are ambiguous has no decidable "free" status
+
+    def unamb(hit):
+        frac = (hit & dec).sum(1).double() / dec.sum(1).clamp(min=1).double()
+        free = ((hit & dec).sum(1) == 0)[traj_dec]
+        return {"collision_free_rate": float(free.float().mean()) if free.numel() else float("nan"), "collision_intensity": float(frac.mean())}
+    hip_u, f64_u = unamb(mask_hip), unamb(hit64)
+    hip_u.update(path_length=float(m[:, 1].mean()), smoothness=float(m[:, 2].mean()))
+    z = xu_hip.double().numpy()
+    f64_u.update(path_length=float(omet.compute_path_length(z, qd).mean()), smoothness=float(omet.compute_smoothness(z, qd).mean()))
+    equal = {"collision_free_rate": bool(disagree == 0 and hip_u["collision_free_rate"] == f64_u["collision_free_rate"]),
+             "collision_intensity": bool(disagree == 0 and hip_u["collision_intensity"] == f64_u["collision_intensity"]),
+             "path_length": bool(abs(hip_u["path_length"] - f64_u["path_length"]) <= 2e-5 * abs(f64_u["path_length"])),
+             "smoothness": bool(abs(hip_u["smoothness"] - f64_u["smoothness"]) <= 2e-5 * abs(f64_u["smoothness"]))}
+    # ---- (2) chain class: final flags of the three chains
+    hit32c, hit64c = oracle_hinge_slack(ds, xu32, n_check) > 0, oracle_hinge_slack(ds, xu64, n_check) > 0
+    flips_hip, flips_32 = int((mask_hip != hit64c).sum()), int((hit32c != hit64c).sum())
+    div = lambda a: int(((a.double() - x64).abs().amax((1, 2)) > 1e-3).sum())
+    fig = {"hip": {"collision_free_rate": float((m[:, 0] == 0).float().mean()), "collision_intensity": float((m[:, 0] / m[:, 3]).mean()),
+                   "path_length": float(m[:, 1].mean()), "smoothness": float(m[:, 2].mean())},
+           "oracle_fp32": figures(hit32c, xu32), "oracle_fp64": figures(hit64c, xu64)}
+    r6 = lambda d: {k: float(f"{v:.6g}") for k, v in d.items()}
+    return {
+        "trajectories": nb, "waypoints_checked": int(nb * n_check), "eps": eps,
+        "definition": "equal_to_3sf = the HIP metrics kernel against an fp64 evaluation of the SAME (HIP) plan over the waypoints whose fp64 hinge slack is "
+                      "not within +-eps of zero (ambiguous_waypoints excluded; counts must agree exactly, path length / smoothness to 2e-5); chain_class = "
+                      "hinge flips of the final plan against the fp64 oracle chain, HIP vs the fp32 CPU oracle (tests/helpers.py::guided_parity_record)",
+        "ambiguous_waypoints": int(amb.sum()), "undecidable_trajectories": int((~traj_dec).sum()), "flag_disagreements_outside_ambiguous": disagree,
+        "same_plan": {"hip_kernel": r6(hip_u), "fp64_evaluation": r6(f64_u)},
+        "equal_to_3sf": equal,
+        "chain_class": {"flips_vs_fp64_chain": {"hip": flips_hip, "oracle_fp32": flips_32}, "bound": "hip <= 2 * oracle_fp32 + 2",
+                        "within_fp32_class": bool(flips_hip <= 2 * flips_32 + 2),
+                        "trajectories_diverged_gt_1e-3_from_fp64_chain": {"hip": div(x_hip), "oracle_fp32": div(x32)},
+                        "max_abs_diff_final_trajectories": {"hip_vs_fp64": float((x_hip.double() - x64).abs().max()),
+                                                            "oracle_fp32_vs_fp64": float((x32.double() - x64).abs().max()),
+                                                            "hip_vs_oracle_fp32": float((x_hip - x32).abs().max())}},
+        "plan_figures": {k: r6(v) for k, v in fig.items()},
+        "cross_chain_equal_to_3sf": {"hip_vs_oracle_fp64": {k: bool(same3(fig["hip"][k], fig["oracle_fp64"][k])) for k in fig["hip"]},
+                                     "oracle_fp32_vs_oracle_fp64": {k: bool(same3(fig["oracle_fp32"][k], fig["oracle_fp64"][k])) for k in fig["hip"]},
+                                     "note": "different chains: the third figure of a count over nb x n_check waypoints moves between ANY two fp32 evaluations "
+                                             "(second row: the CPU oracle against itself in fp64) - decided by chain_class instead"},
+        "oracle_cpu_plan_s": {"fp32": round(s32, 2), "fp64": round(s64, 2)}, "weights": "synthetic (random-init): the figures are those of un-trained plans"}

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""s_memtime phase stamps of the guide kernel, all 8 waves of workgroup 0 (dev tool, needs a GPU)."""
+"""s_memtime phase stamps of the guide kernel, all 8 waves of workgroup 0 (dev tool, needs a GPU and a -DMPDX_DEV_HOOKS build):
+   MPDX_LIB=build_ab/libmpdx_dev.so python tools/guide_trace.py [B]   (B >= 512: the dense Panda variant, two workgroups per CU)"""
 import ctypes as C, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -12,7 +13,7 @@ lab = {"RobotPointMass": ["entry->staged", "collision slice", "wait all waves", 
        "RobotPanda": ["entry->staged", "FK->LDS", "forces (sphere group)", "wait all waves", "gather+clip", "GP prior", "apply"]}
 for env_id, robot_id in (("EnvNarrowPassageDense2D", "RobotPointMass"), ("EnvSpheres3D", "RobotPanda")):
     ds = m.TrajectoryDataset(env_id, robot_id, tensor_args={"device": "cuda", "dtype": torch.float32})
-    B = 100
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     x = obstacle_hugging_trajs(ds, B, seed="trace", scale=0.95).cuda()
     pg = product_guide(ds).cuda()
     gp = pg.device_params(x.device)
@@ -22,7 +23,7 @@ for env_id, robot_id in (("EnvNarrowPassageDense2D", "RobotPointMass"), ("EnvSph
     stamps = (C.c_longlong * 128)()
     for rep in range(2):
         _lib.check(lib.mpdx_guide_trace(C.byref(gp), x.data_ptr(), flag.data_ptr(), B, 64, ds.state_dim, st, stamps))
-    print(robot_id)
+    print(robot_id, f"B={B}")
     for w in range(8):
         v = [stamps[w * 16 + k] for k in range(8) if stamps[w * 16 + k]]
         d = [b - a for a, b in zip(v, v[1:])]
