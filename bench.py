@@ -404,61 +404,141 @@ def _all_ranks(dist, vals, device):
     return [[float(v) for v in t.cpu()] for t in out]
 
 
-def sharded_leg(rank, world, dist, device, plans=2):
+class _Watchdog:
+    """Arms a timer around a leg that ends in collectives: if the leg has not returned after `seconds`, rank 0 prints the record it
+    holds so far (the headline line, with the leg marked as timed out) and the process exits with status 0 - a hung collective in a
+    sub-record must not cost the driver its bench line."""
+
+    def __init__(self, seconds, rank, out):
+        import threading
+        self.rank, self.out = rank, out
+        self.t = threading.Timer(seconds, self._fire, args=(seconds,))
+        self.t.daemon = True
+        self.t.start()
+
+    def _fire(self, seconds):
+        if self.rank == 0:
+            rec = dict(self.out)
+            rec["sharded"] = {"error": f"watchdog: the sharded leg did not return within {seconds:g} s (a collective never completed)"}
+            for k in ("cpu_baseline", "guided", "serving", "planner_baseline", "training"):
+                rec.setdefault(k, None)
+            print(json.dumps(rec), flush=True)
+        os._exit(0)
+
+    def cancel(self):
+        self.t.cancel()
+
+
+def _agree(dist, ok, device):
+    """True iff EVERY rank passes ok=True (one MIN all-reduce of a flag): the ranks decide together whether to enter a step that only
+    works if all of them do - a rank that already failed cannot leave its peers waiting in it."""
+    import torch
+    if dist is None:
+        return bool(ok)
+    gloo = dist.get_backend() == "gloo"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if gloo else device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.cpu()[0]) == 1)
+
+
+class _Stopwatch:
+    """elapsed ms between marks: HIP events on the current stream for a GPU device, the host clock (after a synchronise) otherwise
+    (the CPU rig of tests/test_parallel_cpu.py runs this leg's sharding / gather / record code on the gloo backend without a GPU)."""
+
+    def __init__(self, device, n):
+        import torch
+        self.gpu = str(device).startswith("cuda")
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(n)] if self.gpu else [0.0] * n
+
+    def mark(self, i):
+        if self.gpu:
+            self.ev[i].record()
+        else:
+            self.ev[i] = time.perf_counter()
+
+    def ms(self, i, j):
+        return self.ev[i].elapsed_time(self.ev[j]) if self.gpu else (self.ev[j] - self.ev[i]) * 1e3
+
+
+def sharded_leg(rank, world, dist, device, plans=2, n_ctx=None, n_samples=None, plan_fn=None, hop_timeout_s=60.0, hop_precheck=None):
     """BASELINE configs[4] per-GPU shard: 128 start/goal contexts x 50 Panda trajectories per rank (weak scaling: 128*N contexts in
     total), guided, per-trajectory hard conditions, per-context range tests, zero exchange during the loop, ONE gather of the
     planned trajectories at the end (RCCL over xGMI when N > 1).  Self-checking: the gathered tensor is verified block by block
     against checksums the owning ranks publish; both gather variants (all_gather_into_tensor / one-hop grouped send+recv over the
-    direct links) are timed in the same run; per-rank plan times are reported as min / median / max, not only the max."""
+    direct links) are timed in the same run; per-rank plan times are reported as min / median / max, not only the max.
+    n_ctx / n_samples / plan_fn: the CPU rig (tests/test_parallel_cpu.py: world 8 on gloo, one context per rank) replaces the planner by
+    a stand-in `plan_fn(hs, hg) -> [B, 64, D]` so that the shard arithmetic, both gathers, the agreement protocol and the record's
+    shape are exercised every round without a GPU; bench.py itself never passes them.  hop_precheck(rank) -> error string or None:
+    a rank's own pre-flight check of the one-hop form (tests inject a failure there).
+    A failure INSIDE a one-hop attempt (a peer dying between its sends) can leave the communicator unusable: main() therefore arms a
+    watchdog (_Watchdog) around this leg at N > 1 that prints the headline line and exits if the leg does not return."""
     import statistics
     import torch
     from mpd_public_amd import synthetic as syn
     from mpd_public_amd.parallel import expand_contexts, gather_trajectories, verify_gather
-    env_id, robot, D, mults, T, B, n0, _, n_ctx = CONFIGS["cfg5"]
-    dm, _sd = build_model(D, mults, T, device)
-    dm.manual_seed(1000 + rank)
-    gk = build_guide(env_id, robot, T, device)
+    env_id, robot, D, mults, T, B, n0, _, cfg_ctx = CONFIGS["cfg5"]
+    n_ctx = int(n_ctx or cfg_ctx)
+    n_samples = int(n_samples or B // cfg_ctx)
+    B = n_ctx * n_samples
+    on_gpu = str(device).startswith("cuda")
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
+    if dist is not None and dist.get_world_size() != world:
+        raise RuntimeError(f"process group has {dist.get_world_size()} ranks, the launcher announced {world}")
     st = torch.from_numpy(syn.synth_tensor(f"bench_ctx_s{rank}", (n_ctx, D), "uniform", 0.6)).to(device)
     gl = torch.from_numpy(syn.synth_tensor(f"bench_ctx_g{rank}", (n_ctx, D), "uniform", 0.6)).to(device)
-    hs, hg = expand_contexts(st, gl, B // n_ctx)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    hs, hg = expand_contexts(st, gl, n_samples)
+    if plan_fn is None:
+        dm, _sd = build_model(D, mults, T, device)
+        dm.manual_seed(1000 + rank)
+        gk = build_guide(env_id, robot, T, device)
+
+        def plan_fn(hs_, hg_):
+            return dm.plan({0: hs_, 63: hg_}, B, 64, n0, None, lambda t: 0.5, return_chain=False, n_per_context=n_samples, **gk)[0]
+    sw = _Stopwatch(device, 3)
     plan_ms, gather_ms, hop_ms = [], [], []
     verified, hop_error = True, None
     x = g = None
     for it in range(plans + 1):
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
-        ev[0].record()
-        x, _ = dm.plan({0: hs, 63: hg}, B, 64, n0, None, lambda t: 0.5, return_chain=False, n_per_context=B // n_ctx, **gk)
-        ev[1].record()
-        g = gather_trajectories(x, n_ctx * world, B // n_ctx, force_collective=dist is not None, mode="collective")
-        ev[2].record()
-        torch.cuda.synchronize()
+        sync()
+        sw.mark(0)
+        x = plan_fn(hs, hg)
+        sw.mark(1)
+        g = gather_trajectories(x, n_ctx * world, n_samples, force_collective=dist is not None, mode="collective")
+        sw.mark(2)
+        sync()
         assert g.shape[0] == world * B and bool(torch.isfinite(g[-1]).all())
         if it == plans:   # transport check on the last plan: every block against its owner's checksum
-            verified = verify_gather(g, x, n_ctx * world, B // n_ctx)
+            verified = verify_gather(g, x, n_ctx * world, n_samples)
         if it > 0:
-            plan_ms.append(ev[0].elapsed_time(ev[1])); gather_ms.append(ev[1].elapsed_time(ev[2]))
+            plan_ms.append(sw.ms(0, 1)); gather_ms.append(sw.ms(1, 2))
     # the default form's record is complete HERE (the headline comes from it alone).  The one-hop form is measured afterwards, on the last
-    # plan's trajectories, with bounded waits: a rank that fails before posting its sends makes its peers raise after the timeout instead of
-    # blocking them, and the ranks agree on the outcome before anything is compared.
+    # plan's trajectories.  First contact with a real 8-GPU fabric happens in the driver's run, so the attempt is defensive: before EVERY
+    # attempt the ranks agree (one MIN all-reduce) that none of them has failed yet - an asymmetric failure cannot strand the others in a
+    # grouped send / receive - and every wait inside the attempt is bounded (a rank that dies mid-way makes its peers raise after the timeout).
     hop_ok = True
+    hop_skipped_by_agreement = False
+    if hop_precheck is not None:
+        hop_error = hop_precheck(rank)
     for it in range(plans):
         g1 = None
-        if hop_error is None:
-            try:
-                if dist is not None:
-                    dist.barrier()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                g1 = gather_trajectories(x, n_ctx * world, B // n_ctx, force_collective=dist is not None, mode="one_hop", timeout_s=60.0)
-                torch.cuda.synchronize()
-                hop_ms.append((time.perf_counter() - t0) * 1e3)
-            except Exception as e:
-                hop_error = f"{type(e).__name__}: {e}"
+        if not _agree(dist, hop_error is None, device):
+            hop_skipped_by_agreement = hop_error is None
+            hop_error = hop_error or "skipped: another rank reported a failure before this attempt"
+            break
+        try:
+            if dist is not None:
+                dist.barrier()
+            sync()
+            t0 = time.perf_counter()
+            g1 = gather_trajectories(x, n_ctx * world, n_samples, force_collective=dist is not None, mode="one_hop", timeout_s=hop_timeout_s)
+            sync()
+            hop_ms.append((time.perf_counter() - t0) * 1e3)
+        except Exception as e:
+            hop_error = f"{type(e).__name__}: {e}"
         if hop_error is None and it == plans - 1 and g1 is not None:
-            hop_ok = verify_gather(g1, x, n_ctx * world, B // n_ctx) and bool(torch.equal(g, g1))
+            hop_ok = verify_gather(g1, x, n_ctx * world, n_samples) and bool(torch.equal(g, g1))
     if hop_error is not None or not hop_ms:
         hop_ms = [float("nan")]
     table = _all_ranks(dist, [statistics.median(plan_ms), max(plan_ms), statistics.median(gather_ms), max(gather_ms),
@@ -473,10 +553,16 @@ def sharded_leg(rank, world, dist, device, plans=2):
     if not hop_failed and not all(r[8] == 1.0 for r in table):
         hop_failed, hop_error = True, "one-hop result does not match the per-rank checksums / the collective's result"
     nccl_env = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_")) and k not in ("NCCL_ASYNC_ERROR_HANDLING",)}
-    return {"workload": f"cfg5 shard per rank: {n_ctx} contexts x {B // n_ctx} = {B} Panda trajectories, T={T} (+{n0}), guided; {n_ctx * world} contexts in total",
+    try:
+        rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if on_gpu else None
+    except Exception as e:   # (a build without the binding must not cost the record)
+        rccl_version = f"unavailable ({type(e).__name__})"
+    return {"workload": f"cfg5 shard per rank: {n_ctx} contexts x {n_samples} = {B} Panda trajectories, T={T} (+{n0}), guided; {n_ctx * world} contexts in total",
             "ranks": world, "backend": (dist.get_backend() if dist is not None else None),
             "process_group_world_size": (dist.get_world_size() if dist is not None else None),
-            "ranks_per_gpu": (max(1, world // max(1, torch.cuda.device_count())) if dist is not None else 1),
+            "cuda_device_count": (torch.cuda.device_count() if on_gpu else 0),
+            "ranks_per_gpu": (max(1, world // max(1, torch.cuda.device_count())) if dist is not None and on_gpu else 1),
+            "rccl_version": rccl_version, "hip_version": getattr(torch.version, "hip", None),
             "nccl_env": nccl_env or None,
             "collective": "all_gather_into_tensor of the final trajectories" if dist is not None else None,
             "headline_gather": "all_gather_into_tensor (the default mode; the one-hop form is reported beside it, never mixed into the headline)",
@@ -484,9 +570,11 @@ def sharded_leg(rank, world, dist, device, plans=2):
                                  "max": round(max(per_rank_plan), 2), "all": [round(v, 2) for v in per_rank_plan]},
             "plan_ms_per_rank_max": round(pm, 2), "all_gather_ms_max": round(gm, 3),
             "gather_ms": {"all_gather_into_tensor": {"median_over_ranks": round(statistics.median(r[2] for r in table), 3), "max": round(gm, 3)},
-                          "one_hop_send_recv": ({"error": hop_error or "failed on another rank"} if hop_failed else
+                          "one_hop_send_recv": ({"error": hop_error or "failed on another rank", "skipped_by_agreement": bool(hop_skipped_by_agreement)}
+                                                if hop_failed else
                                                 {"median_over_ranks": round(statistics.median(r[4] for r in table), 3), "max": round(hm, 3),
-                                                 "timed": "host clock around the call, synchronised (after the main record)"})},
+                                                 "timed": "host clock around the call, synchronised (after the main record); the ranks agree before "
+                                                          "every attempt, waits bounded at %g s" % hop_timeout_s})},
             "gather_verified": "per-block position-weighted bit-pattern checksums published by the owning ranks match on every rank" +
                                ("" if hop_failed else "; both variants bit-identical"),
             "one_hop_denoising_steps_per_s": (None if hop_failed else round(world * (T + n0) / ((pm + hm) * 1e-3), 2)),
@@ -562,7 +650,7 @@ def training_leg(steps=100, B=32, T=25, D=4, opt=1, baseline=True):
         ts.step(x0, hc, 1e-4, max_norm=1.0)
         if k % 10 == 0:
             ema.update_model_average(ema_model, dm)
-    for k in range(5):
+    for k in range(8):   # (covers step()'s own measurement of the two launch forms: 6 calls)
         native(k)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -571,7 +659,8 @@ def training_leg(steps=100, B=32, T=25, D=4, opt=1, baseline=True):
     torch.cuda.synchronize()
     dt_native = (time.perf_counter() - t0) / steps
     rec = {"workload": f"p_losses + backward + clip_grad_norm_ + Adam + EMA/10, batch {B} x H=64 x D={D}, T={T}, dim_mults option {opt}, fp32",
-           "launch_mode": "TrainStep.step: " + ("the iteration's launches replayed as one hipGraph (batch <= 64: host-bound; MPDX_TRAIN_GRAPH=0: eager)" if B <= 64 and os.environ.get("MPDX_TRAIN_GRAPH") != "0" else "eager launches (GPU-bound batch)"),
+           "launch_mode": {"note": "TrainStep.step measures both forms on this host + GPU (eager launches: calls 2-3; one hipGraph replay per iteration: "
+                                   "calls 5-6) and keeps the faster; MPDX_TRAIN_GRAPH=1 / 0 forces either", "decided": ts.launch_mode()},
            "train_steps_per_s": round(1.0 / dt_native, 1), "ms_per_train_step": round(dt_native * 1e3, 3)}
     # roofline of the iteration: algorithmic FLOPs = 3 x the forward pass (forward + input gradients + weight gradients of every
     # convolution; GroupNorm / Mish / Adam are O(activations + parameters)), the forward count from the library's own layer table
@@ -671,7 +760,10 @@ def main():
         if rig:   # RCCL refuses two ranks on one device; the rig exercises the sharding / gather / checksum code, not the fabric
             dist.init_process_group("gloo")
         else:
+            os.environ.setdefault("NCCL_DEBUG", "VERSION")   # RCCL prints its version line at init (the driver's log keeps stderr)
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))  # nccl == RCCL on ROCm
+        if dist.get_world_size() != world or (args.gpus > 1 and dist.get_world_size() != args.gpus):
+            raise SystemExit(f"process group of {dist.get_world_size()} ranks, WORLD_SIZE={world}, --gpus {args.gpus}")
 
     env_id, robot, D, mults, T, B, n0, guided, n_ctx = CONFIGS[args.config]
     dm, sd = build_model(D, mults, T, device)
@@ -752,7 +844,10 @@ def main():
                 print(f"# {c['us_per_pass']:9.1f} us {c['share']*100:5.1f}%  {c['launches_per_pass']:3d} launches  {c['tflops']:7.2f} TF/s "
                       f"({c['frac']*100:4.1f}% of peak)  {c['class']}", file=sys.stderr)
     if not args.no_extras and args.config == "cfg2":
-        # every rank takes part in the sharded sub-record (it ends in a collective when N > 1)
+        # every rank takes part in the sharded sub-record (it ends in a collective when N > 1).  At N > 1 a watchdog stands behind it:
+        # should a collective of this leg never return (first contact with the 8-GPU fabric happens in the driver's run), rank 0 still
+        # prints the headline line - already complete above - and every rank exits instead of blocking the driver.
+        dog = _Watchdog(900.0, rank, out) if world > 1 else None
         try:
             rec = sharded_leg(rank, world, dist, device)
             if rank == 0:
@@ -760,6 +855,9 @@ def main():
         except Exception as e:  # the headline line must survive a failing sub-record
             if rank == 0:
                 out["sharded"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            if dog is not None:
+                dog.cancel()
         if rank == 0 and world == 1:
             try:
                 out["guided"] = guided_leg(device)

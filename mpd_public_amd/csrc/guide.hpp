@@ -433,9 +433,12 @@ __device__ __forceinline__ void clip_waypoint_grad(const mpdx_guide_params& gp, 
 // GP prior (constant-velocity, GPMP2: 3-point stencil over the horizon) added to the gathered collision gradient, then
 //     x = x + (-grad);  [+ the step's noise term on the last guide iteration];  hard conditioning;  max|x| for the next
 // range test.  One wave, lane = support point.  tr: optional two cycle stamps (dev tool).
+// snoise (or null): the step's noise of THIS trajectory, drawn by idle waves into LDS (guide_draw_noise: element k of the trajectory at
+// snoise[k + (e0 & 3)]) - the same Philox values philox_normal_at gives, one counter per FOUR elements instead of one per element.
 template <int QD>
 __device__ __forceinline__ void guide_gp_apply(const GuideArgs& a, int b, int ctx, int lane, int h, int H, bool live, const float (&xn)[2 * QD],
-                                               const float (&xu)[2 * QD], const float* sx, float (&total)[2 * QD], size_t base, long long* tr) {
+                                               const float (&xu)[2 * QD], const float* sx, float (&total)[2 * QD], size_t base, long long* tr,
+                                               const float* snoise = nullptr) {
     constexpr int D = 2 * QD;
     const bool interior = live && h > 0 && h < H - 1;
     if (a.gp.use_gp) {
@@ -479,7 +482,10 @@ __device__ __forceinline__ void guide_gp_apply(const GuideArgs& a, int b, int ct
                 a.grad_out[base + d] = inc;
             } else {
                 float r = __fadd_rn(xn[d], inc);
-                if (a.rng.on) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.noise_scale, philox_normal_at(a.rng.seed, a.rng.offset, a.rng.elem0 + base + d)), a.noise_extra));
+                if (a.rng.on) {
+                    const float z = snoise ? snoise[h * D + d] : philox_normal_at(a.rng.seed, a.rng.offset, a.rng.elem0 + base + d);
+                    r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.noise_scale, z), a.noise_extra));
+                }
                 else if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.noise_scale, a.noise[base + d]), a.noise_extra));
                 if (a.hs && h == 0) r = a.hs[(size_t)b * D + d];
                 if (a.hg && h == H - 1) r = a.hg[(size_t)b * D + d];
@@ -495,6 +501,20 @@ __device__ __forceinline__ void guide_gp_apply(const GuideArgs& a, int b, int ct
         if (lane == 0) atomicMax(a.amax_out + ctx, __float_as_uint(vmax));
     }
     if (tr) tr[1] = (long long)__builtin_readcyclecounter();  // applied
+}
+
+// The step's noise for one trajectory (H * D consecutive elements of the plan's Philox stream, first element e0), drawn by `nthr`
+// threads (thread `t` of them) into LDS: one Philox counter yields FOUR consecutive elements, so H * D / 4 (+1 when e0 is not a multiple
+// of 4) evaluations serve the trajectory - the support wave used to evaluate one counter PER ELEMENT (14 per lane for the Panda: the
+// noise launches took 330 us against 200 us for the others at B = 6400, profiles/r05_cfg5_kernel_stats_a.csv).  sn[k] = element e0 - (e0 & 3) + k.
+__device__ __forceinline__ void guide_draw_noise(const NoiseRng& rng, unsigned long long e0, int n_elems, float* sn, int t, int nthr) {
+    const unsigned long long q0 = e0 >> 2;
+    const int nq = (int)(((e0 + (unsigned long long)n_elems + 3ull) >> 2) - q0);
+    for (int k = t; k < nq; k += nthr) {
+        float z[4];
+        philox_normal4(rng.seed, rng.offset + q0 + (unsigned long long)k, z);
+        *(f32x4*)(sn + 4 * k) = (f32x4){z[0], z[1], z[2], z[3]};
+    }
 }
 
 // Point-mass robots (QD = DIM = 2 or 3).  WPT = waves per trajectory.  The collision part (SDF force per interpolated point
@@ -828,7 +848,8 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void guide_step_panda_kernel(co
     float* sfk = sx + H * D;                  // [N][kPandaFKS]   (not in the DENSE variant)
     float* sG = sfk + (DENSE ? 0 : N * kPandaFKS);   // [MAXF][NP][N][QD]  partial joint gradients
     float* sC = sG + MAXF * NP * N * QD;      // [MAXF][H][QD]      clipped, weighted per-field support-point gradients
-    float* sprim = sC + MAXF * H * QD;
+    float* snz = sC + ((MAXF * H * QD + (int)((sC - sm) & 3) + 3) & ~3) - (int)((sC - sm) & 3);   // 16-byte aligned: [H * D + 4] the step's noise of this
+    float* sprim = snz + H * D + 4;           //                    trajectory (last guide iteration of a step, rng.on)
     for (int i = threadIdx.x; i < gp.n_prim_floats; i += 64 * WPT) sprim[i] = gp.prims[i];
 
     // ---- load + unnormalise (normalization.py:156-167): the support wave(s) only; the state is NOT kept in registers across the force
@@ -909,6 +930,10 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void guide_step_panda_kernel(co
         for (int d = 0; d < D; ++d) xn[d] = live ? a.x[base + d] : 0.f;   // same floats as the prologue read (nothing has written x since)
     }
 
+    // the step's noise (last guide iteration, drawn in place): by the waves that do not gather, under the gather
+    const unsigned long long ne0 = a.rng.elem0 + (unsigned long long)b * H * D;
+    if (a.rng.on && !a.grad_out && wv >= MAXF) guide_draw_noise(a.rng, ne0, H * D, snz, threadIdx.x - 64 * MAXF, 64 * (WPT - MAXF));
+
     // ---- phase 3: wave f gathers field f to the support points (one or two blocks of 64), clips, weights
     if (wv < gp.n_fields) {
         const int f = wv;
@@ -979,7 +1004,8 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void guide_step_panda_kernel(co
             for (int j = 0; j < QD; ++j) total[j] += sC[(f * H + hs_) * QD + j];
         }
     }
-    guide_gp_apply<QD>(a, b, ctx, lane, hs_, H, live, xn, xu, sx, total, base, (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) ? a.trace + wv * 16 + 6 : nullptr);
+    guide_gp_apply<QD>(a, b, ctx, lane, hs_, H, live, xn, xu, sx, total, base, (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) ? a.trace + wv * 16 + 6 : nullptr,
+                       snz + (int)(ne0 & 3ull));
 #undef G_STAMP
 }
 
@@ -987,7 +1013,7 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void guide_step_panda_kernel(co
 inline size_t guide_lds_bytes(const mpdx_guide_params& gp, int H, int D, bool dense = false) {
     const int N = gp.interpolate ? gp.n_interp : H;
     if (gp.robot == MPDX_ROBOT_PANDA)
-        return (size_t)(H * D + (dense ? 0 : N * kPandaFKS) + MPDX_MAX_FIELDS * kPandaParts * N * 7 + MPDX_MAX_FIELDS * H * 7 + gp.n_prim_floats) * sizeof(float);
+        return (size_t)(H * D + (dense ? 0 : N * kPandaFKS) + MPDX_MAX_FIELDS * kPandaParts * N * 7 + MPDX_MAX_FIELDS * H * 7 + (H * D + 4 + 3) + gp.n_prim_floats) * sizeof(float);
     return (size_t)(H * D + 2 * MPDX_MAX_FIELDS * N * (D / 2) + gp.n_prim_floats) * sizeof(float);
 }
 

@@ -115,9 +115,11 @@ __device__ __forceinline__ void weighted_loss_wave_block(const float* pred, cons
     if (tid >= 64u) return;
     acc = weighted_loss_wave_sum(acc);
     if (tid == 0) {
+        // last-ticket reduction in the memory model's own terms (MI355X_MICROARCH.md, inter-workgroup visibility): the partial sum is
+        // published by the RELEASE half of the ticket's acq_rel read-modify-write, the last arriver's ACQUIRE half makes the other 15
+        // visible to its loads (round 4 leaned on relaxed atomics + an inline vmcnt(0): right on gfx950 as compiled, not by contract)
         __hip_atomic_store(gpart + w, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (atomicAdd(ticket, 1u) == 15u) {
+        if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 15u) {
             double tot = 0.0;
             for (int k = 0; k < 16; ++k) tot += __hip_atomic_load(gpart + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out[0] = (float)(tot / (double)((size_t)B * H * D));

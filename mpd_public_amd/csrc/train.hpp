@@ -623,7 +623,10 @@ __global__ __launch_bounds__(512) void time_train_fwd_kernel(const TimeTrainArgs
         const int HD = a.H * a.D, nq = HD >> 2;
         for (int q4 = tid; q4 < nq; q4 += 512) {
             float z[4];
-            philox_normal4(a.rng_seed, rng_pos * (unsigned long long)nq + (unsigned)q4, z);
+            // key domain-separated from mpdx_randn / fill_randn (seed, offset + q) and from the planning loop's in-kernel draws, which use the
+            // model's seed as is: the eager steps between replays (summary / warm-up steps) advance THAT stream's offset and must not meet
+            // noise a replayed step already used (the timestep stream above has its own key for the same reason)
+            philox_normal4(a.rng_seed ^ 0x747261696E6E6F69ull, rng_pos * (unsigned long long)nq + (unsigned)q4, z);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = 4 * q4 + e, l = i / a.D, d = i - l * a.D;

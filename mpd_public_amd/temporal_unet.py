@@ -109,6 +109,10 @@ class TemporalUnet(nn.Module):
         self._ws = None
         self._ws_B = 0
         self._stamp = None
+        # the native model is created HERE (host-side only: no GPU needed), so that a configuration libmpdx cannot run - a GroupNorm
+        # group of 2 or 64 channels, a width that is not a multiple of 16, a horizon the strided convolutions do not map back onto
+        # itself - is refused at construction with the layer named, not at the first forward
+        self._handle()
 
     # ------------------------------------------------------------------------------------------- engine plumbing
     _DEVICE_STATE = {"_h": None, "_packed": None, "_timetab": None, "_timetab_T": 0, "_ws": None, "_ws_B": 0, "_stamp": None}

@@ -87,6 +87,18 @@ class FlatParams:
             self.slices[name] = (off.value, cnt.value)
             self.order.append(name)
         self.packedT = torch.zeros(int(lib.mpdx_train_dgrad_pack_floats(h)), dtype=torch.float32, device=dev)
+        self._pending = None   # weakref to the _GradHolder of the autograd loss whose gradient currently sits in self.grad (snapshot_pending)
+
+    def snapshot_pending(self):
+        """The flat gradient buffer is shared by EVERY native pass on this U-Net (any TrainStep: trainer.train()'s own and the one behind
+        model.loss()).  An autograd loss (_PLossesFn) normally reads it in place in its backward(); only when another pass is about
+        to overwrite it first (summed losses, gradient accumulation, a second model.loss() before backward(), a TrainStep.step()) is
+        that loss's gradient copied out - lazily, here, by whoever is about to overwrite the buffer.  Never called inside a graph capture."""
+        ref = self._pending
+        holder = ref() if ref is not None else None
+        if holder is not None and holder.flat is None:
+            holder.flat = self.grad.clone()
+        self._pending = None
 
     def aliased(self, full: bool = False) -> bool:
         """Do the module's parameters still live in the flat vector?  (`.to()` / `.cuda()` / re-creating parameters breaks the
@@ -184,11 +196,13 @@ class TrainStep:
         if self._ws is None or self._ws_B < B:
             self._ws = torch.empty(int(lib.mpdx_train_workspace_floats(h, B)), dtype=torch.float32, device=dev)
             self._ws_B = B
-            # graphs captured by step() hold the OLD workspace's address: drop them (they are re-captured after their next two eager calls)
-            self.__dict__.pop("_graphs", None)
-            self.__dict__.pop("_graph_warm", None)
+            # graphs captured by step() hold the OLD workspace's address: drop them (they are re-captured after their next eager calls);
+            # with no graph captured yet there is nothing to invalidate, and the warm-up count of the running sequence stands
+            if self.__dict__.pop("_graphs", None):
+                self.__dict__.pop("_graph_state", None)
         self.pack(sync_engine=False)
-        self._snapshot_pending()   # an autograd loss whose backward() has not run yet still needs the gradients about to be overwritten
+        if not torch.cuda.is_current_stream_capturing():   # (a capture must not record the copy; step() snapshots before it captures / replays)
+            self.fp.snapshot_pending()   # an autograd loss whose backward() has not run yet still needs the gradients about to be overwritten
         _lib.check(lib.mpdx_train_loss_backward(
             h, self.fp.flat.data_ptr(), self._packed().data_ptr(), self.fp.packedT.data_ptr(), self.fp.grad.data_ptr(), x_start.data_ptr(),
             noise.data_ptr(), t.data_ptr(), m.sqrt_alphas_cumprod.data_ptr(), m.sqrt_one_minus_alphas_cumprod.data_ptr(),
@@ -198,16 +212,6 @@ class TrainStep:
         if bind_grads and not self.fp.grads_bound():   # the docstring's promise: the gradients ARE in p.grad after this call
             self.fp.bind_grads()
         return (self.loss_buf[0] if _static_loss else self.loss_buf[0].clone()), {}   # (_static_loss: the graph's own output tensor, TrainStep.step)
-
-    def _snapshot_pending(self):
-        """The flat gradient buffer is shared by every native pass.  An autograd loss (_PLossesFn) normally reads it in place in its
-        backward(); only when ANOTHER pass is about to overwrite it first (summed losses, gradient accumulation: a second
-        model.loss() before backward()) is that loss's gradient copied out - lazily, here."""
-        ref = getattr(self, "_pending", None)
-        holder = ref() if ref is not None else None
-        if holder is not None and holder.flat is None:
-            holder.flat = self.fp.grad.clone()
-        self._pending = None
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, max_norm=None):
         """clip_grad_norm_(max_norm) if given, then one torch.optim.Adam step (defaults as trainer.py:140); returns the
@@ -222,42 +226,69 @@ class TrainStep:
         return self.scratch[0] if mn > 0 else None
 
     # ------------------------------------------------------------------------------------------------ one iteration as a hipGraph
+    _MAX_GRAPHS = 4   # captured iterations kept (least recently used beyond that are dropped: each owns a private memory pool)
+
     def step(self, x_start, hard_conds=None, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=None, t=None, noise=None, use_graph=None):
         """One training iteration of trainer.py:186-283 - p_losses + backward (loss_backward) and clip + Adam (adam_step) - returning the loss.
 
-        From the third call with the same shapes and hyper-parameters on, the iteration is REPLAYED AS ONE hipGraph (torch.cuda.CUDAGraph over the
-        same native launches): at the reference's batch of 32 the ~85 launches of an iteration take the host as long to enqueue (0.70-0.80 ms,
-        box dependent) as the GPU to run (0.71 ms), and a slower host is then what a step costs; the replay is one host call.  What a captured
-        graph freezes is kept out of its kernel arguments: the batch and the hard conditions are copied into static buffers, t and the noise
-        are drawn ON THE DEVICE by the pass's first launch (mpdx_train_draw: Philox keyed by the model's seed and the device-resident step count -
-        what diffusion_model_base.py:356 / :337 draw with torch.randint / torch.randn_like; pass `t` / `noise` to supply them instead), and Adam's
-        step count lives on the device (mpdx_adam_step with step < 0).
-        `use_graph=False` (or MPDX_TRAIN_GRAPH=0) runs the two eager calls; by default batches of more than 64 trajectories do (GPU-bound)."""
+        The iteration can be REPLAYED AS ONE hipGraph (torch.cuda.CUDAGraph over the same native launches): at the reference's batch of 32 the
+        ~85 launches of an iteration take the host as long to enqueue as the GPU to run, and a slower host is then what a step costs; the
+        replay is one host call.  Whether that pays depends on the box (round 4: batch 128 x D = 14 ran 0.955 ms eager on one host and 1.064
+        ms on the driver's), so by default it is MEASURED per (shapes, hyper-parameters): calls 1-3 run eager (2 and 3 timed), call 4
+        captures, calls 5-6 time the replay, and the faster form is kept (`launch_mode()` says which).  use_graph=True / False (or
+        MPDX_TRAIN_GRAPH=1 / 0) force either.  What a captured graph freezes is kept out of its kernel arguments: the batch and the hard
+        conditions are copied into static buffers, t and the noise are drawn ON THE DEVICE by the pass's first launch (mpdx_train_draw:
+        Philox keyed by the model's seed and the device-resident step count - what diffusion_model_base.py:356 / :337 draw with
+        torch.randint / torch.randn_like; pass `t` / `noise` to supply them instead), and Adam's step count lives on the device
+        (mpdx_adam_step with step < 0).  A new learning rate is a new graph (at most _MAX_GRAPHS are kept).
+        In graph mode the returned 0-dim tensor is the graph's own output buffer: the next replay overwrites it - read it (float(loss))
+        or clone it before the next call if you keep it (the eager form returns a fresh tensor)."""
         import os
-        if use_graph is None:   # default: replay where the HOST is the bound - small batches (measured: batch 32 0.77 -> 0.73 ms, batch 128 x D=14 1.255 -> 1.274 ms:
-            # there the GPU is the bound and the replay only adds the copies into the static buffers); MPDX_TRAIN_GRAPH=1 / 0 forces either
-            env = os.environ.get("MPDX_TRAIN_GRAPH")
-            use_graph = (env != "0") if env is not None else x_start.shape[0] <= 64
+        import time
+        env = os.environ.get("MPDX_TRAIN_GRAPH")
+        if use_graph is None and env is not None:
+            use_graph = env != "0"
         hard_conds = hard_conds or {}
         mn = float(max_norm) if max_norm else 0.0
         key = (tuple(x_start.shape), tuple(sorted((int(k), tuple(v.shape)) for k, v in hard_conds.items())), float(lr), tuple(betas), float(eps), mn,
                t is not None, noise is not None)
         graphs = self.__dict__.setdefault("_graphs", {})
-        g = graphs.get(key) if use_graph else None
+        state = self.__dict__.setdefault("_graph_state", {})
+        s = state.setdefault(key, {"calls": 0, "eager_ms": [], "graph_ms": [], "mode": None})   # mode: None undecided, "graph", "eager"
+        if use_graph is not None:
+            s["mode"] = "graph" if use_graph else "eager"
+        g = graphs.get(key) if s["mode"] != "eager" else None
         if g is not None and g["ptrs"] != self._static_ptrs():
             # a buffer the graph reads or writes has moved since the capture (e.g. the TemporalUnet's inference engine re-created its weight pack after
-            # a summary / validation pass): the graph is stale - drop it; it is re-captured after two eager steps
+            # a summary / validation pass): the graph is stale - drop it; it is re-captured after the next eager steps
             del graphs[key]
-            self.__dict__.setdefault("_graph_warm", {})[key] = 0
-            g = None
+            s["calls"], g = 0, None
+        s["calls"] += 1
+        timed = None
         if g is None:
-            warm = self.__dict__.setdefault("_graph_warm", {})
-            warm[key] = warm.get(key, 0) + 1
-            if not use_graph or warm[key] < 3:   # eager (also the warm-up of everything a capture must not do: allocations, one-off attribute calls)
+            if s["mode"] == "eager" or s["calls"] < (4 if s["mode"] is None else 3):   # eager (also the warm-up of everything a capture must not do:
+                # allocations, one-off attribute calls); a forced graph is captured on the third call, a measured one on the fourth
+                measure = s["mode"] is None and s["calls"] in (2, 3)
+                if measure:
+                    torch.cuda.synchronize()
+                    timed = time.perf_counter()
                 loss, _ = self.loss_backward(x_start, hard_conds, t=t, noise=noise)
                 self.adam_step(lr, betas, eps, max_norm)
+                if measure:
+                    torch.cuda.synchronize()
+                    s["eager_ms"].append((time.perf_counter() - timed) * 1e3)
                 return loss
+            self.fp.snapshot_pending()   # (outside the capture)
             g = graphs[key] = self._capture(x_start, hard_conds, lr, betas, eps, mn, t, noise)
+            while len(graphs) > self._MAX_GRAPHS:
+                graphs.pop(next(iter(graphs)))
+        else:
+            graphs[key] = graphs.pop(key)   # most recently used last
+        measure = s["mode"] is None and len(s["graph_ms"]) < 2 and s["calls"] > 4
+        if measure:
+            torch.cuda.synchronize()
+            timed = time.perf_counter()
+        self.fp.snapshot_pending()   # the replay overwrites the flat gradient: a pending autograd loss keeps its own copy
         dsts, srcs = [g["x"]] + [g["hc"][k] for k in hard_conds], [x_start] + [hard_conds[k] for k in hard_conds]
         if noise is not None:
             dsts.append(g["noise"]); srcs.append(noise)
@@ -279,7 +310,21 @@ class TrainStep:
         self.unet._timetab, self.unet._timetab_T = None, 0
         if not self.fp.grads_bound():
             self.fp.bind_grads()
+        if measure:
+            torch.cuda.synchronize()
+            s["graph_ms"].append((time.perf_counter() - timed) * 1e3)
+            if len(s["graph_ms"]) == 2:   # both forms measured on THIS host and GPU: keep the faster (ties go to the graph: one host call per step)
+                s["mode"] = "graph" if min(s["graph_ms"]) <= 1.02 * min(s["eager_ms"] or [float("inf")]) else "eager"
+                if s["mode"] == "eager":
+                    loss = g["loss"].clone()
+                    del graphs[key]
+                    return loss
         return g["loss"]
+
+    def launch_mode(self):
+        """how step() runs each (shapes, hyper-parameters) it has seen: {'mode': 'graph' | 'eager' | None (still measuring), 'eager_ms', 'graph_ms'}"""
+        return [{"batch": k[0][0], "mode": v["mode"], "eager_ms": [round(x, 3) for x in v["eager_ms"]], "graph_ms": [round(x, 3) for x in v["graph_ms"]]}
+                for k, v in self.__dict__.get("_graph_state", {}).items()]
 
     def _static_ptrs(self):
         """addresses of every persistent buffer a captured iteration touches"""
@@ -330,9 +375,9 @@ class _PLossesFn(torch.autograd.Function):
         ctx.step = step
         ctx.n_params = len(params)
         # THIS call's gradients sit in the shared flat buffer; they are copied out only if another native pass runs before this
-        # loss's backward() (TrainStep._snapshot_pending) - the common single-loss iteration makes no parameter-sized copy
+        # loss's backward() (FlatParams.snapshot_pending) - the common single-loss iteration makes no parameter-sized copy
         ctx.holder = _GradHolder()
-        step._pending = weakref.ref(ctx.holder)
+        step.fp._pending = weakref.ref(ctx.holder)
         return loss
 
     @staticmethod
@@ -349,7 +394,7 @@ class _PLossesFn(torch.autograd.Function):
 
 
 class _GradHolder:
-    """weakly referenced by TrainStep._pending: `flat` is filled only when the shared gradient buffer is about to be overwritten"""
+    """weakly referenced by FlatParams._pending: `flat` is filled only when the shared gradient buffer is about to be overwritten"""
     __slots__ = ("flat", "__weakref__")
 
     def __init__(self):

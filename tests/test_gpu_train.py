@@ -419,8 +419,8 @@ def test_gn_backward_epilogue_matches_the_separate_kernel():
 
 
 def test_graph_replayed_steps_equal_eager_steps():
-    """TrainStep.step replays an iteration (loss + backward + clip + Adam) as ONE hipGraph from the third call on (the first two run eagerly
-    and warm everything a capture must not do).  With t and the noise supplied, six steps through step() leave the parameters, both Adam
+    """TrainStep.step(use_graph=True) replays an iteration (loss + backward + clip + Adam) as ONE hipGraph from the third call on (the first two
+    run eagerly and warm everything a capture must not do).  With t and the noise supplied, six steps through step() leave the parameters, both Adam
     moments and the loss of every step where six eager loss_backward + adam_step pairs leave them: the launches are the same; what the
     graph cannot take as (frozen) kernel arguments - Adam's bias corrections - is computed on the device from a device-resident step count
     (double pow, float result, as the host computes it: allowed to differ in the last bit of the correction, 1e-6 relative here)."""
@@ -437,7 +437,7 @@ def test_graph_replayed_steps_equal_eager_steps():
         le, _ = ts_e.loss_backward(xb, hc, t=tt, noise=nz)
         ts_e.adam_step(1e-3, max_norm=1.0)
         losses_e.append(float(le))
-        losses_g.append(float(ts_g.step(xb, hc, 1e-3, max_norm=1.0, t=tt, noise=nz)))
+        losses_g.append(float(ts_g.step(xb, hc, 1e-3, max_norm=1.0, t=tt, noise=nz, use_graph=True)))
     assert "_graphs" in ts_g.__dict__ and len(ts_g._graphs) == 1, "the third step was meant to capture"
     assert ts_g.step_count == ts_e.step_count == 6
     np.testing.assert_allclose(losses_g, losses_e, rtol=1e-6)
@@ -450,7 +450,7 @@ def test_graph_replayed_steps_equal_eager_steps():
     ts_e.loss_backward(x0, hc, t=TTS[0].cuda(), noise=noise); ts_e.adam_step(1e-3, max_norm=1.0)
     ts_g.loss_backward(x0, hc, t=TTS[0].cuda(), noise=noise); ts_g.adam_step(1e-3, max_norm=1.0)
     le, _ = ts_e.loss_backward(x0, hc, t=TTS[1].cuda(), noise=noise); ts_e.adam_step(1e-3, max_norm=1.0)
-    lg = ts_g.step(x0, hc, 1e-3, max_norm=1.0, t=TTS[1].cuda(), noise=noise)
+    lg = ts_g.step(x0, hc, 1e-3, max_norm=1.0, t=TTS[1].cuda(), noise=noise, use_graph=True)
     assert ts_g.step_count == ts_e.step_count == 8
     assert float((ts_g.fp.flat - ts_e.fp.flat).abs().max().cpu()) <= 1e-6 * float(ts_e.fp.flat.abs().max().cpu())
     # a larger batch re-allocates the workspace the captured graph points into: the graphs are dropped and re-captured, results stay those of eager steps
@@ -461,7 +461,7 @@ def test_graph_replayed_steps_equal_eager_steps():
     assert "_graphs" not in ts_g.__dict__, "the workspace moved: the captured graphs had to go"
     for k in range(4):
         ts_e.loss_backward(x0, hc, t=TTS[k % 2].cuda(), noise=noise); ts_e.adam_step(1e-3, max_norm=1.0)
-        ts_g.step(x0, hc, 1e-3, max_norm=1.0, t=TTS[k % 2].cuda(), noise=noise)
+        ts_g.step(x0, hc, 1e-3, max_norm=1.0, t=TTS[k % 2].cuda(), noise=noise, use_graph=True)
     assert len(ts_g._graphs) == 1 and ts_g.step_count == ts_e.step_count
     assert float((ts_g.fp.flat - ts_e.fp.flat).abs().max().cpu()) <= 1e-6 * float(ts_e.fp.flat.abs().max().cpu())
     # the inference engine re-creates the TemporalUnet's weight pack after a training step (a summary pass that plans with the model): the captured
@@ -470,14 +470,14 @@ def test_graph_replayed_steps_equal_eager_steps():
         dm_.model.engine(25, 4)
     for k in range(3):
         ts_e.loss_backward(x0, hc, t=TTS[k % 2].cuda(), noise=noise); ts_e.adam_step(1e-3, max_norm=1.0)
-        ts_g.step(x0, hc, 1e-3, max_norm=1.0, t=TTS[k % 2].cuda(), noise=noise)
+        ts_g.step(x0, hc, 1e-3, max_norm=1.0, t=TTS[k % 2].cuda(), noise=noise, use_graph=True)
     assert float((ts_g.fp.flat - ts_e.fp.flat).abs().max().cpu()) <= 1e-6 * float(ts_e.fp.flat.abs().max().cpu())
     # without t / noise the graph draws them itself (torch's graph-safe generator): the loss differs from replay to replay
     dm_r = _model(4, 1)
     ts_r = TrainStep(dm_r)
     ls, tts, nzs = [], [], []
     for _ in range(8):
-        ls.append(float(ts_r.step(x0, hc, 1e-3, max_norm=1.0)))
+        ls.append(float(ts_r.step(x0, hc, 1e-3, max_norm=1.0, use_graph=True)))
         if getattr(ts_r, "_graphs", None):
             g = next(iter(ts_r._graphs.values()))
             tts.append(g["t"].cpu().clone()); nzs.append(g["noise"].cpu().clone())
@@ -488,6 +488,56 @@ def test_graph_replayed_steps_equal_eager_steps():
     allz = torch.cat([v.flatten() for v in nzs])
     assert abs(float(allz.mean())) < 0.05 and abs(float(allz.std()) - 1.0) < 0.05
     assert len(torch.unique(torch.cat(tts))) >= 10   # 6 samples x >= 5 replays over 25 timesteps
+
+
+def test_step_measures_both_launch_forms_and_keeps_one():
+    """By default TrainStep.step times the eager launches (calls 2-3) and the hipGraph replay (calls 5-6) on the host + GPU it runs on and keeps
+    the faster form (round 4's fixed `batch <= 64` rule was wrong on the driver's host); whichever wins, the parameters are those of eager steps."""
+    from mpd_public_amd.trainer import TrainStep
+    x0, noise, hc = _batch(4)
+    x0, noise, hc = x0.cuda(), noise.cuda(), {k: v.cuda() for k, v in hc.items()}
+    dm_e, dm_a = _model(4, 1), _model(4, 1)
+    ts_e, ts_a = TrainStep(dm_e), TrainStep(dm_a)
+    for k in range(9):
+        tt, nz = TTS[k % 2].cuda(), noise * (1.0 + 0.05 * k)
+        le, _ = ts_e.loss_backward(x0, hc, t=tt, noise=nz)
+        ts_e.adam_step(1e-3, max_norm=1.0)
+        la = ts_a.step(x0, hc, 1e-3, max_norm=1.0, t=tt, noise=nz)
+        assert abs(float(la) - float(le)) <= 1e-6 * abs(float(le)), k
+    (mode,) = ts_a.launch_mode()
+    print(mode)
+    assert mode["mode"] in ("graph", "eager") and len(mode["eager_ms"]) == 2 and len(mode["graph_ms"]) == 2
+    assert (mode["mode"] == "graph") == (len(ts_a._graphs) == 1)
+    assert ts_a.step_count == ts_e.step_count == 9
+    assert float((ts_a.fp.flat - ts_e.fp.flat).abs().max().cpu()) <= 1e-6 * float(ts_e.fp.flat.abs().max().cpu())
+
+
+def test_pending_autograd_loss_survives_another_pass_on_the_same_unet():
+    """The flat gradient buffer belongs to the U-Net, not to a TrainStep: an autograd loss from model.loss() whose backward() has not run yet
+    keeps ITS gradient when another TrainStep (trainer.train()'s own) runs an eager pass or a graph replay on the same U-Net in between
+    (the snapshot was per TrainStep and missed graph replays)."""
+    from mpd_public_amd.trainer import TrainStep, loss_with_grad
+    x0, noise, hc = _batch(4)
+    x0, noise, hc = x0.cuda(), noise.cuda(), {k: v.cuda() for k, v in hc.items()}
+    dm = _model(4, 1)
+
+    def grads_of(pending_then):
+        for p in dm.model.parameters():
+            p.grad = None
+        loss = loss_with_grad(dm, x0, hc, t=TTS[0].cuda(), noise=noise)   # what model.loss() returns with gradients enabled
+        pending_then()
+        loss.backward()
+        return torch.cat([p.grad.flatten().clone() for p in dm.model.parameters()])
+    ref = grads_of(lambda: None)
+    other = TrainStep(dm)   # a second TrainStep on the same U-Net (shares the flat gradient buffer)
+    x1 = x0 * 0.5
+    g_eager = grads_of(lambda: other.loss_backward(x1, hc, t=TTS[1].cuda(), noise=noise * 2.0))
+    assert torch.equal(g_eager, ref)
+    for _ in range(3):   # bring `other` to a captured graph, with lr = 0 so that the weights (and the reference gradient) stay put
+        other.step(x1, hc, 0.0, max_norm=1.0, t=TTS[1].cuda(), noise=noise * 2.0, use_graph=True)
+    assert len(other._graphs) == 1
+    g_replay = grads_of(lambda: other.step(x1, hc, 0.0, max_norm=1.0, t=TTS[1].cuda(), noise=noise * 2.0, use_graph=True))
+    assert torch.equal(g_replay, ref)
 
 
 @pytest.mark.parametrize("H", [32, 128])

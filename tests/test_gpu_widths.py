@@ -1,0 +1,79 @@
+"""Network widths other than the shipped unet_input_dim = 32 (mpd/models/diffusion_models/temporal_unet.py:22-35,80-116 accept any
+unet_input_dim x dim_mults): every configuration mpdx_unet_create ACCEPTS runs and matches the reference / the oracle on both kernel
+paths; every configuration it cannot run is REJECTED at construction with a message that names the layer (no accepted-but-untested
+configuration: VERDICT r4 item 5)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import t, load_npz, kernel_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(D, width, mults):
+    import mpd_public_amd as m
+    from mpd_public_amd import synthetic as syn
+    from oracle.unet import unet_param_shapes
+    sd = syn.synth_state_dict(unet_param_shapes(D, width, mults))
+    net = m.TemporalUnet(n_support_points=64, state_dim=D, unet_input_dim=width, dim_mults=mults)
+    net.load_state_dict(sd, strict=True)
+    return net.cuda().eval(), sd
+
+
+@pytest.mark.parametrize("D", [4, 14])
+@pytest.mark.parametrize("fused", [True, False])
+def test_width64_unet_vs_reference_golden(golden_dir, D, fused):
+    g = load_npz(golden_dir / "unet_widths.npz")
+    net, _ = _net(D, 64, (1, 2, 4))
+    x = t(f"w64_x_D{D}", (3, 64, D)).cuda()
+    with kernel_path(fused):
+        for tt in (0, 12, 24):
+            y = net(x, torch.full((3,), tt, dtype=torch.long, device="cuda"), None).cpu().numpy()
+            np.testing.assert_allclose(y, g[f"w64_D{D}_t{tt}"], rtol=0, atol=2e-5, err_msg=f"D={D} t={tt} fused={fused}")
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_width64_chain_vs_reference_golden(golden_dir, fused):
+    """unguided T = 25 (+3) chain at the cfg1 tolerances (test_gpu_parity.py::test_unguided_chain_cfg1_vs_reference_golden)."""
+    import mpd_public_amd as m
+    g = load_npz(golden_dir / "unet_widths.npz")
+    D, T, B, n0 = 4, 25, 4, 3
+    net, _ = _net(D, 64, (1, 2, 4))
+    dm = m.GaussianDiffusionModel(model=net, variance_schedule="exponential", n_diffusion_steps=T, predict_epsilon=True).cuda().eval()
+    noise = t("w64_noise", (T + n0 + 1, B, 64, D)).cuda()
+    hc = {0: t("w64_hc0", (D,), "uniform").cuda(), 63: t("w64_hc1", (D,), "uniform").cuda()}
+    with kernel_path(fused):
+        chain = dm.run_inference(None, hc, n_samples=B, horizon=64, return_chain=True, sample_fn=m.ddpm_sample_fn,
+                                 n_diffusion_steps_without_noise=n0, noise_std_extra_schedule_fn=lambda tt: 0.5, noise=noise).cpu().numpy()
+    ref = g["w64_chain"]
+    assert chain.shape == ref.shape
+    np.testing.assert_allclose(chain, ref, rtol=0, atol=2e-3)
+    np.testing.assert_allclose(chain[-1], ref[-1], rtol=0, atol=5e-4)
+
+
+@pytest.mark.parametrize("width,mults", [(64, (1, 2)), (32, (1, 2)), (32, (2, 4, 8)), (64, (1, 1, 2))])
+def test_other_accepted_widths_vs_oracle(width, mults):
+    """further accepted channel plans (GroupNorm groups of 4 ... 32 channels), large and ragged batches on both kernel paths vs the oracle"""
+    from oracle.unet import unet_forward
+    D = 4
+    net, sd = _net(D, width, mults)
+    for B in (3, 130):
+        x = t(f"wx_{width}_{B}", (B, 64, D))
+        tv = torch.full((B,), 7, dtype=torch.long)
+        ref = unet_forward(sd, x[:3], tv[:3]).numpy()
+        for fused in (True, False):
+            with kernel_path(fused):
+                y = net(x.cuda(), tv.cuda(), None).cpu().numpy()
+            np.testing.assert_allclose(y[:3], ref, rtol=0, atol=2e-5, err_msg=f"width={width} mults={mults} B={B} fused={fused}")
+
+
+@pytest.mark.parametrize("width,mults", [(16, (1, 2, 4)), (16, (1, 2, 4, 8)), (64, (1, 2, 4, 8)), (48, (1, 2, 4)), (40, (1, 2))])
+def test_unsupported_widths_are_rejected_loudly(width, mults):
+    """GroupNorm groups of 2 (width 16), 64 (width 64 x 8) or 6 channels (width 48), widths that are not multiples of 16: the engine
+    refuses at construction - it never silently runs something else."""
+    import mpd_public_amd as m
+    with pytest.raises(RuntimeError, match="GroupNorm region|unet_input_dim"):
+        net = m.TemporalUnet(n_support_points=64, state_dim=4, unet_input_dim=width, dim_mults=mults)
+        net = net.cuda()
+        net(torch.zeros(1, 64, 4, device="cuda"), torch.zeros(1, dtype=torch.long, device="cuda"), None)

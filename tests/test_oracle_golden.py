@@ -224,3 +224,22 @@ def test_training_step_vs_reference_golden(golden_dir, D, opt):
     k0 = "final_conv.1.bias"
     ema = otrain.ema_update({k0: sd0[k0]}, {k0: params[k0]}, 0.995)[k0]
     np.testing.assert_allclose(ema.numpy(), g[f"D{D}_ema::{k0}"], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("D", [4, 14])
+def test_width64_unet_and_chain_match_reference(golden_dir, D):
+    """A network width other than the shipped 32 (temporal_unet.py:22-35: any unet_input_dim): unet_input_dim = 64, dim_mults (1, 2, 4)
+    against the REAL reference (tests/golden/make_golden.py --only widths)."""
+    from mpd_public_amd import synthetic as syn
+    g = load_npz(golden_dir / "unet_widths.npz")
+    sd = syn.synth_state_dict(unet.unet_param_shapes(D, 64, (1, 2, 4)))
+    x = t(f"w64_x_D{D}", (3, 64, D))
+    for tt in (0, 12, 24):
+        y = unet.unet_forward(sd, x, torch.full((3,), tt, dtype=torch.long)).numpy()
+        np.testing.assert_allclose(y, g[f"w64_D{D}_t{tt}"], rtol=0, atol=2e-6)
+    if D == 4:
+        T, B, n0 = 25, 4, 3
+        noise = t("w64_noise", (T + n0 + 1, B, 64, D))
+        hc = {0: t("w64_hc0", (D,), "uniform"), 63: t("w64_hc1", (D,), "uniform")}
+        chain = diffusion.run_inference(sd, hc, noise, T, n_diffusion_steps_without_noise=n0, noise_std=0.5).numpy()
+        np.testing.assert_allclose(chain, g["w64_chain"], rtol=0, atol=2e-5)

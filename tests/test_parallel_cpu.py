@@ -108,3 +108,67 @@ def test_checksum_is_position_weighted_over_bit_patterns():
     # block-local positions: a block's checksum does not depend on where it sits in the gathered tensor
     cs = block_checksums(y, [2, 1, 3])
     assert [int(v) for v in cs] == [int(shard_checksum(y[0:2])), int(shard_checksum(y[2:3])), int(shard_checksum(y[3:6]))]
+
+
+# ---------------------------------------------------------------------------------------------- bench.py's sharded leg on the CPU rig
+def _rig_worker(rank, world, port, fail_rank, q):
+    """bench.sharded_leg on gloo with a stand-in planner: ONE context per rank (the 8-GPU run's shard arithmetic at its smallest),
+    both gathers, the checksum protocol, the pre-attempt agreement and the record's shape - no GPU, no kernels."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def fake_plan(hs, hg):
+        s = torch.linspace(0, 1, 64).reshape(1, 64, 1)
+        return (hs[:, None, :] * (1 - s) + hg[:, None, :] * s + rank * 1e-3).contiguous()
+    # an asymmetric failure BEFORE the one-hop attempt (one rank's pre-flight check fails): the ranks must skip the attempt TOGETHER
+    pre = (lambda r: "injected: this rank cannot post its sends" if r == fail_rank else None) if fail_rank >= 0 else None
+    rec = bench.sharded_leg(rank, world, dist, "cpu", plans=1, n_ctx=1, n_samples=5, plan_fn=fake_plan, hop_timeout_s=20.0, hop_precheck=pre)
+    q.put((rank, rec))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fail_rank", [(8, -1), (3, 1)])
+def test_bench_sharded_leg_on_the_gloo_rig(world, fail_rank):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rig_worker, args=(r, world, port, fail_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rec = res[0]
+    assert rec["ranks"] == world == rec["process_group_world_size"] and rec["backend"] == "gloo"
+    assert rec["workload"].startswith("cfg5 shard per rank: 1 contexts x 5 = 5") and f"{world} contexts in total" in rec["workload"]
+    assert len(rec["plan_ms_per_rank"]["all"]) == world and rec["all_gather_bytes_per_rank"] == 5 * 64 * 14 * 4
+    assert rec["scaling"] == "weak" and rec["denoising_steps_per_s"] > 0
+    hop = rec["gather_ms"]["one_hop_send_recv"]
+    if fail_rank < 0:
+        assert "error" not in hop and "both variants bit-identical" in rec["gather_verified"]
+    else:   # nobody entered the grouped send / receive (the workers returned at once) and the headline record is intact
+        assert "error" in hop and rec["one_hop_denoising_steps_per_s"] is None
+        assert all("error" in res[r]["gather_ms"]["one_hop_send_recv"] for r in range(world))
+        assert res[0]["gather_ms"]["one_hop_send_recv"]["skipped_by_agreement"] and "injected" in res[fail_rank]["gather_ms"]["one_hop_send_recv"]["error"]
+
+
+def test_bench_watchdog_prints_the_headline_and_exits():
+    """a hung collective in the sharded leg must not cost the bench line: the watchdog prints the record held so far and exits 0"""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; "
+            "bench._Watchdog(0.5, 0, {'metric': 'denoising-steps/s', 'value': 1.0}); time.sleep(30)" % str(root))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    import json
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["value"] == 1.0 and "watchdog" in rec["sharded"]["error"] and rec["cpu_baseline"] is None
