@@ -79,15 +79,17 @@ def _unit_classes(lib, hdl, B, names, flops, n):
             lib.mpdx_unet_layer_tile(hdl, li, B, buf, 64)
             tile = buf.value.decode()
             kind = "conv_k5_gn_mish" if ".block.0." in nm else ("conv_k1" if "residual" in nm else ("down_k3s2" if "downs" in nm else "up_k4s2"))
-            ws = tile.startswith("ws")   # weight-stationary persistent kernel (large batches)
+            ws = tile.split(" ")[0] if tile.startswith("ws") else ""   # weight-stationary persistent kernels (large batches): ws (K split over
+            # the waves, conv_ws.hpp), wsn (whole K per wave) / wsp (a pair of waves per tile) (conv_wsn.hpp)
             # kernel name as rocprofv3 prints it, down to the tile arguments (the PMC traffic files are keyed by full kernel names)
-            mtnt = tile.replace("ws ", "").split("/")[0].split("x")
+            mtnt = tile.split(" ")[-1].split("/")[0].split("x")
             if lib.mpdx_unet_unit_is_pair(hdl, B, i):
-                kn = "conv_ws_kernel<32, 16, true" if ws else f"conv_pair_kernel<{mtnt[0]}, {mtnt[1]}"
+                kn = "conv_wsp_kernel" if ws == "wsp" else "conv_ws_kernel<32, 16, true" if ws else f"conv_pair_kernel<{mtnt[0]}, {mtnt[1]}"
                 out.append((f"conv_k5_gn_mish+conv_k1 pair[{tile}] {flops[i]:.3e} flop", kn))
             else:
                 mode = {"conv_k5_gn_mish": "0, 5, 1", "conv_k1": "0, 1, 0", "down_k3s2": "1, 3, 0", "up_k4s2": "2, 4, 0"}[kind]
-                kn = "conv_ws_kernel<16, 32, false" if ws else f"conv_block_kernel<{mode}, {mtnt[0]}, {mtnt[1]}, "
+                kn = (f"conv_wsn_kernel<{'2' if kind == 'up_k4s2' else '0'}, " if ws == "wsn" else "conv_ws_kernel<16, 32, false" if ws
+                      else f"conv_block_kernel<{mode}, {mtnt[0]}, {mtnt[1]}, ")
                 out.append((f"{kind}[{tile}] {flops[i]:.3e} flop", kn))
         elif nm.startswith("fused"):
             out.append(("fused level programs (fused_program_kernel<...>: whole-trajectory U-Net levels)", "fused_program_kernel"))
@@ -142,6 +144,31 @@ def _pmc_traffic(B, kernel, pattern="r*_pmc_traffic*.json"):
                "measured_on_these_sources": (fp == csrc_fingerprint()) if fp else None}
         return traffic, f.name, age
     return None, None, None
+
+
+def _rocprof_class_us(B, kernel, launches_per_pass):
+    """Per-pass kernel time of a launch class from the newest committed rocprofv3 summary (profiles/r*_kernel_stats.json, written by
+    tools/kernel_stats_json.py from `rocprofv3 --kernel-trace --stats` of this command) that was measured at batch B ON THE KERNEL SOURCES
+    THIS RUN USES (fingerprints equal) - else (None, None).  = launches_per_pass x the call-weighted average duration of the class's kernels."""
+    import re
+
+    def _round_key(f):
+        m = re.match(r"r(\d+)([a-z]?)_", f.name)
+        return (int(m.group(1)), m.group(2) or "~") if m else (-1, "")
+    pats = ("fused_program_kernel", "fused_level_kernel") if kernel.startswith("fused") else (kernel,)
+    for f in sorted((ROOT / "profiles").glob("r*_kernel_stats.json"), key=_round_key, reverse=True):
+        try:
+            rec = json.loads(f.read_text())
+        except Exception:
+            continue
+        if rec.get("batch") != B or rec.get("csrc_fingerprint") != csrc_fingerprint():
+            continue
+        hit = [v for k, v in rec.get("kernels", {}).items() if any(p in k for p in pats)]
+        calls = sum(v["calls"] for v in hit)
+        if not calls:
+            continue
+        return launches_per_pass * sum(v["calls"] * v["avg_ns"] for v in hit) / calls * 1e-3, f.name
+    return None, None
 
 
 def _alg_bytes(c):
@@ -213,7 +240,18 @@ def roofline_leg(dm, B, T, reps=30):
         c["traffic"] = tr
         c["traffic_source"] = src
         c["traffic_over_algorithmic"] = round(tr / c["algorithmic_bytes_per_launch"], 2) if tr and c["algorithmic_bytes_per_launch"] else None
+    # the headline figure comes from the committed rocprofv3 summary when that was measured on these kernel sources (the in-situ
+    # event figure carries the event pair and the gaps inside a run of launches, ~8 % at cfg 2); both are in the record
+    rp_us, rp_file = _rocprof_class_us(B, dom["kernel_pattern"], dom["launches_per_pass"])
+    in_situ = {"achieved": dom["tflops"], "frac": dom["frac"], "avg_launch_us": dom["avg_launch_us"]}
+    if rp_us:
+        dom["tflops"] = round(dom["flop_per_pass"] / (rp_us * 1e-6) / 1e12, 2)
+        dom["frac"] = round(dom["tflops"] / FP32_PEAK_TFLOPS, 4)
+        dom["avg_launch_us"] = round(rp_us / dom["launches_per_pass"], 2)
     roof = {"bound": "mfma", "achieved": dom["tflops"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
+            "duration_source": (f"rocprofv3 --kernel-trace --stats average of the class's kernels, profiles/{rp_file} (measured on these kernel sources)" if rp_us
+                                else "in situ HIP events (no committed rocprofv3 summary of these kernel sources at this batch)"),
+            "in_situ": in_situ,
             "traffic": traffic, "traffic_source": traffic_src, "traffic_age": traffic_age,
             "traffic_over_algorithmic": (round(traffic / _alg_bytes(dom), 2) if traffic and _alg_bytes(dom) else None),
             "kernel": dom["kernel"].split("<")[0], "kernel_instance": dom["kernel"], "class": dom["class"],

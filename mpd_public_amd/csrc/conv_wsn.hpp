@@ -215,4 +215,170 @@ __global__ __launch_bounds__(kWsnThreads) void conv_wsn_kernel(const ConvArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_wsp_kernel - the same idea for the first ResidualTemporalBlock of downs[3] at large batch: Conv1dBlock 128 -> 256 (k5, GroupNorm(8):
+// groups of 32 channels, + time bias) TOGETHER with the block's residual 1x1 convolution 128 -> 256 on the same input
+// (temporal_unet.py:141-150 via layers.py:323-355), which ran as conv_pair_kernel<32, 64, GeoL8<8>> at 59 % of the fp32 MFMA peak.
+//
+// A GroupNorm group is 32 channels = two MFMA row tiles, and one wave's registers hold the weights of ONE of them (40 A fragments of the k5
+// conv + 8 of the 1x1 = 192 VGPRs), so a tile belongs to a PAIR of waves: both read the SAME LDS window (2 trajectories, double-buffered
+// per pair), each computes its 16 channels for the whole K (k5: the 8 K-split chains of the per-layer kernel, two at a time, summed in its
+// order; 1x1: its 8 single-k-group partials in order), both put their halves into the pair's LDS patch, and after ONE workgroup barrier
+// each wave runs the per-layer GroupNorm epilogue for ONE of the two trajectories (region = 32 channels x 8 positions, f32x4 per lane) and
+// stores the residual conv's rows of that trajectory.  Workgroup = 2 pairs = 256 threads at <= 256 VGPRs: TWO workgroups per CU, whose
+// tile phases drift apart - one workgroup's epilogues run under the other's k-loops.  512 workgroups = 8 channel tiles x 64 position
+// groups, b = mt * 64 + p (the channel tiles of a position group share an XCD).  Outputs BIT-IDENTICAL to the per-layer pair.
+constexpr int kWspGroups = 64;
+constexpr int kWspThreads = 256;
+constexpr size_t conv_wsp_lds_bytes() { return ((size_t)2 * (2 * 2 * wsn_lp<CONV_S1>() * wsn_rs<CONV_S1>() + 2 * 16 * 36) + 5 * 32) * sizeof(float); }
+
+__global__ __launch_bounds__(kWspThreads, 2) void conv_wsp_kernel(const ConvArgs a, const ConvArgs a2) {
+    constexpr int NC16 = kWsnC / 16, L = 8, NTAP = 5, PAD = 2, NG = NC16 * NTAP, WK = 8, NIT = NG / WK;
+    constexpr int LP = wsn_lp<CONV_S1>(), RS4 = wsn_rs<CONV_S1>() / 4, WIN4 = 2 * LP * RS4;
+    constexpr int PT4 = 16 * 9;            // float4 per patch: [16 positions][32 + 4 channels]
+    constexpr int C_OUT = 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* const smem4 = (f32x4*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pr = wv >> 1, hf = wv & 1;                                   // pair of the workgroup, channel half / epilogue trajectory of the pair
+    const int mt = blockIdx.x / kWspGroups, p = blockIdx.x % kWspGroups;
+    f32x4* const win = smem4 + pr * 2 * WIN4;                              // the pair's two window buffers
+    f32x4* const patch = smem4 + 2 * 2 * WIN4 + pr * 2 * PT4;              // the pair's patches: k5 tile | 1x1 tile
+    const int n_pairs = (a.B + 1) >> 1;
+    const int t_step = kWspGroups * 2;
+    int t = p * 2 + pr;
+
+    // ---- this wave's weights: its 16-channel half of the group, every k-group of both convolutions
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)a2.wp, 0, 0x7fffffff, 0x00020000);
+    const int m16 = mt * 2 + hf;
+    f32x4 af[NG], af2[NC16];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) af[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, (m16 * NC16 * NTAP + g) * 1024, 0));
+#pragma unroll
+    for (int g = 0; g < NC16; ++g) af2[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs2, lane * 16, (m16 * NC16 + g) * 1024, 0));
+    // ---- halo rows of both window buffers (this wave: trajectory hf of each buffer)
+    for (int idx = lane; idx < 2 * 2 * PAD * (kWsnC / 4); idx += 64) {
+        const int c4 = idx % (kWsnC / 4), hr = idx / (kWsnC / 4);   // hr over [buffer][4 halo rows]
+        const int k = hr % (2 * PAD), buf = hr / (2 * PAD);
+        const int lp = k < PAD ? k : L + k;
+        win[buf * WIN4 + (hf * LP + lp) * RS4 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // window of a tile: this wave fetches trajectory hf (8 rows x 128 channels = 1024 contiguous floats: float4 u * 64 + lane = row 2 u + (lane >> 5))
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src1, 0, 0x7fffffff, 0x00020000);
+    constexpr int SB = L * (kWsnC / 4) / 64;   // 4 loads per lane
+    const int wbase = (hf * LP + (lane >> 5) + PAD) * RS4 + (lane & 31);
+    f32x4 wreg[SB];
+    const int last_b = a.B - 1;
+    auto window_load = [&](int tile) {
+        const int b = tile * 2 + hf <= last_b ? tile * 2 + hf : last_b;
+#pragma unroll
+        for (int u = 0; u < SB; ++u) wreg[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, lane * 16 + u * 1024, b * (L * kWsnC * 4), 0));
+    };
+    auto window_write = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < SB; ++u) win[buf * WIN4 + wbase + 2 * u * RS4] = wreg[u];
+    };
+    const int j = lane & 15, q = lane >> 4;
+    const int boff = ((j >> 3) * LP + (j & 7)) * RS4 + q;
+    // ---- epilogue constants: region = 32 channels x 8 positions over 64 lanes: lane -> position lane >> 3, channels (lane & 7) * 4 .. + 3
+    const int el = lane >> 3, ec = (lane & 7) * 4, co = mt * 32 + ec;
+    // bias | gamma | beta | time-bias row (ONE per launch: the launcher checks tb_stride == 0) | 1x1 bias of the group's 32 channels: staged in
+    // LDS once and read per tile (20 VGPRs the k-loop needs: the kernel sits at the 256-register limit of two workgroups per CU)
+    float* const prm = smem + (2 * 2 * WIN4 + 2 * 2 * PT4) * 4;
+    if (tid < 160) {
+        const int row = tid >> 5, c = mt * 32 + (tid & 31);
+        prm[tid] = (row == 0 ? a.bias : row == 1 ? a.gamma : row == 2 ? a.beta : row == 3 ? a.tbias : a2.bias)[c];
+    }
+
+    if (t < n_pairs) { window_load(t); window_write(0); }
+    __syncthreads();
+    // (the trip count is that of pair 0 - the two pairs of a workgroup meet at the barriers, and the last tile may exist for pair 0 only)
+    for (int i = 0; t - pr < n_pairs; t += t_step, ++i) {
+        const int cur = i & 1;
+        const bool active = t < n_pairs, more = t + t_step < n_pairs;
+        if (more) window_load(t + t_step);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4* const w = win + cur * WIN4;
+        if (active) {
+        // ------------------------------------------------------------------ k5: chains wk = 0 .. 7 (k-groups wk, wk + 8, ...), two at a time
+        f32x4 v;
+        {
+            auto bload = [&](int c0, int it, f32x4 (&bf)[2]) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int g = c0 + c + it * WK, c16 = g / NTAP, ts = g - c16 * NTAP;
+                    bf[c] = w[boff + ts * RS4 + c16 * 4];
+                }
+            };
+            f32x4 bfr[2][2];
+            bload(0, 0, bfr[0]);
+#pragma unroll
+            for (int c0 = 0; c0 < WK; c0 += 2) {
+                f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int step = (c0 / 2) * NIT + it;
+                    if (it + 1 < NIT) bload(c0, it + 1, bfr[(step + 1) & 1]);
+                    else if (c0 + 2 < WK) bload(c0 + 2, 0, bfr[(step + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c0 + c + it * WK][e], bfr[step & 1][c][e], acc[c], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (c0 == 0) v = acc[0]; else v += acc[0];
+                v += acc[1];
+            }
+        }
+        patch[j * 9 + hf * 4 + q] = v;                     // this half's rows of the k5 tile
+        // ------------------------------------------------------------------ 1x1: its 8 single-k-group partials (centre row of the same window), in order
+        {
+            f32x4 v2;
+#pragma unroll
+            for (int g0 = 0; g0 < NC16; g0 += 2) {
+                f32x4 bf[2], acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) bf[c] = w[boff + PAD * RS4 + (g0 + c) * 4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af2[g0 + c][e], bf[c][e], acc[c], 0, 0, 0);
+                if (g0 == 0) v2 = acc[0]; else v2 += acc[0];
+                v2 += acc[1];
+            }
+            patch[PT4 + j * 9 + hf * 4 + q] = v2;
+        }
+        }
+        if (more) window_write(cur ^ 1);                   // (that buffer was last read before the previous tile's barrier)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // ------------------------------------------------------------------ epilogues of trajectory hf of the pair's tile (the per-layer kernels' code)
+        if (active) {
+            const int b = t * 2 + hf;
+            const f32x4 bi = *(const f32x4*)(prm + ec), ga = *(const f32x4*)(prm + 32 + ec), be = *(const f32x4*)(prm + 64 + ec);
+            const f32x4 tb = *(const f32x4*)(prm + 96 + ec), bi2 = *(const f32x4*)(prm + 128 + ec);
+            f32x4 x = patch[(hf * L + el) * 9 + (lane & 7)];
+            x += bi;
+            const float mean = wave_sum((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / 256.0f);
+            const f32x4 d = x - mean;
+            const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 256.0f);
+            const float rstd = gn_rstd(var);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = mish_nosel(d[e] * rstd * ga[e] + be[e]);
+            y += tb;
+            f32x4 r2 = patch[PT4 + (hf * L + el) * 9 + (lane & 7)];
+            r2 += bi2;
+            if (b <= last_b) {
+                *(f32x4*)(a.dst + ((size_t)b * L + el) * C_OUT + co) = y;
+                *(f32x4*)(a2.dst + ((size_t)b * L + el) * C_OUT + co) = r2;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the patches are free for the next tile
+    }
+}
+
 }  // namespace mpdx

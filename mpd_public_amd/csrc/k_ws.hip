@@ -41,8 +41,19 @@ static int launch_wsn_t(const Layer& l, ConvArgs& a, int B, hipStream_t st) {
     return 0;
 }
 
+// downs[3]'s first block at large batch: Conv1dBlock 128 -> 256 + the residual 1x1 conv on the same input, one launch (conv_wsp_kernel)
+static int launch_wsp(const Layer& l, ConvArgs& a, const ConvArgs& a2, int B, hipStream_t st) {
+    if (l.L_in != 8 || l.L_out != 8 || l.c1 != kWsnC || l.c2 != 0 || l.cin_pad != kWsnC || l.cout != 256 || l.gs != 32 || a2.C_out != 256 || a2.L_out != 8 ||
+        !a.tbias || a.tb_stride || a.res || a.pre || a2.pre || a2.accum || a2.dst2 || a2.c_split || (a.Lv_out > 0 && a.Lv_out < 8) || (long)B * 8 * kWsnC * 4 > 0x7fffffffL)
+        return fail(MPDX_E_STATE, "layer %s does not have the geometry conv_wsp_kernel is compiled for", l.name.c_str());
+    if (int rc = raise_lds_limit((const void*)conv_wsp_kernel)) return rc;
+    hipLaunchKernelGGL(conv_wsp_kernel, dim3(8 * kWspGroups), dim3(kWspThreads), conv_wsp_lds_bytes(), st, a, a2);
+    return 0;
+}
+
 int launch_weight_stationary(int variant, const Layer& l, ConvArgs& a, const ConvArgs& a2, int B, hipStream_t st) {
     switch (variant) {
+        case 6: return launch_wsp(l, a, a2, B, st);
         case 4:
             if (a.tbias && a.res) return fail(MPDX_E_STATE, "layer %s: time bias AND residual on one weight-stationary launch", l.name.c_str());
             if (a.tbias) return launch_wsn_t<CONV_S1, 1>(l, a, B, st);

@@ -917,6 +917,8 @@ static int weight_stationary_variant(const Layer& l, const Layer* l2, const Conv
     if (l2) {
         if (!(l2->mode == CONV_S1 && l2->ks == 1 && l2->epi == EPI_BIAS && l2->cout == l.cout && l2->L_out == 8 && l2->c1 == l.c1 && l2->c2 == l.c2)) return 0;
         if (l.cout == 128 && l.gs == 16 && l.cin_pad == 512) return 3;
+        if (l.cout == 256 && l.gs == 32 && l.cin_pad == 128 && l.c2 == 0 && wsn_on && !a.res && !(getenv("MPDX_WSP") && atoi(getenv("MPDX_WSP")) == 0))
+            return 6;   // conv_wsp_kernel: 128 -> 256 k5 + 1x1, a pair of waves per tile, whole K per wave (round 5)
         return 0;
     }
     if (l.cout == 256 && l.gs == 32 && l.cin_pad == 256) return 1;
@@ -1186,6 +1188,11 @@ int mpdx_unet_create(const mpdx_unet_cfg* cfg, mpdx_unet** out) {
     if (cfg->state_dim < 1 || cfg->state_dim > 64) return fail(MPDX_E_INVALID, "state_dim %d unsupported", cfg->state_dim);
     if (cfg->time_emb_dim != 32) return fail(MPDX_E_INVALID, "time_emb_dim must be 32 (TimeEncoder(32, .), temporal_unet.py:66)");
     if (cfg->unet_input_dim % 16) return fail(MPDX_E_INVALID, "unet_input_dim must be a multiple of 16");
+    // final_conv is Conv1dBlock(unet_input_dim, unet_input_dim) on the output of the last up level, which has unet_input_dim * dim_mults[0]
+    // channels (temporal_unet.py:98-116): the reference's own forward fails for dim_mults[0] != 1
+    if (cfg->dim_mults[0] != 1) return fail(MPDX_E_INVALID, "dim_mults[0] must be 1: final_conv takes unet_input_dim channels (temporal_unet.py:113-116)");
+    for (int i = 0; i < cfg->n_levels; ++i)
+        if (cfg->dim_mults[i] < 1) return fail(MPDX_E_INVALID, "dim_mults[%d] = %d", i, cfg->dim_mults[i]);
     const int H = cfg->n_support_points;
     // the reference's U-Net takes every horizon its stride-2 / transposed convolutions map back onto itself: H % 2^(levels - 1) == 0
     // (temporal_unet.py:24,80-103).  Powers of two run natively; the others (24, 40, 48, 96 ...) in the next power-of-two container
@@ -1711,7 +1718,8 @@ int mpdx_unet_layer_tile(const mpdx_unet* u, int i, int B, char* buf, size_t buf
     memset(&dummy, 0, sizeof(dummy));
     const Layer* l2 = (i + 1 < (int)u->layers.size() && pair_tile(l, u->layers[i + 1], B, MT, NT)) ? &u->layers[i + 1] : nullptr;
     if (const int v = weight_stationary_variant(l, l2, dummy, B, 0)) {   // "ws": the weight-stationary persistent kernel (conv_ws.hpp)
-        if (v >= 4) snprintf(buf, buflen, "wsn 16x16/8x1");   // conv_wsn_kernel: 8 waves = 8 position tiles, whole K per wave
+        if (v == 6) snprintf(buf, buflen, "wsp 32x16/2x1+1x1");   // conv_wsp_kernel: a pair of waves per tile, whole K per wave
+        else if (v >= 4) snprintf(buf, buflen, "wsn 16x16/8x1");   // conv_wsn_kernel: 8 waves = 8 position tiles, whole K per wave
         else snprintf(buf, buflen, "ws %dx16/1x8%s", v == 1 ? 32 : 16, v == 3 ? "+1x1" : "");
         return 0;
     }

@@ -95,79 +95,86 @@ __device__ __forceinline__ void gn_point(const mpdx_guide_params& gp, const floa
         for (int s = 0; s < kPandaNS; ++s)
 #pragma unroll
             for (int r = 0; r < 3; ++r) P[s][r] = O[kPandaSF[s] - 1][r] + kPandaSO[s] * Z[kPandaSF[s] - 1][r];
-        // d c / d theta_k = f . (z_k x (P - O_k)) for joints k <= frame of the sphere
-        auto jac_row = [&](const float (&f3)[3], int s, float sign, float (&jr)[QD]) {
+        // The factors of ONE link sphere s share its position Jacobian J_s (3 x 7, column k = z_k x (P_s - O_k) for joints k <= frame(s)):
+        // a factor with value c and gradient f (w.r.t. the sphere centre) has the Jacobian row f^T J_s, so the sphere's contribution is
+        //     M += J_s^T (sum_i f_i f_i^T) J_s,      v += J_s^T (sum_i c_i f_i),      c2 += sum_i c_i^2
+        // - the 3 x 3 / 3-vector sums over the sphere's factors (objects fields, six workspace faces) are a few FMAs per factor, and the
+        // 7 x 7 congruence is done ONCE per sphere, branch-free.  Round 4 ran a 35-FMA rank-1 update of M per ACTIVE factor at ~48 inlined call
+        // sites behind divergent branches: 5.7 k VALU instructions, 256 + 256 registers and 1.26 KB of scratch per lane for this kernel.
+        auto sphere_jac = [&](int s, float (&J)[3][QD]) {
             const int fr = kPandaSF[s] - 1;
 #pragma unroll
             for (int k = 0; k < 7; ++k) {
                 if (k <= fr) {
                     const float rx = P[s][0] - O[k][0], ry = P[s][1] - O[k][1], rz = P[s][2] - O[k][2];
-                    const float cx = Z[k][1] * rz - Z[k][2] * ry, cy = Z[k][2] * rx - Z[k][0] * rz, cz = Z[k][0] * ry - Z[k][1] * rx;
-                    jr[k] += sign * (f3[0] * cx + f3[1] * cy + f3[2] * cz);
-                }
+                    J[0][k] = Z[k][1] * rz - Z[k][2] * ry; J[1][k] = Z[k][2] * rx - Z[k][0] * rz; J[2][k] = Z[k][0] * ry - Z[k][1] * rx;
+                } else { J[0][k] = J[1][k] = J[2][k] = 0.f; }
             }
         };
         constexpr int s_beg = half ? 6 : 0, s_end = half ? kPandaNS : 6;     // static sphere / pair ranges: P[s], kPandaSF[s] are compile-time
         constexpr int p_beg = half ? 6 : 0, p_end = half ? kPandaNP : 6;
-        for (int f = 0; f < gp.n_fields; ++f) {
-            const int kind = gp.fields[f].kind;
-            if (kind == MPDX_FIELD_OBJECTS) {
 #pragma unroll
-                for (int s = s_beg; s < s_end; ++s) {
-                    const float p3[3] = {P[s][0], P[s][1], P[s][2]};
+        for (int s = s_beg; s < s_end; ++s) {
+            const int fr = kPandaSF[s] - 1;
+            const float p3[3] = {P[s][0], P[s][1], P[s][2]};
+            const float margin = kPandaSR[s] + gp.cutoff_margin;
+            float A[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, g[3] = {0.f, 0.f, 0.f};   // A: xx xy yy xz yz zz of sum f f^T; g = sum c f
+            for (int f = 0; f < gp.n_fields; ++f) {
+                const int kind = gp.fields[f].kind;
+                if (kind == MPDX_FIELD_OBJECTS) {
                     float fo[3];
-                    const float c = objects_force<3>(sprim, gp.fields[f], p3, kPandaSR[s] + gp.cutoff_margin, fo);
-                    if (c > 0.f) {
-                        float jr[QD];
+                    const float c = objects_force<3>(sprim, gp.fields[f], p3, margin, fo);   // (c == 0: fo == 0 - nothing is added)
+                    A[0] += fo[0] * fo[0]; A[1] += fo[0] * fo[1]; A[2] += fo[1] * fo[1]; A[3] += fo[0] * fo[2]; A[4] += fo[1] * fo[2]; A[5] += fo[2] * fo[2];
+                    g[0] += c * fo[0]; g[1] += c * fo[1]; g[2] += c * fo[2];
+                    c2 += c * c;
+                } else if (kind == MPDX_FIELD_WORKSPACE) {
 #pragma unroll
-                        for (int k = 0; k < QD; ++k) jr[k] = 0.f;
-                        jac_row(fo, s, 1.f, jr);
-                        gn_accumulate<QD>(c, jr, M, v, c2);
+                    for (int ax = 0; ax < 3; ++ax) {   // one factor per face: c = margin -+ (P - bound), gradient -+ e_ax
+                        const float clo = fmaxf(margin - (p3[ax] - gp.fields[f].ws_min[ax]), 0.f), chi = fmaxf(margin - (gp.fields[f].ws_max[ax] - p3[ax]), 0.f);
+                        const int d = ax == 0 ? 0 : (ax == 1 ? 2 : 5);
+                        A[d] += (clo > 0.f ? 1.f : 0.f) + (chi > 0.f ? 1.f : 0.f);
+                        g[ax] += chi - clo;
+                        c2 += clo * clo + chi * chi;
                     }
                 }
-            } else if (kind == MPDX_FIELD_WORKSPACE) {
+            }
+            float J[3][QD];
+            sphere_jac(s, J);
+            // T = A J (3 x 7), then M += J^T T (lower triangle), v += J^T g; columns beyond the sphere's frame are zero (compile time)
 #pragma unroll
-                for (int s = s_beg; s < s_end; ++s) {
-                    const float margin = kPandaSR[s] + gp.cutoff_margin;
+            for (int c = 0; c < QD; ++c) {
+                if (c > fr) continue;
+                const float t0 = A[0] * J[0][c] + A[1] * J[1][c] + A[3] * J[2][c];
+                const float t1 = A[1] * J[0][c] + A[2] * J[1][c] + A[4] * J[2][c];
+                const float t2 = A[3] * J[0][c] + A[4] * J[1][c] + A[5] * J[2][c];
 #pragma unroll
-                    for (int ax = 0; ax < 3; ++ax) {
-                        const float clo = margin - (P[s][ax] - gp.fields[f].ws_min[ax]), chi = margin - (gp.fields[f].ws_max[ax] - P[s][ax]);
-                        if (clo > 0.f || chi > 0.f) {
-                            float e3[3] = {0.f, 0.f, 0.f};
-                            e3[ax] = 1.f;
-                            float jr[QD];
-#pragma unroll
-                            for (int k = 0; k < QD; ++k) jr[k] = 0.f;
-                            jac_row(e3, s, 1.f, jr);     // d P_ax / d theta
-                            if (clo > 0.f) {              // c = margin - (P - min): Jacobian -dP
-                                float jm[QD];
-#pragma unroll
-                                for (int k = 0; k < QD; ++k) jm[k] = -jr[k];
-                                gn_accumulate<QD>(clo, jm, M, v, c2);
-                            }
-                            if (chi > 0.f) gn_accumulate<QD>(chi, jr, M, v, c2);
-                        }
-                    }
+                for (int r = c; r < QD; ++r) {
+                    if (r > fr) continue;
+                    M[r * (r + 1) / 2 + c] += J[0][r] * t0 + J[1][r] * t1 + J[2][r] * t2;
                 }
-            } else if (kind == MPDX_FIELD_SELF) {
+                v[c] += J[0][c] * g[0] + J[1][c] * g[1] + J[2][c] * g[2];
+            }
+        }
+        bool has_self = false;
+        for (int f = 0; f < gp.n_fields; ++f) has_self |= gp.fields[f].kind == MPDX_FIELD_SELF;
+        if (has_self) {
 #pragma unroll
-                for (int pr = p_beg; pr < p_end; ++pr) {
-                    const int sa_ = kPandaPA[pr], sb_ = kPandaPB[pr];
-                    const float dx = P[sa_][0] - P[sb_][0], dy = P[sa_][1] - P[sb_][1], dz = P[sa_][2] - P[sb_][2];
-                    const float d2 = dx * dx + dy * dy + dz * dz;
-                    const float dist = __builtin_amdgcn_sqrtf(d2);
-                    const float c = kPandaSR[sa_] + kPandaSR[sb_] - dist;
-                    if (c > 0.f && dist > 0.f) {
-                        const float inv = __builtin_amdgcn_rsqf(d2);
-                        const float u[3] = {dx * inv, dy * inv, dz * inv};   // d c / d P_a = -u, d c / d P_b = +u
-                        float jr[QD];
+            for (int pr = p_beg; pr < p_end; ++pr) {
+                const int sa_ = kPandaPA[pr], sb_ = kPandaPB[pr];
+                const float dx = P[sa_][0] - P[sb_][0], dy = P[sa_][1] - P[sb_][1], dz = P[sa_][2] - P[sb_][2];
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                const float dist = __builtin_amdgcn_sqrtf(d2);
+                const float cr = kPandaSR[sa_] + kPandaSR[sb_] - dist;
+                const bool act = cr > 0.f && dist > 0.f;
+                const float c = act ? cr : 0.f;
+                const float inv = act ? __builtin_amdgcn_rsqf(d2) : 0.f;
+                const float u[3] = {dx * inv, dy * inv, dz * inv};   // d c / d P_a = -u, d c / d P_b = +u  (inactive: u = 0 adds nothing)
+                float Ja[3][QD], Jb[3][QD], jr[QD];
+                sphere_jac(sa_, Ja);
+                sphere_jac(sb_, Jb);
 #pragma unroll
-                        for (int k = 0; k < QD; ++k) jr[k] = 0.f;
-                        jac_row(u, sa_, -1.f, jr);
-                        jac_row(u, sb_, 1.f, jr);
-                        gn_accumulate<QD>(c, jr, M, v, c2);
-                    }
-                }
+                for (int k = 0; k < QD; ++k) jr[k] = u[0] * (Jb[0][k] - Ja[0][k]) + u[1] * (Jb[1][k] - Ja[1][k]) + u[2] * (Jb[2][k] - Ja[2][k]);
+                gn_accumulate<QD>(c, jr, M, v, c2);
             }
         }
     }

@@ -526,6 +526,8 @@ def test_pending_autograd_loss_survives_another_pass_on_the_same_unet():
             p.grad = None
         loss = loss_with_grad(dm, x0, hc, t=TTS[0].cuda(), noise=noise)   # what model.loss() returns with gradients enabled
         pending_then()
+        for p in dm.model.parameters():   # (the other pass left ITS gradient bound to p.grad, and backward() accumulates: start from nothing)
+            p.grad = None
         loss.backward()
         return torch.cat([p.grad.flatten().clone() for p in dm.model.parameters()])
     ref = grads_of(lambda: None)
