@@ -29,7 +29,7 @@
 #include <type_traits>
 
 // Development hooks (cycle stamps, phase-ablation masks) exist only in builds with -DMPDX_DEV_HOOKS
-// (MPDX_BUILD_DEFS=-DMPDX_DEV_HOOKS python -m mpd_public_amd.build --force; -DMPDX_LOOP_ABLATION implies it): in the production
+// (MPDX_BUILD_DEFS=-DMPDX_DEV_HOOKS MPDX_BUILD_OUT=build_ab/libmpdx_dev.so python -m mpd_public_amd.build; -DMPDX_LOOP_ABLATION implies it): in the production
 // library the trace pointer is the constant nullptr and the ablation mask the constant 0, so every hook folds away at compile time.
 #if defined(MPDX_LOOP_ABLATION) && !defined(MPDX_DEV_HOOKS)
 #define MPDX_DEV_HOOKS 1

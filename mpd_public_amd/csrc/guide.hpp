@@ -849,23 +849,36 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void guide_step_panda_kernel(co
     float* sG = sfk + (DENSE ? 0 : N * kPandaFKS);   // [MAXF][NP][N][QD]  partial joint gradients
     float* sC = sG + MAXF * NP * N * QD;      // [MAXF][H][QD]      clipped, weighted per-field support-point gradients
     float* snz = sC + ((MAXF * H * QD + (int)((sC - sm) & 3) + 3) & ~3) - (int)((sC - sm) & 3);   // 16-byte aligned: [H * D + 4] the step's noise of this
-    float* sprim = snz + H * D + 4;           //                    trajectory (last guide iteration of a step, rng.on)
+    float* snz_x = snz + H * D + 4;           //                    trajectory (last guide iteration of a step, rng.on) | [H * D] the normalised state
+    float* sprim = snz_x + H * D;
     for (int i = threadIdx.x; i < gp.n_prim_floats; i += 64 * WPT) sprim[i] = gp.prims[i];
 
-    // ---- load + unnormalise (normalization.py:156-167): the support wave(s) only; the state is NOT kept in registers across the force
-    //      phases (28 VGPRs that every one of the 8 waves held - and, in the 128-register dense variant, spilled to scratch: 112 B per
-    //      lane, 148 MB written per launch at B = 6400); phase 4 reads x again (L2) and the unnormalised state from LDS
+    // ---- load + unnormalise (normalization.py:156-167), by the whole workgroup: the trajectory's H * D floats are CONTIGUOUS - one coalesced
+    //      16-byte load per thread into LDS (sxn), then element-wise unnormalisation (two elements per thread).  (Rounds 1-4: the support
+    //      wave read its D floats per lane with D strided loads while the other seven waves waited at the barrier - 4.7-6.3 k cycles per
+    //      workgroup, tools/guide_trace.py.)  The state is NOT kept in registers across the force phases (28 VGPRs that every wave held -
+    //      and, in the 128-register dense variant, spilled to scratch: 112 B per lane, 148 MB written per launch at B = 6400): phase 4
+    //      reads the normalised state back from sxn and the unnormalised one from sx.
     const int ctx = b / a.n_per_ctx;
-    if (wv < nsw) {
-        const size_t base = ((size_t)b * H + (live ? hs_ : 0)) * D;
-        const bool clipall = __uint_as_float(a.amax_in[ctx]) > 1.0001f;
+    {
+        const int n = H * D;
+        const float* const xb = a.x + (size_t)b * n;   // (16-byte aligned: H * D * 4 is a multiple of 16 for even H)
+        for (int i = threadIdx.x; i < (n >> 2); i += 64 * WPT) *(f32x4*)(snz_x + 4 * i) = *(const f32x4*)(xb + 4 * i);
+        for (int i = (n & ~3) + threadIdx.x; i < n; i += 64 * WPT) snz_x[i] = xb[i];
+        // the limits, one per lane (static index -> scalar loads), fetched per element through the crossbar below
+        float mn = 0.f, mx = 0.f;
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float xnd = live ? a.x[base + d] : 0.f;
+        for (int d = 0; d < D; ++d) { mn = lane == d ? gp.mins[d] : mn; mx = lane == d ? gp.maxs[d] : mx; }
+        const bool clipall = __uint_as_float(a.amax_in[ctx]) > 1.0001f;
+        __syncthreads();
+        for (int i = threadIdx.x; i < ((n + 64 * WPT - 1) / (64 * WPT)) * (64 * WPT); i += 64 * WPT) {   // (whole waves take part in the shuffles)
+            const int ic = i < n ? i : 0, d = ic % D;
+            const float lo = __shfl(mn, d, 64), hi = __shfl(mx, d, 64);
+            const float xnd = snz_x[ic];
             const float c = clipall ? fminf(fmaxf(xnd, -1.f), 1.f) : xnd;
             const float u01 = __fadd_rn(c, 1.0f) * 0.5f;
-            const float xud = gp.identity_normalizer ? xnd : __fadd_rn(__fmul_rn(u01, __fsub_rn(gp.maxs[d], gp.mins[d])), gp.mins[d]);
-            if (live) sx[hs_ * D + d] = xud;
+            const float xud = gp.identity_normalizer ? xnd : __fadd_rn(__fmul_rn(u01, __fsub_rn(hi, lo)), lo);
+            if (i < n) sx[i] = xud;
         }
     }
     __syncthreads();
@@ -918,17 +931,6 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void guide_step_panda_kernel(co
     G_STAMP();  // 3 this wave's forces done
     __syncthreads();
     G_STAMP();  // 4 all waves done
-
-    // the support wave(s) request x again HERE: the round trip hides under the gather (requested in phase 4 it sat on the critical path of
-    // the one wave that finishes the trajectory: 1.8 k cycles, tools/guide_trace.py)
-    float xn[D];
-    int hs_o = hs_;
-    asm volatile("" : "+v"(hs_o));   // the 64-bit element address is re-derived here, not carried (as a spilled register pair) through the force phases
-    const size_t base = ((size_t)b * H + (live ? hs_o : 0)) * D;
-    if (wv < nsw) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) xn[d] = live ? a.x[base + d] : 0.f;   // same floats as the prologue read (nothing has written x since)
-    }
 
     // the step's noise (last guide iteration, drawn in place): by the waves that do not gather, under the gather
     const unsigned long long ne0 = a.rng.elem0 + (unsigned long long)b * H * D;
@@ -992,11 +994,13 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void guide_step_panda_kernel(co
     if (wv >= nsw) return;
 
     // ---- phase 4 (the support wave(s)): sum over fields, GP prior, apply
-    float total[D], xu[D];
+    float total[D], xu[D], xn[D];
+    const size_t base = ((size_t)b * H + (live ? hs_ : 0)) * D;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         total[d] = 0.f;
         xu[d] = live ? sx[hs_ * D + d] : 0.f;        // = the unnormalised state the prologue staged
+        xn[d] = live ? snz_x[hs_ * D + d] : 0.f;     // = the normalised state as loaded (nothing has written x since)
     }
     if (live) {
         for (int f = 0; f < gp.n_fields; ++f) {
@@ -1013,7 +1017,7 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void guide_step_panda_kernel(co
 inline size_t guide_lds_bytes(const mpdx_guide_params& gp, int H, int D, bool dense = false) {
     const int N = gp.interpolate ? gp.n_interp : H;
     if (gp.robot == MPDX_ROBOT_PANDA)
-        return (size_t)(H * D + (dense ? 0 : N * kPandaFKS) + MPDX_MAX_FIELDS * kPandaParts * N * 7 + MPDX_MAX_FIELDS * H * 7 + (H * D + 4 + 3) + gp.n_prim_floats) * sizeof(float);
+        return (size_t)(H * D + (dense ? 0 : N * kPandaFKS) + MPDX_MAX_FIELDS * kPandaParts * N * 7 + MPDX_MAX_FIELDS * H * 7 + (2 * H * D + 4 + 3) + gp.n_prim_floats) * sizeof(float);
     return (size_t)(H * D + 2 * MPDX_MAX_FIELDS * N * (D / 2) + gp.n_prim_floats) * sizeof(float);
 }
 

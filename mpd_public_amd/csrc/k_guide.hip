@@ -26,6 +26,8 @@ int launch_guide(const mpdx_guide_params* gp, float* x, float* grad_out, const f
     if (gp->n_fields < 0 || gp->n_fields > MPDX_MAX_FIELDS) return fail(MPDX_E_INVALID, "n_fields %d", gp->n_fields);
     if (gp->interpolate && (gp->n_interp < H || gp->n_interp > 8 * H)) return fail(MPDX_E_INVALID, "n_interp %d unsupported", gp->n_interp);
     if (gp->n_prim_floats > 0 && !gp->prims) return fail(MPDX_E_INVALID, "primitive table missing");
+    if (gp->robot == MPDX_ROBOT_PANDA && (((uintptr_t)x & 15) || ((size_t)H * D) % 4))
+        return fail(MPDX_E_INVALID, "Panda guide: x must be 16-byte aligned with H * D a multiple of 4 (the trajectory is staged with 16-byte loads)");
     GuideArgs a;
     a.gp = *gp; a.x = x; a.grad_out = grad_out; a.hs = hs; a.hg = hg; a.amax_in = amax_in; a.amax_out = amax_out;
     a.B = B; a.H = H; a.D = D; a.n_per_ctx = n_per_ctx > 0 ? n_per_ctx : B;
@@ -127,7 +129,7 @@ int mpdx_guide_time(const mpdx_guide_params* gp, float* x, float* grad_out, cons
 /* dev tool: one guide launch with s_memtime stamps (16 slots per wave, 8 waves -> 128 values) of workgroup 0 */
 int mpdx_guide_trace(const mpdx_guide_params* gp, float* x, const uint32_t* absmax_in, int B, int H, int D, void* stream, long long* stamps64) {
 #ifndef MPDX_DEV_HOOKS
-    return fail(MPDX_E_STATE, "%s needs a development build of libmpdx.so (MPDX_BUILD_DEFS=-DMPDX_DEV_HOOKS python -m mpd_public_amd.build --force): "
+    return fail(MPDX_E_STATE, "%s needs a development build of libmpdx.so (MPDX_BUILD_DEFS=-DMPDX_DEV_HOOKS MPDX_BUILD_OUT=build_ab/libmpdx_dev.so python -m mpd_public_amd.build, then MPDX_LIB=build_ab/libmpdx_dev.so): "
                 "the production kernels carry no trace / ablation hooks", __func__);
 #endif
     if (!stamps64) return fail(MPDX_E_INVALID, "null argument");

@@ -1539,7 +1539,7 @@ int mpdx_unet_profile(mpdx_unet* u, const float* packed, const float* timetab, i
 int mpdx_layer_trace(mpdx_unet* u, const float* packed, const float* timetab, const float* x, int layer, int B, float* ws, void* stream,
                      long long* stamps32) {
 #ifndef MPDX_DEV_HOOKS
-    return fail(MPDX_E_STATE, "%s needs a development build of libmpdx.so (MPDX_BUILD_DEFS=-DMPDX_DEV_HOOKS python -m mpd_public_amd.build --force): "
+    return fail(MPDX_E_STATE, "%s needs a development build of libmpdx.so (MPDX_BUILD_DEFS=-DMPDX_DEV_HOOKS MPDX_BUILD_OUT=build_ab/libmpdx_dev.so python -m mpd_public_amd.build, then MPDX_LIB=build_ab/libmpdx_dev.so): "
                 "the production kernels carry no trace / ablation hooks", __func__);
 #endif
     if (!u || layer < 0 || layer >= (int)u->layers.size() || !stamps32) return fail(MPDX_E_INVALID, "bad argument");
@@ -1561,7 +1561,7 @@ int mpdx_layer_trace(mpdx_unet* u, const float* packed, const float* timetab, co
 int mpdx_fused_trace(mpdx_unet* u, const float* packed, const float* timetab, const float* x, int seg, int B, float* ws, void* stream,
                      long long* stamps_out, int cap, int* n_out, int* nops_out) {
 #ifndef MPDX_DEV_HOOKS
-    return fail(MPDX_E_STATE, "%s needs a development build of libmpdx.so (MPDX_BUILD_DEFS=-DMPDX_DEV_HOOKS python -m mpd_public_amd.build --force): "
+    return fail(MPDX_E_STATE, "%s needs a development build of libmpdx.so (MPDX_BUILD_DEFS=-DMPDX_DEV_HOOKS MPDX_BUILD_OUT=build_ab/libmpdx_dev.so python -m mpd_public_amd.build, then MPDX_LIB=build_ab/libmpdx_dev.so): "
                 "the production kernels carry no trace / ablation hooks", __func__);
 #endif
     if (!u || seg < 0 || seg >= (int)u->fused.size()) return fail(MPDX_E_INVALID, "bad segment");

@@ -372,16 +372,18 @@ def test_weighted_loss_kernel_vs_formula():
         assert abs(float(out) - float(want)) <= 1e-6 * float(want), (l1, float(out), float(want))
 
 
-@pytest.mark.parametrize("B,guided,fused", [(6, False, True), (6, True, True), (70, False, False)])   # fused final op / guide kernel / final_step_kernel
-def test_in_kernel_noise_equals_pregenerated_stream(B, guided, fused):
+@pytest.mark.parametrize("B,guided,fused,panda", [(6, False, True, False), (6, True, True, False), (70, False, False, False),   # fused final op / guide kernel / final_step_kernel
+                                                  (5, False, True, True), (5, True, True, True), (3, True, False, True)])   # D = 14: the cooperative draws (one Philox counter per four elements)
+def test_in_kernel_noise_equals_pregenerated_stream(B, guided, fused, panda):
     """mpdx_plan with noise == NULL draws every step's noise inside the step kernels from the Philox stream (seed, offset).
     Element i of that stream is what mpdx_randn writes at flat index i of one [steps+1, B, H, D] tensor, so a plan with the
     pre-generated tensor injected must give the SAME BITS (and the 2.4 GB tensor of a 6400-trajectory shard is not needed)."""
     import mpd_public_amd as m
     from helpers import product_guide
     from math import ceil
-    T, n0, D = 25, 5, 4
-    ds = m.TrajectoryDataset("EnvDense2D", "RobotPointMass", tensor_args={"device": "cuda", "dtype": torch.float32})
+    T, n0, D = 25, 5, 14 if panda else 4
+    ds = m.TrajectoryDataset("EnvSpheres3D" if panda else "EnvDense2D", "RobotPanda" if panda else "RobotPointMass",
+                             tensor_args={"device": "cuda", "dtype": torch.float32})
     dm = _gpu_model(D, 0, T)
     hc = {0: t("rng_hc0", (D,), "uniform", 0.6).cuda(), 63: t("rng_hc1", (D,), "uniform", 0.6).cuda()}
     kw = dict(n_diffusion_steps_without_noise=n0, noise_std_extra_schedule_fn=lambda tt: 0.5)
