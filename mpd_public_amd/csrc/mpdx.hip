@@ -901,9 +901,16 @@ static int make_conv_args(const mpdx_unet* u, const Layer& l, const float* packe
 // residual 1x1 conv l2: 3 <32,16,R1> (512 -> 128 on a channel concat).  Measured and NOT used (rocprofv3, B = 6400, us per launch,
 // weight-stationary vs per-layer kernels): 128 -> 128 <8,16>: 142.7 vs 95.9; 128 -> 256 + 1x1 <8,32,R1>: 268 vs 234 - with 5 k-groups per
 // wave a tile's 20-40 MFMAs per wave do not cover its barrier and window hand-over; kept: 256 -> 256: 319 vs 332, 512 -> 128 + 1x1: 387 vs 468.
+constexpr int kWsnMinB = 512, kWspMinB = 512;   // (set from the sweep)
 static int weight_stationary_variant(const Layer& l, const Layer* l2, const ConvArgs& a, int B, int dbg) {
     const char* wsn = getenv("MPDX_WSN");   // dev A/B: 0 = the 128-channel layers stay on the per-layer kernels
-    const bool wsn_on = !(wsn && atoi(wsn) == 0) && !(getenv("MPDX_WS") && atoi(getenv("MPDX_WS")) == 0);
+    // conv_wsn / conv_wsp load a wave's WHOLE weight slice in their prologue (40-48 KB per wave, ~10 us per launch): they pay from a few tiles per
+    // wave on - batch thresholds from tools/wsn_threshold_sweep.py (profiles/r05_wsn_threshold_sweep.txt); MPDX_WSN_MIN_B / MPDX_WSP_MIN_B override
+    static const int wsn_min_b = getenv("MPDX_WSN_MIN_B") ? atoi(getenv("MPDX_WSN_MIN_B")) : kWsnMinB;
+    static const int wsp_min_b = getenv("MPDX_WSP_MIN_B") ? atoi(getenv("MPDX_WSP_MIN_B")) : kWspMinB;
+    const bool ws_env_on = !(getenv("MPDX_WS") && atoi(getenv("MPDX_WS")) == 0);
+    const bool wsn_on = !(wsn && atoi(wsn) == 0) && ws_env_on && B >= wsn_min_b;
+    const bool wsp_on = ws_env_on && B >= wsp_min_b && !(getenv("MPDX_WSP") && atoi(getenv("MPDX_WSP")) == 0);
     // Upsample1d(128) of the innermost up level, 8 -> 16 positions: conv_wsn_kernel<CONV_UPT> (round 5)
     if (l.mode == CONV_UPT && l.ks == 4 && l.epi == EPI_BIAS && !l2 && l.L_in == 8 && l.L_out == 16 && !l.Lv_out && l.c1 == 128 && l.c2 == 0 &&
         l.cin_pad == 128 && l.cout == 128 && !dbg && !a.pre && !a.accum && !a.dst2 && wsn_on && (long)B * 8 >= 16L * kWsGroups * 8)
@@ -917,7 +924,7 @@ static int weight_stationary_variant(const Layer& l, const Layer* l2, const Conv
     if (l2) {
         if (!(l2->mode == CONV_S1 && l2->ks == 1 && l2->epi == EPI_BIAS && l2->cout == l.cout && l2->L_out == 8 && l2->c1 == l.c1 && l2->c2 == l.c2)) return 0;
         if (l.cout == 128 && l.gs == 16 && l.cin_pad == 512) return 3;
-        if (l.cout == 256 && l.gs == 32 && l.cin_pad == 128 && l.c2 == 0 && wsn_on && !a.res && !(getenv("MPDX_WSP") && atoi(getenv("MPDX_WSP")) == 0))
+        if (l.cout == 256 && l.gs == 32 && l.cin_pad == 128 && l.c2 == 0 && wsp_on && !a.res)
             return 6;   // conv_wsp_kernel: 128 -> 256 k5 + 1x1, a pair of waves per tile, whole K per wave (round 5)
         return 0;
     }

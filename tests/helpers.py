@@ -220,8 +220,9 @@ def guided_parity_record(dm, sd, guide, gk, hc, T, n0, nb, n_check=256, eps=1e-5
     qd = D // 2
     noise = torch.randn((T + n0 + 1, nb, 64, D), generator=torch.Generator().manual_seed(seed))
     kw = dict(n_guide_steps=gk["n_guide_steps"], t_start_guide=gk["t_start_guide"], n_diffusion_steps_without_noise=n0)
+    dev = next(iter(hc.values())).device   # (the product path is CUDA-only; the CPU test of THIS function injects stand-ins)
     chain = dm.run_inference(None, hc, n_samples=nb, horizon=64, return_chain=True, guide=guide, noise_std_extra_schedule_fn=lambda t: 0.5,
-                             noise=noise.cuda(), **kw)
+                             noise=noise.to(dev), **kw)
     xu_hip_dev = ds.unnormalize_trajectories(chain[-1])
     m, mask_hip = ds.task.trajectory_metrics(xu_hip_dev, n_check=n_check, return_mask=True)
     m, mask_hip, x_hip, xu_hip = m.cpu(), mask_hip.cpu(), chain[-1].cpu(), xu_hip_dev.cpu()

@@ -56,12 +56,13 @@ def test_unet_forward_ragged_batches_vs_oracle(B, fused):
     np.testing.assert_allclose(y, ref, rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize("B", [512, 777, 2051])
+@pytest.mark.parametrize("B", [512, 777, 1601, 2051])
 def test_weight_stationary_inner_levels_are_bit_identical(B):
-    """Large batches run the 256 -> 256 Conv1dBlocks of the inner levels on the weight-stationary persistent kernel (csrc/conv_ws.hpp:
-    weights in registers, 16-position tiles with a rotating epilogue duty, 32-position tiles from B = 2048 on): same k-group split,
-    accumulation and reduction order and epilogue as conv_block_kernel -> the U-Net output is BIT-identical to the per-layer kernels
-    (MPDX_WS=0), for full and ragged last tiles, and a trajectory's result does not depend on the batch it sits in."""
+    """Large batches run the Conv1dBlocks of the inner levels on the weight-stationary persistent kernels - csrc/conv_ws.hpp (256 -> 256,
+    512 -> 128 + 1x1: K split over the waves, rotating epilogue duty), csrc/conv_wsn.hpp (round 5: 128 -> 128 and Upsample1d(128) with the
+    whole K per wave, 128 -> 256 + 1x1 with a pair of waves per tile): same k-group chains, accumulation and reduction order and epilogue as
+    conv_block_kernel -> the U-Net output is BIT-identical to the per-layer kernels (MPDX_WS=0), for full and ragged last tiles (odd
+    batches: a wave tile is a PAIR of trajectories), and a trajectory's result does not depend on the batch it sits in."""
     import os
     net = _gpu_model(14, 1)
     x = t(f"ws_x_{B}", (B, 64, 14)).cuda()
