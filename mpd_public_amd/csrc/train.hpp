@@ -123,6 +123,87 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnBwdArgs a) {
     }
 }
 
+// The same backward for GroupNorm regions of 64, 512, 1024 or 2048 elements (training at horizons other than 64: the reference's trainer is
+// horizon-agnostic, trainer.py:186-283).  One wave per region; lane -> NCH chunks of W consecutive channels of one position, chunk k =
+// elements (k * 64 + lane) * W ..+W-1 in (position, channel) order - the placement of the forward's EPI_GN_MISH_GEN epilogue (W <= gs).
+template <int W, int NCH>
+__global__ __launch_bounds__(256) void gn_mish_bwd_gen_kernel(const GnBwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int region = blockIdx.x * 4 + wave;
+    if (region >= a.B * a.n_groups) return;
+    const int b = region / a.n_groups, g = region - b * a.n_groups;
+    float u[NCH][W], gy[NCH][W], ga[NCH][W], be[NCH][W];
+    size_t o[NCH];
+    int cc[NCH];
+    const float inv_n = 1.0f / (float)(64 * W * NCH);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int e0 = (k * 64 + lane) * W;
+        const int l = e0 >> a.lg_gs;
+        cc[k] = g * a.gs + (e0 & (a.gs - 1));
+        o[k] = ((size_t)b * a.L + l) * a.C + cc[k];
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            u[k][e] = a.pre[o[k] + e]; gy[k][e] = a.gy[o[k] + e]; ga[k][e] = a.gamma[cc[k] + e]; be[k][e] = a.beta[cc[k] + e];
+            s += u[k][e];
+        }
+        if (a.gres) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) a.gres[o[k] + e] = a.gres_store ? gy[k][e] : a.gres[o[k] + e] + gy[k][e];
+        }
+    }
+    const float mean = wave_sum(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < W; ++e) { u[k][e] -= mean; q += u[k][e] * u[k][e]; }
+    const float var = wave_sum(q) * inv_n;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    float gm[NCH][W], dvh[NCH][W];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            u[k][e] *= rstd;   // vhat
+            gm[k][e] = gy[k][e] * mish_grad(u[k][e] * ga[k][e] + be[k][e]);
+            dvh[k][e] = gm[k][e] * ga[k][e];
+            s1 += dvh[k][e];
+            s2 += dvh[k][e] * u[k][e];
+        }
+    s1 = wave_sum(s1) * inv_n;
+    s2 = wave_sum(s2) * inv_n;
+    // per-channel sums over the horizon: a lane's chunks hold the same W channels (gs divides 64 W), lanes with the same channel offset
+    // differ in the bits >= log2(gs / W)
+    float r[4 * W];
+#pragma unroll
+    for (int e = 0; e < 4 * W; ++e) r[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            const float du = rstd * (dvh[k][e] - s1 - u[k][e] * s2);
+            a.du[o[k] + e] = du;
+            r[e] += gm[k][e] * u[k][e]; r[W + e] += gm[k][e]; r[2 * W + e] += du; r[3 * W + e] += gy[k][e];
+        }
+    for (int off = a.gs / W; off < 64; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 4 * W; ++k) r[k] += __shfl_xor(r[k], off, 64);
+    }
+    if (lane * W < a.gs) {   // the lanes of position 0 of chunk 0: one per W channels of the group
+        const size_t po = (size_t)b * a.C + cc[0];
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            a.pg[po + e] = r[e];
+            a.pb[po + e] = r[W + e];
+            a.pbias[po + e] = r[2 * W + e];
+            if (a.dT) a.dT[(size_t)b * a.dT_stride + cc[0] + e] = r[3 * W + e];
+        }
+    }
+}
+
 // out_k[c] = sum_b part_k[b][c]   for up to 4 arrays (k = blockIdx.y); fixed summation order (4 row phases, then ((0+1)+(2+3)))
 struct ColsumArgs { const float* part[4]; float* out[4]; int B, C; };
 __global__ __launch_bounds__(256) void colsum_kernel(const ColsumArgs a) {
@@ -447,9 +528,18 @@ struct ReduceAllArgs {
     const float* ws;
     float* grad;
     int n;
-    struct E { unsigned long long part, g; int S, M, N, KS, n_tot, n_off; } e[96];
-    int cstart[97];   // first block of entry j (1024 outputs per block); cstart[n] = blocks of the launch
+    struct E { unsigned long long part, g; int S, M, N, KS, n_tot, n_off, zsl, pad_; } e[96];   // zsl: reduce_zsl() of the entry (0: scalar form)
+    int cstart[97];   // first block of entry j (1024 outputs per block, 1024 / zsl when zsl > 1); cstart[n] = blocks of the launch
 };
+// The 16-byte form of wgrad_reduce_all_body needs every index involved to be a multiple of four floats (always, for the networks the library
+// builds: a factor 32 in every M N KS); then 1 / 4 / 16 z-slices per block for S <= 8 / <= 32 / more.  0: the scalar form.
+static inline int reduce_zsl(const ReduceAllArgs::E& e) {
+    const unsigned per = (unsigned)e.M * e.N * e.KS, NK = (unsigned)e.N * e.KS;
+    const bool vec = (per & 3u) == 0u && (e.part & 3ull) == 0ull && (e.g & 3ull) == 0ull &&
+                     (e.n_tot == e.N || ((NK & 3u) == 0u && (((unsigned)e.n_tot * e.KS) & 3u) == 0u && (((unsigned)e.n_off * e.KS) & 3u) == 0u));
+    if (!vec) return 0;
+    return e.S <= 8 ? 1 : (e.S <= 32 ? 4 : 16);
+}
 // one block = 1024 outputs of one entry (found by bisection of cstart): every block has work, a thread's loads fly together
 __device__ __forceinline__ void wgrad_reduce_all_body(const ReduceAllArgs& a, const int block_id, const int tid) {
     int lo = 0, hi = a.n;
@@ -458,6 +548,57 @@ __device__ __forceinline__ void wgrad_reduce_all_body(const ReduceAllArgs& a, co
     const float* part = a.ws + e.part;
     float* g = a.grad + e.g;
     const unsigned per = (unsigned)e.M * e.N * e.KS, KS = (unsigned)e.KS, N = (unsigned)e.N;   // (32-bit index arithmetic, as pack_train_kernel)
+    const unsigned NK0 = N * KS;
+    // Round 5: the 16-byte form - a thread sums the four CONSECUTIVE outputs i .. i + 3 with one dwordx4 load per split, exactly its splits' loads
+    // (the scalar form below issues eight clamped loads per output whatever S is).  What the launch actually waited for were the SMALL layers: a
+    // 32 x 32 layer has one tile, so the rule "about one block per CU" splits its batch into min(256, B) partial sums, and a thread walked them
+    // eight at a time - 16 dependent round trips at batch 128 (47.8 us for 79 MB).  With zsl > 1 (host: reduce_zsl) a block takes 1024 / zsl outputs
+    // and its threads split the z range into zsl contiguous slices (each ascending), combined through LDS in slice order: fixed order, deterministic.
+    if (e.zsl > 0) {
+        __shared__ f32x4 comb[256];
+        const unsigned zsl = (unsigned)e.zsl, qpb = 256u / zsl;
+        const unsigned quad = (unsigned)tid % qpb, slice = (unsigned)tid / qpb;
+        const unsigned i = (unsigned)(block_id - a.cstart[lo]) * (1024u / zsl) + 4u * quad;
+        const bool live = i < per;
+        const f32x4* p4 = (const f32x4*)(part + (live ? i : 0u));
+        const size_t zs = (size_t)(per >> 2);   // split stride in f32x4 units
+        const int zper = (e.S + (int)zsl - 1) / (int)zsl;
+        int z = (int)slice * zper;
+        const int ze = min(e.S, z + zper);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (; z + 8 <= ze; z += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int zz = 0; zz < 8; ++zz) v[zz] = p4[(size_t)(z + zz) * zs];
+#pragma unroll
+            for (int zz = 0; zz < 8; ++zz) acc += v[zz];
+        }
+        if (ze - z >= 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int zz = 0; zz < 4; ++zz) v[zz] = p4[(size_t)(z + zz) * zs];
+#pragma unroll
+            for (int zz = 0; zz < 4; ++zz) acc += v[zz];
+            z += 4;
+        }
+        if (ze - z >= 2) {
+            const f32x4 v0 = p4[(size_t)z * zs], v1 = p4[(size_t)(z + 1) * zs];
+            acc += v0; acc += v1;
+            z += 2;
+        }
+        if (ze - z >= 1) acc += p4[(size_t)z * zs];
+        if (zsl > 1) {   // (block-uniform)
+            comb[tid] = acc;
+            __syncthreads();
+            if (slice != 0) return;
+            for (unsigned sl = 1; sl < zsl; ++sl) acc += comb[sl * qpb + quad];
+        }
+        if (!live) return;
+        size_t o = i;
+        if ((unsigned)e.n_tot != N) { const unsigned m = i / NK0, r = i - m * NK0; o = ((size_t)m * e.n_tot + e.n_off) * KS + r; }
+        *(f32x4*)(g + o) = acc;
+        return;
+    }
     const unsigned base = (unsigned)(block_id - a.cstart[lo]) * 1024u + (unsigned)tid;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     unsigned ic[4];

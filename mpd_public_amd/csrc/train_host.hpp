@@ -254,6 +254,16 @@ static bool wgrad_two_groups(const WgradJob& j) {
     return (LA & 7) == 0 && LB == ((j.KS == 3 || j.KS == 4) ? 2 * LA : LA) && (nr == 1 || nr == 2 || nr == 4 || nr == 8);
 }
 
+// does bwd_pair_kernel exist for the tile the forward engine picks for this input-gradient convolution?  (levels of more than 64 positions -
+// n_support_points = 128 - run one trajectory per 128-position tile: per-layer launches there)
+static bool bwd_pair_has_tile(const Layer& dgl, int B) {
+    int MT, NT;
+    choose_tile(dgl, B, MT, NT);
+    if (dgl.cout % MT) MT = 16;
+    if (dgl.cout % MT || NT % dgl.L_out) return false;
+    return (MT == 32 || MT == 16) && (NT == 64 || NT == 32 || NT == 16);
+}
+
 // dgrad convolution + the layer's weight-gradient GEMM(s) in ONE launch (bwd_pair_kernel); the jobs must use distinct partial buffers
 // GN_BWD: the dgrad blocks run the EPI_GN_BWD epilogue (cd carries its operands; `dgl` then has epi = EPI_GN_MISH and the group size
 // of the Conv1dBlock below, so that the tile holds whole GroupNorm regions)
@@ -605,9 +615,15 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             { int k = 0; while ((1 << k) < l.gs) ++k; g.lg_gs = k; }
             if (l.cout > 512) return fail(MPDX_E_INVALID, "layer %s: more than 512 channels", l.name.c_str());
             const int re = l.gs * l.L_out, regions = B * g.n_groups;
-            if (re == 256) hipLaunchKernelGGL(gn_mish_bwd_kernel<4>, dim3((regions + 3) / 4), dim3(256), 0, st, g);
-            else if (re == 128) hipLaunchKernelGGL(gn_mish_bwd_kernel<2>, dim3((regions + 3) / 4), dim3(256), 0, st, g);
-            else return fail(MPDX_E_INVALID, "layer %s: GroupNorm region of %d elements", l.name.c_str(), re);
+            const dim3 ggrid((regions + 3) / 4);
+            if (re == 256) hipLaunchKernelGGL(gn_mish_bwd_kernel<4>, ggrid, dim3(256), 0, st, g);
+            else if (re == 128) hipLaunchKernelGGL(gn_mish_bwd_kernel<2>, ggrid, dim3(256), 0, st, g);
+            // horizons other than 64 (power-of-two containers 16 ... 128): regions of 64 / 512 / 1024 / 2048 elements
+            else if (re == 64) hipLaunchKernelGGL((gn_mish_bwd_gen_kernel<1, 1>), ggrid, dim3(256), 0, st, g);
+            else if (re == 512 && l.gs >= 4) hipLaunchKernelGGL((gn_mish_bwd_gen_kernel<4, 2>), ggrid, dim3(256), 0, st, g);
+            else if (re == 1024 && l.gs >= 4) hipLaunchKernelGGL((gn_mish_bwd_gen_kernel<4, 4>), ggrid, dim3(256), 0, st, g);
+            else if (re == 2048 && l.gs >= 4) hipLaunchKernelGGL((gn_mish_bwd_gen_kernel<4, 8>), ggrid, dim3(256), 0, st, g);
+            else return fail(MPDX_E_INVALID, "layer %s: GroupNorm region of %d elements (group of %d channels)", l.name.c_str(), re, l.gs);
             ColsumArgs cs;
             memset(&cs, 0, sizeof(cs));
             cs.part[0] = g.pg; cs.out[0] = gflat(l.gamma);
@@ -634,7 +650,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         }
         static const bool pair_off = getenv("MPDX_TRAIN_PAIR") && atoi(getenv("MPDX_TRAIN_PAIR")) == 0;
         // one launch for all of them needs every job on its own partial buffer (the deferred mode)
-        const bool paired = t.need_dgrad && !pair_off && jobs[0].deferred && (njobs == 1 || jobs[1].deferred);
+        const bool paired = t.need_dgrad && !pair_off && jobs[0].deferred && (njobs == 1 || jobs[1].deferred) && bwd_pair_has_tile(t.dg, B);
         if (!paired)
             for (int k = 0; k < njobs; ++k) {
                 if (!t.need_dgrad && !pair_off && jobs[k].deferred) lone.push_back(jobs[k]);
@@ -714,7 +730,10 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         int blocks = 0;
         for (int k = 0; k < df.red.n; ++k) {
             df.red.cstart[k] = blocks;
-            blocks += (int)(((size_t)df.red.e[k].M * df.red.e[k].N * df.red.e[k].KS + 1023) / 1024);
+            auto& e = df.red.e[k];
+            e.zsl = reduce_zsl(e);
+            const size_t opb = 1024 / (size_t)std::max(1, e.zsl);   // outputs per block
+            blocks += (int)(((size_t)e.M * e.N * e.KS + opb - 1) / opb);
         }
         df.red.cstart[df.red.n] = blocks;
         hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(blocks), dim3(256), 0, st, df.red);
