@@ -50,6 +50,29 @@ def test_get_dataset_split_and_batches(tmp_path):
     assert get_num_epochs(100, 8, 36) == 23   # trainer.py:16-17
 
 
+def test_batch_gather_loader_yields_the_dataloaders_batches(tmp_path):
+    """train.BatchGatherLoader (one gather per batch) against torch's DataLoader over the same Subset - the reference's loaders
+    (train_loaders.py:92-93: sequential sampler, default collate): every batch, the ragged last one included, bit for bit."""
+    from torch.utils.data import DataLoader
+    from mpd_public_amd import train as train_script
+    base = tmp_path / "data" / "EnvSimple2D-RobotPointMass"
+    _write_shards(base, [13, 9, 7])
+    tr, trl, va, val = train_script.get_dataset(dataset_subdir="EnvSimple2D-RobotPointMass", batch_size=8, val_set_size=0.1,
+                                               data_dir=str(tmp_path / "data"))
+    assert isinstance(trl, train_script.BatchGatherLoader) and isinstance(val, train_script.BatchGatherLoader)
+    ref = DataLoader(tr, batch_size=8)
+    assert len(trl) == len(ref) == 4
+    n = 0
+    for a, b in zip(trl, ref):
+        assert set(a) == set(b) and set(a["hard_conds"]) == set(b["hard_conds"]) == {0, 63}
+        assert torch.equal(a["traj_normalized"], b["traj_normalized"]) and torch.equal(a["task_normalized"], b["task_normalized"])
+        for k in (0, 63):
+            assert torch.equal(a["hard_conds"][k], b["hard_conds"][k])
+        n += len(a["traj_normalized"])
+    assert n == len(tr) == 26
+    assert [len(b["traj_normalized"]) for b in trl] == [8, 8, 8, 2]   # (a second pass: the loader is re-iterable, like a DataLoader)
+
+
 def test_training_step_has_no_cpu_fallback():
     import mpd_public_amd as m
     from mpd_public_amd.trainer import TrainStep
