@@ -159,6 +159,7 @@ int check_ready(const mpdx_unet* u);
 unsigned fused_mask(int B);
 bool fused_save_variant(const mpdx_unet::Fused& f);
 int ensure_fused_streams(mpdx_unet* u, const float* packed, hipStream_t st);
+int claim_fused_stream_jobs(mpdx_unet* u, const float* packed, const void** jobs, int* n);   // training: the copies ride on the pass's first launch
 int launch_final_step(const FinalArgs& fa, hipStream_t st);   // final_step_kernel (fa.B/H/D/C set)
 // ---- k_conv.hip: every conv_block_kernel / conv_pair_kernel instantiation
 int launch_conv_layer(const Layer& l, ConvArgs& a, int B, hipStream_t st);

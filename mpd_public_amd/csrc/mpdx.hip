@@ -1046,23 +1046,12 @@ __global__ void restream_kernel(float* __restrict__ packed, size_t src, size_t d
     }
 }
 
-// all strided copies of every fused segment in ONE launch (blockIdx.y = job; the table lives in device memory)
-struct CopyJobDev { unsigned long long src, dst; int n0, ss0, ds0, n1, ss1, ds1, n_inner; };
+// all strided copies of every fused segment in ONE launch (blockIdx.y = job; the table lives in device memory; CopyJobDev, restream_job: train_types.hpp)
 __global__ __launch_bounds__(256) void restream_all_kernel(float* __restrict__ packed, const CopyJobDev* __restrict__ jobs) {
-    const CopyJobDev j = jobs[blockIdx.y];
-    const unsigned total = (unsigned)j.n0 * (unsigned)j.n1 * (unsigned)j.n_inner, ni = (unsigned)j.n_inner, n1 = (unsigned)j.n1;   // (32-bit index arithmetic)
-#pragma unroll 4
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-        const unsigned k = i % ni, r = i / ni;
-        const unsigned i1 = r % n1, i0 = r / n1;
-        packed[j.dst + (size_t)i0 * j.ds0 + (size_t)i1 * j.ds1 + k] = packed[j.src + (size_t)i0 * j.ss0 + (size_t)i1 * j.ss1 + k];
-    }
+    restream_job(packed, jobs[blockIdx.y], blockIdx.x * 256u + threadIdx.x, gridDim.x * 256u);
 }
 
-// The fused segments read stream-ordered copies of their weights and one contiguous parameter block (fused_level.hpp);
-// (re)assemble them in `packed` after the state dict was (re)packed.  Enqueues copies on `st`; no synchronisation.
-int ensure_fused_streams(mpdx_unet* u, const float* packed, hipStream_t st) {
-    if (u->streams_for == packed && u->streams_version == u->pack_version) return 0;
+static int ensure_stream_jobs(mpdx_unet* u) {
     if (!u->jobs_dev) {   // the job table never changes after build_units
         std::vector<CopyJobDev> all;
         for (const auto& f : u->fused)
@@ -1073,9 +1062,26 @@ int ensure_fused_streams(mpdx_unet* u, const float* packed, hipStream_t st) {
             HIP_TRY(hipMemcpy(u->jobs_dev, all.data(), all.size() * sizeof(CopyJobDev), hipMemcpyHostToDevice));
         }
     }
+    return 0;
+}
+// The fused segments read stream-ordered copies of their weights and one contiguous parameter block (fused_level.hpp);
+// (re)assemble them in `packed` after the state dict was (re)packed.  Enqueues copies on `st`; no synchronisation.
+int ensure_fused_streams(mpdx_unet* u, const float* packed, hipStream_t st) {
+    if (u->streams_for == packed && u->streams_version == u->pack_version) return 0;
+    if (int rc = ensure_stream_jobs(u)) return rc;
     if (u->n_jobs)
         hipLaunchKernelGGL(restream_all_kernel, dim3(64, (unsigned)u->n_jobs), dim3(256), 0, st, const_cast<float*>(packed), (const CopyJobDev*)u->jobs_dev);
     HIP_TRY(hipGetLastError());
+    u->streams_for = packed; u->streams_version = u->pack_version;
+    return 0;
+}
+// training: the caller runs the copies itself, as side blocks of its next launch (time_train_fwd_kernel) - hands out the device job table (null / 0:
+// the streams are current) and marks the streams of `packed` current
+int claim_fused_stream_jobs(mpdx_unet* u, const float* packed, const void** jobs, int* n) {
+    *jobs = nullptr; *n = 0;
+    if (u->streams_for == packed && u->streams_version == u->pack_version) return 0;
+    if (int rc = ensure_stream_jobs(u)) return rc;
+    *jobs = u->jobs_dev; *n = u->n_jobs;
     u->streams_for = packed; u->streams_version = u->pack_version;
     return 0;
 }

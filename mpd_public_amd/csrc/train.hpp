@@ -732,7 +732,14 @@ struct TimeTrainArgs {
     const int* rng_counter;     // null: t and noise are inputs
     long long* t_out;
     float* noise_out;
+    // side blocks [B, B + kRestreamBlocksPerJob * n_jobs): the fused programs' weight-stream copies inside `packed` (train_types.hpp restream_job) - they
+    // depend on the pack launch before this one only, and were a launch of their own (restream_all_kernel, 5.8 us) between this kernel and the programs
+    int B;
+    float* packed;
+    const CopyJobDev* jobs;
+    int n_jobs;
 };
+constexpr int kRestreamBlocksPerJob = 32;
 
 // uniform integer in [0, T) from one Philox counter (multiply-shift of 32 random bits)
 __device__ __forceinline__ int philox_randint(uint64_t seed, uint64_t ctr, int T) {
@@ -752,10 +759,15 @@ __global__ __launch_bounds__(512) void time_train_fwd_kernel(const TimeTrainArgs
     __shared__ float emb[32], h1m[128], tm[32];
     __shared__ int s_toff[41];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= a.B) {   // a side block: its share of one copy job
+        const int rb = b - a.B, job = rb / kRestreamBlocksPerJob, part = rb - job * kRestreamBlocksPerJob;
+        restream_job(a.packed, a.jobs[job], (unsigned)part * 512u + (unsigned)tid, (unsigned)kRestreamBlocksPerJob * 512u);
+        return;
+    }
     if (tid < a.nblk) s_toff[tid] = a.toff[tid];
     if (tid == 0) s_toff[a.nblk] = a.row;
     const bool draw = a.rng_counter != nullptr;
-    const unsigned long long rng_pos = draw ? (unsigned long long)(unsigned)(*a.rng_counter) * gridDim.x + (unsigned)b : 0ull;
+    const unsigned long long rng_pos = draw ? (unsigned long long)(unsigned)(*a.rng_counter) * (unsigned)a.B + (unsigned)b : 0ull;
     const long long t_b = draw ? (long long)philox_randint(a.rng_seed ^ 0x74696D6573746570ull, rng_pos, a.T) : a.t[b];
     if (draw && tid == 0) a.t_out[b] = t_b;
     if (a.xn && draw) {   // the sample's noise drawn in place (HD % 4 == 0: checked on the host), then q_sample's arithmetic
@@ -871,6 +883,7 @@ struct TimeBwdArgs {
     unsigned* ticket;           // zero at launch: the sample blocks of time_bwd_all_kernel count themselves here
     unsigned long long w1, b1, w3, b3;
     int B, row, nblk;
+    int split_tail;             // the encoder tail runs in its own launch (time_tail_kernel): the sample blocks take no ticket
     unsigned long long woff[40], boff[40];
     int cout[40], toff[40];
 };
@@ -987,6 +1000,7 @@ __device__ __forceinline__ void time_bwd_all_body(const TimeBwdArgs& a, const in
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     TB_STAMP();
+    if (a.split_tail) return;   // (the tail is the next launch: the kernel boundary orders the rows)
     __syncthreads();   // every store of the row has drained (above) before the ticket is taken
     if (tid == 0) s_ticket = atomicAdd(a.ticket, 1u);
     __syncthreads();
@@ -1084,6 +1098,69 @@ __device__ __forceinline__ void time_bwd_all_body(const TimeBwdArgs& a, const in
 // (Measured and rejected: these blocks and the weight-gradient reductions in ONE launch - 59 us against 32 + 27 us apart: under the
 //  reductions' memory traffic every dependent load of this chain takes several times longer.)
 __global__ __launch_bounds__(1024) void time_bwd_all_kernel(const TimeBwdArgs a) { time_bwd_all_body(a, (int)blockIdx.x); }
+
+// The encoder tail of the time backward (time_mlp.encoder.3 / encoder.1: dW3, db3, dh1 = mish'(h1) W3^T dtemb, dW1, db1) as its OWN launch of 8 blocks
+// (round 5).  Inside time_bwd_all_kernel the tail is the work of ONE block - the last sample block to finish - and walks the batch 32 samples at a
+// time: ~6.6 us per chunk, 26 of the launch's 37 us at batch 128, 105 us at batch 512.  Every quantity of the tail is independent per hidden unit k
+// (128 of them): block q takes k in [16 q, 16 q + 16).  Same sums in the same order (samples ascending, fmaf chains over e ascending): same bits.
+constexpr int kTimeTailBlocks = 8;
+__global__ __launch_bounds__(512) void time_tail_kernel(const TimeBwdArgs a) {
+    __shared__ float dtmS[32 * 32], embS[32 * 32], h1mS[32 * 16], dh1S[32 * 16];
+    const int tid = threadIdx.x, q = blockIdx.x, k0 = 16 * q;
+    const int eA = tid >> 4, kA = tid & 15;       // dW3[eA][k0 + kA];  phase B: sample bb = eA, hidden unit kA
+    const int kC = tid >> 5, jC = tid & 31;       // dW1[k0 + kC][jC]
+    float w3c[32];                                // W3[e][k0 + kA], e = 0..31
+#pragma unroll
+    for (int e = 0; e < 32; ++e) w3c[e] = a.flat[a.w3 + (size_t)e * 128 + k0 + kA];
+    float w3g = 0.f, w1g = 0.f, b3s = 0.f, b1s = 0.f;
+    // a chunk's operands are fetched while the chunk before it is worked on; samples beyond the batch are staged as ZEROS (fmaf(0, x, acc) == acc)
+    float z0[2], z1[2], z2, zh;
+    auto fetch = [&](int b0) {
+        const int nb = a.B - b0 < 32 ? a.B - b0 : 32;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + u * 512;
+            z0[u] = idx < nb * 32 ? a.dtm[(size_t)b0 * 32 + idx] : 0.f;
+            z1[u] = idx < nb * 32 ? a.emb[(size_t)b0 * 32 + idx] : 0.f;
+        }
+        z2 = eA < nb ? a.h1m[(size_t)(b0 + eA) * 128 + k0 + kA] : 0.f;
+        zh = eA < nb ? a.h1[(size_t)(b0 + eA) * 128 + k0 + kA] : 0.f;
+    };
+    fetch(0);
+    for (int b0 = 0; b0 < a.B; b0 += 32) {
+        const int nb = a.B - b0 < 32 ? a.B - b0 : 32;
+        __syncthreads();   // the previous chunk's reads are done
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { dtmS[tid + u * 512] = z0[u]; embS[tid + u * 512] = z1[u]; }
+        h1mS[tid] = z2;
+        const float hv = zh;
+        __syncthreads();
+        fetch(b0 + 32);
+#pragma unroll 8
+        for (int bb = 0; bb < 32; ++bb) w3g = fmaf(dtmS[bb * 32 + eA], h1mS[bb * 16 + kA], w3g);
+        if (q == 0 && tid < 32) {
+#pragma unroll 8
+            for (int bb = 0; bb < 32; ++bb) b3s += dtmS[bb * 32 + tid];
+        }
+        {
+            float sacc = 0.f;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) sacc = fmaf(dtmS[eA * 32 + e], w3c[e], sacc);
+            dh1S[tid] = eA < nb ? sacc * mish_grad(hv) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int bb = 0; bb < 32; ++bb) w1g = fmaf(dh1S[bb * 16 + kC], embS[bb * 32 + jC], w1g);
+        if (tid < 16) {
+#pragma unroll 8
+            for (int bb = 0; bb < 32; ++bb) b1s += dh1S[bb * 16 + tid];
+        }
+    }
+    a.grad[a.w3 + (size_t)eA * 128 + k0 + kA] = w3g;
+    a.grad[a.w1 + (size_t)(k0 + kC) * 32 + jC] = w1g;
+    if (q == 0 && tid < 32) a.grad[a.b3 + tid] = b3s;
+    if (tid < 16) a.grad[a.b1 + k0 + tid] = b1s;
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Loss gradient (helpers.py:71-99; mean over B*H*D of |e| or e^2 [* weights]):  dE = s * w * d|e|^p / de / (B H D), zero where

@@ -471,7 +471,18 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
                 ta.t_out = const_cast<long long*>(t_dev); ta.noise_out = const_cast<float*>(noise);
             }
         }
-        hipLaunchKernelGGL(time_train_fwd_kernel, dim3(B), dim3(512), 0, st, ta);
+        ta.B = B; ta.packed = const_cast<float*>(packed); ta.jobs = nullptr; ta.n_jobs = 0;
+        {   // the fused forward programs' weight streams: re-assembled by side blocks of this launch (the pack launch before it wrote `packed`)
+            static const bool fused_fwd_off0 = getenv("MPDX_TRAIN_FUSED_FWD") && atoi(getenv("MPDX_TRAIN_FUSED_FWD")) == 0;
+            static const bool ride_off = getenv("MPDX_TRAIN_RESTREAM_RIDE") && atoi(getenv("MPDX_TRAIN_RESTREAM_RIDE")) == 0;   // dev A/B switch
+            if (!fused_fwd_off0 && !ride_off && fused_mask(B) != 0u && (w.total < ((size_t)1 << 31))) {
+                const void* jb = nullptr;
+                int nj = 0;
+                if (int rc = claim_fused_stream_jobs(u, packed, &jb, &nj)) return rc;
+                ta.jobs = (const CopyJobDev*)jb; ta.n_jobs = nj;
+            }
+        }
+        hipLaunchKernelGGL(time_train_fwd_kernel, dim3(B + kRestreamBlocksPerJob * ta.n_jobs), dim3(512), 0, st, ta);
         tb.flat = flat; tb.grad = grads_flat; tb.dT = ws + w.dT; tb.emb = ta.emb; tb.h1 = ta.h1; tb.temb = ta.temb; tb.tm = ta.tm; tb.h1m = ta.h1m;
         tb.dtm = ws + w.dtm; tb.dh1 = ws + w.dh1; tb.ticket = (unsigned*)(ws + w.ticket);
         if (ta.row > kTimeBwdMaxRow)   // time_bwd_all_kernel carves dTs | roff | red out of LDS at fixed offsets of kTimeBwdMaxRow
@@ -739,7 +750,10 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(blocks), dim3(256), 0, st, df.red);
     }
     if (df.col.n) hipLaunchKernelGGL(colsum_all_kernel, dim3(2, df.col.n), dim3(256), 0, st, df.col);
+    static const bool tail_join = getenv("MPDX_TIME_TAIL_SPLIT") && atoi(getenv("MPDX_TIME_TAIL_SPLIT")) == 0;   // dev A/B switch: the tail inside the launch
+    tb.split_tail = tail_join ? 0 : 1;
     hipLaunchKernelGGL(time_bwd_all_kernel, dim3(B + (tb.row + 31) / 32), dim3(1024), 0, st, tb);   // the time conditioning's backward
+    if (tb.split_tail) hipLaunchKernelGGL(time_tail_kernel, dim3(kTimeTailBlocks), dim3(512), 0, st, tb);   // ... and its encoder tail, 8 blocks
     HIP_TRY(hipGetLastError());
     return 0;
 }
