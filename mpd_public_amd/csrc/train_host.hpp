@@ -747,7 +747,13 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             blocks += (int)(((size_t)e.M * e.N * e.KS + opb - 1) / opb);
         }
         df.red.cstart[df.red.n] = blocks;
-        hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(blocks), dim3(256), 0, st, df.red);
+        static const bool join_off = getenv("MPDX_TRAIN_REDUCE_JOIN") && atoi(getenv("MPDX_TRAIN_REDUCE_JOIN")) == 0;   // dev A/B switch
+        if (df.col.n && !join_off) {   // the column sums ride on the same launch (side blocks behind the reduction's)
+            ReduceColsumArgs rc;   // (8 KB of kernel arguments; the launch copies them)
+            rc.red = df.red; rc.col = df.col; rc.n_red_blocks = blocks;
+            hipLaunchKernelGGL(wgrad_reduce_colsum_kernel, dim3(blocks + 2 * df.col.n), dim3(256), 0, st, rc);
+            df.col.n = 0;
+        } else hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(blocks), dim3(256), 0, st, df.red);
     }
     if (df.col.n) hipLaunchKernelGGL(colsum_all_kernel, dim3(2, df.col.n), dim3(256), 0, st, df.col);
     static const bool tail_join = getenv("MPDX_TIME_TAIL_SPLIT") && atoi(getenv("MPDX_TIME_TAIL_SPLIT")) == 0;   // dev A/B switch: the tail inside the launch
