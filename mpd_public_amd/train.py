@@ -32,6 +32,13 @@ class BatchGatherLoader:
         idx = subset.indices if hasattr(subset, "indices") else range(len(subset))
         self._base = base
         self._idx = torch.as_tensor(list(idx), dtype=torch.long, device=base.fields["traj_normalized"].device)
+        # TrajectoryDataset.get_hard_conditions of EVERY trajectory, once (trajectories.py:205-223: end positions, zero velocities): a batch is
+        # then four gathers - no slicing / cat / zeros launches per batch
+        x = base.fields["traj_normalized"]
+        s, g = base.robot.get_position(x[:, 0]), base.robot.get_position(x[:, -1])
+        if base.include_velocity:
+            s, g = torch.cat((s, torch.zeros_like(s)), dim=-1), torch.cat((g, torch.zeros_like(g)), dim=-1)
+        self._hs, self._hg = s.contiguous(), g.contiguous()
 
     def __len__(self):
         n = len(self._idx)
@@ -44,14 +51,8 @@ class BatchGatherLoader:
             idx = self._idx[i:i + self.batch_size]
             if self.drop_last and len(idx) < self.batch_size:
                 return
-            x = b.fields["traj_normalized"].index_select(0, idx)
-            batch = {"traj_normalized": x, "task_normalized": b.fields["task_normalized"].index_select(0, idx)}
-            # TrajectoryDataset.get_hard_conditions per sample (trajectories.py:205-223), batched: end positions, zero velocities
-            s, g = b.robot.get_position(x[:, 0]), b.robot.get_position(x[:, -1])
-            if b.include_velocity:
-                s, g = torch.cat((s, torch.zeros_like(s)), dim=-1), torch.cat((g, torch.zeros_like(g)), dim=-1)
-            batch["hard_conds"] = {0: s, H - 1: g}
-            yield batch
+            yield {"traj_normalized": b.fields["traj_normalized"].index_select(0, idx), "task_normalized": b.fields["task_normalized"].index_select(0, idx),
+                   "hard_conds": {0: self._hs.index_select(0, idx), H - 1: self._hg.index_select(0, idx)}}
 
 
 def get_dataset(dataset_class="TrajectoryDataset", dataset_subdir=None, batch_size=2, val_set_size=0.05, results_dir=None,

@@ -72,5 +72,5 @@ timeout 300 python tools/gpmp_phase_probe.py 2>&1 | grep "solve=\|sigma_obs" > $
 # multi-GPU dry run on the single-GPU rig (8 ranks share the GPU over gloo): record shape + sharding / gather / checksum code, no fabric
 timeout 1200 python bench.py --gpus 8 --steps 2 --warmup 1 > $O/bench_rig8_single_gpu.json 2> $O/bench_rig8.err; tail -1 $O/bench_rig8_single_gpu.json | cut -c1-200
 head -4 $O/cfg2_kernel_stats.csv | cut -c1-160
-timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log > $O/pytest_gpu_tail.txt; cat $O/pytest_gpu_tail.txt
+timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; grep -h "passed\|failed" $O/pytest_gpu.log | tail -3 > $O/pytest_gpu_tail.txt; cat $O/pytest_gpu_tail.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt

@@ -22,5 +22,5 @@ import json, bench
 print(json.dumps({'batch32_D4': bench.training_leg(), 'batch128_D14': bench.training_leg(B=128, D=14), 'batch512_D14': bench.training_leg(steps=20, B=512, D=14, baseline=False)}, indent=1))
 " 2>/dev/null > $O/training.json
 (for v in 1 0; do MPDX_TORCH_DATALOADER=$v timeout 300 python tools/train_loop_probe.py 3000 2>/dev/null | tail -1; done) > $O/train_loop_probe.txt
-timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log > $O/pytest_gpu_tail.txt; cat $O/pytest_gpu_tail.txt
+timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; grep -h "passed\|failed" $O/pytest_gpu.log | tail -3 > $O/pytest_gpu_tail.txt; cat $O/pytest_gpu_tail.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
