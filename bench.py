@@ -1134,7 +1134,7 @@ def main():
             try:
                 out["training"] = training_leg()
                 # the larger shapes of the same iteration (no torch-autograd leg): where the step stops being launch-bound
-                for nm, (tb, td, tsteps) in {"batch128_D14": (128, 14, 40), "batch512_D14": (512, 14, 15)}.items():
+                for nm, (tb, td, tsteps) in {"batch128_D14": (128, 14, 100), "batch512_D14": (512, 14, 60)}.items():
                     r = training_leg(steps=tsteps, B=tb, D=td, baseline=False)
                     out["training"][nm] = {"ms_per_train_step": r["ms_per_train_step"], "train_steps_per_s": r["train_steps_per_s"],
                                            "fp32_TFLOPs": r.get("roofline", {}).get("achieved"), "fp32_peak_frac": r.get("roofline", {}).get("frac"),

@@ -292,11 +292,17 @@ class TrainStep:
         dsts, srcs = [g["x"]] + [g["hc"][k] for k in hard_conds], [x_start] + [hard_conds[k] for k in hard_conds]
         if noise is not None:
             dsts.append(g["noise"]); srcs.append(noise)
-        if all(a.dtype == b.dtype and a.device == b.device and a.shape == b.shape for a, b in zip(dsts, srcs)):
-            torch._foreach_copy_(dsts, srcs)   # ONE launch for the batch and its hard conditions
-        else:
-            for a, b in zip(dsts, srcs):
+        # the batch (and a supplied noise tensor) by plain copies - contiguous device-to-device: the runtime's copy kernel, 2-3 us; the hard conditions
+        # (a few KB each) in ONE launch.  (All of them in one _foreach_copy_ was 4.7 us at batch 32 but 17.5 us at batch 128 x D = 14: multi_tensor_apply
+        # hands a 458-KB tensor to two blocks - profiles/r05_train128_kernel_stats.csv.)
+        small_d, small_s = [], []
+        for a, b in zip(dsts, srcs):
+            if a.dtype == b.dtype and a.device == b.device and a.shape == b.shape and a.numel() <= 16384:
+                small_d.append(a); small_s.append(b)
+            else:
                 a.copy_(b, non_blocking=True)
+        if small_d:
+            torch._foreach_copy_(small_d, small_s)
         if t is not None:
             g["t"].copy_(t, non_blocking=True)
         if self.__dict__.get("_dev_steps") != self.step_count:   # eager adam_step calls in between moved the host's count: re-seed the device's

@@ -598,3 +598,48 @@ def test_training_at_padded_horizons_is_refused_loudly(H):
     ts = TrainStep(dm)
     with pytest.raises(RuntimeError, match="power-of-two horizons"):
         ts.loss_backward(x0.cuda(), {k: v.cuda() for k, v in hc.items()}, t=torch.tensor([3, 24, 0, 12, 7]).cuda(), noise=noise.cuda())
+
+
+def test_launch_merges_leave_every_gradient_bit_identical():
+    """Round-5 launch merges of the training pass - the time backward's encoder tail as its own 8-block launch (MPDX_TIME_TAIL_SPLIT), the fused programs'
+    weight-stream copies as side blocks of the first launch (MPDX_TRAIN_RESTREAM_RIDE), the column sums as side blocks of the weight-gradient reduction
+    (MPDX_TRAIN_REDUCE_JOIN): each switched off in its own process (the switches are read once per process), loss + every gradient + the parameters after
+    a clipped Adam step must hash to the same bytes as with all of them on (batch 40: two 32-sample chunks of the tail, the second ragged)."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = r'''
+import hashlib, sys, torch
+sys.path.insert(0, "ROOT"); sys.path.insert(0, "ROOT/tests")
+import mpd_public_amd as m
+from mpd_public_amd.trainer import TrainStep
+from helpers import synth_sd, t, DIM_MULTS
+D, opt, B, T = 14, 1, 40, 100
+net = m.TemporalUnet(n_support_points=64, state_dim=D, unet_input_dim=32, dim_mults=DIM_MULTS[opt])
+net.load_state_dict(synth_sd(D, opt), strict=True)
+dm = m.GaussianDiffusionModel(model=net, n_diffusion_steps=T, predict_epsilon=True, loss_type="l2").cuda()
+x0, noise = t("merge_x0", (B, 64, D), "uniform", 0.8), t("merge_noise", (B, 64, D))
+hc = {0: t("merge_hc0", (B, D), "uniform", 0.7), 63: t("merge_hc1", (B, D), "uniform", 0.7)}
+tt = torch.arange(B) % T
+ts = TrainStep(dm)
+h = hashlib.sha256()
+for it in range(2):
+    loss, _ = ts.loss_backward(x0.cuda(), {k: v.cuda() for k, v in hc.items()}, t=tt.cuda(), noise=noise.cuda())
+    h.update(loss.cpu().numpy().tobytes()); h.update(ts.fp.grad.cpu().numpy().tobytes())
+    ts.adam_step(1e-4, max_norm=1.0)
+    h.update(ts.fp.flat.detach().cpu().numpy().tobytes())
+print("HASH", h.hexdigest())
+'''.replace("ROOT", str(root))
+
+    def run(extra):
+        env = dict(os.environ, **extra)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("HASH ")]
+        assert out.returncode == 0 and lines, out.stderr[-2000:]
+        return lines[-1]
+    ref = run({})
+    for sw in ("MPDX_TIME_TAIL_SPLIT", "MPDX_TRAIN_RESTREAM_RIDE", "MPDX_TRAIN_REDUCE_JOIN"):
+        assert run({sw: "0"}) == ref, sw

@@ -42,7 +42,7 @@ cd $GRAFT_REPO_ROOT
 for n in cfg5 train train128 planner; do cp $(find $O/prof_$n -name "*kernel_stats.csv" | head -1) $O/${n}_kernel_stats.csv; rm -rf $O/prof_$n; done
 timeout 900 python -c "
 import json, bench
-print(json.dumps({'batch32_D4': bench.training_leg(), 'batch128_D14': bench.training_leg(B=128, D=14)}, indent=1))
+print(json.dumps({'batch32_D4': bench.training_leg(), 'batch128_D14': bench.training_leg(B=128, D=14), 'batch512_D14': bench.training_leg(steps=20, B=512, D=14, baseline=False)}, indent=1))
 " 2>/dev/null > $O/training.json
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/cfg2_kernel_stats.csv
 cp $(find $O/prof_default -name "*kernel_stats.csv" | head -1) $O/default_cmd_kernel_stats.csv
