@@ -1221,6 +1221,45 @@ __global__ __launch_bounds__(1024) void train_loss_kernel(const float* __restric
     }
     const size_t rows = (size_t)B * H, total = rows * C;
     const float inv = scale / (float)(rows * D);
+    if (1024 % C == 0 && C <= 1024) {
+        // Round 5: a block takes 1024 / C rows at a time - the rows' dE terms are computed ONCE (D per row, by the first rows x D threads) and staged in
+        // LDS with final_conv[1]'s weights, then thread (row, c) runs its D FMAs out of LDS.  (Below: every (row, c) thread loaded all of its row's D
+        // predictions, targets and weights itself - 64 loads per output, 16.6 us for the launch at batch 128 x D = 14.)  Same g, same fmaf chain over d.
+        __shared__ float gS[64 * 16], wS[16 * 1024 / 16];   // [rows per block <= 64][16] | [D][C] (D * C <= 16 * 64 ... see the guard)
+        const int rpb = 1024 / C;
+        if (rpb <= 64 && D * C <= 1024) {
+            const int tid = threadIdx.x, rl = tid / C, c = tid - rl * C;
+            for (int k = tid; k < D * C; k += 1024) wS[k] = w[k];
+            for (size_t r0 = (size_t)blockIdx.x * rpb; r0 < rows; r0 += (size_t)nb * rpb) {
+                __syncthreads();   // the previous trip's reads of gS are done (and wS is staged)
+                if (tid < rpb * D) {
+                    const int rr = tid / D, d = tid - rr * D;
+                    const size_t r = r0 + rr;
+                    float g = 0.f;
+                    if (r < rows) {
+                        const int h = (int)(r % H);
+                        const bool hard = (hs && h == 0) || (hg && h == H - 1);
+                        if (!hard) {
+                            const float e = pred[r * D + d] - targ[r * D + d];
+                            g = l1 ? (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) : 2.0f * e;
+                            if (weights_hd) g *= weights_hd[h * D + d];
+                            g *= inv;
+                        }
+                        dE[r * D + d] = g;
+                    }
+                    gS[rr * 16 + d] = g;
+                }
+                __syncthreads();
+                const size_t r = r0 + rl;
+                if (r < rows) {
+                    float sacc = 0.f;
+                    for (int d = 0; d < D; ++d) sacc = fmaf(gS[rl * 16 + d], wS[d * C + c], sacc);
+                    gH[r * C + c] = sacc;
+                }
+            }
+            return;
+        }
+    }
     for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < total; i += (size_t)nb * 1024) {
         const int c = (int)(i % C);
         const size_t r = i / C;
