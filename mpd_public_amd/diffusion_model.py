@@ -153,6 +153,23 @@ class GaussianDiffusionModel(nn.Module):
         return x, chain
 
     # ---------------------------------------------------------------------------------------------- sampling
+    # The three elementwise helpers of the reference's class (diffusion_model_base.py:109-141), kept for callers that use them directly: plain tensor
+    # arithmetic on the registered schedule buffers (any device).  The planning loop itself never calls them - its U-Net pass, x0 prediction, clamp and
+    # posterior mean are ONE fused kernel sequence (p_mean_variance below / mpdx_plan).
+    def predict_noise_from_start(self, x_t, t, x0):
+        if self.predict_epsilon:   # the network output already is the noise
+            return x0
+        return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - x0) / extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape)
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        if not self.predict_epsilon:   # the network output already is x0
+            return noise
+        return extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise
+
+    def q_posterior(self, x_start, x_t, t):
+        mean = extract(self.posterior_mean_coef1, t, x_t.shape) * x_start + extract(self.posterior_mean_coef2, t, x_t.shape) * x_t
+        return mean, extract(self.posterior_variance, t, x_t.shape), extract(self.posterior_log_variance_clipped, t, x_t.shape)
+
     def p_mean_variance(self, x, hard_conds, context, t):
         """(model_mean, posterior_variance, posterior_log_variance) as diffusion_model_base.py:143-155."""
         if context is not None:

@@ -196,3 +196,31 @@ def test_standard_networks_run_the_static_programs_with_compile_time_geometry(li
     rc, h = _create(lib, n_support_points=48)
     assert rc == 0 and lib.mpdx_unet_fused_program(h, 0) == -2
     lib.mpdx_unet_destroy(h)
+
+
+def test_elementwise_helpers_of_the_diffusion_class_match_the_oracle():
+    """predict_start_from_noise / predict_noise_from_start / q_posterior (diffusion_model_base.py:109-141): kept on the class for callers that use them
+    directly; plain tensor arithmetic on the schedule buffers (the planning loop runs the same formulas inside its fused kernels) - against the oracle."""
+    import torch
+    import mpd_public_amd as m
+    from oracle import diffusion as odiff, schedules as osched
+    T, B, H, D = 25, 3, 64, 4
+    net = m.TemporalUnet(n_support_points=H, state_dim=D, unet_input_dim=32, dim_mults=m.UNET_DIM_MULTS[0])
+    g = torch.Generator().manual_seed(3)
+    x, eps = torch.randn((B, H, D), generator=g), torch.randn((B, H, D), generator=g)
+    buf = osched.make_buffers(T, "exponential")
+    for pe in (True, False):
+        dm = m.GaussianDiffusionModel(model=net, n_diffusion_steps=T, predict_epsilon=pe)
+        for ti in (0, 7, T - 1):
+            t = torch.full((B,), ti, dtype=torch.long)
+            x0 = dm.predict_start_from_noise(x, t, eps)
+            assert torch.equal(x0, odiff.predict_start_from_noise(buf, x, ti, eps, predict_epsilon=pe))
+            back = dm.predict_noise_from_start(x, t, x0)
+            if pe:
+                assert back is x0
+            else:   # x0 = eps here: (a x - x0) / b
+                assert torch.equal(back, (buf["sqrt_recip_alphas_cumprod"][ti] * x - x0) / buf["sqrt_recipm1_alphas_cumprod"][ti])
+            mean, var, logvar = dm.q_posterior(x0, x, t)
+            assert torch.equal(mean, buf["posterior_mean_coef1"][ti] * x0 + buf["posterior_mean_coef2"][ti] * x)
+            assert var.shape == (B, 1, 1) and float(var[0]) == float(buf["posterior_variance"][ti])
+            assert float(logvar[0]) == float(buf["posterior_log_variance_clipped"][ti])
