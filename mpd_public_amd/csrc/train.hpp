@@ -769,18 +769,24 @@ __device__ __forceinline__ int philox_randint(uint64_t seed, uint64_t ctr, int T
 __global__ __launch_bounds__(512) void time_train_fwd_kernel(const TimeTrainArgs a) {
     __shared__ float emb[32], h1m[128], tm[32];
     __shared__ int s_toff[41];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (b >= a.B) {   // a side block: its share of one copy job
-        const int rb = b - a.B, job = rb / kRestreamBlocksPerJob, part = rb - job * kRestreamBlocksPerJob;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= 2 * a.B) {   // a side block: its share of one copy job
+        const int rb = (int)blockIdx.x - 2 * a.B, job = rb / kRestreamBlocksPerJob, part = rb - job * kRestreamBlocksPerJob;
         restream_job(a.packed, a.jobs[job], (unsigned)part * 512u + (unsigned)tid, (unsigned)kRestreamBlocksPerJob * 512u);
         return;
     }
+    // blocks [0, B): the time MLP of sample b; blocks [B, 2 B): its q_sample (+ the draw of t and the noise) - the two halves share nothing but t_b
+    // (round 5: one block ran them one after the other, the noise draw in front of the MLP's chain of four dependent stages)
+    const bool mlp_half = (int)blockIdx.x < a.B;
+    const int b = mlp_half ? (int)blockIdx.x : (int)blockIdx.x - a.B;
     if (tid < a.nblk) s_toff[tid] = a.toff[tid];
     if (tid == 0) s_toff[a.nblk] = a.row;
     const bool draw = a.rng_counter != nullptr;
     const unsigned long long rng_pos = draw ? (unsigned long long)(unsigned)(*a.rng_counter) * (unsigned)a.B + (unsigned)b : 0ull;
     const long long t_b = draw ? (long long)philox_randint(a.rng_seed ^ 0x74696D6573746570ull, rng_pos, a.T) : a.t[b];
-    if (draw && tid == 0) a.t_out[b] = t_b;
+    if (draw && tid == 0 && mlp_half) a.t_out[b] = t_b;
+    if (mlp_half) {
+    } else
     if (a.xn && draw) {   // the sample's noise drawn in place (HD % 4 == 0: checked on the host), then q_sample's arithmetic
         const long long tb = t_b < 0 ? 0 : (t_b >= a.T ? a.T - 1 : t_b);
         const float ca = a.sqrt_ac[tb], cb = a.sqrt_1mac[tb];
@@ -816,6 +822,21 @@ __global__ __launch_bounds__(512) void time_train_fwd_kernel(const TimeTrainArgs
             a.xn[g] = r;
         }
     }
+    if (!mlp_half) return;
+    // encoder.1 / encoder.3 weights of this thread: requested HERE, in front of the chain of stages that use them (behind a barrier each: hipcc does
+    // not move a load across s_barrier, and every stage then began with a round trip to HBM - the optimiser rewrote `flat` two launches ago)
+    f32x4 wv1[8], w3a, w3b;
+    float b1v, b3v;
+    {
+        const int t1 = tid < 128 ? tid : 0;
+        const f32x4* w = (const f32x4*)(a.flat + a.w1 + t1 * 32);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wv1[k] = w[k];
+        b1v = a.flat[a.b1 + t1];
+        const f32x4* w3p = (const f32x4*)(a.flat + a.w3 + (tid >> 4) * 128);
+        w3a = w3p[(tid & 15) * 2]; w3b = w3p[(tid & 15) * 2 + 1];
+        b3v = a.flat[a.b3 + (tid >> 4)];
+    }
     if (b == 0 && a.zero_words)
         for (int i = tid; i < a.n_zero; i += 512) a.zero_words[i] = 0.f;
     if (tid < 16) {
@@ -827,14 +848,10 @@ __global__ __launch_bounds__(512) void time_train_fwd_kernel(const TimeTrainArgs
     }
     __syncthreads();
     if (tid < 128) {
-        const f32x4* w = (const f32x4*)(a.flat + a.w1 + tid * 32);   // parameter offsets are multiples of 4 floats
-        float s = a.flat[a.b1 + tid];
-        f32x4 wv[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) wv[k] = w[k];
+        float s = b1v;   // (parameter offsets are multiples of 4 floats)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            s = fmaf(wv[k][0], emb[4 * k], s); s = fmaf(wv[k][1], emb[4 * k + 1], s); s = fmaf(wv[k][2], emb[4 * k + 2], s); s = fmaf(wv[k][3], emb[4 * k + 3], s);
+            s = fmaf(wv1[k][0], emb[4 * k], s); s = fmaf(wv1[k][1], emb[4 * k + 1], s); s = fmaf(wv1[k][2], emb[4 * k + 2], s); s = fmaf(wv1[k][3], emb[4 * k + 3], s);
         }
         a.h1[(size_t)b * 128 + tid] = s;
         h1m[tid] = mish(s);
@@ -843,8 +860,7 @@ __global__ __launch_bounds__(512) void time_train_fwd_kernel(const TimeTrainArgs
     __syncthreads();
     {   // encoder.3: row r = tid >> 4 (32 rows), 16 lanes per row take two float4 each; the sum runs k ascending inside a lane, lanes by DPP row sum
         const int r = tid >> 4, l16 = tid & 15;
-        const f32x4* w = (const f32x4*)(a.flat + a.w3 + r * 128);
-        const f32x4 w0 = w[l16 * 2], w1 = w[l16 * 2 + 1];
+        const f32x4 w0 = w3a, w1 = w3b;
         const float* h = h1m + l16 * 8;
         float s = w0[0] * h[0];
         s = fmaf(w0[1], h[1], s); s = fmaf(w0[2], h[2], s); s = fmaf(w0[3], h[3], s);
@@ -854,7 +870,7 @@ __global__ __launch_bounds__(512) void time_train_fwd_kernel(const TimeTrainArgs
         s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, true));
         s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xF, 0xF, true));
         if (l16 == 0) {
-            s += a.flat[a.b3 + r];
+            s += b3v;
             a.temb[(size_t)b * 32 + r] = s;
             tm[r] = mish(s);
             a.tm[(size_t)b * 32 + r] = tm[r];

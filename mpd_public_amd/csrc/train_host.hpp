@@ -482,7 +482,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
                 ta.jobs = (const CopyJobDev*)jb; ta.n_jobs = nj;
             }
         }
-        hipLaunchKernelGGL(time_train_fwd_kernel, dim3(B + kRestreamBlocksPerJob * ta.n_jobs), dim3(512), 0, st, ta);
+        hipLaunchKernelGGL(time_train_fwd_kernel, dim3(2 * B + kRestreamBlocksPerJob * ta.n_jobs), dim3(512), 0, st, ta);
         tb.flat = flat; tb.grad = grads_flat; tb.dT = ws + w.dT; tb.emb = ta.emb; tb.h1 = ta.h1; tb.temb = ta.temb; tb.tm = ta.tm; tb.h1m = ta.h1m;
         tb.dtm = ws + w.dtm; tb.dh1 = ws + w.dh1; tb.ticket = (unsigned*)(ws + w.ticket);
         if (ta.row > kTimeBwdMaxRow)   // time_bwd_all_kernel carves dTs | roff | red out of LDS at fixed offsets of kTimeBwdMaxRow
