@@ -57,6 +57,7 @@ struct GnBwdArgs {
     int gres_store;   // this launch is the first writer of gres in the pass: = gy
     int dT_stride;
     int B, L, C, gs, lg_gs, n_groups;
+    int Lv;           // valid rows of a zero-padded container (horizons that are not powers of two: ConvArgs::Lv_out); 0 or L: all rows
 };
 
 template <int EPL>
@@ -132,21 +133,26 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_gen_kernel(const GnBwdArgs a)
     const int region = blockIdx.x * 4 + wave;
     if (region >= a.B * a.n_groups) return;
     const int b = region / a.n_groups, g = region - b * a.n_groups;
+    // a padded container (a.Lv < a.L): the statistics run over the valid rows only, rows behind them carry no gradient (the forward's producers
+    // keep them zero whatever the convolution put there: conv_block.hpp EPI_GN_MISH_GEN) - du = 0 there, and nothing of them enters a sum
+    const int Lv = (a.Lv > 0 && a.Lv < a.L) ? a.Lv : a.L;
     float u[NCH][W], gy[NCH][W], ga[NCH][W], be[NCH][W];
     size_t o[NCH];
     int cc[NCH];
-    const float inv_n = 1.0f / (float)(64 * W * NCH);
+    bool ok[NCH];
+    const float inv_n = 1.0f / (float)(a.gs * Lv);   // (= 1 / (64 W NCH), a power of two, when nothing is masked)
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const int e0 = (k * 64 + lane) * W;
         const int l = e0 >> a.lg_gs;
+        ok[k] = l < Lv;
         cc[k] = g * a.gs + (e0 & (a.gs - 1));
         o[k] = ((size_t)b * a.L + l) * a.C + cc[k];
 #pragma unroll
         for (int e = 0; e < W; ++e) {
-            u[k][e] = a.pre[o[k] + e]; gy[k][e] = a.gy[o[k] + e]; ga[k][e] = a.gamma[cc[k] + e]; be[k][e] = a.beta[cc[k] + e];
-            s += u[k][e];
+            u[k][e] = a.pre[o[k] + e]; gy[k][e] = ok[k] ? a.gy[o[k] + e] : 0.f; ga[k][e] = a.gamma[cc[k] + e]; be[k][e] = a.beta[cc[k] + e];
+            s += ok[k] ? u[k][e] : 0.f;
         }
         if (a.gres) {
 #pragma unroll
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_gen_kernel(const GnBwdArgs a)
 #pragma unroll
     for (int k = 0; k < NCH; ++k)
 #pragma unroll
-        for (int e = 0; e < W; ++e) { u[k][e] -= mean; q += u[k][e] * u[k][e]; }
+        for (int e = 0; e < W; ++e) { u[k][e] -= mean; q += ok[k] ? u[k][e] * u[k][e] : 0.f; }
     const float var = wave_sum(q) * inv_n;
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
     float gm[NCH][W], dvh[NCH][W];
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_gen_kernel(const GnBwdArgs a)
 #pragma unroll
         for (int e = 0; e < W; ++e) {
             u[k][e] *= rstd;   // vhat
-            gm[k][e] = gy[k][e] * mish_grad(u[k][e] * ga[k][e] + be[k][e]);
+            gm[k][e] = gy[k][e] * mish_grad(u[k][e] * ga[k][e] + be[k][e]);   // (0 on masked rows: gy is)
             dvh[k][e] = gm[k][e] * ga[k][e];
             s1 += dvh[k][e];
             s2 += dvh[k][e] * u[k][e];
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_gen_kernel(const GnBwdArgs a)
     for (int k = 0; k < NCH; ++k)
 #pragma unroll
         for (int e = 0; e < W; ++e) {
-            const float du = rstd * (dvh[k][e] - s1 - u[k][e] * s2);
+            const float du = ok[k] ? rstd * (dvh[k][e] - s1 - u[k][e] * s2) : 0.f;
             a.du[o[k] + e] = du;
             r[e] += gm[k][e] * u[k][e]; r[W + e] += gm[k][e]; r[2 * W + e] += du; r[3 * W + e] += gy[k][e];
         }
@@ -749,6 +755,7 @@ struct TimeTrainArgs {
     float* packed;
     const CopyJobDev* jobs;
     int n_jobs;
+    int Hc;                     // rows per trajectory of xn: the power-of-two container of a horizon that is not one (rows [H, Hc) written as zeros); 0: H
 };
 constexpr int kRestreamBlocksPerJob = 32;
 
@@ -785,6 +792,7 @@ __global__ __launch_bounds__(512) void time_train_fwd_kernel(const TimeTrainArgs
     const unsigned long long rng_pos = draw ? (unsigned long long)(unsigned)(*a.rng_counter) * (unsigned)a.B + (unsigned)b : 0ull;
     const long long t_b = draw ? (long long)philox_randint(a.rng_seed ^ 0x74696D6573746570ull, rng_pos, a.T) : a.t[b];
     if (draw && tid == 0 && mlp_half) a.t_out[b] = t_b;
+    const size_t xn_stride = (size_t)(a.Hc > a.H ? a.Hc : a.H) * a.D;   // floats per trajectory of xn
     if (mlp_half) {
     } else
     if (a.xn && draw) {   // the sample's noise drawn in place (HD % 4 == 0: checked on the host), then q_sample's arithmetic
@@ -805,7 +813,7 @@ __global__ __launch_bounds__(512) void time_train_fwd_kernel(const TimeTrainArgs
                 float r = __fadd_rn(__fmul_rn(ca, a.x0[g]), __fmul_rn(cb, z[e]));
                 if (a.hs && l == 0) r = a.hs[b * a.D + d];
                 if (a.hg && l == a.H - 1) r = a.hg[b * a.D + d];
-                a.xn[g] = r;
+                a.xn[(size_t)b * xn_stride + i] = r;
             }
         }
     } else if (a.xn) {   // x_t = sqrt(acp[t_b]) x0 + sqrt(1 - acp[t_b]) noise, hard conditions: q_sample_kernel's arithmetic (mpdx.hip)
@@ -819,10 +827,14 @@ __global__ __launch_bounds__(512) void time_train_fwd_kernel(const TimeTrainArgs
             float r = __fadd_rn(__fmul_rn(ca, a.x0[g]), __fmul_rn(cb, a.noise[g]));
             if (a.hs && l == 0) r = a.hs[b * a.D + d];
             if (a.hg && l == a.H - 1) r = a.hg[b * a.D + d];
-            a.xn[g] = r;
+            a.xn[(size_t)b * xn_stride + i] = r;
         }
     }
-    if (!mlp_half) return;
+    if (!mlp_half) {
+        if (a.xn && a.Hc > a.H)   // the container's rows behind the horizon
+            for (int i = a.H * a.D + tid; i < a.Hc * a.D; i += 512) a.xn[(size_t)b * xn_stride + i] = 0.f;
+        return;
+    }
     // encoder.1 / encoder.3 weights of this thread: requested HERE, in front of the chain of stages that use them (behind a barrier each: hipcc does
     // not move a load across s_barrier, and every stage then began with a round trip to HBM - the optimiser rewrote `flat` two launches ago)
     f32x4 wv1[8], w3a, w3b;
@@ -1228,7 +1240,8 @@ __global__ __launch_bounds__(256) void final_dgrad_kernel(const float* __restric
 __global__ __launch_bounds__(1024) void train_loss_kernel(const float* __restrict__ pred, const float* __restrict__ targ, const float* __restrict__ weights_hd,
                                                           const float* __restrict__ hs, const float* __restrict__ hg, int l1, float scale, float* __restrict__ dE,
                                                           const float* __restrict__ w, float* __restrict__ gH, int B, int H, int D, int C, float* __restrict__ loss_out,
-                                                          double* __restrict__ loss_part, unsigned* __restrict__ loss_ticket) {
+                                                          double* __restrict__ loss_part, unsigned* __restrict__ loss_ticket, int Hc) {
+    // Hc > H: dE and gH are written in the network's container layout [B][Hc][.] (rows [H, Hc) zero) - a horizon that is not a power of two
     const unsigned nb = gridDim.x - 16;
     if (blockIdx.x >= nb) {   // the loss value: wave w of weighted_loss_kernel's sum as its own one-wave workgroup (loss.hpp)
         __shared__ float lq[64 * kLossChunk];
@@ -1237,6 +1250,29 @@ __global__ __launch_bounds__(1024) void train_loss_kernel(const float* __restric
     }
     const size_t rows = (size_t)B * H, total = rows * C;
     const float inv = scale / (float)(rows * D);
+    if (Hc > H) {   // (rare: the plain form, rows of the container; pred / targ are [B][H][D])
+        const size_t crow = (size_t)B * Hc;
+        for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < crow * C; i += (size_t)nb * 1024) {
+            const int c = (int)(i % C);
+            const size_t rc = i / C;
+            const int h = (int)(rc % Hc);
+            const size_t b = rc / Hc, r = b * H + h;
+            float sacc = 0.f;
+            for (int d = 0; d < D; ++d) {
+                float g = 0.f;
+                if (h < H && !((hs && h == 0) || (hg && h == H - 1))) {
+                    const float e = pred[r * D + d] - targ[r * D + d];
+                    g = l1 ? (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) : 2.0f * e;
+                    if (weights_hd) g *= weights_hd[h * D + d];
+                    g *= inv;
+                }
+                if (c == d) dE[rc * D + d] = g;
+                sacc = fmaf(g, w[(size_t)d * C + c], sacc);
+            }
+            gH[i] = sacc;
+        }
+        return;
+    }
     if (1024 % C == 0 && C <= 1024) {
         // Round 5: a block takes 1024 / C rows at a time - the rows' dE terms are computed ONCE (D per row, by the first rows x D threads) and staged in
         // LDS with final_conv[1]'s weights, then thread (row, c) runs its D FMAs out of LDS.  (Below: every (row, c) thread loaded all of its row's D

@@ -31,6 +31,8 @@ static void build_train_plan(mpdx_unet* u) {
             d.ks = l.mode == CONV_S1 ? l.ks : (l.mode == CONV_DOWN ? 3 : 5);
             d.c1 = l.cout; d.c2 = 0; d.cout = l.c1 + l.c2;
             d.L_in = d.L_out = l.mode == CONV_UPT ? l.L_out : l.L_in;
+            // a padded container: valid rows of the dgrad's output = of the layer's input (ConvTranspose: full resolution, decimated at the store)
+            d.Lv_out = l.Lv_out == 0 ? 0 : (l.mode == CONV_UPT ? l.Lv_out : (l.mode == CONV_DOWN ? 2 * l.Lv_out : l.Lv_out));
             d.cin_pad = (d.c1 + 15) / 16 * 16;
             d.rs = pick_row_stride(d.cin_pad, CONV_S1, d.L_in, d.L_out, d.L_in + 2 * (d.ks / 2));
             t.dg = d;
@@ -110,7 +112,7 @@ static TrainWs train_ws(const mpdx_unet* u, int B) {
     const size_t n = u->layers.size();
     const int H = u->cfg.n_support_points, D = u->cfg.state_dim;
     w.slotB = u->slot_floats * (size_t)B;
-    const size_t xs = ((size_t)B * H * D + 3) / 4 * 4;
+    const size_t xs = ((size_t)B * std::max(H, u->Hc) * D + 3) / 4 * 4;   // (xn and dE live in the network's container layout)
     size_t o = 0;
     auto take = [&](size_t k) { const size_t r = o; o += (k + 3) / 4 * 4; return r; };
     w.xn = take(xs); w.eps = take(xs); w.dE = take(xs);
@@ -166,6 +168,7 @@ static int fill_geom(const Layer& l, int B, ConvArgs& a) {
     a.c1 = l.c1; a.c2 = l.c2;
     a.B = B; a.L_in = l.L_in; a.L_out = l.L_out; a.C_out = l.cout;
     a.cin_pad = l.cin_pad; a.rs = l.rs; a.gs = l.gs;
+    a.Lv_out = l.Lv_out;
     auto lg2 = [](int v) { int k = 0; while ((1 << k) < v) ++k; return k; };
     a.lg_c4n = lg2(l.cin_pad / 4); a.lg_Lin = lg2(l.L_in); a.lg_Lout = lg2(l.L_out); a.lg_gs = l.gs > 0 ? lg2(l.gs) : 0;
     if ((1 << a.lg_c4n) != l.cin_pad / 4 || (1 << a.lg_Lin) != l.L_in || (1 << a.lg_Lout) != l.L_out || (l.gs > 0 && (1 << a.lg_gs) != l.gs))
@@ -423,11 +426,12 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     if (!u || !flat || !packed || !packedT || !grads_flat || !x_start || !noise || !t_dev || !freqs16 || !loss_out || !ws || B <= 0)
         return fail(MPDX_E_INVALID, "bad argument");
     build_train_plan(u);
-    if (u->masked()) return fail(MPDX_E_INVALID, "the training kernels take power-of-two horizons (n_support_points %d runs in a padded container)", u->cfg.n_support_points);
     if (int rc = check_ready(u)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const mpdx_unet_cfg& c = u->cfg;
     const int H = c.n_support_points, D = c.state_dim, n = (int)u->layers.size();
+    const int Hc = u->Hc;   // rows per trajectory of every activation / gradient tensor: H, or its power-of-two container (24, 40, 48, 96 ...: rows [H, Hc) zero)
+    const bool masked = u->masked();
     const TrainWs w = train_ws(u, B);
     float* const xn = ws + w.xn;
     float* const eps = ws + w.eps;
@@ -472,6 +476,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             }
         }
         ta.B = B; ta.packed = const_cast<float*>(packed); ta.jobs = nullptr; ta.n_jobs = 0;
+        ta.Hc = masked ? Hc : 0;
         {   // the fused forward programs' weight streams: re-assembled by side blocks of this launch (the pack launch before it wrote `packed`)
             static const bool fused_fwd_off0 = getenv("MPDX_TRAIN_FUSED_FWD") && atoi(getenv("MPDX_TRAIN_FUSED_FWD")) == 0;
             static const bool ride_off = getenv("MPDX_TRAIN_RESTREAM_RIDE") && atoi(getenv("MPDX_TRAIN_RESTREAM_RIDE")) == 0;   // dev A/B switch
@@ -549,14 +554,15 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         fa.bias = packed + u->params[u->pidx.at("final_conv.1.bias")].off;
         fa.out = eps; fa.mode = 0; fa.n_per_ctx = 1;
         fa.B = B; fa.H = H; fa.D = D; fa.C = c.unet_input_dim;
+        fa.Hc = masked ? Hc : 0;
         if (!eps_done) launch_final_step(fa, st);
         const float* target = predict_epsilon ? noise : x_start;
         // loss value + dE + the gradient wrt final_conv[0]'s output (back through final_conv[1]) in one launch
         if (fa.C < D || D > 16) return fail(MPDX_E_INVALID, "training: unet_input_dim %d / state_dim %d (the loss kernel takes state_dim <= 16 <= unet_input_dim)", fa.C, D);
-        const size_t tot = (size_t)B * H * fa.C;
+        const size_t tot = (size_t)B * Hc * fa.C;
         hipLaunchKernelGGL(train_loss_kernel, dim3((unsigned)std::min<size_t>((tot + 1023) / 1024, 1024) + 16), dim3(1024), 0, st, (const float*)eps, target, weights_hd,
                            hard_start, hard_goal, l1, loss_scale, dE, flat + u->params[u->pidx.at("final_conv.1.weight")].foff, ws + w.grad0 + (size_t)(n - 1) * w.slotB,
-                           B, H, D, fa.C, loss_out, (double*)(ws + w.lossp), (unsigned*)(ws + w.ticket) + 1);   // (ticket word 1: zeroed by the pass's first launch)
+                           B, H, D, fa.C, loss_out, (double*)(ws + w.lossp), (unsigned*)(ws + w.ticket) + 1, masked ? Hc : 0);   // (ticket word 1: zeroed by the pass's first launch)
     }
     HIP_TRY(hipGetLastError());
 
@@ -571,10 +577,10 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     {   // final_conv[1]
         const int C = c.unet_input_dim;
         const int wi = u->pidx.at("final_conv.1.weight"), bi = u->pidx.at("final_conv.1.bias");
-        const size_t rows = (size_t)B * H;
+        const size_t rows = (size_t)B * Hc;   // (dE in the container layout: its rows behind the horizon are zero)
         // (grd(n - 1) = dE W was written by train_loss_kernel)
         WgradJob fj;
-        if (int rc = make_wgrad(dE, H, D, 0, D, out(n - 1), H, C, 0, C, 1, 0, 1, B, part, gflat(wi), C, 0, &df, fj)) return rc;
+        if (int rc = make_wgrad(dE, Hc, D, 0, D, out(n - 1), Hc, C, 0, C, 1, 0, 1, B, part, gflat(wi), C, 0, &df, fj)) return rc;
         const bool fb = attach_bias(fj, &df, gflat(bi), false);
         if (fj.deferred) lone.push_back(fj);   // rides with the other GEMMs that have no dgrad convolution (one launch behind the loop)
         else run_wgrad(fj, st);
@@ -627,8 +633,12 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             if (l.cout > 512) return fail(MPDX_E_INVALID, "layer %s: more than 512 channels", l.name.c_str());
             const int re = l.gs * l.L_out, regions = B * g.n_groups;
             const dim3 ggrid((regions + 3) / 4);
-            if (re == 256) hipLaunchKernelGGL(gn_mish_bwd_kernel<4>, ggrid, dim3(256), 0, st, g);
-            else if (re == 128) hipLaunchKernelGGL(gn_mish_bwd_kernel<2>, ggrid, dim3(256), 0, st, g);
+            g.Lv = l.Lv_out;
+            const bool mrows = l.Lv_out > 0 && l.Lv_out < l.L_out;   // a padded container: the general kernel carries the row mask
+            if (re == 256 && !mrows) hipLaunchKernelGGL(gn_mish_bwd_kernel<4>, ggrid, dim3(256), 0, st, g);
+            else if (re == 128 && !mrows) hipLaunchKernelGGL(gn_mish_bwd_kernel<2>, ggrid, dim3(256), 0, st, g);
+            else if (re == 256 && l.gs >= 4) hipLaunchKernelGGL((gn_mish_bwd_gen_kernel<4, 1>), ggrid, dim3(256), 0, st, g);
+            else if (re == 128 && l.gs >= 2) hipLaunchKernelGGL((gn_mish_bwd_gen_kernel<2, 1>), ggrid, dim3(256), 0, st, g);
             // horizons other than 64 (power-of-two containers 16 ... 128): regions of 64 / 512 / 1024 / 2048 elements
             else if (re == 64) hipLaunchKernelGGL((gn_mish_bwd_gen_kernel<1, 1>), ggrid, dim3(256), 0, st, g);
             else if (re == 512 && l.gs >= 4) hipLaunchKernelGGL((gn_mish_bwd_gen_kernel<4, 2>), ggrid, dim3(256), 0, st, g);
@@ -698,7 +708,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             }
             const int j = t.src1_l;
             bool gn_fused = false;
-            if (paired && !gnfuse_off && ((l.mode == CONV_S1 && l.ks == 5) || (l.mode == CONV_DOWN && dgl.ks == 3)) && l.c2 == 0 && j >= 0 && j != n - 1 && first_consumer[j] == i && t.res_l != j &&
+            if (paired && !masked && !gnfuse_off && ((l.mode == CONV_S1 && l.ks == 5) || (l.mode == CONV_DOWN && dgl.ks == 3)) && l.c2 == 0 && j >= 0 && j != n - 1 && first_consumer[j] == i && t.res_l != j &&
                 u->layers[j].epi == EPI_GN_MISH && u->layers[j].cout == l.c1 && df.on && df.col.n + 3 <= 120) {
                 const Layer& lj = u->layers[j];
                 const int re = lj.gs * lj.L_out;
