@@ -78,3 +78,30 @@ def test_unsupported_widths_are_rejected_loudly(width, mults):
         net = m.TemporalUnet(n_support_points=64, state_dim=4, unet_input_dim=width, dim_mults=mults)
         net = net.cuda()
         net(torch.zeros(1, 64, 4, device="cuda"), torch.zeros(1, dtype=torch.long, device="cuda"), None)
+
+
+@pytest.mark.parametrize("width,mults", [(64, (1, 2, 4)), (64, (1, 2)), (32, (1, 4, 8))])
+def test_training_at_other_widths_vs_oracle(width, mults):
+    """The training step on the channel plans the planning path accepts beyond the shipped ones (the reference's trainer is width-agnostic,
+    trainer.py:186-283 over temporal_unet.py:22-35): every gradient of p_losses against float64 autograd of the oracle."""
+    import mpd_public_amd as m
+    from mpd_public_amd.trainer import TrainStep
+    from oracle import train as otrain
+    D, B, T = 4, 6, 25
+    net, sd = _net(D, width, mults)
+    dm = m.GaussianDiffusionModel(model=net, n_diffusion_steps=T, predict_epsilon=True, loss_type="l2").cuda()
+    x0, noise = t(f"trw_x0_{width}", (B, 64, D), "uniform", 0.8), t(f"trw_noise_{width}", (B, 64, D))
+    hc = {0: t(f"trw_hc0_{width}", (B, D), "uniform", 0.7), 63: t(f"trw_hc1_{width}", (B, D), "uniform", 0.7)}
+    tt = torch.tensor([3, 24, 0, 12, 12, 7])
+    ts = TrainStep(dm)
+    loss, _ = ts.loss_backward(x0.cuda(), {k: v.cuda() for k, v in hc.items()}, t=tt.cuda(), noise=noise.cuda())
+    ref_loss, ref = otrain.loss_and_grads(sd, x0, tt, hc, noise, T, dtype=torch.float64)
+    assert abs(float(loss) - float(ref_loss)) < 5e-6 * max(1.0, abs(float(ref_loss)))
+    worst = 0.0
+    for name, p in dm.model.named_parameters():
+        g, r = p.grad.detach().cpu().double(), ref[name]
+        assert g.shape == r.shape and bool(torch.isfinite(g).all()), name
+        err = float((g - r).abs().max())
+        worst = max(worst, err / max(float(r.abs().max()), 1e-7))
+        assert err <= 2e-4 * max(float(r.abs().max()), 1e-7), (name, err, float(r.abs().max()))
+    print(f"width {width} x {mults}: worst relative gradient error {worst:.2e}")
