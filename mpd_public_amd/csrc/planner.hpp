@@ -52,9 +52,11 @@ __device__ __forceinline__ void gn_accumulate(float c, const float (&j)[QD], flo
 
 // Linearise every collision factor of interpolated point i whose index parity / group matches `half` (2 threads per point).
 // q: the point's configuration.  Writes MSZ = QD(QD+1)/2 + QD + 1 floats.
-template <int QD, int DIM, int ROBOT, int HALF>
+// PART of NPARTS (2 or 4): the point's factors are split over that many threads (of different waves) - Panda: ranges of link spheres and of
+// self-collision pairs, point mass: fields round-robin
+template <int QD, int DIM, int ROBOT, int PART, int NPARTS>
 __device__ __forceinline__ void gn_point(const mpdx_guide_params& gp, const float* sprim, const float (&q)[QD], float* out) {
-    constexpr int half = HALF;
+    static_assert(NPARTS == 2 || NPARTS == 4, "two or four parts");
     constexpr int NT = QD * (QD + 1) / 2;
     float M[NT], v[QD], c2 = 0.f;
 #pragma unroll
@@ -67,7 +69,7 @@ __device__ __forceinline__ void gn_point(const mpdx_guide_params& gp, const floa
         for (int j = 0; j < DIM; ++j) p[j] = q[j];
         const float margin = gp.link_margin + gp.cutoff_margin;
         for (int f = 0; f < gp.n_fields; ++f) {
-            if ((f & 1) != half) continue;
+            if ((f % NPARTS) != PART) continue;
             if (gp.fields[f].kind == MPDX_FIELD_OBJECTS) {
                 float fo[DIM];
                 const float c = objects_force<DIM>(sprim, gp.fields[f], p, margin, fo);
@@ -111,8 +113,9 @@ __device__ __forceinline__ void gn_point(const mpdx_guide_params& gp, const floa
                 } else { J[0][k] = J[1][k] = J[2][k] = 0.f; }
             }
         };
-        constexpr int s_beg = half ? 6 : 0, s_end = half ? kPandaNS : 6;     // static sphere / pair ranges: P[s], kPandaSF[s] are compile-time
-        constexpr int p_beg = half ? 6 : 0, p_end = half ? kPandaNP : 6;
+        // static sphere / pair ranges (P[s], kPandaSF[s] are compile-time): halves {0-5, 6-10} / {0-5, 6-11}, quarters {0-2, 3-5, 6-8, 9-10} / {0-2, 3-5, 6-8, 9-11}
+        constexpr int s_beg = NPARTS == 2 ? (PART ? 6 : 0) : 3 * PART, s_end = NPARTS == 2 ? (PART ? kPandaNS : 6) : (PART == 3 ? kPandaNS : 3 * PART + 3);
+        constexpr int p_beg = NPARTS == 2 ? (PART ? 6 : 0) : 3 * PART, p_end = NPARTS == 2 ? (PART ? kPandaNP : 6) : (PART == 3 ? kPandaNP : 3 * PART + 3);
 #pragma unroll
         for (int s = s_beg; s < s_end; ++s) {
             const int fr = kPandaSF[s] - 1;
@@ -185,7 +188,7 @@ __device__ __forceinline__ void gn_point(const mpdx_guide_params& gp, const floa
     out[NT + QD] = c2;
 }
 
-constexpr int kGpmpThreads = 256;
+constexpr int kGpmpThreads = 512;   // (round 5: 256 -> 512: the assembly and the solve's substitution / Schur phases are task-parallel over the threads - 102.6 -> 80.6 us per Panda iteration)
 
 template <int QD>
 inline size_t gpmp_lds_bytes(int H, int N, int n_prim_floats) {
@@ -220,7 +223,7 @@ struct Bcr {
 
 template <int QD>
 __device__ __forceinline__ void gpmp_bcr_solve(float* Dm, float* Cm, float* rhs, float* Lp, const int n, const int tid) {
-    constexpr int D = 2 * QD, DD = D * D, LSZ = D * (D + 1) / 2, NTHR = 256;
+    constexpr int D = 2 * QD, DD = D * D, LSZ = D * (D + 1) / 2, NTHR = kGpmpThreads;
     using G = Bcr<D>;
     int nlev = 0;
     for (int nl = n, s = 1; nl >= 1; nl >>= 1, s <<= 1, ++nlev) {
@@ -464,8 +467,7 @@ __global__ __launch_bounds__(kGpmpThreads, 1) void gpmp_lm_kernel(const GpmpArgs
 
     // linearise the collision factors at `src` and return F(src) (uniform over the workgroup)
     auto linearise = [&](const float* src) -> float {
-        for (int idx = tid; idx < 2 * N; idx += NTHR) {
-            const int half = idx >= N ? 1 : 0, i = idx - half * N;   // N is a multiple of 64 in practice: the half is wave-uniform
+        auto point_q = [&](int i, float (&q)[QD]) {
             int i0 = i, i1 = i;
             float l0 = 1.f, l1 = 0.f;
             if (gp.interpolate) {
@@ -476,11 +478,36 @@ __global__ __launch_bounds__(kGpmpThreads, 1) void gpmp_lm_kernel(const GpmpArgs
                 l1 = u - (float)i0;
                 l0 = 1.0f - l1;
             }
-            float q[QD];
 #pragma unroll
             for (int j = 0; j < QD; ++j) q[j] = l0 * src[i0 * D + j] + l1 * src[i1 * D + j];
-            if (half) gn_point<QD, DIM, ROBOT, 1>(gp, sprim, q, sM + (size_t)idx * MSZ);
-            else gn_point<QD, DIM, ROBOT, 0>(gp, sprim, q, sM + (size_t)idx * MSZ);
+        };
+        if (2 * N <= NTHR && (size_t)2 * N * MSZ <= (size_t)2 * n * DD) {
+            // FOUR threads per point (round 5; N is a multiple of 64 in practice: the part is wave-uniform): parts 0 / 1 write the two [N][MSZ] term
+            // arrays, parts 2 / 3 write theirs into the system's storage (Dm | Cm: not assembled yet) and add them behind a barrier - the term arrays
+            // stay two (four would not fit 160 KB of LDS next to the Panda's block-tridiagonal system).  Two threads per point left half of the 512
+            // threads idle for the iteration's largest phase.
+            const int part = tid / N, i = tid - part * N;   // (threads behind 4 N: no task)
+            float* const mine = part < 2 ? sM + ((size_t)part * N + i) * MSZ : Dm + ((size_t)(part - 2) * N + i) * MSZ;
+            if (part < 4) {
+                float q[QD];
+                point_q(i, q);
+                if (part == 0) gn_point<QD, DIM, ROBOT, 0, 4>(gp, sprim, q, mine);
+                else if (part == 1) gn_point<QD, DIM, ROBOT, 1, 4>(gp, sprim, q, mine);
+                else if (part == 2) gn_point<QD, DIM, ROBOT, 2, 4>(gp, sprim, q, mine);
+                else gn_point<QD, DIM, ROBOT, 3, 4>(gp, sprim, q, mine);
+            }
+            __syncthreads();
+            if (part == 2 || part == 3) {
+                float* dst = sM + ((size_t)(part - 2) * N + i) * MSZ;
+                for (int e = 0; e < MSZ; ++e) dst[e] += mine[e];
+            }
+        } else
+        for (int idx = tid; idx < 2 * N; idx += NTHR) {
+            const int half = idx >= N ? 1 : 0, i = idx - half * N;   // N is a multiple of 64 in practice: the half is wave-uniform
+            float q[QD];
+            point_q(i, q);
+            if (half) gn_point<QD, DIM, ROBOT, 1, 2>(gp, sprim, q, sM + (size_t)idx * MSZ);
+            else gn_point<QD, DIM, ROBOT, 0, 2>(gp, sprim, q, sM + (size_t)idx * MSZ);
         }
         // cost: GP prior (one thread per factor) + collision (c2 of every point half)
         float part = 0.f;

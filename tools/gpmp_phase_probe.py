@@ -29,14 +29,20 @@ for env_id, robot_id in (("EnvNarrowPassageDense2D", "RobotPointMass"), ("EnvSph
         st = _lib.current_stream()
         for _ in range(3):
             lib.mpdx_gpmp_step(C.byref(opt.gp), C.byref(opt.opts), x.data_ptr(), delta.data_ptr(), state.data_ptr(), B, H, D, solve, st)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        torch.cuda.synchronize()
+        early = delta[0].clone()   # (-DMPDX_GPMP_STAMPS build: the stamps of trajectory 0's third iteration - it may have converged by the end of the timed loop)
+        t0 = time.perf_counter()
         for _ in range(50):
             lib.mpdx_gpmp_step(C.byref(opt.gp), C.byref(opt.opts), x.data_ptr(), delta.data_ptr(), state.data_ptr(), B, H, D, solve, st)
         torch.cuda.synchronize()
         print(f"{env_id}-{robot_id}: solve={solve}: {(time.perf_counter() - t0) / 50 * 1e6:.1f} us per launch (B={B}, early iterations: every trajectory active)")
-        if solve and float(delta[0, 0].abs().max()) > 0:   # -DMPDX_GPMP_STAMPS build: s_memtime ticks of workgroup 0's phases
-            tk = delta[0, 0, :4].tolist()
+        if solve and float(early[0].abs().max()) > 0:   # -DMPDX_GPMP_STAMPS build: s_memtime ticks of workgroup 0's phases
+            tk = early[0, :4].tolist()
             print(f"   stamps (shader clocks): linearise+judge {tk[0]:.0f}  assemble {tk[1]:.0f}  solve {tk[2]:.0f}  write-back {tk[3]:.0f}")
+            bs = early[0:4].reshape(-1)[8:48].tolist() if early.numel() >= 48 and early.shape[1] >= 12 else []
+            if bs and any(bs):   # block cyclic reduction: after P1 / P2 / P3 of every level (slots 1 + 3 lev ..), 30 = forward done, 31 + lev = substitution level done
+                fw = [(round(bs[1 + 3 * l]), round(bs[2 + 3 * l]), round(bs[3 + 3 * l])) for l in range(6)]
+                print("   bcr stamps (ticks from solve start) per level (P1, P2, P3):", fw, " forward done", round(bs[30]), " substitution levels 5..0 done", [round(bs[31 + l]) for l in range(5, -1, -1)])
     for sig in (1e-3, 5e-4, 2e-4):
         for iters in (500, 1000):
             o = GPMP2(ds, dt, sigma_obs=sig)
