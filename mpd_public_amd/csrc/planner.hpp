@@ -221,11 +221,18 @@ struct Bcr {
     }
 };
 
+#ifdef MPDX_GPMP_STAMPS   // dev probe (tools/gpmp_phase_probe.py): s_memtime after P1 / P2 / P3 of every level (slots 1 + 3 lev ..), 30 = forward done, 31 + lev = substitution level done
+__device__ long long g_bcr_st[64];
+#define BCR_STAMP(i) do { if (tid == 0 && blockIdx.x == 0) g_bcr_st[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BCR_STAMP(i)
+#endif
 template <int QD>
 __device__ __forceinline__ void gpmp_bcr_solve(float* Dm, float* Cm, float* rhs, float* Lp, const int n, const int tid) {
     constexpr int D = 2 * QD, DD = D * D, LSZ = D * (D + 1) / 2, NTHR = kGpmpThreads;
     using G = Bcr<D>;
     int nlev = 0;
+    BCR_STAMP(0);
     for (int nl = n, s = 1; nl >= 1; nl >>= 1, s <<= 1, ++nlev) {
         const int ne = (nl + 1) >> 1, nk = nl >> 1;
         // ---- P1: Cholesky of the eliminated diagonal blocks (registers; l_kk is stored as its reciprocal)
@@ -253,6 +260,7 @@ __device__ __forceinline__ void gpmp_bcr_solve(float* Dm, float* Cm, float* rhs,
             for (int i = 0; i < LSZ; ++i) L[i] = a[i];
         }
         __syncthreads();
+        BCR_STAMP(1 + 3 * nlev);
         // ---- P2: forward substitutions, one lane per right-hand-side column
         for (int task = tid; task < ne * (2 * D + 1); task += NTHR) {
             const int t = task / (2 * D + 1), c = task - t * (2 * D + 1), p = 2 * t, e = G::idx(p, s);
@@ -280,6 +288,7 @@ __device__ __forceinline__ void gpmp_bcr_solve(float* Dm, float* Cm, float* rhs,
             for (int i = 0; i < D; ++i) v[i * stride] = y[i];
         }
         __syncthreads();
+        BCR_STAMP(2 + 3 * nlev);
         // ---- P3: Schur complements onto the kept blocks and the next level's couplings
         if constexpr (D > 8 && D < 16) {
             // d x d x d products on the matrix cores: one wave = one product, four v_mfma_f32_16x16x4_f32 (d padded to 16 by zero operands; exact fp32
@@ -380,7 +389,9 @@ __device__ __forceinline__ void gpmp_bcr_solve(float* Dm, float* Cm, float* rhs,
         }
         }
         __syncthreads();
+        BCR_STAMP(3 + 3 * nlev);
     }
+    BCR_STAMP(30);
     // ---- substitution, deepest level first
     for (int lev = nlev - 1; lev >= 0; --lev) {
         const int s = 1 << lev, nl = n >> lev, ne = (nl + 1) >> 1;
@@ -420,6 +431,7 @@ __device__ __forceinline__ void gpmp_bcr_solve(float* Dm, float* Cm, float* rhs,
             for (int i = 0; i < D; ++i) xe[i] = x[i];
         }
         __syncthreads();
+        BCR_STAMP(31 + lev);
     }
 }
 
@@ -684,6 +696,7 @@ __global__ __launch_bounds__(kGpmpThreads, 1) void gpmp_lm_kernel(const GpmpArgs
         GPMP_STAMP(4);
         // [linearise + judge, assemble, solve, write back] in s_memtime ticks (shader clock)
         for (int i = 0; i < 4; ++i) a.delta[base + i] = (float)(stamp[i + 1] - stamp[i]);
+        for (int i = 0; i < 40; ++i) a.delta[base + 8 + i] = (float)(g_bcr_st[i] - g_bcr_st[0]);   // (dev build only: overwrites trajectory 0's first proposals)
     }
 #endif
 }
