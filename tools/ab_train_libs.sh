@@ -1,5 +1,5 @@
 #!/bin/bash
-# gpurun job: training tests + A/B of two libraries on the training iteration (batch 32 / 128 / 512), interleaved
+# gpurun job: training tests + A/B of two libraries on the training iteration (batch 32 / 128 / 512), interleaved: build_ab/libmpdx_head.so (a build of the commit to compare with) vs the tree
 cd $GRAFT_REPO_ROOT; O=gpurun_out/s3; mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_train.py tests/test_gpu_parity.py -m gpu -x -q -k "train or loss or gradient or golden" 2>&1 | grep -v "amdgpu.ids" | tail -3 | tee $O/train_tests_ab.txt
 for r in 1 2 3; do
