@@ -1277,9 +1277,9 @@ __global__ __launch_bounds__(1024) void train_loss_kernel(const float* __restric
         // Round 5: a block takes 1024 / C rows at a time - the rows' dE terms are computed ONCE (D per row, by the first rows x D threads) and staged in
         // LDS with final_conv[1]'s weights, then thread (row, c) runs its D FMAs out of LDS.  (Below: every (row, c) thread loaded all of its row's D
         // predictions, targets and weights itself - 64 loads per output, 16.6 us for the launch at batch 128 x D = 14.)  Same g, same fmaf chain over d.
-        __shared__ float gS[64 * 16], wS[16 * 1024 / 16];   // [rows per block <= 64][16] | [D][C] (D * C <= 16 * 64 ... see the guard)
+        __shared__ float gS[64 * 32], wS[1024];   // [rows per block <= 64][32] | [D][C] (D <= 32, D * C <= 1024, rows per block x D <= 1024: the guard below)
         const int rpb = 1024 / C;
-        if (rpb <= 64 && D * C <= 1024) {
+        if (rpb <= 64 && D <= 32 && D * C <= 1024 && rpb * D <= 1024) {
             const int tid = threadIdx.x, rl = tid / C, c = tid - rl * C;
             for (int k = tid; k < D * C; k += 1024) wS[k] = w[k];
             for (size_t r0 = (size_t)blockIdx.x * rpb; r0 < rows; r0 += (size_t)nb * rpb) {
@@ -1299,13 +1299,13 @@ __global__ __launch_bounds__(1024) void train_loss_kernel(const float* __restric
                         }
                         dE[r * D + d] = g;
                     }
-                    gS[rr * 16 + d] = g;
+                    gS[rr * 32 + d] = g;
                 }
                 __syncthreads();
                 const size_t r = r0 + rl;
                 if (r < rows) {
                     float sacc = 0.f;
-                    for (int d = 0; d < D; ++d) sacc = fmaf(gS[rl * 16 + d], wS[d * C + c], sacc);
+                    for (int d = 0; d < D; ++d) sacc = fmaf(gS[rl * 32 + d], wS[d * C + c], sacc);
                     gH[r * C + c] = sacc;
                 }
             }

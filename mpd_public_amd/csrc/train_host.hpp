@@ -558,7 +558,11 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         if (!eps_done) launch_final_step(fa, st);
         const float* target = predict_epsilon ? noise : x_start;
         // loss value + dE + the gradient wrt final_conv[0]'s output (back through final_conv[1]) in one launch
-        if (fa.C < D || D > 16) return fail(MPDX_E_INVALID, "training: unet_input_dim %d / state_dim %d (the loss kernel takes state_dim <= 16 <= unet_input_dim)", fa.C, D);
+        {   // train_loss_kernel: state_dim <= 16 in its plain form (padded containers, odd widths), <= 32 in the LDS-staged form (1024 % C == 0, D C <= 1024)
+            const bool staged = !masked && fa.C > 0 && 1024 % fa.C == 0 && 1024 / fa.C <= 64 && D * fa.C <= 1024 && (1024 / fa.C) * D <= 1024;
+            if (fa.C < D || D > 32 || (D > 16 && !staged))
+                return fail(MPDX_E_INVALID, "training: unet_input_dim %d / state_dim %d (the loss kernel takes state_dim <= 32 <= unet_input_dim; <= 16 for padded horizons)", fa.C, D);
+        }
         const size_t tot = (size_t)B * Hc * fa.C;
         hipLaunchKernelGGL(train_loss_kernel, dim3((unsigned)std::min<size_t>((tot + 1023) / 1024, 1024) + 16), dim3(1024), 0, st, (const float*)eps, target, weights_hd,
                            hard_start, hard_goal, l1, loss_scale, dE, flat + u->params[u->pidx.at("final_conv.1.weight")].foff, ws + w.grad0 + (size_t)(n - 1) * w.slotB,

@@ -29,7 +29,7 @@ def _batch(D, B=6):
 TTS = [torch.tensor([3, 24, 0, 12, 12, 7]), torch.tensor([1, 5, 20, 9, 0, 17])]
 
 
-@pytest.mark.parametrize("D,opt", [(4, 1), (14, 0), (6, 1), (2, 0)])
+@pytest.mark.parametrize("D,opt", [(4, 1), (14, 0), (6, 1), (2, 0), (24, 1), (32, 0)])
 @pytest.mark.parametrize("loss_type,pred_eps", [("l2", True), ("l1", False)])
 def test_loss_backward_every_gradient_vs_oracle(D, opt, loss_type, pred_eps):
     """d loss / d (every parameter) of p_losses (diffusion_model_base.py:331-352) against float64 autograd of the oracle."""
