@@ -139,6 +139,10 @@ class TemporalUnet(nn.Module):
     def _handle(self):
         if self._h is None:
             lib = _lib.load()
+            pad = (int(self.state_dim) + 15) // 16 * 16   # the first convolution's input channels as the kernels pad them
+            if pad & (pad - 1):   # 48: state_dim 33 ... 48 - refused here, at construction of the engine, with the layer's reason (the kernels index by shifts)
+                raise RuntimeError(f"state_dim {self.state_dim} unsupported: the first convolution reads {pad} padded input channels, the kernels take a power of "
+                                   "two (state_dim <= 32 or 49 ... 64)")
             mults = (C.c_int32 * _lib.MAX_LEVELS)(*self.dim_mults)
             cfg = _lib.UnetCfg(int(self.state_dim), int(self.n_support_points), int(self.unet_input_dim), len(self.dim_mults),
                                mults, int(self.time_emb_dim))

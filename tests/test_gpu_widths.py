@@ -105,3 +105,42 @@ def test_training_at_other_widths_vs_oracle(width, mults):
         worst = max(worst, err / max(float(r.abs().max()), 1e-7))
         assert err <= 2e-4 * max(float(r.abs().max()), 1e-7), (name, err, float(r.abs().max()))
     print(f"width {width} x {mults}: worst relative gradient error {worst:.2e}")
+
+
+@pytest.mark.parametrize("D", [2, 6, 24, 64])
+def test_state_dimensions_other_than_the_shipped_ones_vs_oracle(D):
+    """state_dim is free in the reference (temporal_unet.py:22-35: the first conv reads it, final_conv[1] writes it).  mpdx_unet_create accepts
+    1 ... 32 and 49 ... 64 (the first convolution's padded input channels must be a power of two: 33 ... 48 are refused at construction): the U-Net pass
+    on both kernel paths and a short unguided chain on both, against the oracle."""
+    import mpd_public_amd as m
+    from oracle.unet import unet_forward
+    from oracle import diffusion as odiff
+    net, sd = _net(D, 32, (1, 2, 4, 8))
+    for B in (3, 70):
+        x = t(f"sd_x_{D}_{B}", (B, 64, D))
+        tv = torch.full((B,), 11, dtype=torch.long)
+        ref = unet_forward(sd, x[:3], tv[:3]).numpy()
+        for fused in (True, False):
+            with kernel_path(fused):
+                y = net(x.cuda(), tv.cuda(), None).cpu().numpy()
+            np.testing.assert_allclose(y[:3], ref, rtol=0, atol=2e-5, err_msg=f"D={D} B={B} fused={fused}")
+    T, Bc, n0 = 10, 4, 2
+    dm = m.GaussianDiffusionModel(model=net, variance_schedule="exponential", n_diffusion_steps=T, predict_epsilon=True).cuda().eval()
+    noise = t(f"sd_noise_{D}", (T + n0 + 1, Bc, 64, D))
+    hc = {0: t(f"sd_hc0_{D}", (D,), "uniform"), 63: t(f"sd_hc1_{D}", (D,), "uniform")}
+    ref = odiff.run_inference(sd, hc, noise, T, n_diffusion_steps_without_noise=n0, noise_std=0.5)
+    chains = []
+    for fused in (True, False):
+        with kernel_path(fused):
+            chains.append(dm.run_inference(None, {k: v.cuda() for k, v in hc.items()}, n_samples=Bc, horizon=64, return_chain=True, sample_fn=m.ddpm_sample_fn,
+                                           n_diffusion_steps_without_noise=n0, noise_std_extra_schedule_fn=lambda tt: 0.5, noise=noise.cuda()).cpu())
+    np.testing.assert_allclose(chains[0].numpy(), ref.numpy(), rtol=0, atol=2e-3)
+    np.testing.assert_allclose(chains[0][-1].numpy(), ref[-1].numpy(), rtol=0, atol=5e-4)
+    np.testing.assert_allclose(chains[1].numpy(), ref.numpy(), rtol=0, atol=2e-3)
+
+
+def test_state_dim_with_48_padded_channels_is_refused_at_construction():
+    import mpd_public_amd as m
+    with pytest.raises(RuntimeError, match="state_dim 40 unsupported"):
+        net = m.TemporalUnet(n_support_points=64, state_dim=40, unet_input_dim=32, dim_mults=(1, 2, 4, 8)).cuda()
+        net(torch.zeros(1, 64, 40, device="cuda"), torch.zeros(1, dtype=torch.long, device="cuda"), None)
