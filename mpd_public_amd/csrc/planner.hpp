@@ -493,7 +493,7 @@ __global__ __launch_bounds__(kGpmpThreads, 1) void gpmp_lm_kernel(const GpmpArgs
 #pragma unroll
             for (int j = 0; j < QD; ++j) q[j] = l0 * src[i0 * D + j] + l1 * src[i1 * D + j];
         };
-        if (2 * N <= NTHR && (size_t)2 * N * MSZ <= (size_t)2 * n * DD) {
+        if (4 * N <= NTHR && (size_t)2 * N * MSZ <= (size_t)2 * n * DD) {   // (one task per thread: 4 N of them)
             // FOUR threads per point (round 5; N is a multiple of 64 in practice: the part is wave-uniform): parts 0 / 1 write the two [N][MSZ] term
             // arrays, parts 2 / 3 write theirs into the system's storage (Dm | Cm: not assembled yet) and add them behind a barrier - the term arrays
             // stay two (four would not fit 160 KB of LDS next to the Panda's block-tridiagonal system).  Two threads per point left half of the 512

@@ -135,7 +135,11 @@ def test_rrt_connect_full_tree_or_iteration_cap_reports_unsolved():
         assert bool(edges_free(ds.task, p[:-1].cuda().contiguous(), p[1:].cuda().contiguous(), 64).all())
 
 
-@pytest.mark.parametrize("env_id,robot_id,H,n_interp", [("EnvDense2D", "RobotPointMass", 64, 128), ("EnvSpheres3D", "RobotPanda", 16, 32)])
+@pytest.mark.parametrize("env_id,robot_id,H,n_interp", [("EnvDense2D", "RobotPointMass", 64, 128), ("EnvSpheres3D", "RobotPanda", 16, 32),
+                                                         # the linearisation's thread mappings: 4 N = 512 threads (above), N = 96 (parts not wave-aligned), N = 256 (two
+                                                         # threads per point: 4 N > 512), the Panda at the generator's size (H = 64, 128 points: the four-part mapping)
+                                                         ("EnvDense2D", "RobotPointMass", 64, 96), ("EnvDense2D", "RobotPointMass", 64, 256),
+                                                         ("EnvSpheres3D", "RobotPanda", 64, 128)])
 def test_gpmp2_lm_step_vs_oracle(env_id, robot_id, H, n_interp):
     """One Levenberg-Marquardt step of the HIP kernel (hand-derived factor Jacobians, block-tridiagonal system assembled and solved
     in LDS, fp32) == oracle/gpmp.py (forward-mode autograd Jacobian of the stacked residuals, dense float64 solve), and the
