@@ -34,7 +34,16 @@ class GaussianDiffusionModel(nn.Module):
         self.predict_epsilon = predict_epsilon
         self.loss_type = loss_type
         self.loss_fn = {"l1": "WeightedL1", "l2": "WeightedL2"}.get(loss_type, loss_type)  # the reference keeps the loss module here
-        for name, value in diffusion_buffers(variance_schedule, n_diffusion_steps).items():
+        bufs = diffusion_buffers(variance_schedule, n_diffusion_steps)
+        if not all(bool(torch.isfinite(v).all()) for v in bufs.values()):
+            # the reference's exponential_beta_schedule (helpers.py:40-46) rounds beta_{T-1} ABOVE 1 for most step counts (finite for T = 1, 25, 47, 50, 55,
+            # 61, 73, 94, 97, 100, ... - the shipped models use 25 and 100): alphas turn negative and the square roots NaN.  Reproduced bit for bit, like
+            # every other buffer - but said out loud, because every plan of such a model is NaN (in the reference too)
+            import warnings
+            warnings.warn(f"variance_schedule={variance_schedule!r} with n_diffusion_steps={n_diffusion_steps} yields non-finite schedule buffers (the reference's "
+                          "formula does: its last beta rounds above 1) - sampling and training will produce NaN; use 25 / 50 / 100 steps or the cosine schedule",
+                          RuntimeWarning, stacklevel=2)
+        for name, value in bufs.items():
             self.register_buffer(name, value)
         self._host = None
         self._host_stamp = None

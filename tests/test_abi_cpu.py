@@ -224,3 +224,17 @@ def test_elementwise_helpers_of_the_diffusion_class_match_the_oracle():
             assert torch.equal(mean, buf["posterior_mean_coef1"][ti] * x0 + buf["posterior_mean_coef2"][ti] * x)
             assert var.shape == (B, 1, 1) and float(var[0]) == float(buf["posterior_variance"][ti])
             assert float(logvar[0]) == float(buf["posterior_log_variance_clipped"][ti])
+
+
+def test_non_finite_reference_schedule_is_said_out_loud():
+    """helpers.py:40-46 (exponential_beta_schedule) rounds its last beta above 1 for most step counts: the buffers - reproduced bit for bit - are NaN
+    there, in the reference too.  The constructor warns; the shipped step counts (25, 100) and the cosine schedule are finite and silent."""
+    import warnings
+    import mpd_public_amd as m
+    net = m.TemporalUnet(n_support_points=64, state_dim=4, unet_input_dim=32, dim_mults=m.UNET_DIM_MULTS[0])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for sched, T in (("exponential", 25), ("exponential", 100), ("cosine", 40), ("cosine", 7)):
+            m.GaussianDiffusionModel(model=net, variance_schedule=sched, n_diffusion_steps=T)
+    with pytest.warns(RuntimeWarning, match="non-finite schedule buffers"):
+        m.GaussianDiffusionModel(model=net, variance_schedule="exponential", n_diffusion_steps=40)
