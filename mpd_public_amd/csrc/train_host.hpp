@@ -560,8 +560,8 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         // loss value + dE + the gradient wrt final_conv[0]'s output (back through final_conv[1]) in one launch
         {   // train_loss_kernel: state_dim <= 16 in its plain form (padded containers, odd widths), <= 32 in the LDS-staged form (1024 % C == 0, D C <= 1024)
             const bool staged = !masked && fa.C > 0 && 1024 % fa.C == 0 && 1024 / fa.C <= 64 && D * fa.C <= 1024 && (1024 / fa.C) * D <= 1024;
-            if (fa.C < D || D > 32 || (D > 16 && !staged))
-                return fail(MPDX_E_INVALID, "training: unet_input_dim %d / state_dim %d (the loss kernel takes state_dim <= 32 <= unet_input_dim; <= 16 for padded horizons)", fa.C, D);
+            if (fa.C < D || D > 32 || (D > 16 && !staged && !masked))   // (the padded-container form loops over d: any D)
+                return fail(MPDX_E_INVALID, "training: unet_input_dim %d / state_dim %d (the loss kernel takes state_dim <= 32 <= unet_input_dim)", fa.C, D);
         }
         const size_t tot = (size_t)B * Hc * fa.C;
         hipLaunchKernelGGL(train_loss_kernel, dim3((unsigned)std::min<size_t>((tot + 1023) / 1024, 1024) + 16), dim3(1024), 0, st, (const float*)eps, target, weights_hd,
