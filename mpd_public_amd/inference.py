@@ -207,5 +207,7 @@ if __name__ == "__main__":
     ap.add_argument("--n_samples", type=int, default=50)
     ap.add_argument("--seed", type=int, default=30)
     ap.add_argument("--results_dir", default="logs")
+    ap.add_argument("--model_dir", default=None, help="a results directory of mpd_public_amd.train (args.yaml, limits.yaml, checkpoints/): plan with its trained weights")
+    ap.add_argument("--n_diffusion_steps_without_noise", type=int, default=5)
     a = ap.parse_args()
     experiment(**vars(a))
