@@ -116,6 +116,17 @@ def test_generate_collision_free_trajectories_entry(tmp_path):
     assert float(acc(last["trajs_iters"][-1])) < float(acc(last["trajs_init"]))
 
 
+def test_generation_experiment_entry_writes_metadata(tmp_path):
+    """experiment(...) of scripts/generate_data/generate_trajectories.py:170-246: metadata.yaml beside the trajectory files, unknown keyword arguments swallowed."""
+    import yaml
+    from mpd_public_amd.generate_trajectories import experiment
+    n_coll, n_free = experiment(env_id="EnvSimple2D", robot_id="RobotPointMass", num_trajectories=8, threshold_start_goal_pos=1.0, results_dir=str(tmp_path),
+                                seed=5, debug=False, gpmp_opt_iters=150, some_launcher_key=1)
+    md = yaml.safe_load(open(tmp_path / "metadata.yaml"))
+    assert md["env_id"] == "EnvSimple2D" and md["num_trajectories"] == 8 and md["num_trajectories_generated"] == n_coll + n_free == 8
+    assert md["num_trajectories_generated_free"] == n_free and (tmp_path / "trajs-free.pt").exists() and (tmp_path / "results_data_dict.pickle").exists()
+
+
 def test_rrt_connect_full_tree_or_iteration_cap_reports_unsolved():
     """a problem whose tree fills up (or that runs out of iterations) must END unsolved - never record a link through a
     node that was not inserted.  A tiny node budget in the narrow-passage environment forces both outcomes."""
