@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-@pytest.mark.parametrize("tool,cases,seed", [("fuzz_plan.py", 12, 11), ("fuzz_contexts.py", 6, 12), ("fuzz_guide.py", 12, 13), ("fuzz_train.py", 8, 14)])
+@pytest.mark.parametrize("tool,cases,seed", [("fuzz_plan.py", 12, 11), ("fuzz_contexts.py", 6, 12), ("fuzz_guide.py", 12, 13), ("fuzz_train.py", 8, 14), ("fuzz_planner.py", 8, 15)])
 def test_fuzz_tool_reports_no_mismatch(tool, cases, seed):
     out = subprocess.run([sys.executable, str(ROOT / "tools" / tool), str(cases), str(seed)], capture_output=True, text=True, timeout=900)
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
