@@ -12,6 +12,26 @@ def synth_sd(D, opt):
     return syn.synth_state_dict(unet_param_shapes(D, 32, DIM_MULTS[opt]))
 
 
+# (horizon, state_dim, dim_mults option) of tests/golden/shapes.npz (make_golden.py::SHAPE_CASES) and the probe vector stored per case
+SHAPE_CASES = ((32, 4, 1), (128, 4, 0), (48, 4, 1), (24, 6, 0), (40, 2, 1), (96, 14, 1), (64, 24, 0))
+
+
+def grad_probe(grads, names):
+    """16 strided samples of every gradient tensor, parameter order (make_golden.py::grad_probe)"""
+    parts = []
+    for k in names:
+        v = grads[k].detach().reshape(-1).to(torch.float32).cpu()
+        parts.append(v[::max(1, v.numel() // 16)][:16])
+    return torch.cat(parts)
+
+
+def shape_case_batch(H, D, opt, B=5):
+    tag = f"H{H}_D{D}_opt{opt}"
+    x0, noise = t(f"shp_x0_{tag}", (B, H, D), "uniform", 0.8), t(f"shp_noise_{tag}", (B, H, D))
+    hc = {0: t(f"shp_hc0_{tag}", (B, D), "uniform", 0.7), H - 1: t(f"shp_hc1_{tag}", (B, D), "uniform", 0.7)}
+    return tag, x0, noise, hc, torch.tensor([3, 24, 0, 12, 7])
+
+
 def toy_cost(x, x_interpolated=None, return_invidual_costs_and_weights=False, **kw):
     q = x.shape[-1] // 2
     c1 = (x_interpolated[..., :q] - 0.3).pow(2).sum((-1, -2)) * 3.0

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import synth_sd, t, load_npz, DIM_MULTS
+from helpers import synth_sd, t, load_npz, DIM_MULTS, SHAPE_CASES, grad_probe, shape_case_batch, kernel_path
 
 pytestmark = pytest.mark.gpu
 
@@ -583,6 +583,37 @@ def test_training_at_other_horizons_vs_oracle(H, opt):
     for name, p in dm.model.named_parameters():
         d = (p.detach().cpu() - want[name]).abs()
         assert float(d.max()) < 1.01e-4 and int((d > 5e-6).sum()) <= max(2, int(1e-3 * d.numel())), (name, float(d.max()), int((d > 5e-6).sum()))
+
+
+@pytest.mark.parametrize("H,D,opt", SHAPE_CASES)
+def test_other_horizons_and_state_dims_vs_reference_golden(golden_dir, H, D, opt):
+    """The shapes this round added to the training step and the planning path - horizons 24 ... 128 (padded ones in their containers), state
+    dimensions 2 / 6 / 24 - against what the REAL reference produced for them (tests/golden/shapes.npz, make_golden.py --only shapes): eps on both
+    kernel paths, one training iteration's loss, every parameter's gradient norm, the gradient probe, the total norm of clip_grad_norm_."""
+    import mpd_public_amd as m
+    from mpd_public_amd.trainer import TrainStep
+    g = load_npz(golden_dir / "shapes.npz")
+    tag, x0, noise, hc, tt = shape_case_batch(H, D, opt)
+    net = m.TemporalUnet(n_support_points=H, state_dim=D, unet_input_dim=32, dim_mults=DIM_MULTS[opt])
+    net.load_state_dict(synth_sd(D, opt), strict=True)
+    dm = m.GaussianDiffusionModel(model=net, n_diffusion_steps=25, predict_epsilon=True, loss_type="l2").cuda()
+    x = t(f"shp_x_{tag}", (3, H, D)).cuda()
+    for fused in (True, False):
+        with kernel_path(fused):
+            for ts in (0, 12):
+                y = dm.model(x, torch.full((3,), ts, dtype=torch.long, device="cuda"), None).cpu().numpy()
+                np.testing.assert_allclose(y, g[f"{tag}_eps_t{ts}"], rtol=0, atol=2e-5, err_msg=f"{tag} t={ts} fused={fused}")
+    names = [str(k) for k in g[f"names_opt{opt}"]]
+    step = TrainStep(dm)
+    loss, _ = step.loss_backward(x0.cuda(), {k: v.cuda() for k, v in hc.items()}, t=tt.cuda(), noise=noise.cuda())
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 5e-6 * max(1.0, float(loss))
+    named = dict(dm.model.named_parameters())
+    grads = {k: named[k].grad for k in names}
+    np.testing.assert_allclose(np.array([float(grads[k].norm()) for k in names]), g[f"{tag}_grad_norms"], rtol=3e-4, atol=1e-7)
+    ref = g[f"{tag}_grad_probe"]
+    np.testing.assert_allclose(grad_probe(grads, names).numpy(), ref, rtol=0, atol=3e-4 * np.abs(ref).max())
+    norm = step.adam_step(1e-4, max_norm=1.0)
+    assert abs(float(norm) - float(g[f"{tag}_total_norm"])) < 3e-4 * float(norm)
 
 
 def test_launch_merges_leave_every_gradient_bit_identical():

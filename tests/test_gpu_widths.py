@@ -144,3 +144,25 @@ def test_state_dim_with_48_padded_channels_is_refused_at_construction():
     with pytest.raises(RuntimeError, match="state_dim 40 unsupported"):
         net = m.TemporalUnet(n_support_points=64, state_dim=40, unet_input_dim=32, dim_mults=(1, 2, 4, 8)).cuda()
         net(torch.zeros(1, 64, 40, device="cuda"), torch.zeros(1, dtype=torch.long, device="cuda"), None)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_padded_horizon_chain_vs_reference_golden(golden_dir, fused):
+    """unguided T = 25 (+3) chain at horizon 48 (a 64-row container on the device) against the REAL reference (make_golden.py --only shapes),
+    at the cfg1 tolerances"""
+    import mpd_public_amd as m
+    from helpers import synth_sd, DIM_MULTS
+    g = load_npz(golden_dir / "shapes.npz")
+    H, D, opt, T, B, n0 = 48, 4, 1, 25, 3, 3
+    net = m.TemporalUnet(n_support_points=H, state_dim=D, unet_input_dim=32, dim_mults=DIM_MULTS[opt])
+    net.load_state_dict(synth_sd(D, opt), strict=True)
+    dm = m.GaussianDiffusionModel(model=net, variance_schedule="exponential", n_diffusion_steps=T, predict_epsilon=True).cuda().eval()
+    noise = t("shp_chain_noise", (T + n0 + 1, B, H, D)).cuda()
+    hc = {0: t("shp_chain_hc0", (D,), "uniform").cuda(), H - 1: t("shp_chain_hc1", (D,), "uniform").cuda()}
+    with kernel_path(fused):
+        chain = dm.run_inference(None, hc, n_samples=B, horizon=H, return_chain=True, sample_fn=m.ddpm_sample_fn,
+                                 n_diffusion_steps_without_noise=n0, noise_std_extra_schedule_fn=lambda tt: 0.5, noise=noise).cpu().numpy()
+    ref = g["H48_chain"]
+    assert chain.shape == ref.shape
+    np.testing.assert_allclose(chain, ref, rtol=0, atol=2e-3)
+    np.testing.assert_allclose(chain[-1], ref[-1], rtol=0, atol=5e-4)

@@ -10,7 +10,7 @@ from oracle import schedules, unet, diffusion
 from oracle.guide import GuideManager
 from oracle.normalizer import LimitsNormalizer
 from mpd_public_amd import synthetic as syn
-from helpers import synth_sd, toy_cost, t, load_npz, DIM_MULTS
+from helpers import synth_sd, toy_cost, t, load_npz, DIM_MULTS, SHAPE_CASES, grad_probe, shape_case_batch
 
 
 def test_synthetic_weights_are_reproducible(golden_dir):
@@ -243,3 +243,38 @@ def test_width64_unet_and_chain_match_reference(golden_dir, D):
         hc = {0: t("w64_hc0", (D,), "uniform"), 63: t("w64_hc1", (D,), "uniform")}
         chain = diffusion.run_inference(sd, hc, noise, T, n_diffusion_steps_without_noise=n0, noise_std=0.5).numpy()
         np.testing.assert_allclose(chain, g["w64_chain"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("H,D,opt", SHAPE_CASES)
+def test_other_horizons_and_state_dims_match_reference(golden_dir, H, D, opt):
+    """Horizons 24 ... 128 and state dimensions 2 / 6 / 24 (temporal_unet.py:22-35,80-116 and trainer.py:186-283 take any horizon divisible by
+    2^(levels - 1) and any state_dim) against the REAL reference (tests/golden/make_golden.py --only shapes): eps at two timesteps, and one
+    training iteration's loss, per-parameter gradient norms, gradient probe and total norm."""
+    from oracle import train as otrain
+    g = load_npz(golden_dir / "shapes.npz")
+    sd = synth_sd(D, opt)
+    tag, x0, noise, hc, tt = shape_case_batch(H, D, opt)
+    x = t(f"shp_x_{tag}", (3, H, D))
+    for ts in (0, 12):
+        y = unet.unet_forward(sd, x, torch.full((3,), ts, dtype=torch.long)).numpy()
+        np.testing.assert_allclose(y, g[f"{tag}_eps_t{ts}"], rtol=0, atol=2e-6)
+    names = [str(k) for k in g[f"names_opt{opt}"]]
+    assert set(names) == set(sd)
+    loss, grads = otrain.loss_and_grads(sd, x0, tt, hc, noise, 25)
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 2e-6 * max(1.0, abs(float(loss)))
+    np.testing.assert_allclose(np.array([float(grads[k].norm()) for k in names]), g[f"{tag}_grad_norms"], rtol=2e-4, atol=1e-7)
+    ref = g[f"{tag}_grad_probe"]
+    np.testing.assert_allclose(grad_probe(grads, names).numpy(), ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+    total, _ = otrain.clip_grad_norm(grads, 1.0)
+    assert abs(float(total) - float(g[f"{tag}_total_norm"])) < 2e-4 * float(total)
+
+
+def test_padded_horizon_chain_matches_reference(golden_dir):
+    """unguided T = 25 (+3) chain at horizon 48 against the REAL reference (make_golden.py --only shapes)"""
+    g = load_npz(golden_dir / "shapes.npz")
+    H, D, opt, T, B, n0 = 48, 4, 1, 25, 3, 3
+    noise = t("shp_chain_noise", (T + n0 + 1, B, H, D))
+    hc = {0: t("shp_chain_hc0", (D,), "uniform"), H - 1: t("shp_chain_hc1", (D,), "uniform")}
+    chain = diffusion.run_inference(synth_sd(D, opt), hc, noise, T, n_diffusion_steps_without_noise=n0, noise_std=0.5).numpy()
+    assert chain.shape == g["H48_chain"].shape
+    np.testing.assert_allclose(chain, g["H48_chain"], rtol=0, atol=2e-5)
