@@ -9,8 +9,10 @@ from .sample_functions import ddpm_sample_fn, guide_gradient_steps, apply_hard_c
 
 from .guides import GuideManagerTrajectoriesWithVelocity  # noqa: F401
 from .planning import CostCollision, CostGPTrajectory, CostComposite, PlanningTask, make_env, make_robot  # noqa: F401
-from .datasets import TrajectoryDataset, LimitsNormalizer  # noqa: F401
+from .datasets import (TrajectoryDataset, LimitsNormalizer, SafeLimitsNormalizer, FixedLimitsNormalizer, GaussianNormalizer, Identity,  # noqa: F401
+                       make_normalizer)
 
 __all__ = ["TemporalUnet", "UNET_DIM_MULTS", "GaussianDiffusionModel", "ddpm_sample_fn", "guide_gradient_steps",
            "apply_hard_conditioning", "extract", "GuideManagerTrajectoriesWithVelocity", "CostCollision", "CostGPTrajectory",
-           "CostComposite", "PlanningTask", "TrajectoryDataset", "LimitsNormalizer", "make_env", "make_robot"]
+           "CostComposite", "PlanningTask", "TrajectoryDataset", "LimitsNormalizer", "SafeLimitsNormalizer", "FixedLimitsNormalizer", "GaussianNormalizer", "Identity",
+           "make_normalizer", "make_env", "make_robot"]

@@ -1,6 +1,6 @@
-"""LimitsNormalizer and the slice of TrajectoryDataset the planning loop touches.
+"""The field normalisers and the slice of TrajectoryDataset the planning loop touches.
 
-Reference: mpd/datasets/normalization.py:144-167 (LimitsNormalizer) and mpd/datasets/trajectories.py:196-237
+Reference: mpd/datasets/normalization.py:85-195 (LimitsNormalizer - the default, trajectories.py:26 - and the four others) and mpd/datasets/trajectories.py:196-237
 (unnormalize_trajectories, get_hard_conditions).  Without a dataset directory the limits are given explicitly (synthetic,
 SURVEY 8d).  With `base_dir=` the `trajs-free.pt` shards under it are loaded as the reference does (trajectories.py:84-110:
 os.walk, one task id per shard, the `task` field = start/goal positions) and the limits come from the data
@@ -18,7 +18,9 @@ from .planning import PlanningTask, make_env, make_robot
 
 
 class LimitsNormalizer:
-    """maps [xmin, xmax] to [-1, 1]"""
+    """maps [xmin, xmax] to [-1, 1] (normalization.py:144-167); built from the limits (what the planning path holds) or, the reference's way,
+    from a flattened field with `make_normalizer`"""
+    kind = "limits"   # what the HIP guide kernel un-normalises with: limits + the whole-tensor range test
 
     def __init__(self, mins, maxs):
         self.mins = torch.as_tensor(mins, dtype=torch.float32)
@@ -27,6 +29,9 @@ class LimitsNormalizer:
     def to(self, device):
         self.mins, self.maxs = self.mins.to(device), self.maxs.to(device)
         return self
+
+    def __call__(self, x):
+        return self.normalize(x)
 
     def normalize(self, x):
         x = (x - self.mins) / (self.maxs - self.mins)
@@ -39,6 +44,91 @@ class LimitsNormalizer:
         return x * (self.maxs - self.mins) + self.mins
 
 
+class SafeLimitsNormalizer(LimitsNormalizer):
+    """LimitsNormalizer for data with a constant dimension (normalization.py:170-184): as soon as ONE dimension is constant the reference widens
+    EVERY dimension's limits by eps (its loop subtracts from / adds to the whole vectors), once."""
+
+    def __init__(self, mins, maxs, eps=1):
+        super().__init__(mins, maxs)
+        if eps != 0 and bool((self.mins == self.maxs).any()):
+            self.mins, self.maxs = self.mins - eps, self.maxs + eps
+
+
+class FixedLimitsNormalizer(LimitsNormalizer):
+    """LimitsNormalizer with given limits instead of the data's (normalization.py:187-195)"""
+
+    def __init__(self, mins, maxs, min=-1, max=1):
+        super().__init__(mins, maxs)
+        self.mins, self.maxs = torch.ones_like(self.mins) * min, torch.ones_like(self.maxs) * max
+
+
+class Identity:
+    """normalization.py:111-116.  The guide kernel skips its un-normalisation (`identity_normalizer`, as the baseline planners run it)."""
+    kind = "identity"
+
+    def __init__(self, mins=None, maxs=None):
+        self.mins = None if mins is None else torch.as_tensor(mins, dtype=torch.float32)
+        self.maxs = None if maxs is None else torch.as_tensor(maxs, dtype=torch.float32)
+
+    def to(self, device):
+        if self.mins is not None:
+            self.mins, self.maxs = self.mins.to(device), self.maxs.to(device)
+        return self
+
+    def __call__(self, x):
+        return x
+
+    def normalize(self, x):
+        return x
+
+    def unnormalize(self, x):
+        return x
+
+
+class GaussianNormalizer:
+    """zero mean / unit variance per dimension (normalization.py:119-141; unbiased std).  Training and unguided sampling take it; the HIP guide
+    kernel un-normalises with limits or not at all, so a guide on such a dataset is refused (guides.py of this package)."""
+    kind = "gaussian"
+
+    def __init__(self, means, stds, mins=None, maxs=None):
+        self.means, self.stds = torch.as_tensor(means, dtype=torch.float32), torch.as_tensor(stds, dtype=torch.float32)
+        self.mins = None if mins is None else torch.as_tensor(mins, dtype=torch.float32)
+        self.maxs = None if maxs is None else torch.as_tensor(maxs, dtype=torch.float32)
+        self.z = 1
+
+    def to(self, device):
+        self.means, self.stds = self.means.to(device), self.stds.to(device)
+        if self.mins is not None:
+            self.mins, self.maxs = self.mins.to(device), self.maxs.to(device)
+        return self
+
+    def __call__(self, x):
+        return self.normalize(x)
+
+    def normalize(self, x):
+        return (x - self.means) / self.stds
+
+    def unnormalize(self, x):
+        return x * self.stds + self.means
+
+
+NORMALIZERS = {c.__name__: c for c in (Identity, GaussianNormalizer, LimitsNormalizer, SafeLimitsNormalizer, FixedLimitsNormalizer)}
+
+
+def make_normalizer(normalizer, X, **kw):
+    """What DatasetNormalizer.__init__ does per field (normalization.py:14-22: `eval(normalizer)(X)` on the flattened field [N, dim]):
+    `normalizer` is one of the five class names (or classes) of the reference's module."""
+    name = normalizer if isinstance(normalizer, str) else normalizer.__name__
+    if name not in NORMALIZERS:
+        raise NameError(f"name {name!r} is not defined")   # (the reference's eval() of an unknown name)
+    X = torch.as_tensor(X, dtype=torch.float32)
+    X = X.reshape(-1, X.shape[-1])
+    mins, maxs = X.min(dim=0).values, X.max(dim=0).values   # Normalizer.__init__ (normalization.py:90-93)
+    if name == "GaussianNormalizer":
+        return GaussianNormalizer(X.mean(dim=0), X.std(dim=0), mins, maxs)
+    return NORMALIZERS[name](mins, maxs, **kw)
+
+
 class TrajectoryDataset:
     """`dataset` as inference.py uses it: .env .robot .task .n_support_points .state_dim .threshold_start_goal_pos,
     normalize/unnormalize_trajectories, get_hard_conditions."""
@@ -46,15 +136,26 @@ class TrajectoryDataset:
     field_key_traj = "traj"
 
     def __init__(self, env_id="EnvDense2D", robot_id="RobotPointMass", n_support_points=64, include_velocity=True,
-                 obstacle_cutoff_margin=0.05, use_extra_objects=True, tensor_args=None, base_dir=None, **kw):
+                 obstacle_cutoff_margin=0.05, use_extra_objects=True, tensor_args=None, base_dir=None, normalizer="LimitsNormalizer", **kw):
         self.tensor_args = tensor_args or {"device": "cpu", "dtype": torch.float32}
         self.env, self.robot = make_env(env_id), make_robot(robot_id)
         self.task = PlanningTask(self.env, self.robot, obstacle_cutoff_margin=obstacle_cutoff_margin,
                                  use_extra_objects=use_extra_objects, tensor_args=self.tensor_args)
         self.n_support_points, self.include_velocity = n_support_points, include_velocity
         self.state_dim = self.robot.q_dim * (2 if include_velocity else 1)
+        # `normalizer`: one of the reference's five class names (trajectories.py:26,78).  Without a dataset directory the limits are this package's
+        # synthetic ones (a GaussianNormalizer needs data: base_dir)
+        self.normalizer_name = normalizer if isinstance(normalizer, str) else normalizer.__name__
+        if self.normalizer_name not in NORMALIZERS:
+            raise NameError(f"name {self.normalizer_name!r} is not defined")
         mins, maxs = syn.limits_for(robot_id)
-        self.normalizer = LimitsNormalizer(mins[: self.state_dim], maxs[: self.state_dim]).to(self.tensor_args["device"])
+        mins, maxs = mins[: self.state_dim], maxs[: self.state_dim]
+        if self.normalizer_name == "GaussianNormalizer":
+            if base_dir is None:
+                raise ValueError("normalizer='GaussianNormalizer' takes its statistics from the data: give base_dir")
+            self.normalizer = None
+        else:
+            self.normalizer = NORMALIZERS[self.normalizer_name](mins, maxs).to(self.tensor_args["device"])
         self.threshold_start_goal_pos = 1.0 if self.robot.q_dim <= 3 else 1.83  # launch_generate_trajectories.py:13-16
         self.fields = {}
         self.map_task_id_to_trajectories_id, self.map_trajectory_id_to_task_id = {}, {}
@@ -91,9 +192,9 @@ class TrajectoryDataset:
         self.n_trajs, self.n_support_points = trajs.shape[0], trajs.shape[1]
         self.trajectory_dim = (self.n_support_points, self.state_dim)
         flat = trajs.reshape(-1, self.state_dim)
-        self.normalizer = LimitsNormalizer(flat.min(0).values, flat.max(0).values).to(dev)   # normalization.py:144-153
+        self.normalizer = make_normalizer(self.normalizer_name, flat).to(dev)   # normalization.py:14-22,90-93
         tflat = self.fields["task"]
-        self._task_normalizer = LimitsNormalizer(tflat.min(0).values, tflat.max(0).values).to(dev)
+        self._task_normalizer = make_normalizer(self.normalizer_name, tflat).to(dev)
         self.fields["traj_normalized"] = self.normalizer.normalize(trajs)
         self.fields["task_normalized"] = self._task_normalizer.normalize(tflat)
 

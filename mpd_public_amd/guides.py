@@ -100,10 +100,16 @@ class GuideManagerTrajectoriesWithVelocity(nn.Module):
         ds = self.dataset
         if ds.state_dim != 2 * ds.robot.q_dim:
             raise NotImplementedError("the velocity guide needs include_velocity=True (state = pos + vel)")
+        kind = getattr(ds.normalizer, "kind", "limits")
+        if kind not in ("limits", "identity"):
+            raise NotImplementedError(f"the HIP guide un-normalises with limits (LimitsNormalizer and its subclasses) or not at all (Identity); "
+                                      f"{type(ds.normalizer).__name__} is not supported under a guide")
+        ident = kind == "identity"
         self._params, self._prims = build_device_params(
-            ds.robot, ds.env.dim, ds.task.obstacle_cutoff_margin, ds.normalizer.mins, ds.normalizer.maxs, self.cost.cost_l,
-            self.cost.weight_cost_l, self.interpolate_trajectories_for_collision, self.num_interpolated_points_for_collision,
-            self.clip_grad, self.max_grad_norm, device, clip_grad_rule=self.clip_grad_rule, max_grad_value=self.max_grad_value)
+            ds.robot, ds.env.dim, ds.task.obstacle_cutoff_margin, None if ident else ds.normalizer.mins, None if ident else ds.normalizer.maxs,
+            self.cost.cost_l, self.cost.weight_cost_l, self.interpolate_trajectories_for_collision, self.num_interpolated_points_for_collision,
+            self.clip_grad, self.max_grad_norm, device, clip_grad_rule=self.clip_grad_rule, max_grad_value=self.max_grad_value,
+            identity_normalizer=ident)
         return self._params
 
     # ------------------------------------------------------------------------------------------- guide protocol

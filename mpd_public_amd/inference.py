@@ -79,10 +79,16 @@ def experiment(model_id: str = "EnvSpheres3D-RobotPanda", planner_alg: str = "mp
             import yaml
             with open(lim) as f:
                 lm = yaml.safe_load(f)
-            from .datasets import LimitsNormalizer
+            from .datasets import LimitsNormalizer, GaussianNormalizer, Identity
             if len(lm["mins"]) != dataset.state_dim or len(lm["maxs"]) != dataset.state_dim:
                 raise ValueError(f"{lim}: expected {dataset.state_dim} mins/maxs")
-            dataset.normalizer = LimitsNormalizer(lm["mins"], lm["maxs"]).to(tensor_args["device"])
+            kind = lm.get("normalizer", "LimitsNormalizer")   # (written by train.py of this package; the limits are final: a Safe / Fixed one is a LimitsNormalizer here)
+            if kind == "GaussianNormalizer":
+                dataset.normalizer = GaussianNormalizer(lm["means"], lm["stds"], lm["mins"], lm["maxs"]).to(tensor_args["device"])
+            elif kind == "Identity":
+                dataset.normalizer = Identity(lm["mins"], lm["maxs"]).to(tensor_args["device"])
+            else:
+                dataset.normalizer = LimitsNormalizer(lm["mins"], lm["maxs"]).to(tensor_args["device"])
         elif not kwargs.get("allow_synthetic_limits", False):
             raise RuntimeError(f"{model_dir} holds trained weights but no limits.yaml: the normaliser limits (and the environment "
                                "geometry) of this package are synthetic stand-ins (DESIGN.md section 5) and would not match the "

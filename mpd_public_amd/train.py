@@ -106,7 +106,11 @@ def experiment(dataset_subdir: str = "EnvSimple2D-RobotPointMass", include_veloc
     with open(os.path.join(results_dir, "args.yaml"), "w") as f:
         yaml.safe_dump(args, f)
     with open(os.path.join(results_dir, "limits.yaml"), "w") as f:
-        yaml.safe_dump({"mins": [float(v) for v in dataset.normalizer.mins.cpu()], "maxs": [float(v) for v in dataset.normalizer.maxs.cpu()]}, f)
+        nrm = dataset.normalizer
+        lim = {"normalizer": type(nrm).__name__, "mins": [float(v) for v in nrm.mins.cpu()], "maxs": [float(v) for v in nrm.maxs.cpu()]}
+        if hasattr(nrm, "means"):
+            lim.update(means=[float(v) for v in nrm.means.cpu()], stds=[float(v) for v in nrm.stds.cpu()])
+        yaml.safe_dump(lim, f)
     loss_fn = trainer.GaussianDiffusionLoss.loss_fn
     summary_fn = getattr(summaries, summary_class)(seed=seed).summary_fn if summary_class else None   # train_loaders.py:102-107
     model, ema_model, losses = trainer.train(

@@ -76,8 +76,12 @@ def oracle_guide(dataset, w_coll=1e-2, w_smooth=1e-7, clip_grad=True, interpolat
     cl.append(oc.CostGPTrajectory(robot, 64, dt, sigma_gp=1.0, half_factor=gp_half_factor))
     wl.append(w_smooth)
     comp = oc.CostComposite(robot, 64, cl, weights_cost_l=wl)
-    nrm = LimitsNormalizer(dataset.normalizer.mins.cpu(), dataset.normalizer.maxs.cpu())
-    nrm.mins, nrm.maxs = nrm.mins.to(dtype), nrm.maxs.to(dtype)
+    if getattr(dataset.normalizer, "kind", "limits") == "identity":
+        from oracle.normalizer import Identity
+        nrm = Identity()
+    else:
+        nrm = LimitsNormalizer(dataset.normalizer.mins.cpu(), dataset.normalizer.maxs.cpu())
+        nrm.mins, nrm.maxs = nrm.mins.to(dtype), nrm.maxs.to(dtype)
     return GuideManager(nrm, comp, clip_grad=clip_grad, interpolate=interpolate, n_interp=n_interp, clip_grad_rule=clip_grad_rule,
                         max_grad_value=max_grad_value), comp
 

@@ -278,3 +278,43 @@ def test_padded_horizon_chain_matches_reference(golden_dir):
     chain = diffusion.run_inference(synth_sd(D, opt), hc, noise, T, n_diffusion_steps_without_noise=n0, noise_std=0.5).numpy()
     assert chain.shape == g["H48_chain"].shape
     np.testing.assert_allclose(chain, g["H48_chain"], rtol=0, atol=2e-5)
+
+
+NORMALIZER_CASES = (("Identity", False, {}), ("GaussianNormalizer", False, {}), ("LimitsNormalizer", False, {}), ("SafeLimitsNormalizer", True, {}),
+                    ("SafeLimitsNormalizer", False, {}), ("FixedLimitsNormalizer", False, {}), ("FixedLimitsNormalizer", False, {"min": -2.0, "max": 3.0}))
+
+
+@pytest.mark.parametrize("side", ["oracle", "product"])
+@pytest.mark.parametrize("name,const,kw", NORMALIZER_CASES)
+def test_field_normalizers_match_reference(golden_dir, side, name, const, kw):
+    """All five normalisers of mpd/datasets/normalization.py, built from a flattened field the reference's way, against the REAL classes
+    (make_golden.py --only normalizers): limits, normalize, unnormalize of in-range points and of points beyond the limits (LimitsNormalizer's
+    whole-tensor clip); one field has a constant dimension (SafeLimitsNormalizer widens EVERY dimension).  Both the oracle's restatement and the
+    product's host classes (plain torch, no device needed)."""
+    g = load_npz(golden_dir / "normalizers.npz")
+    X = t("norm_X", (50, 4), "uniform", 2.0)
+    if const:
+        X = X.clone()
+        X[:, 2] = 0.25
+    pts = t("norm_pts", (6, 8, 4), "uniform", 0.9)
+    if side == "oracle":
+        from oracle.normalizer import from_data
+        n = from_data(name, X, **kw)
+    else:
+        from mpd_public_amd.datasets import make_normalizer
+        n = make_normalizer(name, X, **kw)
+    tag = name + ("_const" if const else "") + ("_kw" if kw else "")
+    np.testing.assert_array_equal(n.mins.numpy(), g[f"{tag}_mins"])
+    np.testing.assert_array_equal(n.maxs.numpy(), g[f"{tag}_maxs"])
+    np.testing.assert_array_equal(n.normalize(X[:10].clone()).numpy(), g[f"{tag}_normalize"])
+    np.testing.assert_array_equal(n.unnormalize(pts.clone()).numpy(), g[f"{tag}_unnormalize"])
+    np.testing.assert_array_equal(n.unnormalize((pts * 1.5).clone()).numpy(), g[f"{tag}_unnormalize_far"])
+
+
+def test_unknown_normalizer_name_is_a_name_error():
+    """DatasetNormalizer evaluates the name (normalization.py:17-18): an unknown one is a NameError"""
+    from mpd_public_amd.datasets import make_normalizer
+    from oracle.normalizer import from_data
+    for f in (make_normalizer, from_data):
+        with pytest.raises(NameError):
+            f("NoSuchNormalizer", t("norm_X", (50, 4), "uniform", 2.0))

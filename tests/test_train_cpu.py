@@ -37,6 +37,27 @@ def test_training_set_loader_matches_reference_semantics(tmp_path):
     assert ds.fields["task"].shape == (12, 4)
 
 
+@pytest.mark.parametrize("name", ["GaussianNormalizer", "SafeLimitsNormalizer", "FixedLimitsNormalizer", "Identity"])
+def test_training_set_with_the_other_normalizers(tmp_path, name):
+    """TrajectoryDataset(normalizer=...) (trajectories.py:26,78): each field normalised by the named class built from the flattened field, as
+    DatasetNormalizer does (normalization.py:14-22); the classes themselves are pinned to the reference in test_oracle_golden.py"""
+    from mpd_public_amd.datasets import TrajectoryDataset
+    from oracle.normalizer import from_data
+    base = tmp_path / "EnvSimple2D-RobotPointMass"
+    allt = _write_shards(base, [5, 3, 4])
+    ds = TrajectoryDataset(env_id="EnvSimple2D", robot_id="RobotPointMass", base_dir=str(base), normalizer=name)
+    assert type(ds.normalizer).__name__ == name
+    want = from_data(name, allt.reshape(-1, 4))
+    assert torch.equal(ds.fields["traj_normalized"], want.normalize(allt))
+    assert torch.allclose(ds.unnormalize_trajectories(ds.fields["traj_normalized"]), allt, atol=1e-6)
+    task = torch.cat((allt[:, 0, :2], allt[:, -1, :2]), -1)
+    assert torch.equal(ds.fields["task_normalized"], from_data(name, task).normalize(task))
+    with pytest.raises(NameError):
+        TrajectoryDataset(env_id="EnvSimple2D", robot_id="RobotPointMass", normalizer="NoSuchNormalizer")
+    with pytest.raises(ValueError):
+        TrajectoryDataset(env_id="EnvSimple2D", robot_id="RobotPointMass", normalizer="GaussianNormalizer")   # needs data
+
+
 def test_get_dataset_split_and_batches(tmp_path):
     from mpd_public_amd import train as train_script
     base = tmp_path / "data" / "EnvSimple2D-RobotPointMass"
