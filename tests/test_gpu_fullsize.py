@@ -167,6 +167,21 @@ def test_cfg5_shard_size_matches_small_batch_plans(T):
                 assert np.median(d) < 1e-5 and d.max() < 2e-3, (label, c, np.median(d), d.max())
             else:
                 _assert_guided_close(d, f"cfg5 T={T} context {c}: batched (fused programs) vs alone (per-layer kernels)")
+        # (3) the CPU oracle on two of the shard's contexts, same noise: the full-size plan's trajectories of those contexts against the oracle's
+        #     (unguided: the chain tolerance; guided: the statistics above)
+        from oracle import diffusion as odiff
+        og, _ = oracle_guide(ds, 1e-2, 1e-7, dtype=torch.float32)
+        okw = dict(noise_std=0.5, n_diffusion_steps_without_noise=n0)
+        if label == "guided":
+            okw.update(guide=og, n_guide_steps=5, t_start_guide=ceil(0.25 * T))
+        for c in (0, 127):
+            sc = slice(c * n, (c + 1) * n)
+            ref = odiff.run_inference(synth_sd(D, 1), {0: starts[c].cpu(), 63: goals[c].cpu()}, noise[:, sc].cpu(), T, **okw)[-1]
+            d = (x[sc].cpu() - ref).abs().amax(-1).numpy()
+            if label == "unguided":
+                assert np.median(d) < 1e-4 and d.max() < 2e-3, (label, c, np.median(d), d.max())
+            else:
+                _assert_guided_close(d, f"cfg5 T={T} context {c}: full-size plan vs the CPU oracle on that context")
 
 
 def test_rccl_world_of_one_runs_real_planner_under_parallel():
