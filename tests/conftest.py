@@ -18,6 +18,8 @@ def pytest_configure(config):
     cap = int(os.environ.get("MPDX_TEST_THREADS", "16"))
     if cap > 0 and torch.get_num_threads() > cap:
         torch.set_num_threads(cap)
+    if cap > 0:   # child processes of the tests (the fuzz tools, the variant / two-rank scripts) inherit the same cap
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(cap, os.cpu_count() or cap))))
 
 
 @pytest.fixture(scope="session")
