@@ -87,6 +87,26 @@ def test_unguided_chain_cfg1_matches_reference(golden_dir, opt):
     np.testing.assert_allclose(chain, ref, rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("D", [4, 14])
+def test_unguided_chain_T100_headline_shapes_match_reference(golden_dir, D):
+    """The HEADLINE configurations through the real reference (make_golden.py --only chain_T100): cfg2 shape (D = 4) / cfg4-unguided shape (D = 14),
+    dim_mults (1,2,4,8), T = 100 (+5), B = 8 - chain rows {0, 25, 50, 75, 100, 105}.  The fp32 oracle against the reference's fp32 run, the fp64 oracle
+    against the reference's own modules run in fp64 (diffusion_model_base.py:157-182,285-316)."""
+    g = load_npz(golden_dir / "chain_T100.npz")
+    rows = [int(r) for r in g["rows"]]
+    T, B, n0 = 100, 8, 5
+    sd = synth_sd(D, 1)
+    noise = t(f"chain_noise_T100_D{D}", (T + n0 + 1, B, 64, D))
+    hc = {0: t(f"chain_T100_hc0_D{D}", (D,), "uniform", 0.6), 63: t(f"chain_T100_hc1_D{D}", (D,), "uniform", 0.6)}
+    chain = diffusion.run_inference(sd, hc, noise, T, n_diffusion_steps_without_noise=n0, noise_std=0.5).numpy()
+    assert chain.shape == (T + n0 + 1, B, 64, D) and rows[-1] == T + n0
+    np.testing.assert_allclose(chain[rows], g[f"D{D}_f32"], rtol=0, atol=2e-5)
+    chain64 = diffusion.run_inference({k: v.double() for k, v in sd.items()}, {k: v.double() for k, v in hc.items()}, noise.double(), T,
+                                      n_diffusion_steps_without_noise=n0, noise_std=0.5, dtype=torch.float64).numpy()
+    # (the fp64 reference builds its sinusoid frequencies in fp64, the oracle keeps the fp32 values: 6e-7 at the end of the chain)
+    np.testing.assert_allclose(chain64[rows], g[f"D{D}_f64"], rtol=0, atol=5e-6)
+
+
 @pytest.mark.parametrize("robot,D", [("RobotPointMass", 4), ("RobotPanda", 14)])
 def test_normalizer_and_guide_glue_match_reference(golden_dir, robot, D):
     g = load_npz(golden_dir / "guide.npz")
