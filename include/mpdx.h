@@ -36,7 +36,7 @@ typedef struct mpdx_unet mpdx_unet; /* opaque */
  * for the only configuration the reference builds: conditioning_type=None, self_attention=False. */
 typedef struct mpdx_unet_cfg {
     int32_t state_dim;                  /* D */
-    int32_t n_support_points;           /* H: 64 in every shipped configuration; a power of two in [16, 128] (GroupNorm regions >= 64 elements) */
+    int32_t n_support_points;           /* H: 64 in every shipped configuration; 16 ... 128 with H % 2^(n_levels-1) == 0 (powers of two run as they are, 24 / 40 / 48 / 96 ... in the next power-of-two container, zero rows kept zero) */
     int32_t unet_input_dim;             /* 32 */
     int32_t n_levels;                   /* len(dim_mults) */
     int32_t dim_mults[MPDX_MAX_LEVELS]; /* (1,2,4,8) or (1,2,4): UNET_DIM_MULTS, temporal_unet.py:14-17 */
@@ -105,7 +105,13 @@ int mpdx_ddpm_step(mpdx_unet* u, const float* packed_dev, const float* timetab_d
 int mpdx_add_noise(float* x_io, const float* noise, const float* hard_start, const float* hard_goal,
                    float noise_scale, float noise_std_extra, float* chain_out, int B, int H, int D, void* stream);
 
-/* ---- forward loss (what the reference's validation loop evaluates under no_grad; the backward pass is out of scope).
+/* apply_hard_conditioning (sample_functions.py:5-8) for ARBITRARY horizon indices:  x[:, horizon_idx[k], :] = values[k]  ([B,D] device tables) for
+ * k < n <= 16, in order (python semantics: negative indices count from the end, a later entry wins on a repeated index); chain_out (optional) receives
+ * the same writes.  horizon_idx / values are HOST arrays.  The step kernels fold indices 0 and H-1 into their epilogue (hard_start / hard_goal above);
+ * this is the step-by-step loop's path for every other index (the fused mpdx_plan takes 0 and H-1 only). */
+int mpdx_hard_conds(float* x_io, float* chain_out, int n, const int32_t* horizon_idx, const float* const* values, int B, int H, int D, void* stream);
+
+/* ---- forward loss (what the reference's validation loop evaluates under no_grad; the pass WITH its gradient is mpdx_train_loss_backward below).
  * q_sample (diffusion_model_base.py:320-330) followed by apply_hard_conditioning (:335): per-trajectory timesteps t_dev[B]
  * (int64, clamped to [0,T)), schedule buffers on the device. */
 int mpdx_q_sample(const float* x_start, const float* noise, const long long* t_dev, const float* sqrt_alphas_cumprod_dev,
@@ -142,7 +148,8 @@ int    mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* pa
 /* torch.nn.utils.clip_grad_norm_(max_norm) if max_norm > 0, then torch.optim.Adam.step() (no weight decay, no amsgrad);
  * step counts from 1; scratch: >= 1032 floats (scratch[0] <- the gradient norm before clipping, scratch[1] <- the clip factor).
  * step < 0: the count lives on the device - the int at scratch + 4 holds the number of steps taken so far and this call advances it (the form a
- * training step captured into a hipGraph needs: kernel arguments are frozen at capture, trainer.TrainStep.step) */
+ * training step captured into a hipGraph needs: kernel arguments are frozen at capture, trainer.TrainStep.step); with step < 0, lr < 0 takes the
+ * learning rate from the float at scratch + 5 as well (an LR schedule then neither re-captures nor re-keys anything) */
 int    mpdx_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
                       float eps, int step, float max_norm, float* scratch, void* stream);
 /* EMA.update_model_average (trainer.py:67-85): ema = beta * ema + (1 - beta) * params */
@@ -198,8 +205,10 @@ typedef struct mpdx_guide_params {
     int32_t clip_rule;                  /* 0: clip_grad_rule 'norm' (guides.py:224-230); 1: 'value' (guides.py:232-236) */
     float   max_grad_value;             /* 0.1 (guides.py:151) */
     int32_t gp_half_factor;             /* 0: cost_GP = sum e^T Qinv e (default);  1: 1/2 sum e^T Qinv e (GPMP2's convention) */
-    int32_t identity_normalizer;        /* 1: x is ALREADY in robot units (no LimitsNormalizer, no range test): the trajectory optimiser of
-                                         * generate_trajectories (scripts/generate_data/generate_trajectories.py:94-117) works on raw trajectories */
+    int32_t identity_normalizer;        /* 0: LimitsNormalizer (mins / maxs above, whole-tensor range test; normalization.py:156-167);
+                                         * 1: x is ALREADY in robot units (Identity :111-116; no range test): the trajectory optimiser of
+                                         *    generate_trajectories (scripts/generate_data/generate_trajectories.py:94-117) works on raw trajectories;
+                                         * 2: GaussianNormalizer (:140-141): x * stds + means with means in `mins`, stds in `maxs`, no range test */
 } mpdx_guide_params;
 
 /* one guide iteration on x[B,H,D] (normalised).  grad_out == NULL: x <- hard_cond(x + guide(x)) in place and

@@ -76,6 +76,7 @@ SIGNATURES = {
     "mpdx_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "mpdx_ddpm_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, C.POINTER(StepCoefs), _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "mpdx_add_noise": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _i, _i, _i, _vp]),
+    "mpdx_hard_conds": (_i, [_vp, _vp, _i, C.POINTER(C.c_int32), C.POINTER(_vp), _i, _i, _i, _vp]),
     "mpdx_q_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mpdx_weighted_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "mpdx_plan": (_i, [_vp, _vp, _vp, _i, C.POINTER(StepCoefs), _i, _vp, _vp, _vp, _vp, _vp, _i, _vp,
@@ -118,23 +119,27 @@ def lib_path() -> Path:
     return _LIB_PATH
 
 
+class LibraryUnavailable(RuntimeError):
+    """libmpdx.so is missing or cannot be loaded on this host (every compute entry point raises it; nothing falls back)"""
+
+
 def load():
-    """Load libmpdx.so and bind every declared symbol; raises RuntimeError (never falls back) when unavailable."""
+    """Load libmpdx.so and bind every declared symbol; raises LibraryUnavailable (a RuntimeError; never falls back) when unavailable."""
     global _lib
     if _lib is not None:
         return _lib
     if not _LIB_PATH.exists():
-        raise RuntimeError(f"{_LIB_PATH} is missing - build it with `python -m mpd_public_amd.build` (hipcc, gfx950). "
+        raise LibraryUnavailable(f"{_LIB_PATH} is missing - build it with `python -m mpd_public_amd.build` (hipcc, gfx950). "
                            "mpd_public_amd has no CPU fallback.")
     try:
         lib = C.CDLL(str(_LIB_PATH))
     except OSError as e:  # pragma: no cover
-        raise RuntimeError(f"cannot load {_LIB_PATH}: {e}") from e
+        raise LibraryUnavailable(f"cannot load {_LIB_PATH}: {e}") from e
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise RuntimeError(f"{_LIB_PATH} does not export {name}; rebuild it") from e
+            raise LibraryUnavailable(f"{_LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib

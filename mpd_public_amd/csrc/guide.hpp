@@ -559,7 +559,10 @@ __global__ __launch_bounds__(64 * WPT) void guide_step_kernel(const GuideArgs a)
         xn[d] = live ? a.x[base + d] : 0.f;
         const float c = clipall ? fminf(fmaxf(xn[d], -1.f), 1.f) : xn[d];
         const float u01 = __fadd_rn(c, 1.0f) * 0.5f;
-        xu[d] = gp.identity_normalizer ? xn[d] : __fadd_rn(__fmul_rn(u01, __fsub_rn(gp.maxs[d], gp.mins[d])), gp.mins[d]);
+        // identity_normalizer: 0 limits (normalization.py:156-167), 1 Identity (:111-116), 2 GaussianNormalizer (:140-141: x * stds + means - the
+        // host passes means in `mins`, stds in `maxs`; no range test)
+        xu[d] = gp.identity_normalizer == 1 ? xn[d] : gp.identity_normalizer == 2 ? __fadd_rn(__fmul_rn(xn[d], gp.maxs[d]), gp.mins[d])
+                                                    : __fadd_rn(__fmul_rn(u01, __fsub_rn(gp.maxs[d], gp.mins[d])), gp.mins[d]);
         if (live && wv < nsw) sx[hs_ * D + d] = xu[d];
     }
     __syncthreads();
@@ -877,7 +880,8 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void guide_step_panda_kernel(co
             const float xnd = snz_x[ic];
             const float c = clipall ? fminf(fmaxf(xnd, -1.f), 1.f) : xnd;
             const float u01 = __fadd_rn(c, 1.0f) * 0.5f;
-            const float xud = gp.identity_normalizer ? xnd : __fadd_rn(__fmul_rn(u01, __fsub_rn(hi, lo)), lo);
+            const float xud = gp.identity_normalizer == 1 ? xnd : gp.identity_normalizer == 2 ? __fadd_rn(__fmul_rn(xnd, hi), lo)   // (Gaussian: lo = mean, hi = std)
+                                                            : __fadd_rn(__fmul_rn(u01, __fsub_rn(hi, lo)), lo);
             if (i < n) sx[i] = xud;
         }
     }

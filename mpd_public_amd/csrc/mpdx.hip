@@ -175,6 +175,24 @@ __global__ __launch_bounds__(256) void add_noise_kernel(float* x, const float* n
     }
 }
 
+// apply_hard_conditioning (sample_functions.py:5-8) for ARBITRARY horizon indices: x[:, idx[k], :] = vals[k][:, :] for k < n, in the dict's
+// order (a later entry wins on a repeated index, as successive indexed writes do).  One thread per (entry, trajectory, dimension).
+constexpr int kMaxHardConds = 16;
+struct HardCondArgs { int idx[kMaxHardConds]; const float* vals[kMaxHardConds]; int n; };
+__global__ __launch_bounds__(256) void hard_conds_kernel(float* x, float* chain, const HardCondArgs a, int B, int H, int D) {
+    const size_t per = (size_t)B * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / D;
+        const int d = (int)(i - b * D);
+        for (int k = 0; k < a.n; ++k) {   // in order: every thread owns its (b, d) column of all entries, so a repeated index resolves as in the reference
+            const float v = a.vals[k][i];
+            const size_t o = (b * H + a.idx[k]) * D + d;
+            x[o] = v;
+            if (chain) chain[o] = v;
+        }
+    }
+}
+
 // q_sample (diffusion_model_base.py:320-330) + apply_hard_conditioning (:335): per-trajectory timestep, schedule rows
 // looked up on the device.  x_t = sqrt(acp[t_b]) * x0 + sqrt(1 - acp[t_b]) * noise
 __global__ __launch_bounds__(256) void q_sample_kernel(const float* x0, const float* noise, const long long* t, const float* sqrt_ac,
@@ -272,6 +290,14 @@ static int gn_groups(int c) {  // layers.py:389-395
     return 1;
 }
 
+// input channels as the kernels see them: a multiple of 16 (one MFMA k-group) that is also a power of two (channel indices are shifts) - 33 ... 48
+// real channels run in a 64-channel container whose extra channels are zero in the staged input AND in the packed weights
+static int pad_cin(int c) {
+    int p = (c + 15) / 16 * 16;
+    while (p & (p - 1)) p += 16;
+    return p;
+}
+
 static int add_param(mpdx_unet* u, const std::string& name, std::initializer_list<int> shape, int kind = PK_VEC) {
     Param p;
     p.name = name;
@@ -288,7 +314,7 @@ static int add_param(mpdx_unet* u, const std::string& name, std::initializer_lis
         p.nslot = 4;
     }
     if (kind != PK_VEC) {
-        p.cin_pad = (p.cin + 15) / 16 * 16;
+        p.cin_pad = pad_cin(p.cin);
         p.pn = (size_t)(p.cout / 16) * (p.cin_pad / 16) * p.nslot * 256;
     } else {
         p.pn = (p.n + 3) / 4 * 4;
@@ -361,7 +387,7 @@ static void build_model(mpdx_unet* u) {
         if (mode == CONV_UPT) l.w = add_param(u, wname, {c1 + c2, cout, ks}, PK_CONVT);
         else l.w = add_param(u, wname, {cout, c1 + c2, ks}, PK_CONV);
         l.b = add_param(u, bname, {cout});
-        l.cin_pad = (c1 + c2 + 15) / 16 * 16;
+        l.cin_pad = pad_cin(c1 + c2);
         const int pad = (mode == CONV_S1) ? ks / 2 : 1;
         l.rs = pick_row_stride(l.cin_pad, mode, L_in, L_out, L_in + 2 * pad);
         slot = std::max(slot, (size_t)cout * L_out);
@@ -1333,6 +1359,26 @@ int mpdx_add_noise(float* x_io, const float* noise, const float* hard_start, con
     const size_t n = (size_t)B * H * D;
     hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream,
                        x_io, noise, hard_start, hard_goal, noise_scale, noise_std_extra, chain_out, B, H, D);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mpdx_hard_conds(float* x_io, float* chain_out, int n, const int32_t* horizon_idx, const float* const* values, int B, int H, int D, void* stream) {
+    if (!x_io || B <= 0 || H <= 0 || D <= 0 || n < 0 || (n && (!horizon_idx || !values))) return fail(MPDX_E_INVALID, "bad argument");
+    if (n > kMaxHardConds) return fail(MPDX_E_INVALID, "at most 16 hard conditions per call");
+    if (n == 0) return 0;
+    HardCondArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = n;
+    for (int k = 0; k < n; ++k) {
+        int t = horizon_idx[k];
+        if (t < 0) t += H;   // python indexing: x[:, -1, :]
+        if (t < 0 || t >= H) return fail(MPDX_E_INVALID, "hard condition index out of range for this horizon");
+        if (!values[k]) return fail(MPDX_E_INVALID, "null hard condition table");
+        a.idx[k] = t; a.vals[k] = values[k];
+    }
+    const size_t per = (size_t)B * D;
+    hipLaunchKernelGGL(hard_conds_kernel, dim3((unsigned)std::min<size_t>((per + 255) / 256, 1024)), dim3(256), 0, (hipStream_t)stream, x_io, chain_out, a, B, H, D);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -1399,6 +1399,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         }
         __syncthreads();
         bc1 = s_bc[0]; bc2_sqrt = s_bc[1];
+        if (lr < 0.f) lr = norm[5];   // the learning rate from device memory as well (a schedule must not re-capture the graph): scratch[5]
     }
     if (part) {
         float s = 0.f;

@@ -783,6 +783,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
 int mpdx_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2, float eps,
                    int step, float max_norm, float* scratch, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch || n == 0 || step == 0) return fail(MPDX_E_INVALID, "bad argument");
+    if (lr < 0.f && step > 0) return fail(MPDX_E_INVALID, "lr < 0 (the learning rate from scratch[5]) needs the device-resident step count (step < 0)");
     hipStream_t st = (hipStream_t)stream;
     const float* clip = nullptr;
     int n_part = 0;

@@ -86,8 +86,8 @@ class Identity:
 
 
 class GaussianNormalizer:
-    """zero mean / unit variance per dimension (normalization.py:119-141; unbiased std).  Training and unguided sampling take it; the HIP guide
-    kernel un-normalises with limits or not at all, so a guide on such a dataset is refused (guides.py of this package)."""
+    """zero mean / unit variance per dimension (normalization.py:119-141; unbiased std).  The HIP guide kernel un-normalises with it as the reference does
+    (x * stds + means, no range test: mpdx_guide_params.identity_normalizer == 2)."""
     kind = "gaussian"
 
     def __init__(self, means, stds, mins=None, maxs=None):

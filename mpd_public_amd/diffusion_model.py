@@ -337,10 +337,19 @@ class GaussianDiffusionModel(nn.Module):
             return chain
         return chain[-1]
 
-    # ---------------------------------------------------------------------------------------------- training (out of scope)
-    # ------------------------------------------------------------------------------ forward loss (no backward pass)
-    def _hard_tables(self, hard_conds, B, H, D, device):
-        """{0: v, H-1: v} (v [D] or [B,D]) -> ([B,D] start table or None, [B,D] goal table or None)."""
+    # ---------------------------------------------------------------------------------------------- training half (diffusion_model_base.py:320-357)
+    # q_sample / p_losses: forward values; loss(): with gradients enabled, the native forward + backward pass (trainer.py, csrc/train.hpp)
+    def _hard_tables(self, hard_conds, B, H, D, device, allow_other=False):
+        """{0: v, H-1: v} (v [D] or [B,D]) -> ([B,D] start table or None, [B,D] goal table or None): the two indices the kernels fold into their
+        epilogues (what TrajectoryDataset.get_hard_conditions produces, trajectories.py:214-237).  Any other set of horizon indices: with
+        `allow_other` (the forward-only q_sample / p_losses) -> (None, None) and the caller applies the whole dict with apply_hard_conditioning
+        (mpdx_hard_conds); the native TRAINING pass takes 0 / H-1 only and refuses."""
+        extra = set(int(k) for k in (hard_conds or {}).keys()) - {0, H - 1}
+        if extra:
+            if allow_other:
+                return [None, None]
+            raise NotImplementedError(f"hard conditions at horizon indices {sorted(extra)}: the native training pass supports 0 and H-1 only "
+                                      "(sampling, q_sample and p_losses take any index)")
         out = []
         for key in (0, H - 1):
             v = (hard_conds or {}).get(key)
@@ -349,10 +358,11 @@ class GaussianDiffusionModel(nn.Module):
                 continue
             v = v.to(device=device, dtype=torch.float32)
             out.append((v.expand(B, D) if v.dim() == 1 else v).contiguous())
-        extra = set((hard_conds or {}).keys()) - {0, H - 1}
-        if extra:
-            raise NotImplementedError(f"hard conditions at horizon indices {sorted(extra)}: only 0 and H-1 are supported")
         return out
+
+    @staticmethod
+    def _other_indices(hard_conds, H):
+        return bool(set(int(k) for k in (hard_conds or {}).keys()) - {0, H - 1})
 
     def q_sample(self, x_start, t, noise=None, hard_conds=None):
         """diffusion_model_base.py:320-330 (per-sample t).  `hard_conds` optionally folds the apply_hard_conditioning of
@@ -367,17 +377,19 @@ class GaussianDiffusionModel(nn.Module):
         t = t.to(device=x_start.device, dtype=torch.long).reshape(-1).contiguous()
         if t.numel() != B:
             raise ValueError(f"t must have {B} entries")
-        hs, hg = self._hard_tables(hard_conds, B, H, D, x_start.device)
+        hs, hg = self._hard_tables(hard_conds, B, H, D, x_start.device, allow_other=True)
         out = torch.empty_like(x_start)
         _lib.check(_lib.load().mpdx_q_sample(x_start.data_ptr(), noise.data_ptr(), t.data_ptr(), self.sqrt_alphas_cumprod.data_ptr(),
                                              self.sqrt_one_minus_alphas_cumprod.data_ptr(), hs.data_ptr() if hs is not None else None,
                                              hg.data_ptr() if hg is not None else None, out.data_ptr(), B, H, D, self.n_diffusion_steps,
                                              _lib.current_stream()), "mpdx_q_sample")
+        if self._other_indices(hard_conds, H):
+            apply_hard_conditioning(out, hard_conds)   # any horizon index (mpdx_hard_conds)
         return out
 
     def p_losses(self, x_start, context, t, hard_conds, noise=None):
         """diffusion_model_base.py:331-352, forward value only: (loss, info) with loss a 0-dim tensor WITHOUT autograd history
-        (what the reference's validation pass computes under no_grad; the backward pass / optimiser are out of scope)."""
+        (what the reference's validation pass computes under no_grad; `loss()` below is the entry with the native backward pass)."""
         if context is not None:
             raise NotImplementedError("context is always None on this path")
         if not x_start.is_cuda:
@@ -389,7 +401,9 @@ class GaussianDiffusionModel(nn.Module):
         noise = noise.to(torch.float32).contiguous()
         x_noisy = self.q_sample(x_start, t, noise, hard_conds)
         x_recon = self.model(x_noisy, t, None)
-        hs, hg = self._hard_tables(hard_conds, B, H, D, x_start.device)
+        hs, hg = self._hard_tables(hard_conds, B, H, D, x_start.device, allow_other=True)
+        if self._other_indices(hard_conds, H):
+            x_recon = apply_hard_conditioning(x_recon, hard_conds)   # :343 for any horizon index (x_recon is this call's own tensor)
         target = noise if self.predict_epsilon else x_start
         if self.loss_type not in ("l1", "l2"):
             raise NotImplementedError(self.loss_type)

@@ -28,7 +28,7 @@ def build_device_params(robot, ws_dim, cutoff_margin, mins, maxs, cost_l, weight
     if clip_grad_rule not in ("norm", "value"):
         raise NotImplementedError(f"clip_grad_rule={clip_grad_rule!r}")   # as guides.py:219-220
     gp.clip_rule, gp.max_grad_value = (1 if clip_grad_rule == "value" else 0), float(max_grad_value)
-    gp.identity_normalizer = int(bool(identity_normalizer))
+    gp.identity_normalizer = int(identity_normalizer)   # 0 limits, 1 Identity, 2 GaussianNormalizer (means in `mins`, stds in `maxs`)
     D = 2 * robot.q_dim
     if mins is not None:
         mins, maxs = torch.as_tensor(mins).cpu().numpy(), torch.as_tensor(maxs).cpu().numpy()
@@ -101,15 +101,19 @@ class GuideManagerTrajectoriesWithVelocity(nn.Module):
         if ds.state_dim != 2 * ds.robot.q_dim:
             raise NotImplementedError("the velocity guide needs include_velocity=True (state = pos + vel)")
         kind = getattr(ds.normalizer, "kind", "limits")
-        if kind not in ("limits", "identity"):
-            raise NotImplementedError(f"the HIP guide un-normalises with limits (LimitsNormalizer and its subclasses) or not at all (Identity); "
-                                      f"{type(ds.normalizer).__name__} is not supported under a guide")
-        ident = kind == "identity"
+        if kind not in ("limits", "identity", "gaussian"):
+            raise NotImplementedError(f"the HIP guide un-normalises with limits (LimitsNormalizer and its subclasses), mean / std (GaussianNormalizer) or not at "
+                                      f"all (Identity); {type(ds.normalizer).__name__} is not supported under a guide")
+        # the kernel's un-normalisation: 0 = limits with the whole-tensor range test (normalization.py:156-167), 1 = none (:111-116),
+        # 2 = x * stds + means (:140-141; the two vectors travel in the `mins` / `maxs` slots, no range test)
+        mode = {"limits": 0, "identity": 1, "gaussian": 2}[kind]
+        lo = None if mode == 1 else ds.normalizer.means if mode == 2 else ds.normalizer.mins
+        hi = None if mode == 1 else ds.normalizer.stds if mode == 2 else ds.normalizer.maxs
         self._params, self._prims = build_device_params(
-            ds.robot, ds.env.dim, ds.task.obstacle_cutoff_margin, None if ident else ds.normalizer.mins, None if ident else ds.normalizer.maxs,
+            ds.robot, ds.env.dim, ds.task.obstacle_cutoff_margin, lo, hi,
             self.cost.cost_l, self.cost.weight_cost_l, self.interpolate_trajectories_for_collision, self.num_interpolated_points_for_collision,
             self.clip_grad, self.max_grad_norm, device, clip_grad_rule=self.clip_grad_rule, max_grad_value=self.max_grad_value,
-            identity_normalizer=ident)
+            identity_normalizer=mode)
         return self._params
 
     # ------------------------------------------------------------------------------------------- guide protocol

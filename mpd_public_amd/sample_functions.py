@@ -13,20 +13,38 @@ from . import _lib
 
 
 def apply_hard_conditioning(x, conditions):
-    """x[:, t, :] = val for every (t, val) (in place, as sample_functions.py:5-8)."""
-    H = x.shape[1]
-    keys = set(conditions.keys())
-    if x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and keys <= {0, H - 1} and \
-            all(v.is_cuda and v.shape == (x.shape[0], x.shape[2]) for v in conditions.values()):
-        hs = conditions.get(0)
-        hg = conditions.get(H - 1)
-        hs = hs.contiguous().float() if hs is not None else None
-        hg = hg.contiguous().float() if hg is not None else None
-        _lib.check(_lib.load().mpdx_add_noise(x.data_ptr(), None, _lib.ptr(hs), _lib.ptr(hg), 0.0, 0.0, None,
-                                              x.shape[0], H, x.shape[2], _lib.current_stream()), "mpdx_add_noise")
+    """x[:, t, :] = val for every (t, val) (in place, as sample_functions.py:5-8): horizon indices 0 / H-1 through the step kernels' own epilogue
+    form (mpdx_add_noise), any other set of indices through the scatter kernel mpdx_hard_conds - python indexing semantics (negative indices,
+    a later entry wins on a repeated index), values [D] or [B, D]."""
+    if not conditions:
         return x
-    for t, val in conditions.items():  # exotic conditioning indices: plain indexed writes
-        x[:, t, :] = val.clone()
+    if not x.is_cuda:
+        raise RuntimeError("apply_hard_conditioning runs on the GPU (libmpdx); there is no CPU fallback")
+    if not (x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 3):   # a strided view / another dtype: indexed device writes (plumbing)
+        for k, v in conditions.items():
+            x[:, k, :] = torch.as_tensor(v).to(device=x.device, dtype=x.dtype)
+        return x
+    B, H, D = x.shape
+    vals = {}
+    for k, v in conditions.items():
+        v = torch.as_tensor(v).to(device=x.device, dtype=torch.float32)
+        if v.dim() == 1:
+            v = v.reshape(1, -1).expand(B, -1)
+        if tuple(v.shape) != (B, D):
+            raise ValueError(f"hard condition at horizon index {k}: expected [{D}] or [{B},{D}], got {tuple(v.shape)}")
+        vals[int(k)] = v.contiguous()
+    if set(vals) <= {0, H - 1}:
+        _lib.check(_lib.load().mpdx_add_noise(x.data_ptr(), None, _lib.ptr(vals.get(0)), _lib.ptr(vals.get(H - 1)), 0.0, 0.0, None,
+                                              B, H, D, _lib.current_stream()), "mpdx_add_noise")
+        return x
+    import ctypes as C
+    keys = list(vals)
+    lib = _lib.load()
+    for i in range(0, len(keys), 16):   # (the kernel takes 16 entries per launch; order is kept across launches)
+        part = keys[i:i + 16]
+        idx = (C.c_int32 * len(part))(*part)
+        ptrs = (C.c_void_p * len(part))(*[vals[k].data_ptr() for k in part])
+        _lib.check(lib.mpdx_hard_conds(x.data_ptr(), None, len(part), idx, ptrs, B, H, D, _lib.current_stream()), "mpdx_hard_conds")
     return x
 
 

@@ -111,8 +111,13 @@ class TemporalUnet(nn.Module):
         self._stamp = None
         # the native model is created HERE (host-side only: no GPU needed), so that a configuration libmpdx cannot run - a GroupNorm
         # group of 2 or 64 channels, a width that is not a multiple of 16, a horizon the strided convolutions do not map back onto
-        # itself - is refused at construction with the layer named, not at the first forward
-        self._handle()
+        # itself - is refused at construction with the layer named, not at the first forward.  On a host where the library itself is
+        # unavailable the module can still be BUILT (to inspect or convert a state_dict): the check then happens at the first engine() call,
+        # which raises - there is no fallback.
+        try:
+            self._handle()
+        except _lib.LibraryUnavailable:
+            pass
 
     # ------------------------------------------------------------------------------------------- engine plumbing
     _DEVICE_STATE = {"_h": None, "_packed": None, "_timetab": None, "_timetab_T": 0, "_ws": None, "_ws_B": 0, "_stamp": None}
@@ -139,10 +144,6 @@ class TemporalUnet(nn.Module):
     def _handle(self):
         if self._h is None:
             lib = _lib.load()
-            pad = (int(self.state_dim) + 15) // 16 * 16   # the first convolution's input channels as the kernels pad them
-            if pad & (pad - 1):   # 48: state_dim 33 ... 48 - refused here, at construction of the engine, with the layer's reason (the kernels index by shifts)
-                raise RuntimeError(f"state_dim {self.state_dim} unsupported: the first convolution reads {pad} padded input channels, the kernels take a power of "
-                                   "two (state_dim <= 32 or 49 ... 64)")
             mults = (C.c_int32 * _lib.MAX_LEVELS)(*self.dim_mults)
             cfg = _lib.UnetCfg(int(self.state_dim), int(self.n_support_points), int(self.unet_input_dim), len(self.dim_mults),
                                mults, int(self.time_emb_dim))

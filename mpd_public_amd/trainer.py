@@ -225,24 +225,27 @@ class TrainStep:
         self.unet._stamp = None   # the inference engine's pack of these weights is stale until the next pack()
         return self.scratch[0] if mn > 0 else None
 
-    # ------------------------------------------------------------------------------------------------ one iteration as a hipGraph
+    # ------------------------------------------------------------------------------------------------ one iteration, eager or as a hipGraph
     _MAX_GRAPHS = 4   # captured iterations kept (least recently used beyond that are dropped: each owns a private memory pool)
+    _MAX_STATES = 16  # (shapes, hyper-parameters) whose launch form is remembered
 
     def step(self, x_start, hard_conds=None, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=None, t=None, noise=None, use_graph=None):
-        """One training iteration of trainer.py:186-283 - p_losses + backward (loss_backward) and clip + Adam (adam_step) - returning the loss.
+        """One training iteration of trainer.py:186-283 - p_losses + backward (loss_backward) and clip + Adam - returning the loss.
 
-        The iteration can be REPLAYED AS ONE hipGraph (torch.cuda.CUDAGraph over the same native launches): at the reference's batch of 32 the
-        ~85 launches of an iteration take the host as long to enqueue as the GPU to run, and a slower host is then what a step costs; the
-        replay is one host call.  Whether that pays depends on the box (round 4: batch 128 x D = 14 ran 0.955 ms eager on one host and 1.064
-        ms on the driver's), so by default it is MEASURED per (shapes, hyper-parameters): calls 1-3 run eager (2 and 3 timed), call 4
-        captures, calls 5-6 time the replay, and the faster form is kept (`launch_mode()` says which).  use_graph=True / False (or
-        MPDX_TRAIN_GRAPH=1 / 0) force either.  What a captured graph freezes is kept out of its kernel arguments: the batch and the hard
-        conditions are copied into static buffers, t and the noise are drawn ON THE DEVICE by the pass's first launch (mpdx_train_draw:
-        Philox keyed by the model's seed and the device-resident step count - what diffusion_model_base.py:356 / :337 draw with
-        torch.randint / torch.randn_like; pass `t` / `noise` to supply them instead), and Adam's step count lives on the device
-        (mpdx_adam_step with step < 0).  A new learning rate is a new graph (at most _MAX_GRAPHS are kept).
-        In graph mode the returned 0-dim tensor is the graph's own output buffer: the next replay overwrites it - read it (float(loss))
-        or clone it before the next call if you keep it (the eager form returns a fresh tensor)."""
+        The iteration runs as eager launches or is REPLAYED AS ONE hipGraph (torch.cuda.CUDAGraph over the same native launches): at the reference's
+        batch of 32 the launches of an iteration take the host as long to enqueue as the GPU to run, and a slower host is then what a step costs;
+        the replay is one host call.  Whether that pays depends on the box, so by default it is MEASURED per (shapes, hyper-parameters): calls 1-3
+        run eager (2 and 3 timed), call 4 captures, calls 5-6 time the replay, and the faster form is kept (`launch_mode()` says which).
+        use_graph=True / False (or MPDX_TRAIN_GRAPH=1 / 0) force either.
+
+        BOTH forms are the same launches with the same arguments, so the choice never changes the numbers: t and the noise are drawn ON THE DEVICE by
+        the pass's first launch (mpdx_train_draw: Philox keyed by the model's seed and the device-resident step count - what
+        diffusion_model_base.py:356 / :337 draw with torch.randint / torch.randn_like; pass `t` / `noise` to supply them instead), Adam's step count
+        and the learning rate live on the device (mpdx_adam_step with step < 0, lr < 0: scratch[4], scratch[5]) - a fixed seed gives the same
+        losses and weights whichever form a host ends up with, and an LR schedule neither re-captures a graph nor grows any cache.
+        In graph mode the batch and the hard conditions are copied into the graph's static buffers, and the returned 0-dim tensor is the graph's
+        own output buffer: the next replay overwrites it - read it (float(loss)) or clone it before the next call if you keep it (the eager form
+        returns a fresh tensor)."""
         import os
         import time
         env = os.environ.get("MPDX_TRAIN_GRAPH")
@@ -250,11 +253,16 @@ class TrainStep:
             use_graph = env != "0"
         hard_conds = hard_conds or {}
         mn = float(max_norm) if max_norm else 0.0
-        key = (tuple(x_start.shape), tuple(sorted((int(k), tuple(v.shape)) for k, v in hard_conds.items())), float(lr), tuple(betas), float(eps), mn,
+        key = (tuple(x_start.shape), tuple(sorted((int(k), tuple(v.shape)) for k, v in hard_conds.items())), tuple(betas), float(eps), mn,
                t is not None, noise is not None)
         graphs = self.__dict__.setdefault("_graphs", {})
         state = self.__dict__.setdefault("_graph_state", {})
-        s = state.setdefault(key, {"calls": 0, "eager_ms": [], "graph_ms": [], "mode": None})   # mode: None undecided, "graph", "eager"
+        s = state.pop(key, None) or {"calls": 0, "eager_ms": [], "graph_ms": [], "mode": None, "bufs": None}   # mode: None undecided, "graph", "eager"
+        state[key] = s   # most recently used last
+        while len(state) > self._MAX_STATES:
+            old = next(iter(state))
+            state.pop(old)
+            graphs.pop(old, None)
         if use_graph is not None:
             s["mode"] = "graph" if use_graph else "eager"
         g = graphs.get(key) if s["mode"] != "eager" else None
@@ -264,6 +272,14 @@ class TrainStep:
             del graphs[key]
             s["calls"], g = 0, None
         s["calls"] += 1
+        if not self.fp.aliased():
+            raise RuntimeError("the model's parameters no longer alias the flat training vector (was the model moved or re-created?) - build a new TrainStep")
+        # device-resident step count and learning rate (both forms read them there)
+        if self.__dict__.get("_dev_steps") != self.step_count:   # adam_step() calls in between moved the host's count: re-seed the device's
+            self.scratch.view(torch.int32)[4] = self.step_count
+        if self.__dict__.get("_dev_lr") != float(lr):
+            self.scratch[5:6].fill_(float(lr))
+            self._dev_lr = float(lr)
         timed = None
         if g is None:
             if s["mode"] == "eager" or s["calls"] < (4 if s["mode"] is None else 3):   # eager (also the warm-up of everything a capture must not do:
@@ -272,14 +288,24 @@ class TrainStep:
                 if measure:
                     torch.cuda.synchronize()
                     timed = time.perf_counter()
-                loss, _ = self.loss_backward(x_start, hard_conds, t=t, noise=noise)
-                self.adam_step(lr, betas, eps, max_norm)
+                draw = t is None and noise is None
+                if draw:
+                    if s["bufs"] is None or s["bufs"][1].device != x_start.device:
+                        s["bufs"] = (torch.zeros(x_start.shape[0], dtype=torch.long, device=x_start.device),
+                                     torch.empty(tuple(x_start.shape), dtype=torch.float32, device=x_start.device))
+                    tt, nz = s["bufs"]
+                else:   # one of the two supplied: the other from torch's generator, as inside a capture
+                    tt = t if t is not None else torch.randint(0, self.model.n_diffusion_steps, (x_start.shape[0],), device=x_start.device).long()
+                    nz = noise if noise is not None else torch.randn_like(x_start, dtype=torch.float32)
+                self.fp.snapshot_pending()
+                loss = self._iteration(x_start, hard_conds, tt, nz, draw, betas, eps, mn, static_loss=False)
+                self._after_iteration()
                 if measure:
                     torch.cuda.synchronize()
                     s["eager_ms"].append((time.perf_counter() - timed) * 1e3)
                 return loss
             self.fp.snapshot_pending()   # (outside the capture)
-            g = graphs[key] = self._capture(x_start, hard_conds, lr, betas, eps, mn, t, noise)
+            g = graphs[key] = self._capture(x_start, hard_conds, betas, eps, mn, t, noise)
             while len(graphs) > self._MAX_GRAPHS:
                 graphs.pop(next(iter(graphs)))
         else:
@@ -305,17 +331,8 @@ class TrainStep:
             torch._foreach_copy_(small_d, small_s)
         if t is not None:
             g["t"].copy_(t, non_blocking=True)
-        if self.__dict__.get("_dev_steps") != self.step_count:   # eager adam_step calls in between moved the host's count: re-seed the device's
-            self.scratch.view(torch.int32)[4] = self.step_count
-        if not self.fp.aliased():
-            raise RuntimeError("the model's parameters no longer alias the flat training vector (was the model moved or re-created?) - build a new TrainStep")
         g["graph"].replay()
-        self.step_count += 1
-        self._dev_steps = self.step_count
-        self.unet._stamp = None
-        self.unet._timetab, self.unet._timetab_T = None, 0
-        if not self.fp.grads_bound():
-            self.fp.bind_grads()
+        self._after_iteration()
         if measure:
             torch.cuda.synchronize()
             s["graph_ms"].append((time.perf_counter() - timed) * 1e3)
@@ -327,6 +344,30 @@ class TrainStep:
                     return loss
         return g["loss"]
 
+    def _iteration(self, x, hard_conds, tt, nz, draw, betas, eps, mn, static_loss):
+        """the launches of one iteration - what step() runs eagerly and what _capture records: loss_backward (with the device draw of t and the noise
+        armed when `draw`) and clip + Adam reading the step count and the learning rate from the device"""
+        lib, m = _lib.load(), self.model
+        if draw:
+            _lib.check(lib.mpdx_train_draw(self.unet._handle(), int(m._rng_seed) & (2 ** 64 - 1), self.scratch.data_ptr() + 16), "mpdx_train_draw")
+        try:
+            loss, _ = self.loss_backward(x, hard_conds, t=tt, noise=nz, _static_loss=static_loss)
+        finally:
+            if draw:
+                lib.mpdx_train_draw(self.unet._handle(), 0, None)
+        _lib.check(lib.mpdx_adam_step(self.fp.flat.data_ptr(), self.fp.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                      self.fp.n, -1.0, float(betas[0]), float(betas[1]), float(eps), -1, mn,
+                                      self.scratch.data_ptr(), _lib.current_stream()), "mpdx_adam_step")
+        return loss
+
+    def _after_iteration(self):
+        self.step_count += 1
+        self._dev_steps = self.step_count
+        self.unet._stamp = None   # the inference engine's pack of these weights is stale until the next pack()
+        self.unet._timetab, self.unet._timetab_T = None, 0
+        if not self.fp.grads_bound():
+            self.fp.bind_grads()
+
     def launch_mode(self):
         """how step() runs each (shapes, hyper-parameters) it has seen: {'mode': 'graph' | 'eager' | None (still measuring), 'eager_ms', 'graph_ms'}"""
         return [{"batch": k[0][0], "mode": v["mode"], "eager_ms": [round(x, 3) for x in v["eager_ms"]], "graph_ms": [round(x, 3) for x in v["graph_ms"]]}
@@ -337,34 +378,23 @@ class TrainStep:
         return (self._packed().data_ptr(), self.fp.packedT.data_ptr(), self.fp.flat.data_ptr(), self.fp.grad.data_ptr(), self.exp_avg.data_ptr(),
                 self.exp_avg_sq.data_ptr(), self.scratch.data_ptr(), self.loss_buf.data_ptr(), 0 if self._ws is None else self._ws.data_ptr())
 
-    def _capture(self, x_start, hard_conds, lr, betas, eps, mn, t, noise):
-        m, dev = self.model, x_start.device
+    def _capture(self, x_start, hard_conds, betas, eps, mn, t, noise):
+        dev = x_start.device
         B = x_start.shape[0]
         st = {"x": x_start.to(torch.float32).contiguous().clone(), "hc": {k: v.to(device=dev, dtype=torch.float32).contiguous().clone() for k, v in hard_conds.items()},
               "t": None if t is None else t.to(device=dev, dtype=torch.long).reshape(-1).contiguous().clone(),
               "noise": None if noise is None else noise.to(torch.float32).contiguous().clone()}
-        self.scratch.view(torch.int32)[4] = self.step_count
-        self._dev_steps = self.step_count
-        lib = _lib.load()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         graph = torch.cuda.CUDAGraph()
         draw = st["t"] is None and st["noise"] is None   # both drawn: on the device, inside the pass's first launch (mpdx_train_draw)
         if draw:
             st["t"], st["noise"] = torch.zeros(B, dtype=torch.long, device=dev), torch.empty_like(st["x"])
+        m = self.model
         with torch.cuda.graph(graph, stream=side):
             tt = st["t"] if st["t"] is not None else torch.randint(0, m.n_diffusion_steps, (B,), device=dev).long()
             nz = st["noise"] if st["noise"] is not None else torch.randn_like(st["x"])
-            if draw:
-                _lib.check(lib.mpdx_train_draw(self.unet._handle(), int(m._rng_seed) & (2 ** 64 - 1), self.scratch.data_ptr() + 16), "mpdx_train_draw")
-            try:
-                loss, _ = self.loss_backward(st["x"], st["hc"], t=tt, noise=nz, _static_loss=True)
-            finally:
-                if draw:
-                    lib.mpdx_train_draw(self.unet._handle(), 0, None)
-            _lib.check(lib.mpdx_adam_step(self.fp.flat.data_ptr(), self.fp.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                          self.fp.n, float(lr), float(betas[0]), float(betas[1]), float(eps), -1, mn,
-                                          self.scratch.data_ptr(), _lib.current_stream()), "mpdx_adam_step")
+            loss = self._iteration(st["x"], st["hc"], tt, nz, draw, betas, eps, mn, static_loss=True)
         torch.cuda.current_stream(dev).wait_stream(side)
         st["graph"], st["loss"], st["ptrs"] = graph, loss, self._static_ptrs()
         return st

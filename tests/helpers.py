@@ -79,6 +79,10 @@ def oracle_guide(dataset, w_coll=1e-2, w_smooth=1e-7, clip_grad=True, interpolat
     if getattr(dataset.normalizer, "kind", "limits") == "identity":
         from oracle.normalizer import Identity
         nrm = Identity()
+    elif getattr(dataset.normalizer, "kind", "limits") == "gaussian":
+        from oracle.normalizer import GaussianNormalizer
+        nrm = GaussianNormalizer(dataset.normalizer.means.cpu(), dataset.normalizer.stds.cpu())
+        nrm.means, nrm.stds = nrm.means.to(dtype), nrm.stds.to(dtype)
     else:
         nrm = LimitsNormalizer(dataset.normalizer.mins.cpu(), dataset.normalizer.maxs.cpu())
         nrm.mins, nrm.maxs = nrm.mins.to(dtype), nrm.maxs.to(dtype)

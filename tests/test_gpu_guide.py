@@ -41,16 +41,24 @@ def test_guide_increment_vs_oracle(env_id, robot_id, scale, weights):
 
 
 @pytest.mark.parametrize("env_id,robot_id", [("EnvSimple2D", "RobotPointMass"), ("EnvSpheres3D", "RobotPanda")])
-@pytest.mark.parametrize("name", ["Identity", "FixedLimitsNormalizer", "SafeLimitsNormalizer"])
+@pytest.mark.parametrize("name", ["Identity", "FixedLimitsNormalizer", "SafeLimitsNormalizer", "GaussianNormalizer"])
 def test_guide_increment_with_the_other_normalizers_vs_oracle(env_id, robot_id, name):
     """TrajectoryDataset(normalizer=...) (trajectories.py:26): the guide kernel un-normalises with the limits a LimitsNormalizer subclass ends up
-    with, or not at all under Identity (trajectories in real units); a GaussianNormalizer is refused under a guide."""
+    with, not at all under Identity (trajectories in real units), or with x * stds + means under a GaussianNormalizer (normalization.py:140-141:
+    no range test - the scale 1.3 trajectories below would be clipped by a limits class)."""
     import mpd_public_amd as m
     ta = {"device": "cuda", "dtype": torch.float32}
     ds0 = m.TrajectoryDataset(env_id, robot_id, tensor_args=ta)
-    ds = m.TrajectoryDataset(env_id, robot_id, tensor_args=ta, normalizer=name)
+    if name == "GaussianNormalizer":   # (built from data in the reference: here statistics that put the same trajectories at the same places)
+        ds = m.TrajectoryDataset(env_id, robot_id, tensor_args=ta)
+        mins, maxs = ds0.normalizer.mins.cpu(), ds0.normalizer.maxs.cpu()
+        means = 0.5 * (mins + maxs) + 0.03 * t(f"gn_mean/{env_id}", (ds.state_dim,), "uniform")
+        stds = 0.5 * (maxs - mins) / 1.3 * (1.0 + 0.1 * t(f"gn_std/{env_id}", (ds.state_dim,), "uniform"))
+        ds.normalizer = m.GaussianNormalizer(means, stds).to("cuda")
+    else:
+        ds = m.TrajectoryDataset(env_id, robot_id, tensor_args=ta, normalizer=name)
     assert type(ds.normalizer).__name__ == name
-    x = obstacle_hugging_trajs(ds0, 7, seed=f"gn/{env_id}", scale=0.9)
+    x = obstacle_hugging_trajs(ds0, 7, seed=f"gn/{env_id}", scale=1.3 if name == "GaussianNormalizer" else 0.9)
     if name == "Identity":
         x = ds0.normalizer.unnormalize(x.cuda()).cpu()
     og, _ = oracle_guide(ds, dtype=torch.float64)
@@ -60,9 +68,30 @@ def test_guide_increment_with_the_other_normalizers_vs_oracle(env_id, robot_id, 
     bad = _mismatch(got, ref, atol=2e-6).any(-1)
     assert bad.mean() < 0.01, f"{bad.sum()} of {bad.size} waypoints differ; max|diff|={np.abs(got-ref).max():.3e}"
     np.testing.assert_allclose(got[~bad], ref[~bad], rtol=1e-3, atol=2e-6)
-    ds.normalizer = m.GaussianNormalizer(torch.zeros(ds.state_dim), torch.ones(ds.state_dim)).to("cuda")
-    with pytest.raises(NotImplementedError):
-        product_guide(ds).cuda()(x.cuda())
+
+
+def test_guided_plan_under_gaussian_normalizer_fused_equals_stepwise_and_oracle_start():
+    """A GaussianNormalizer dataset under the HIP guide: fused plan == step-by-step protocol loop bit for bit, and both track the
+    oracle loop with the oracle's GaussianNormalizer through the first guided steps."""
+    import mpd_public_amd as m
+    from oracle import diffusion as odiff
+    T, B = 25, 4
+    ds, dm, noise, hc, n0 = _guided_setup("EnvDense2D", "RobotPointMass", T, B, 0)
+    mins, maxs = ds.normalizer.mins.cpu(), ds.normalizer.maxs.cpu()
+    ds.normalizer = m.GaussianNormalizer(0.5 * (mins + maxs) + 0.02, 0.45 * (maxs - mins)).to("cuda")
+    pg = product_guide(ds, 1e-2, 1e-7).cuda()
+    kw = dict(n_samples=B, horizon=64, return_chain=True, sample_fn=m.ddpm_sample_fn, guide=pg, n_guide_steps=5,
+              t_start_guide=ceil(0.25 * T), n_diffusion_steps_without_noise=n0, noise_std_extra_schedule_fn=lambda tt: 0.5,
+              noise=noise.cuda())
+    a = dm.run_inference(None, hc, fused=True, **kw)
+    b = dm.run_inference(None, hc, fused=False, **kw)
+    assert torch.equal(a, b)
+    og, _ = oracle_guide(ds, 1e-2, 1e-7)
+    ref = odiff.run_inference(synth_sd(ds.state_dim, 0), {k: v.cpu() for k, v in hc.items()}, noise, T, noise_std=0.5, guide=og, n_guide_steps=5,
+                              t_start_guide=ceil(0.25 * T), n_diffusion_steps_without_noise=n0)
+    k_guide = T - ceil(0.25 * T)
+    err = (a.cpu() - ref).abs().reshape(a.shape[0], -1).amax(1).numpy()
+    assert err[: k_guide + 2].max() < 2e-3, err[: k_guide + 2]
 
 
 @pytest.mark.parametrize("env_id,robot_id", [("EnvDense2D", "RobotPointMass"), ("EnvSpheres3D", "RobotPanda")])

@@ -112,19 +112,19 @@ def test_other_horizons_unet_and_plan_vs_oracle(H, mults, D):
     hc = {0: t(f"hz_hc0_{D}", (D,), "uniform"), H - 1: t(f"hz_hc1_{D}", (D,), "uniform")}
     chain = dm.run_inference(None, {k: v.cuda() for k, v in hc.items()}, n_samples=B, horizon=H, return_chain=True, sample_fn=m.ddpm_sample_fn,
                              n_diffusion_steps_without_noise=n0, noise_std_extra_schedule_fn=lambda tt_: 0.5, noise=noise.cuda()).cpu()
-    ref = odiff.run_inference(sd, hc, noise, T, n_diffusion_steps_without_noise=n0, noise_std=0.5)
+    # the oracle's fp32 chain moves by a few 1e-4 with the host's thread count (ATen's reduction order): ONE thread pins it on every host
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        ref = odiff.run_inference(sd, hc, noise, T, n_diffusion_steps_without_noise=n0, noise_std=0.5)
+    finally:
+        torch.set_num_threads(nthr)
     assert chain.shape == ref.shape == (T + n0 + 1, B, H, D)
     assert torch.equal(chain[-1][:, 0], hc[0].expand(B, D)) and torch.equal(chain[-1][:, H - 1], hc[H - 1].expand(B, D))
     np.testing.assert_allclose(chain.numpy(), ref.numpy(), rtol=0, atol=2e-3)
-    # final trajectories: within 5e-4 of the fp32 oracle, or - the oracle's own fp32 chain moves by that much with the host's thread count (ATen's
-    # reduction order) - as close to the fp64 evaluation of the same algorithm as the fp32 oracle is (test_chain_error_is_fp32_rounding_class)
     d = float((chain[-1] - ref[-1]).abs().max())
-    if d > 5e-4:
-        exact = odiff.run_inference({k: v.double() for k, v in sd.items()}, {k: v.double() for k, v in hc.items()}, noise.double(), T,
-                                    n_diffusion_steps_without_noise=n0, noise_std=0.5, dtype=torch.float64)
-        e_gpu, e_ref = float((chain[-1].double() - exact[-1]).abs().max()), float((ref[-1].double() - exact[-1]).abs().max())
-        print(f"H={H}: |gpu - oracle32| = {d:.3e}, |gpu - fp64| = {e_gpu:.3e}, |oracle32 - fp64| = {e_ref:.3e}")
-        assert d < 1e-3 and e_gpu < 3 * e_ref + 1e-5, (d, e_gpu, e_ref)
+    print(f"H={H}: |gpu - oracle32| on the final trajectories = {d:.3e}")
+    assert d < 5e-4, d   # the cfg1 chain's bound on the result (test_unguided_chain_cfg1_vs_reference_golden)
 
 
 def test_unet_batch_independence():
@@ -388,6 +388,69 @@ def test_forward_loss_vs_reference_golden(golden_dir, D, opt):
             assert abs(float(loss) - want) <= 2e-5 * abs(want), (pe, lt, float(loss), want)
     l2, _ = dm.loss(x0, None, hc)   # random timesteps + device noise: finite, positive
     assert bool(torch.isfinite(l2)) and float(l2.detach()) > 0
+
+
+def test_hard_conditions_at_arbitrary_horizon_indices_vs_oracle():
+    """apply_hard_conditioning writes ANY horizon index in the reference (sample_functions.py:5-8: `x[:, t, :] = val`).  Indices 0 / H-1 ride in the
+    step kernels' epilogues; every other set goes through the scatter kernel mpdx_hard_conds on the step-by-step protocol loop (run_inference takes
+    that loop by itself when the fused plan does not apply).  Checked: the helper itself (python indexing semantics: negative index, [D] and [B,D]
+    values, a repeated index resolved in dict order, 17 entries = two launches) bit-exact against indexed writes; an unguided DDPM chain and a DDIM
+    chain with via-points at {0, 17, 40, 63} against the oracle; q_sample / p_losses (forward) with the same dict against the oracle; the native
+    training pass refuses such a dict by name."""
+    import mpd_public_amd as m
+    from oracle import diffusion as odiff
+    D, T, B, n0, opt = 4, 25, 5, 3, 1
+    # (1) the helper
+    x = t("hcx", (B, 64, D)).cuda()
+    conds = {0: t("hc_a", (D,), "uniform"), 17: t("hc_b", (B, D), "uniform").cuda(), -1: t("hc_c", (D,), "uniform").cuda(), 40: t("hc_d", (B, D), "uniform"),
+             63: t("hc_e", (B, D), "uniform").cuda()}   # -1 and 63 name the same row: the later entry wins
+    want = x.clone()
+    for k, v in conds.items():
+        want[:, k, :] = v.cuda()
+    got = m.apply_hard_conditioning(x.clone(), conds)
+    assert torch.equal(got, want)
+    many = {k: t(f"hc_many{k}", (D,), "uniform") for k in range(3, 3 + 17)}
+    want = x.clone()
+    for k, v in many.items():
+        want[:, k, :] = v.cuda()
+    assert torch.equal(m.apply_hard_conditioning(x.clone(), many), want)
+    with pytest.raises(RuntimeError, match="out of range"):
+        m.apply_hard_conditioning(x.clone(), {64: conds[0], 1: conds[0]})
+    # (2) chains with via-points
+    dm = _gpu_model(D, opt, T)
+    sd = synth_sd(D, opt)
+    hc = {0: t("via0", (D,), "uniform", 0.6), 17: t("via17", (D,), "uniform", 0.6), 40: t("via40", (D,), "uniform", 0.6), 63: t("via63", (D,), "uniform", 0.6)}
+    noise = t("via_noise", (T + n0 + 1, B, 64, D))
+    chain = dm.run_inference(None, {k: v.cuda() for k, v in hc.items()}, n_samples=B, horizon=64, return_chain=True, sample_fn=m.ddpm_sample_fn,
+                             n_diffusion_steps_without_noise=n0, noise_std_extra_schedule_fn=lambda tt: 0.5, noise=noise.cuda()).cpu()
+    ref = odiff.run_inference(sd, hc, noise, T, n_diffusion_steps_without_noise=n0, noise_std=0.5)
+    assert chain.shape == ref.shape
+    err = (chain - ref).abs().reshape(chain.shape[0], -1).amax(1)
+    assert float(err.max()) < 2e-3 and float(err[-1]) < 5e-4, err
+    for k, v in hc.items():
+        assert torch.equal(chain[:, :, k, :], v.expand(chain.shape[0], B, D)), k     # exact at every via-point of every chain row
+    with pytest.raises(NotImplementedError):   # the fused plan itself takes 0 / H-1 only (run_inference routes around it)
+        dm.plan({k: v.cuda() for k, v in hc.items()}, B, 64, n0, noise.cuda(), lambda tt: 0.5)
+    x_T = t("via_ddim_noise", (8, B, 64, D))
+    got = dm.run_inference(None, {k: v.cuda() for k, v in hc.items()}, n_samples=B, horizon=64, return_chain=True, ddim=True, noise=x_T.cuda()).cpu()
+    ref = odiff.ddim_sample(sd, hc, x_T[0], T)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
+    # (3) q_sample / p_losses (forward values)
+    tt = torch.tensor([3, 24, 0, 12, 7], dtype=torch.long)
+    x0, nz = t("via_x0", (B, 64, D), "uniform", 0.8), t("via_nz", (B, 64, D))
+    hcb = {k: v.expand(B, D).contiguous() for k, v in hc.items()}
+    from oracle import schedules as osched
+    xq = dm.q_sample(x0.cuda(), tt.cuda(), nz.cuda(), {k: v.cuda() for k, v in hcb.items()}).cpu()
+    want = odiff.apply_hard_conditioning(odiff.q_sample(osched.make_buffers(T, "exponential"), x0, tt, nz), hcb)
+    np.testing.assert_allclose(xq.numpy(), want.numpy(), rtol=0, atol=3e-7)
+    for lt in ("l2", "l1"):
+        dml = m.GaussianDiffusionModel(model=dm.model, variance_schedule="exponential", n_diffusion_steps=T, predict_epsilon=True, loss_type=lt).cuda().eval()
+        loss, _ = dml.p_losses(x0.cuda(), None, tt.cuda(), {k: v.cuda() for k, v in hcb.items()}, noise=nz.cuda())
+        want = float(odiff.p_losses(sd, x0, tt, hcb, nz, T, loss_type=lt))
+        assert abs(float(loss) - want) <= 5e-5 * abs(want), (lt, float(loss), want)
+    from mpd_public_amd.trainer import TrainStep
+    with pytest.raises(NotImplementedError, match="native training pass"):
+        TrainStep(dml).loss_backward(x0.cuda(), {k: v.cuda() for k, v in hcb.items()}, t=tt.cuda(), noise=nz.cuda())
 
 
 def test_weighted_loss_kernel_vs_formula():

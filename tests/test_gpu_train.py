@@ -490,6 +490,40 @@ def test_graph_replayed_steps_equal_eager_steps():
     assert len(torch.unique(torch.cat(tts))) >= 10   # 6 samples x >= 5 replays over 25 timesteps
 
 
+def test_fixed_seed_gives_the_same_training_run_in_every_launch_form(monkeypatch):
+    """the launch form step() ends up with (eager launches, one hipGraph replay, or the timing-based choice between them) must not change
+    the numbers.  Both forms are the same launches: t and the noise drawn on the device from (seed, device step count), Adam's step count and the
+    learning rate read from device memory.  Ten steps under an LR schedule with MPDX_TRAIN_GRAPH = 0, 1 and unset: identical losses and
+    parameters (bit for bit), one graph at most, bounded state."""
+    from mpd_public_amd.trainer import TrainStep
+    x0, _, hc = _batch(4)
+    x0, hc = x0.cuda(), {k: v.cuda() for k, v in hc.items()}
+    runs = {}
+    for form in ("0", "1", None):
+        if form is None:
+            monkeypatch.delenv("MPDX_TRAIN_GRAPH", raising=False)
+        else:
+            monkeypatch.setenv("MPDX_TRAIN_GRAPH", form)
+        dm = _model(4, 1)
+        dm.manual_seed(1234)
+        ts = TrainStep(dm)
+        losses = [float(ts.step(x0 * (1.0 - 0.02 * k), hc, 1e-3 * (0.9 ** k), max_norm=1.0)) for k in range(10)]
+        assert len(ts.__dict__.get("_graphs", {})) <= 1 and len(ts._graph_state) == 1   # ten learning rates: one key, at most one graph
+        if form == "1":
+            assert len(ts._graphs) == 1
+        if form == "0":
+            assert not ts.__dict__.get("_graphs")
+        runs[form] = (losses, ts.fp.flat.detach().cpu().clone(), ts.exp_avg_sq.detach().cpu().clone())
+    assert len(set(runs["0"][0])) == 10   # fresh draws every step
+    for form in ("1", None):
+        assert runs[form][0] == runs["0"][0], (form, runs[form][0], runs["0"][0])
+        assert torch.equal(runs[form][1], runs["0"][1]) and torch.equal(runs[form][2], runs["0"][2]), form
+    # another seed is another run
+    dm = _model(4, 1)
+    dm.manual_seed(99)
+    assert float(TrainStep(dm).step(x0, hc, 1e-3, max_norm=1.0)) != runs["0"][0][0]
+
+
 def test_step_measures_both_launch_forms_and_keeps_one():
     """By default TrainStep.step times the eager launches (calls 2-3) and the hipGraph replay (calls 5-6) on the host + GPU it runs on and keeps
     the faster form (round 4's fixed `batch <= 64` rule was wrong on the driver's host); whichever wins, the parameters are those of eager steps."""

@@ -107,11 +107,11 @@ def test_training_at_other_widths_vs_oracle(width, mults):
     print(f"width {width} x {mults}: worst relative gradient error {worst:.2e}")
 
 
-@pytest.mark.parametrize("D", [2, 6, 24, 64])
+@pytest.mark.parametrize("D", [2, 6, 24, 33, 40, 48, 64])
 def test_state_dimensions_other_than_the_shipped_ones_vs_oracle(D):
     """state_dim is free in the reference (temporal_unet.py:22-35: the first conv reads it, final_conv[1] writes it).  mpdx_unet_create accepts
-    1 ... 32 and 49 ... 64 (the first convolution's padded input channels must be a power of two: 33 ... 48 are refused at construction): the U-Net pass
-    on both kernel paths and a short unguided chain on both, against the oracle."""
+    1 ... 64 (the first convolution's input channels live in a power-of-two container - 33 ... 48 in 64 channels, the extra ones zero in the staged
+    input and in the packed weights): the U-Net pass on both kernel paths and a short unguided chain on both, against the oracle."""
     import mpd_public_amd as m
     from oracle.unet import unet_forward
     from oracle import diffusion as odiff
@@ -139,11 +139,10 @@ def test_state_dimensions_other_than_the_shipped_ones_vs_oracle(D):
     np.testing.assert_allclose(chains[1].numpy(), ref.numpy(), rtol=0, atol=2e-3)
 
 
-def test_state_dim_with_48_padded_channels_is_refused_at_construction():
+def test_state_dim_beyond_64_is_refused_at_construction():
     import mpd_public_amd as m
-    with pytest.raises(RuntimeError, match="state_dim 40 unsupported"):
-        net = m.TemporalUnet(n_support_points=64, state_dim=40, unet_input_dim=32, dim_mults=(1, 2, 4, 8)).cuda()
-        net(torch.zeros(1, 64, 40, device="cuda"), torch.zeros(1, dtype=torch.long, device="cuda"), None)
+    with pytest.raises(RuntimeError, match="state_dim 65 unsupported"):
+        m.TemporalUnet(n_support_points=64, state_dim=65, unet_input_dim=32, dim_mults=(1, 2, 4, 8))
 
 
 @pytest.mark.parametrize("fused", [True, False])
