@@ -178,6 +178,44 @@ def _alg_bytes(c):
     return c.get("algorithmic_bytes_per_launch")
 
 
+def _unet_pass_flops(dm, B, T):
+    """algorithmic FLOPs of one U-Net pass at batch B from the library's own layer table (mpdx_unet_profile runs one pass)"""
+    import torch
+    from mpd_public_amd import _lib
+    lib = _lib.load()
+    hdl, packed, tab, wsb = dm.model.engine(T, B)
+    x = torch.zeros(B, 64, dm.state_dim, device="cuda")
+    cap = 128
+    ms_ = (C.c_float * cap)(); fl_ = (C.c_double * cap)(); nm_ = (C.c_char_p * cap)(); n_ = C.c_int()
+    _lib.check(lib.mpdx_unet_profile(hdl, packed.data_ptr(), tab.data_ptr(), dm.model._timetab_T, x.data_ptr(), 0, B, wsb.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream, cap, ms_, fl_, nm_, C.byref(n_)), "mpdx_unet_profile")
+    return float(sum(fl_[k] for k in range(n_.value)))
+
+
+def _train_launches_from_profile(B):
+    """launches per training iteration from the newest committed rocprofv3 summary of the training loop at batch B (profiles/r*_train*_kernel_stats.csv,
+    tools/r06_evidence.sh): sum of Calls / the iteration count (= Calls of adam_kernel, launched once per iteration)."""
+    import csv
+    import re
+    name = "train_kernel_stats.csv" if B == 32 else f"train{B}_kernel_stats.csv"
+
+    def _round_key(f):
+        m = re.match(r"r(\d+)([a-z]?)_", f.name)
+        return (int(m.group(1)), m.group(2) or "~") if m else (-1, "")
+    for f in sorted((ROOT / "profiles").glob(f"r*_{name}"), key=_round_key, reverse=True):
+        try:
+            rows = list(csv.DictReader(open(f)))
+            iters = sum(int(r["Calls"]) for r in rows if "adam_kernel" in r["Name"])
+            if not iters:
+                continue
+            mine = sum(int(r["Calls"]) for r in rows if "mpdx::" in r["Name"])
+            return {"file": f"profiles/{f.name}", "launches_per_iteration": round(mine / iters, 1), "iterations_profiled": iters,
+                    "what": "native (mpdx::) kernel launches per iteration, warm-up iterations included"}
+        except Exception:
+            continue
+    return None
+
+
 def roofline_leg(dm, B, T, reps=30):
     """Where the time of one U-Net pass (= one denoising step, unguided) goes, per launch class, measured IN SITU: for every
     maximal run of consecutive launches of one class, one HIP-event pair on the launch stream brackets that run inside
@@ -240,18 +278,20 @@ def roofline_leg(dm, B, T, reps=30):
         c["traffic"] = tr
         c["traffic_source"] = src
         c["traffic_over_algorithmic"] = round(tr / c["algorithmic_bytes_per_launch"], 2) if tr and c["algorithmic_bytes_per_launch"] else None
-    # the headline figure comes from the committed rocprofv3 summary when that was measured on these kernel sources (the in-situ
-    # event figure carries the event pair and the gaps inside a run of launches, ~8 % at cfg 2); both are in the record
+    # The HEADLINE figure is measured LIVE in this run (in-situ HIP events on the launch stream, contract section 4; ADVICE r5: a committed profile's number
+    # ignores this box, its clocks and the runtime switches).  The committed rocprofv3 --kernel-trace --stats summary of the same command - when it was
+    # measured on these kernel sources (fingerprint) - is reported BESIDE it (`rocprof`): the two must agree (the in-situ figure carries the event pair and
+    # the gaps inside a run of launches, ~8 % at cfg 2).
     rp_us, rp_file = _rocprof_class_us(B, dom["kernel_pattern"], dom["launches_per_pass"])
-    in_situ = {"achieved": dom["tflops"], "frac": dom["frac"], "avg_launch_us": dom["avg_launch_us"]}
+    rocprof = None
     if rp_us:
-        dom["tflops"] = round(dom["flop_per_pass"] / (rp_us * 1e-6) / 1e12, 2)
-        dom["frac"] = round(dom["tflops"] / FP32_PEAK_TFLOPS, 4)
-        dom["avg_launch_us"] = round(rp_us / dom["launches_per_pass"], 2)
+        rp_tf = dom["flop_per_pass"] / (rp_us * 1e-6) / 1e12
+        rocprof = {"achieved": round(rp_tf, 2), "frac": round(rp_tf / FP32_PEAK_TFLOPS, 4), "avg_launch_us": round(rp_us / dom["launches_per_pass"], 2),
+                   "file": f"profiles/{rp_file}", "in_situ_over_rocprof": round((dom["us_per_pass"] / rp_us), 3),
+                   "note": "rocprofv3 --kernel-trace --stats average of the class's kernels on these kernel sources (another box of the pool): auxiliary"}
     roof = {"bound": "mfma", "achieved": dom["tflops"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
-            "duration_source": (f"rocprofv3 --kernel-trace --stats average of the class's kernels, profiles/{rp_file} (measured on these kernel sources)" if rp_us
-                                else "in situ HIP events (no committed rocprofv3 summary of these kernel sources at this batch)"),
-            "in_situ": in_situ,
+            "duration_source": "in situ: HIP events on the launch stream inside real U-Net passes of THIS run",
+            "frac_in_situ": dom["frac"], "frac_rocprof": (rocprof or {}).get("frac"), "rocprof": rocprof,
             "traffic": traffic, "traffic_source": traffic_src, "traffic_age": traffic_age,
             "traffic_over_algorithmic": (round(traffic / _alg_bytes(dom), 2) if traffic and _alg_bytes(dom) else None),
             "kernel": dom["kernel"].split("<")[0], "kernel_instance": dom["kernel"], "class": dom["class"],
@@ -579,7 +619,7 @@ def train_small_model(root, env_id="EnvDense2D", robot_id="RobotPointMass", cont
     return logs, rec
 
 
-def trained_leg(device, contexts=64, per_context=16, steps=3000, n_samples=100, n_contexts_planned=3, nb_check=8):
+def trained_leg(device, contexts=256, per_context=16, steps=20000, n_samples=100, n_contexts_planned=3, nb_check=8):
     """North_star's plan figures on TRAINED weights.  Formula-defined weights plan trajectories that all collide (collision-free rate 0.0 on both sides of
     every check); here the whole chain of the reference's scripts runs on this GPU first - generate_trajectories.py (RRT-Connect + GPMP2, f-4) -> train.py
     (the native training step, f-3) -> the EMA model plans `n_samples` trajectories per context unguided (`diffusion_prior`) and guided (`mpd`,
@@ -678,7 +718,7 @@ class _Watchdog:
             rec["sharded"] = {"error": f"watchdog: the sharded leg did not return within {seconds:g} s (a collective never completed)"}
             for k in ("cpu_baseline", "guided", "serving", "planner_baseline", "trained", "training"):
                 rec.setdefault(k, None)
-            print(json.dumps(rec), flush=True)
+            emit(rec)
         os._exit(0)
 
     def cancel(self):
@@ -750,6 +790,12 @@ def sharded_leg(rank, world, dist, device, plans=2, n_ctx=None, n_samples=None, 
 
         def plan_fn(hs_, hg_):
             return dm.plan({0: hs_, 63: hg_}, B, 64, n0, None, lambda t: 0.5, return_chain=False, n_per_context=n_samples, **gk)[0]
+        try:   # algorithmic FLOPs of one U-Net pass at this batch (the library's own layer table) -> the plan's fraction of the fp32 MFMA peak
+            unet_flop_per_step = _unet_pass_flops(dm, B, T)
+        except Exception:   # the record must survive a failing helper
+            unet_flop_per_step = None
+    else:
+        unet_flop_per_step = None
     sw = _Stopwatch(device, 3)
     plan_ms, gather_ms, hop_ms = [], [], []
     verified, hop_error = True, None
@@ -836,6 +882,10 @@ def sharded_leg(rank, world, dist, device, plans=2, n_ctx=None, n_samples=None, 
             "one_hop_denoising_steps_per_s": (None if hop_failed else round(world * (T + n0) / ((pm + hm) * 1e-3), 2)),
             "all_gather_bytes_per_rank": int(B * 64 * D * 4),
             "denoising_steps_per_s": round(world * (T + n0) / ((pm + gm) * 1e-3), 2),
+            "unet_flop_per_step": unet_flop_per_step,
+            "fp32_TFLOPs": (round(unet_flop_per_step * (T + n0) / (pm * 1e-3) / 1e12, 2) if unet_flop_per_step else None),
+            "fp32_peak_frac": (round(unet_flop_per_step * (T + n0) / (pm * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4) if unet_flop_per_step else None),
+            "fp32_peak_frac_note": "U-Net FLOPs only (the guide's are < 1 %) x (T + 5) / the slowest rank's plan time, per GPU",
             "trajectory_steps_per_s": round(world * B * (T + n0) / ((pm + gm) * 1e-3), 1), "scaling": "weak"}
 
 
@@ -933,7 +983,7 @@ def training_leg(steps=100, B=32, T=25, D=4, opt=1, baseline=True):
         rec["roofline"] = {"bound": "launch latency (a chain of ~90 dependent 3-50 us kernels; fp32 MFMA for the convolutions)",
                            "algorithmic_flop_per_iteration": 3.0 * fwd, "forward_flop": fwd, "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 4),
-                           "launches_per_iteration": "see profiles/r04_train_kernel_stats.csv (rocprofv3 of this loop)"}
+                           "launches_per_iteration": _train_launches_from_profile(B)}
     except Exception as e:   # the record must survive a failing helper
         rec["roofline"] = {"error": f"{type(e).__name__}: {e}"}
     if not baseline:
@@ -973,6 +1023,126 @@ def training_leg(steps=100, B=32, T=25, D=4, opt=1, baseline=True):
                                       "what": "the same iteration as torch autograd over ATen/MIOpen kernels + torch.optim.Adam (how the reference trains)"}
     rec["speedup"] = round(dt_eager / dt_native, 2)
     return rec
+
+
+# ------------------------------------------------------------------------------------------------------ the line the driver keeps
+def _get(d, *path, default=None):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+def compact_line(out):
+    """The LAST stdout line: the contract's keys + `roofline` + `cpu_baseline` + every number DESIGN.md section 3 quotes, FLAT, in < 6 KB (the
+    full record is ~60 KB and the driver keeps an 8.7-KB tail - cfg3 / cfg4 / cfg5 and the training numbers fell off it).  The full record goes to
+    bench_full.json beside this script and, as one line, to stderr."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "plan_wall_clock_ms", "per_rank_ms_per_step", "backend", "speedup_vs_cpu_baseline", "cpu_baseline_reason")
+    c = {k: out[k] for k in keep if k in out}
+    cfg = out.get("config", {})
+    c["config"] = {"workload": "cfg2: EnvDense2D-RobotPointMass shape, 100 trajectories x H=64 x D=4, T=100 (+5), unguided, dim_mults (1,2,4,8); one plan = one bench step"
+                   if str(cfg.get("workload", "")).startswith("cfg2") else cfg.get("workload"),
+                   "parallelism": cfg.get("parallelism"), "denoising_steps_per_plan": cfg.get("denoising_steps_per_plan"),
+                   "trajectory_steps_per_s": cfg.get("trajectory_steps_per_s")}
+    r = out.get("roofline")
+    if isinstance(r, dict):
+        c["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "kernel", "avg_launch_us",
+                                               "launches_per_unet_pass", "share_of_pass", "algorithmic_flop_per_launch", "frac_in_situ", "frac_rocprof",
+                                               "unet_pass_us", "unet_pass_tflops")}
+        c["roofline"]["timed"] = "in situ HIP events on the launch stream (this run); frac_rocprof = committed rocprofv3 summary of these sources"
+        c["roofline"]["rocprof_avg_launch_us"] = _get(r, "rocprof", "avg_launch_us")
+        c["roofline"]["rocprof_file"] = _get(r, "rocprof", "file")
+        c["roofline"]["traffic_source"] = r.get("traffic_source")
+        c["roofline"]["frac_of_peak_at_occupancy"] = _get(r, "occupancy", "frac_of_peak_at_occupancy")
+        c["roofline"]["cus_in_use"] = _get(r, "occupancy", "cus_in_use")
+    pr = out.get("plan_roofline")
+    if isinstance(pr, dict):
+        c["plan_roofline"] = {k: pr.get(k) for k in ("hbm_GBps", "hbm_frac", "fp32_TFLOPs", "fp32_peak_frac", "algorithmic_bytes_per_step")}
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "host_cores", "host_cpu", "plan_wall_s")}
+        c["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:200]
+        c["cpu_baseline"]["multi_process_value"] = _get(cb, "multi_process", "value")
+    else:
+        c["cpu_baseline"] = cb
+    # ---- flat figures of the sub-records
+    g = out.get("guided") or {}
+    for cfg_name in ("cfg3", "cfg4"):
+        rec = g.get(cfg_name) or {}
+        c[f"{cfg_name}_plan_ms"] = rec.get("plan_ms")
+        c[f"{cfg_name}_steps_per_s"] = rec.get("denoising_steps_per_s")
+        oc = rec.get("oracle_check") or {}
+        e3 = oc.get("equal_to_3sf") or {}
+        c[f"{cfg_name}_equal_to_3sf"] = [e3.get(k) for k in ("collision_free_rate", "collision_intensity", "path_length", "smoothness")] if e3 else oc.get("error")
+        c[f"{cfg_name}_within_fp32_class"] = _get(oc, "chain_class", "within_fp32_class")
+        c[f"{cfg_name}_flips_hip_vs_oracle32"] = [_get(oc, "chain_class", "flips_vs_fp64_chain", "hip"), _get(oc, "chain_class", "flips_vs_fp64_chain", "oracle_fp32")]
+        c[f"{cfg_name}_ambiguous_waypoints"] = oc.get("ambiguous_waypoints")
+    if "error" in g:
+        c["guided_error"] = g["error"]
+    c["guide_us_per_launch"] = {"2d": _get(g, "cfg3", "guide_kernel", "us_per_launch"), "panda": _get(g, "cfg4", "guide_kernel", "us_per_launch")}
+    sh = out.get("sharded") or {}
+    c["cfg5_shard_plan_ms"] = sh.get("plan_ms_per_rank_max")
+    c["cfg5_steps_per_s"] = sh.get("denoising_steps_per_s")
+    c["cfg5_fp32_peak_frac"] = sh.get("fp32_peak_frac")
+    c["cfg5_fp32_TFLOPs"] = sh.get("fp32_TFLOPs")
+    if "error" in sh:
+        c["sharded_error"] = sh["error"]
+    if sh.get("ranks", 1) and out.get("n_gpus", 1) > 1:
+        c["rccl_world_size"] = sh.get("process_group_world_size")
+        c["rccl_backend"] = sh.get("backend")
+        c["rccl_version"] = sh.get("rccl_version")
+        c["gather_ms"] = {"collective": _get(sh, "gather_ms", "all_gather_into_tensor", "max"),
+                          "one_hop": _get(sh, "gather_ms", "one_hop_send_recv", "max", default=_get(sh, "gather_ms", "one_hop_send_recv", "error"))}
+        c["checksums_ok"] = bool(sh.get("gather_verified")) if "error" not in sh else False
+        c["cfg5_plan_ms_per_rank"] = _get(sh, "plan_ms_per_rank", "all")
+        c["gather_bytes_per_rank"] = sh.get("all_gather_bytes_per_rank")
+    sv = out.get("serving") or {}
+    c["serving_ms_per_context"] = sv.get("ms_per_context")
+    c["serving_plan_ms"] = sv.get("plan_ms")
+    tr = out.get("training") or {}
+    c["train_ms"] = {"b32_D4": tr.get("ms_per_train_step"), "b128_D14": _get(tr, "batch128_D14", "ms_per_train_step"),
+                     "b512_D14": _get(tr, "batch512_D14", "ms_per_train_step")}
+    c["train_fp32_peak_frac"] = {"b32_D4": _get(tr, "roofline", "frac"), "b128_D14": _get(tr, "batch128_D14", "fp32_peak_frac"),
+                                 "b512_D14": _get(tr, "batch512_D14", "fp32_peak_frac")}
+    c["train_launch_mode"] = [m_.get("mode") for m_ in (_get(tr, "launch_mode", "decided") or [])]
+    c["train_launches_per_iteration"] = _get(tr, "roofline", "launches_per_iteration", "launches_per_iteration")
+    c["train_launches_source"] = _get(tr, "roofline", "launches_per_iteration", "file")
+    c["train_speedup_vs_torch_autograd"] = tr.get("speedup")
+    if "error" in tr:
+        c["training_error"] = tr["error"]
+    td = out.get("trained") or {}
+    c["trained"] = {"train_steps": td.get("train_steps"), "train_s": td.get("train_s"), "generate_s": td.get("generate_s"),
+                    "loss_first_last": td.get("diffusion_loss_first_last"),
+                    "free_rate_unguided": [p_.get("collision_free_rate") for p_ in _get(td, "plans", "diffusion_prior", default=[])],
+                    "free_rate_guided": [p_.get("collision_free_rate") for p_ in _get(td, "plans", "mpd", default=[])],
+                    "equal_to_3sf": (lambda e3: [e3.get(k) for k in ("collision_free_rate", "collision_intensity", "path_length", "smoothness")] if e3 else None)(
+                        _get(td, "oracle_check", "equal_to_3sf")),
+                    "within_fp32_class": _get(td, "oracle_check", "chain_class", "within_fp32_class"),
+                    "check_free_rate_hip_o32_o64": [_get(td, "oracle_check", "plan_figures", k, "collision_free_rate") for k in ("hip", "oracle_fp32", "oracle_fp64")],
+                    "error": td.get("error") or _get(td, "oracle_check", "error")}
+    pb = out.get("planner_baseline") or {}
+    c["planner_baseline_ms"] = {k.split("-")[0]: v.get("wall_ms") for k, v in pb.items() if isinstance(v, dict)}
+    c["planner_baseline_free"] = {k.split("-")[0]: v.get("fraction_free") for k, v in pb.items() if isinstance(v, dict)}
+    c["full_record"] = "bench_full.json beside bench.py; also one line on stderr"
+    return c
+
+
+def emit(out):
+    """full record -> bench_full.json + stderr; compact line -> stdout (the last line, the one the driver parses and keeps)"""
+    full = json.dumps(out)
+    try:
+        (ROOT / "bench_full.json").write_text(full + "\n")
+        side = ROOT / "gpurun_out"
+        if side.is_dir():   # (the GPU box merges gpurun_out/ back: the full record survives the box)
+            (side / "bench_full.json").write_text(full + "\n")
+    except OSError:
+        pass
+    print("# bench_full " + full, file=sys.stderr, flush=True)
+    line = json.dumps(compact_line(out))
+    print(line, flush=True)
+
 
 
 def _respawn(args):
@@ -1153,7 +1323,7 @@ def main():
         if world > 1:
             out["sub_records_reason"] = "guided / serving / planner_baseline / trained / training are single-GPU sub-records: N=1 only"
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

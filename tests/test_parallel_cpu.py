@@ -170,5 +170,8 @@ def test_bench_watchdog_prints_the_headline_and_exits():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0
     import json
+    assert len(r.stdout.strip().splitlines()) == 1   # stdout carries exactly ONE line: the compact record (the full one goes to stderr + bench_full.json)
     rec = json.loads(r.stdout.strip().splitlines()[-1])
-    assert rec["value"] == 1.0 and "watchdog" in rec["sharded"]["error"] and rec["cpu_baseline"] is None
+    assert rec["value"] == 1.0 and "watchdog" in rec["sharded_error"] and rec["cpu_baseline"] is None
+    full = [ln for ln in r.stderr.splitlines() if ln.startswith("# bench_full ")]
+    assert len(full) == 1 and "watchdog" in json.loads(full[0][len("# bench_full "):])["sharded"]["error"]
