@@ -259,13 +259,38 @@ def roofline_leg(dm, B, T, reps=30):
         e["flop"] += sum(fl[k] for k in range(a, b + 1))
         e["launches"] += b - a + 1
         e["longest_run"] = max(e["longest_run"], b - a + 1)
+    # DIFFERENTIAL durations (the headline): a class costs the pass what the pass loses when the class's launches are left out - `dreps` back-to-back
+    # passes between ONE event pair, with everything and without the class (mpdx_unet_time_without).  No event sits next to the measured launches: the
+    # bracketed figure above carries ~5 us per event pair (marker processing + a dispatch gap the un-instrumented stream does not have): 15 % of a 35-us launch.
+    dreps = max(reps, 60)
+    full_pass = C.c_float()
+    diff_ok = n_units <= 64
+
+    def _pass_without(mask):
+        v = C.c_float()
+        _lib.check(lib.mpdx_unet_time_without(hdl, packed.data_ptr(), tab.data_ptr(), dm.model._timetab_T, x.data_ptr(), tt, B, ws.data_ptr(), st,
+                                              C.c_uint64(mask), dreps, C.byref(v)), "mpdx_unet_time_without")
+        return v.value * 1e3
+    if diff_ok:
+        full_us = min(_pass_without(0), _pass_without(0))
+        for key, e in table.items():
+            mask = 0
+            for (a, b) in runs:
+                if cls[a][0] == key:
+                    for k in range(a, b + 1):
+                        mask |= 1 << k
+            e["us_diff"] = max(full_us - min(_pass_without(mask), _pass_without(mask)), 0.0)
     tot_us = sum(e["us"] for e in table.values())
     classes = []
     for k, e in sorted(table.items(), key=lambda kv: -kv[1]["us"]):
-        tf = e["flop"] / (e["us"] * 1e-6) / 1e12 if e["us"] > 0 else 0.0
-        classes.append({"class": k, "kernel": e["kernel"], "launches_per_pass": e["launches"], "us_per_pass": round(e["us"], 2),
-                        "share": round(e["us"] / tot_us, 4), "avg_launch_us": round(e["us"] / e["launches"], 2),
+        us = e.get("us_diff") or e["us"]   # the differential duration when it was measured, else the bracketed one
+        tf = e["flop"] / (us * 1e-6) / 1e12 if us > 0 else 0.0
+        tfb = e["flop"] / (e["us"] * 1e-6) / 1e12 if e["us"] > 0 else 0.0
+        classes.append({"class": k, "kernel": e["kernel"], "launches_per_pass": e["launches"], "us_per_pass": round(us, 2),
+                        "share": round(e["us"] / tot_us, 4), "avg_launch_us": round(us / e["launches"], 2),
                         "flop_per_pass": e["flop"], "tflops": round(tf, 2), "frac": round(tf / FP32_PEAK_TFLOPS, 4),
+                        "bracketed": {"us_per_pass": round(e["us"], 2), "avg_launch_us": round(e["us"] / e["launches"], 2), "frac": round(tfb / FP32_PEAK_TFLOPS, 4)},
+                        "duration": "differential" if e.get("us_diff") else "bracketed",
                         "algorithmic_bytes_per_launch": int(e["bytes"] / e["launches"])})
     dom = dict(classes[0])
     dom["kernel_pattern"] = dom["kernel"]
@@ -290,14 +315,18 @@ def roofline_leg(dm, B, T, reps=30):
                    "file": f"profiles/{rp_file}", "in_situ_over_rocprof": round((dom["us_per_pass"] / rp_us), 3),
                    "note": "rocprofv3 --kernel-trace --stats average of the class's kernels on these kernel sources (another box of the pool): auxiliary"}
     roof = {"bound": "mfma", "achieved": dom["tflops"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
-            "duration_source": "in situ: HIP events on the launch stream inside real U-Net passes of THIS run",
-            "frac_in_situ": dom["frac"], "frac_rocprof": (rocprof or {}).get("frac"), "rocprof": rocprof,
+            "duration_source": ("in situ, differential: (U-Net pass) - (U-Net pass without the class's launches), each = back-to-back passes between one HIP-event "
+                                "pair on the launch stream of THIS run" if dom.get("duration") == "differential" else
+                                "in situ: one HIP-event pair around each run of the class's launches inside real U-Net passes of THIS run"),
+            "frac_in_situ": dom["frac"], "frac_bracketed": dom["bracketed"]["frac"], "frac_rocprof": (rocprof or {}).get("frac"), "rocprof": rocprof,
+            "bracketed": dom["bracketed"],
             "traffic": traffic, "traffic_source": traffic_src, "traffic_age": traffic_age,
             "traffic_over_algorithmic": (round(traffic / _alg_bytes(dom), 2) if traffic and _alg_bytes(dom) else None),
             "kernel": dom["kernel"].split("<")[0], "kernel_instance": dom["kernel"], "class": dom["class"],
             "launches_per_unet_pass": dom["launches_per_pass"], "avg_launch_us": dom["avg_launch_us"], "share_of_pass": dom["share"],
             "algorithmic_flop_per_launch": dom["flop_per_pass"] / dom["launches_per_pass"],
-            "timed": f"in situ: one HIP-event pair per run of consecutive launches of the class inside {reps} real U-Net passes",
+            "timed": f"differential: {dreps} back-to-back real U-Net passes between one HIP-event pair, with and without the class (min of 2 each); bracketed: one "
+                     f"HIP-event pair per run of consecutive launches of the class inside {reps} real passes",
             "unet_pass_us": round(whole.value * 1e3, 1), "unet_pass_us_sum_of_classes": round(tot_us, 1),
             "unet_pass_tflops": round(sum(fl[k] for k in range(n)) / (whole.value * 1e-3) / 1e12, 3),
             "classes": classes}
@@ -398,7 +427,7 @@ def _cpu_baseline_worker(idx, cmd_q, res_q, sd, hc, noise, T, n0):
         res_q.put((idx, "error", f"{type(e).__name__}: {e}"))
 
 
-def _cpu_baseline_multiprocess(sd, hc, noise, D, T, B, n0, host_cores, single_plan_s, budget_s=30.0):
+def _cpu_baseline_multiprocess(sd, hc, noise, D, T, B, n0, host_cores, single_plan_s, budget_s=10.0):
     """the batch split over P processes x nthr threads (spawned once; a few (P, nthr) settings are tried on one plan each, the best one is
     then timed on >= 3 plans).  Wall-clock = from the common start signal to the LAST process's finish."""
     import multiprocessing as mp
@@ -460,7 +489,7 @@ def _cpu_baseline_multiprocess(sd, hc, noise, D, T, B, n0, host_cores, single_pl
             if best is None or w < best[0]:
                 best = (w, P, nthr)
         w1, P, nthr = best
-        plans = int(max(3, min(12, 8.0 / max(w1, 1e-3))))
+        plans = int(max(2, min(12, 5.0 / max(w1, 1e-3))))
         w = run(P, nthr, plans, timeout=120.0 + 4 * plans * w1)
     finally:
         for q in cmd_qs:
@@ -1049,9 +1078,10 @@ def compact_line(out):
     r = out.get("roofline")
     if isinstance(r, dict):
         c["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "kernel", "avg_launch_us",
-                                               "launches_per_unet_pass", "share_of_pass", "algorithmic_flop_per_launch", "frac_in_situ", "frac_rocprof",
+                                               "launches_per_unet_pass", "share_of_pass", "algorithmic_flop_per_launch", "frac_in_situ", "frac_bracketed", "frac_rocprof",
                                                "unet_pass_us", "unet_pass_tflops")}
-        c["roofline"]["timed"] = "in situ HIP events on the launch stream (this run); frac_rocprof = committed rocprofv3 summary of these sources"
+        c["roofline"]["timed"] = ("in situ HIP events on the launch stream of this run: frac = differential (pass - pass without the class), frac_bracketed = "
+                                  "event pair around the launches; frac_rocprof = committed rocprofv3 summary of these sources")
         c["roofline"]["rocprof_avg_launch_us"] = _get(r, "rocprof", "avg_launch_us")
         c["roofline"]["rocprof_file"] = _get(r, "rocprof", "file")
         c["roofline"]["traffic_source"] = r.get("traffic_source")
@@ -1125,6 +1155,7 @@ def compact_line(out):
     pb = out.get("planner_baseline") or {}
     c["planner_baseline_ms"] = {k.split("-")[0]: v.get("wall_ms") for k, v in pb.items() if isinstance(v, dict)}
     c["planner_baseline_free"] = {k.split("-")[0]: v.get("fraction_free") for k, v in pb.items() if isinstance(v, dict)}
+    c["leg_seconds"] = out.get("leg_seconds")
     c["full_record"] = "bench_full.json beside bench.py; also one line on stderr"
     return c
 
@@ -1168,6 +1199,7 @@ def main():
 
     if args.gpus > 1 and "RANK" not in os.environ:
         _respawn(args)
+    t_main = time.perf_counter()
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1253,8 +1285,17 @@ def main():
     if world > 1:
         out["per_rank_ms_per_step"] = [round(v / args.steps * 1e3, 3) for v in per_rank_dt]
         out["backend"] = dist.get_backend() + (" (single-GPU rig: ranks share a GPU, no xGMI traffic)" if rig else " (RCCL over xGMI)")
+    leg_s = {"headline": round(time.perf_counter() - t_main, 1)}   # wall seconds of every leg (the driver's budget: where this script's minutes go)
+
+    def timed(name, fn, *a, **k):
+        t_ = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            leg_s[name] = round(time.perf_counter() - t_, 1)
+    out["leg_seconds"] = leg_s
     if rank == 0 and not args.no_roofline:
-        roof, unet_flops = roofline_leg(dm, B, T)
+        roof, unet_flops = timed("roofline", roofline_leg, dm, B, T)
         out["roofline"] = roof
         # whole-plan view: algorithmic bytes (weights once per step + 4 tensor passes) and FLOPs
         w_bytes = sum(int(v.numel()) for v in sd.values()) * 4
@@ -1275,7 +1316,7 @@ def main():
         # prints the headline line - already complete above - and every rank exits instead of blocking the driver.
         dog = _Watchdog(900.0, rank, out) if world > 1 else None
         try:
-            rec = sharded_leg(rank, world, dist, device)
+            rec = timed("sharded", sharded_leg, rank, world, dist, device)
             if rank == 0:
                 out["sharded"] = rec
         except Exception as e:  # the headline line must survive a failing sub-record
@@ -1286,33 +1327,33 @@ def main():
                 dog.cancel()
         if rank == 0 and world == 1:
             try:
-                out["guided"] = guided_leg(device)
+                out["guided"] = timed("guided", guided_leg, device)
             except Exception as e:
                 out["guided"] = {"error": f"{type(e).__name__}: {e}"}
             try:
-                out["serving"] = serving_leg(dm, D, T, n0)
+                out["serving"] = timed("serving", serving_leg, dm, D, T, n0)
             except Exception as e:
                 out["serving"] = {"error": f"{type(e).__name__}: {e}"}
             try:
-                out["planner_baseline"] = planner_baseline_leg()
+                out["planner_baseline"] = timed("planner_baseline", planner_baseline_leg)
             except Exception as e:
                 out["planner_baseline"] = {"error": f"{type(e).__name__}: {e}"}
             try:
-                out["trained"] = trained_leg(device)
+                out["trained"] = timed("trained", trained_leg, device)
             except Exception as e:
                 out["trained"] = {"error": f"{type(e).__name__}: {e}"}
             try:
-                out["training"] = training_leg()
+                out["training"] = timed("training_b32", training_leg)
                 # the larger shapes of the same iteration (no torch-autograd leg): where the step stops being launch-bound
                 for nm, (tb, td, tsteps) in {"batch128_D14": (128, 14, 100), "batch512_D14": (512, 14, 60)}.items():
-                    r = training_leg(steps=tsteps, B=tb, D=td, baseline=False)
+                    r = timed("training_" + nm, training_leg, steps=tsteps, B=tb, D=td, baseline=False)
                     out["training"][nm] = {"ms_per_train_step": r["ms_per_train_step"], "train_steps_per_s": r["train_steps_per_s"],
                                            "fp32_TFLOPs": r.get("roofline", {}).get("achieved"), "fp32_peak_frac": r.get("roofline", {}).get("frac"),
                                            "launch_mode": r.get("launch_mode")}
             except Exception as e:
                 out["training"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_leg(sd, D, T, B, n0)
+        out["cpu_baseline"] = timed("cpu_baseline", cpu_baseline_leg, sd, D, T, B, n0)
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
     elif rank == 0:   # the key is always present: a record consumer must not fail on its shape at N > 1
         out["cpu_baseline"] = None

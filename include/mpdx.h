@@ -334,6 +334,11 @@ int mpdx_fused_trace(mpdx_unet* u, const float* packed_dev, const float* timetab
  * run: real predecessors and cold weights, event cost amortised over the run); *ms_avg = bracketed time per pass. */
 int mpdx_unet_time_units(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, int T, const float* x, int t, int B,
                          float* ws, void* stream, int unit_first, int unit_last, int reps, float* ms_avg);
+/* the DIFFERENTIAL form: `reps` back-to-back U-Net passes WITHOUT the launch units whose bit is set in skip_mask (0: nothing skipped)
+ * between ONE event pair -> *ms_avg per pass.  A launch class costs (pass with everything) - (pass without the class): no event sits next to the
+ * measured launches.  Timing only: the skipped units' consumers read whatever the workspace holds. */
+int mpdx_unet_time_without(mpdx_unet* u, const float* packed_dev, const float* timetab_dev, int T, const float* x, int t, int B,
+                           float* ws, void* stream, unsigned long long skip_mask, int reps, float* ms_avg);
 /* layer index behind launch unit i of mpdx_unet_profile at batch B (-1: fused whole-trajectory segment or the final kernel) */
 int mpdx_unet_unit_layer(const mpdx_unet* u, int B, int i);
 /* introspection: the kernel that runs fused segment `seg` of this network - 0..5: a static whole-trajectory program (0, 3, 5 with

@@ -93,6 +93,7 @@ SIGNATURES = {
     "mpdx_layer_trace": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, C.POINTER(C.c_longlong)]),
     "mpdx_fused_trace": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, C.POINTER(C.c_longlong), _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mpdx_unet_time_units": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float)]),
+    "mpdx_unet_time_without": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, C.c_uint64, _i, C.POINTER(C.c_float)]),
     "mpdx_unet_unit_layer": (_i, [_vp, _i, _i]),
     "mpdx_unet_unit_is_pair": (_i, [_vp, _i, _i]),
     "mpdx_unet_unit_bytes": (C.c_double, [_vp, _i, _i]),

@@ -1692,6 +1692,52 @@ int mpdx_unet_time_units(mpdx_unet* u, const float* packed, const float* timetab
     return rc;
 }
 
+/* measurement helper (bench.py roofline leg, the DIFFERENTIAL form): `reps` back-to-back U-Net passes WITHOUT the launch units whose bit is set in skip_mask
+ * (0: nothing skipped) between ONE HIP-event pair on the launch stream -> average ms per pass.  The cost of a launch class inside
+ * the pass = (pass with everything) - (pass without the class): no event pair sits next to the measured launches (an event pair around a single
+ * 35-us launch adds ~5 us of marker processing + dispatch gap that the un-instrumented stream does not have).  The skipped units' consumers read
+ * whatever the workspace holds: timing only, the output is not meaningful. */
+int mpdx_unet_time_without(mpdx_unet* u, const float* packed, const float* timetab, int T, const float* x, int t, int B, float* ws,
+                           void* stream, unsigned long long skip_mask, int reps, float* ms_avg) {
+    if (!u || !packed || !timetab || !x || !ws || !ms_avg || reps < 1) return fail(MPDX_E_INVALID, "bad argument");
+    if (int rc = check_ready(u)) return rc;
+    if (t < 0 || t >= T) return fail(MPDX_E_INVALID, "timestep %d outside [0,%d)", t, T);
+    hipStream_t st = (hipStream_t)stream;
+    const auto units = current_units(u, B, nullptr);
+    if (units.size() > 64) return fail(MPDX_E_INVALID, "more than 64 launch units");
+    static float* scratch = nullptr;
+    static size_t scratch_n = 0;
+    const size_t need = (size_t)B * u->cfg.n_support_points * u->cfg.state_dim;
+    if (scratch_n < need) { if (scratch) (void)hipFree(scratch); HIP_TRY(hipMalloc(&scratch, need * sizeof(float))); scratch_n = need; }
+    FinalArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.out = scratch; fa.mode = 0; fa.n_per_ctx = 1;
+    const float* row = timetab + (size_t)t * u->tt_row;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    int rc = 0;
+    auto one_pass = [&]() {
+        bool final_done = false;
+        for (int i = 0; i < (int)units.size() && !rc; ++i) {
+            if (units[i].fused >= 0) final_done |= u->fused[units[i].fused].has_final;   // (a skipped program with the final op: no separate final kernel either)
+            if ((skip_mask >> i) & 1ull) continue;
+            rc = run_unit(u, units[i], packed, row, x, ws, B, &fa, st);
+        }
+        if (!rc && !final_done) rc = run_final(u, packed, fa, B, ws, st);
+    };
+    for (int r = 0; r < 3 && !rc; ++r) one_pass();   // warm-up (code objects, clocks)
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int r = 0; r < reps && !rc; ++r) one_pass();
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_avg = ms / (float)reps;
+    return rc;
+}
+
 /* layer index of launch unit i (-1 for a fused unit / the final kernel): lets bench.py query the tile of a unit */
 int mpdx_unet_unit_layer(const mpdx_unet* u, int B, int i) {
     if (!u) return -1;
