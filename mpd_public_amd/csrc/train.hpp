@@ -60,10 +60,9 @@ struct GnBwdArgs {
     int Lv;           // valid rows of a zero-padded container (horizons that are not powers of two: ConvArgs::Lv_out); 0 or L: all rows
 };
 
+// one GroupNorm region (trajectory b, group g) by one wave; du may alias gy (every element is read before it is written, by the same lane)
 template <int EPL>
-__global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnBwdArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int region = blockIdx.x * 4 + wave;
+__device__ __forceinline__ void gn_mish_bwd_body(const GnBwdArgs& a, const int region, const int lane) {
     if (region >= a.B * a.n_groups) return;
     const int b = region / a.n_groups, g = region - b * a.n_groups;
     const int e0 = lane * EPL;
@@ -122,6 +121,10 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnBwdArgs a) {
             if (a.dT) a.dT[(size_t)b * a.dT_stride + c + e] = r[3 * EPL + e];
         }
     }
+}
+template <int EPL>
+__global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnBwdArgs a) {
+    gn_mish_bwd_body<EPL>(a, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
 }
 
 // The same backward for GroupNorm regions of 64, 512, 1024 or 2048 elements (training at horizons other than 64: the reference's trainer is
@@ -509,6 +512,86 @@ __global__ __launch_bounds__(512) void bwd_pair_kernel(const BwdPairArgs a) {
     const int bx = idx % a.gx[which], r = idx / a.gx[which];
     const int by = r % a.gy[which], bz = r / a.gy[which];
     switch (a.ks_w[which]) {
+        case 1: wgrad_body<1>(w, bx, by, bz, ngrp); break;
+        case 3: wgrad_body<3>(w, bx, by, bz, ngrp); break;
+        case 4: wgrad_body<4>(w, bx, by, bz, ngrp); break;
+        default: wgrad_body<5>(w, bx, by, bz, ngrp); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The backward CHAIN of the outer levels as ONE launch (round 6).  At the levels whose trajectories own whole tiles (L = 64 / 32 / 16) the
+// input-gradient convolutions - with the Mish + GroupNorm backward of the Conv1dBlock below in their epilogue - and the stand-alone GroupNorm
+// backwards form a chain in which every step needs only what the SAME trajectory's earlier steps produced.  One 512-thread workgroup per
+// trajectory walks the steps the per-layer path would have launched one by one - same bodies (conv_block_body on the dgrad pack with
+// NT = L positions: one trajectory per tile, the channel tiles one after the other; gn_mish_bwd_body), same operands through the same gradient
+// buffers in global memory (L2), same order - separated by workgroup barriers instead of launch boundaries (a barrier orders the workgroup's
+// global stores before its later loads).  The layers' weight gradients do not ride: they run in wgrad_multi_kernel behind the chains.
+constexpr int kChainMaxConv = 22, kChainMaxGn = 6, kChainMaxSteps = kChainMaxConv + kChainMaxGn;
+struct ChainStep { short kind, sel, n_mt, idx; };   // kind 0: dgrad conv (sel = selector below, idx into cd), 1: GroupNorm backward (sel = EPL, idx into gn)
+struct ChainArgs {
+    int n;
+    ChainStep st[kChainMaxSteps];
+    GnBwdArgs gn[kChainMaxGn];
+    ConvArgs cd[kChainMaxConv];
+};
+// selector of a dgrad body: taps (5 / 3 / 1), positions per trajectory (64 / 32 / 16), epilogue (plain / GroupNorm backward); MT = 32
+__host__ __device__ constexpr int chain_sel(int ks, int nt, int gnbwd) { return ((ks == 5 ? 0 : ks == 3 ? 1 : 2) * 3 + (nt == 64 ? 0 : nt == 32 ? 1 : 2)) * 2 + (gnbwd ? 1 : 0); }
+__global__ __launch_bounds__(512) void bwd_chain_kernel(const ChainArgs a) {
+    warm_kernarg<(int)sizeof(ChainArgs)>();
+    const int b = (int)blockIdx.x;
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    for (int k = 0; k < a.n; ++k) {
+        const ChainStep s = a.st[k];
+        if (s.kind == 1) {
+            const GnBwdArgs& g = a.gn[s.idx];
+            if (wave < g.n_groups) {
+                if (s.sel == 4) gn_mish_bwd_body<4>(g, b * g.n_groups + wave, lane);
+                else gn_mish_bwd_body<2>(g, b * g.n_groups + wave, lane);
+            }
+            __syncthreads();
+            continue;
+        }
+        const ConvArgs& c = a.cd[s.idx];
+        for (int mt = 0; mt < s.n_mt; ++mt) {
+            const int tile = mt + s.n_mt * b;   // conv_block_body: mt = tile % n_mt, position tile = tile / n_mt = this trajectory
+            switch (s.sel) {
+#define MPDX_CHAIN_CASE(KS, NT, GN) case chain_sel(KS, NT, GN): conv_block_body<CONV_S1, KS, GN ? EPI_GN_BWD : EPI_BIAS, 32, NT, 1, 8>(c, tile); break;
+                MPDX_CHAIN_CASE(5, 64, 0) MPDX_CHAIN_CASE(5, 64, 1) MPDX_CHAIN_CASE(5, 32, 0) MPDX_CHAIN_CASE(5, 32, 1) MPDX_CHAIN_CASE(5, 16, 0) MPDX_CHAIN_CASE(5, 16, 1)
+                MPDX_CHAIN_CASE(3, 64, 0) MPDX_CHAIN_CASE(3, 64, 1) MPDX_CHAIN_CASE(3, 32, 0) MPDX_CHAIN_CASE(3, 32, 1) MPDX_CHAIN_CASE(3, 16, 0) MPDX_CHAIN_CASE(3, 16, 1)
+                MPDX_CHAIN_CASE(1, 64, 0) MPDX_CHAIN_CASE(1, 32, 0) MPDX_CHAIN_CASE(1, 16, 0)
+#undef MPDX_CHAIN_CASE
+                default: break;
+            }
+            __syncthreads();   // the tile's epilogue has stored (workgroup-visible) before anything of this workgroup reads it / restages LDS
+        }
+    }
+}
+
+// MANY weight-gradient GEMMs in ONE launch (round 6): every job keeps its own grid (x = N tiles, y = M tiles, z = batch splits); the blocks of job k
+// are [start[k], start[k + 1]) - found by bisection, as wgrad_reduce_all_body does.  The weight gradients of a layer depend only on the layer's dU and on
+// its (kept) input: nothing in the backward chain waits for them, so they need not ride on the chain's launches (where a dgrad launch lasts as long as
+// its longest weight-gradient block) - collected here they run over all 256 CUs at once, behind the chain.
+constexpr int kWgradMultiMax = 64;
+struct WgradMultiArgs {
+    int n;
+    int start[kWgradMultiMax + 1];
+    short gx[kWgradMultiMax], gy[kWgradMultiMax];
+    signed char ks[kWgradMultiMax], two[kWgradMultiMax];
+    WgradArgs w[kWgradMultiMax];
+};
+__global__ __launch_bounds__(512) void wgrad_multi_kernel(const WgradMultiArgs a) {
+    int lo = 0, hi = a.n;
+    const int bid = (int)blockIdx.x;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bid >= a.start[mid]) lo = mid; else hi = mid; }
+    const int which = lo, idx = bid - a.start[which];
+    const int ngrp = a.two[which] ? 2 : 1;
+    if (threadIdx.x >= 256 && ngrp == 1) return;
+    const WgradArgs& w = a.w[which];
+    const int gx = a.gx[which], gy = a.gy[which];
+    const int bx = idx % gx, r = idx / gx;
+    const int by = r % gy, bz = r / gy;
+    switch (a.ks[which]) {
         case 1: wgrad_body<1>(w, bx, by, bz, ngrp); break;
         case 3: wgrad_body<3>(w, bx, by, bz, ngrp); break;
         case 4: wgrad_body<4>(w, bx, by, bz, ngrp); break;

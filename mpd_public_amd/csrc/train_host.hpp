@@ -189,10 +189,18 @@ struct Deferred {
 // a weight-gradient GEMM ready to launch (alone, or inside bwd_pair_kernel)
 struct WgradJob { WgradArgs a; dim3 grid; size_t lds; int KS; bool deferred; float* g; int n_tot, n_off, S; };
 
+// s_div > 1 (weight gradients that run behind the chain in wgrad_multi_kernel, where ALL layers' blocks fill the GPU together): fewer batch splits per
+// layer than the one-workgroup-per-CU rule of a layer on its own - the partial sums written and re-read by the reduction shrink by the same factor
 static int make_wgrad(const float* A, int LA, int lda, int a_off, int M, const float* Bm, int LB, int ldb, int b_off, int N, int sb, int ob, int KS,
-                      int B, float* part, float* g, int n_tot, int n_off, Deferred* df, WgradJob& j) {
+                      int B, float* part, float* g, int n_tot, int n_off, Deferred* df, WgradJob& j, int s_div = 1) {
+    size_t S_use = wgrad_splits(M, N, B);
+    if (s_div > 1 && df && df->on) {
+        const size_t want = std::max<size_t>(1, S_use / (size_t)s_div);
+        const int per = (int)((B + want - 1) / want);
+        S_use = (size_t)((B + per - 1) / per);
+    }
     if (df && df->on && df->red.n < 96) {   // this layer's partial sums get their own storage; reduced at the end of the pass
-        const size_t S0 = wgrad_splits(M, N, B);
+        const size_t S0 = S_use;
         part = df->ws + df->wcur;
         auto& e = df->red.e[df->red.n++];
         e.part = df->wcur; e.g = (unsigned long long)(g - df->grads); e.S = (int)S0; e.M = M; e.N = N; e.KS = KS; e.n_tot = n_tot; e.n_off = n_off;
@@ -204,7 +212,7 @@ static int make_wgrad(const float* A, int LA, int lda, int a_off, int M, const f
     a.LA = LA; a.lda = lda; a.a_off = a_off; a.M = M;
     a.LB = LB; a.ldb = ldb; a.b_off = b_off; a.N = N;
     a.sb = sb; a.ob = ob; a.B = B;
-    const int S = (int)wgrad_splits(M, N, B);
+    const int S = (int)S_use;
     a.b_per_split = (B + S - 1) / S;
     if (LA % 4) return fail(MPDX_E_INVALID, "wgrad: horizon %d is not a multiple of 4", LA);
     if (KS != 1 && KS != 3 && KS != 4 && KS != 5) return fail(MPDX_E_INVALID, "wgrad: %d taps", KS);
@@ -329,6 +337,93 @@ static int launch_lone_wgrads(const WgradJob* jobs, int njobs, hipStream_t st) {
         if (int rc = raise_lds_limit((const void*)kern)) return rc;
     hipLaunchKernelGGL(kern, dim3(total), dim3(512), lds, st, a);
     for (int k = 0; k < njobs; ++k) finish_wgrad(jobs[k], st);
+    return 0;
+}
+
+// The steps of a backward chain (bwd_chain_kernel) collected in launch order; flush() launches them as ONE kernel (more than it can hold: several)
+struct ChainBuilder {
+    bool on = false;
+    int B = 0;
+    hipStream_t st = nullptr;
+    ChainArgs a;
+    int n_conv = 0, n_gn = 0;
+    size_t lds = 0;
+    int launches = 0, steps = 0;
+    ChainBuilder() { memset(&a, 0, sizeof(a)); }
+    int flush() {
+        if (a.n == 0) return 0;
+        if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "backward chain needs %zu B of LDS", lds);
+        if (lds > 64 * 1024)
+            if (int rc = raise_lds_limit((const void*)bwd_chain_kernel)) return rc;
+        hipLaunchKernelGGL(bwd_chain_kernel, dim3(B), dim3(512), lds, st, a);
+        ++launches;
+        a.n = 0; n_conv = 0; n_gn = 0; lds = 0;
+        return 0;
+    }
+    // can this input-gradient convolution run as a chain step?  (one trajectory per tile, 32-channel tiles, an instantiated body)
+    static bool conv_ok(const Layer& dgl, int min_L) {
+        return dgl.mode == CONV_S1 && (dgl.ks == 5 || dgl.ks == 3 || dgl.ks == 1) && dgl.L_in == dgl.L_out && (dgl.L_out == 64 || dgl.L_out == 32 || dgl.L_out == 16) &&
+               dgl.L_out >= min_L && dgl.cout % 32 == 0;
+    }
+    int add_conv(const Layer& dgl, const ConvArgs& cd, bool gnbwd) {
+        if (gnbwd && dgl.ks == 1) return fail(MPDX_E_INVALID, "chain: no GroupNorm-backward body for a 1-tap convolution");
+        if (n_conv == kChainMaxConv || a.n == kChainMaxSteps)
+            if (int rc = flush()) return rc;
+        ChainStep& s = a.st[a.n++];
+        s.kind = 0; s.sel = (short)chain_sel(dgl.ks, dgl.L_out, gnbwd ? 1 : 0); s.n_mt = (short)(dgl.cout / 32); s.idx = (short)n_conv;
+        a.cd[n_conv] = cd;
+        a.cd[n_conv].n_tiles_n = B;
+        ++n_conv; ++steps;
+        const size_t need = dgl.ks == 5 ? conv_block_lds_bytes<CONV_S1, 5, 32, 64, 8>(dgl.L_in, dgl.L_out, cd.rs)
+                          : dgl.ks == 3 ? conv_block_lds_bytes<CONV_S1, 3, 32, 64, 8>(dgl.L_in, dgl.L_out, cd.rs)
+                                        : conv_block_lds_bytes<CONV_S1, 1, 32, 64, 8>(dgl.L_in, dgl.L_out, cd.rs);
+        // (the staged window of ONE trajectory: NT / L_out = 1, whatever NT the template names; the K-partial buffer: 8 x L_out x 36 floats)
+        const size_t stage = (size_t)(dgl.L_in + 2 * (dgl.ks / 2)) * cd.rs * sizeof(float), red = (size_t)8 * dgl.L_out * 36 * sizeof(float);
+        (void)need;
+        lds = std::max(lds, std::max(stage, red));
+        return 0;
+    }
+    int add_gn(const GnBwdArgs& g, int epl) {
+        if (n_gn == kChainMaxGn || a.n == kChainMaxSteps)
+            if (int rc = flush()) return rc;
+        ChainStep& s = a.st[a.n++];
+        s.kind = 1; s.sel = (short)epl; s.n_mt = 1; s.idx = (short)n_gn;
+        a.gn[n_gn++] = g;
+        ++steps;
+        return 0;
+    }
+};
+
+// any number of deferred weight-gradient GEMMs in launches of up to kWgradMultiMax jobs (wgrad_multi_kernel); the longest blocks first
+static int launch_wgrads_multi(std::vector<WgradJob>& jobs, hipStream_t st) {
+    if (jobs.empty()) return 0;
+    std::stable_sort(jobs.begin(), jobs.end(), [](const WgradJob& x, const WgradJob& y) {
+        const long wx = (long)x.a.b_per_split * x.a.LA * x.KS, wy = (long)y.a.b_per_split * y.a.LA * y.KS;
+        return wx > wy;
+    });
+    for (size_t k0 = 0; k0 < jobs.size(); k0 += kWgradMultiMax) {
+        const int nj = (int)std::min<size_t>(kWgradMultiMax, jobs.size() - k0);
+        WgradMultiArgs a;
+        memset(&a, 0, sizeof(a));
+        a.n = nj;
+        size_t lds = 0;
+        int total = 0;
+        for (int k = 0; k < nj; ++k) {
+            const WgradJob& j = jobs[k0 + k];
+            if (!j.deferred) return fail(MPDX_E_INVALID, "wgrad_multi: job without its own partial-sum buffer");
+            a.w[k] = j.a; a.ks[k] = (signed char)j.KS;
+            a.gx[k] = (short)j.grid.x; a.gy[k] = (short)j.grid.y;
+            a.start[k] = total;
+            total += (int)(j.grid.x * j.grid.y * j.grid.z);
+            a.two[k] = wgrad_two_groups(j) ? 1 : 0;
+            lds = std::max(lds, a.two[k] ? std::max(2 * j.lds, (size_t)(256 * j.KS * 4 + 256) * sizeof(float)) : j.lds);
+        }
+        for (int k = nj; k <= kWgradMultiMax; ++k) a.start[k] = total;
+        if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "weight-gradient launch needs %zu B of LDS", lds);
+        if (lds > 64 * 1024)
+            if (int rc = raise_lds_limit((const void*)wgrad_multi_kernel)) return rc;
+        hipLaunchKernelGGL(wgrad_multi_kernel, dim3(total), dim3(512), lds, st, a);
+    }
     return 0;
 }
 
@@ -599,6 +694,18 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         for (int sl : {u->tl[i].src1_l, u->tl[i].src2_l, u->tl[i].res_l})
             if (sl >= 0) first_consumer[sl] = i;
     static const bool gnfuse_off = getenv("MPDX_TRAIN_GN_FUSE") && atoi(getenv("MPDX_TRAIN_GN_FUSE")) == 0;   // dev A/B switch
+    // round 6 EXPERIMENT, OFF by default (MPDX_TRAIN_CHAIN: 0 off (default), 1 auto, 16 / 32 / 64: the smallest level length that chains): the launches of
+    // the outer levels' backward chain COLLECTED and run as one bwd_chain_kernel launch per run of chainable steps.  Bit-identical gradients, but SLOWER
+    // than the launches it replaces (batch 32: 0.608 -> 0.640 ms with L >= 32, 0.749 ms with L >= 16; batch 128 x D = 14: 0.894 -> 0.921 / 1.002 ms;
+    // profiles/r06_train_chain_ab.txt): under a hipGraph a launch boundary costs ~1 us, a chain step still pays the body's own latency chain (operands
+    // through L2, staging, K-split reduction, epilogue loads) AND runs a layer's channel tiles one after the other on ONE CU instead of side by side on
+    // several.  What would pay is keeping the gradients in LDS between the steps (the forward programs' design) - not built.
+    static const int chain_env = getenv("MPDX_TRAIN_CHAIN") ? atoi(getenv("MPDX_TRAIN_CHAIN")) : 0;
+    static const int chain_max_b = getenv("MPDX_TRAIN_CHAIN_MAX_B") ? atoi(getenv("MPDX_TRAIN_CHAIN_MAX_B")) : 256;
+    ChainBuilder chain;
+    chain.B = B; chain.st = st;
+    chain.on = chain_env != 0 && !masked && df.on && B <= chain_max_b;
+    const int chain_min_L = chain_env >= 16 ? chain_env : (B >= 64 ? 16 : 32);
     std::vector<char> du_ready(n, 0);   // grd(j) already holds the gradient wrt layer j's CONVOLUTION output
     std::vector<char> written(n, 0);    // grd(j) has been written in this pass (launches execute in the order they are enqueued here)
     written[n - 1] = 1;                 // train_loss_kernel above
@@ -611,6 +718,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         const float* dy = gy;   // gradient wrt the convolution output (after the GroupNorm/Mish backward for Conv1dBlocks)
         if (!written[i]) {   // nothing downstream of this layer carries a gradient: it is zero
             if (getenv("MPDX_DEBUG_TRAIN")) fprintf(stderr, "[mpdx] backward: layer %d %s has no gradient-carrying consumer (zeroed)\n", i, l.name.c_str());
+            if (int rc = chain.flush()) return rc;
             HIP_TRY(hipMemsetAsync(gy, 0, w.slotB * sizeof(float), st));
             written[i] = 1;
         }
@@ -639,6 +747,13 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             const dim3 ggrid((regions + 3) / 4);
             g.Lv = l.Lv_out;
             const bool mrows = l.Lv_out > 0 && l.Lv_out < l.L_out;   // a padded container: the general kernel carries the row mask
+            const bool gn_chain = chain.on && dcol && !mrows && (re == 256 || re == 128) && g.n_groups <= 8 && l.L_out >= chain_min_L &&
+                                  (l.L_out == 64 || l.L_out == 32 || l.L_out == 16);
+            if (gn_chain) {   // a step of the chain; du IN PLACE (grd(i): it outlives the pass, so the layer's weight gradients can run behind the chains)
+                g.du = gy;
+                if (int rc = chain.add_gn(g, re == 256 ? 4 : 2)) return rc;
+            } else {
+            if (int rc = chain.flush()) return rc;
             if (re == 256 && !mrows) hipLaunchKernelGGL(gn_mish_bwd_kernel<4>, ggrid, dim3(256), 0, st, g);
             else if (re == 128 && !mrows) hipLaunchKernelGGL(gn_mish_bwd_kernel<2>, ggrid, dim3(256), 0, st, g);
             else if (re == 256 && l.gs >= 4) hipLaunchKernelGGL((gn_mish_bwd_gen_kernel<4, 1>), ggrid, dim3(256), 0, st, g);
@@ -649,6 +764,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             else if (re == 1024 && l.gs >= 4) hipLaunchKernelGGL((gn_mish_bwd_gen_kernel<4, 4>), ggrid, dim3(256), 0, st, g);
             else if (re == 2048 && l.gs >= 4) hipLaunchKernelGGL((gn_mish_bwd_gen_kernel<4, 8>), ggrid, dim3(256), 0, st, g);
             else return fail(MPDX_E_INVALID, "layer %s: GroupNorm region of %d elements (group of %d channels)", l.name.c_str(), re, l.gs);
+            }
             ColsumArgs cs;
             memset(&cs, 0, sizeof(cs));
             cs.part[0] = g.pg; cs.out[0] = gflat(l.gamma);
@@ -662,31 +778,60 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         float* gw = gflat(l.w);
         WgradJob jobs[2];
         int njobs = 0;
+        static const bool pair_off0 = getenv("MPDX_TRAIN_PAIR") && atoi(getenv("MPDX_TRAIN_PAIR")) == 0;
+        static const int late_env0 = getenv("MPDX_TRAIN_WGRAD_LATE") ? atoi(getenv("MPDX_TRAIN_WGRAD_LATE")) : -1;
+        static const int late_div = getenv("MPDX_WGRAD_LATE_DIV") ? std::max(1, atoi(getenv("MPDX_WGRAD_LATE_DIV"))) : 1;
+        // will this layer's weight gradients run behind the chain (decided below, once the jobs exist: the same conditions)?  Then with fewer batch splits.
+        const bool late_cand = (late_env0 < 0 ? B >= 64 : late_env0 != 0) && t.need_dgrad && !pair_off0 && df.on && df.red.n + 2 <= 96 && bwd_pair_has_tile(t.dg, B) && dy == gy;
+        const int sdiv = late_cand ? late_div : 1;
         if (l.mode == CONV_UPT) {
-            if (int rc = make_wgrad(tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, dy, l.L_out, l.cout, 0, l.cout, 2, -1, 4, B, part, gw, l.cout, 0, &df, jobs[njobs++])) return rc;
+            if (int rc = make_wgrad(tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, dy, l.L_out, l.cout, 0, l.cout, 2, -1, 4, B, part, gw, l.cout, 0, &df, jobs[njobs++], sdiv)) return rc;
         } else {
             const int sb = l.mode == CONV_DOWN ? 2 : 1, ob = l.mode == CONV_DOWN ? -1 : -(l.ks / 2);
-            if (int rc = make_wgrad(dy, l.L_out, l.cout, 0, l.cout, tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, sb, ob, l.ks, B, part, gw, Cin, 0, &df, jobs[njobs++])) return rc;
+            if (int rc = make_wgrad(dy, l.L_out, l.cout, 0, l.cout, tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, sb, ob, l.ks, B, part, gw, Cin, 0, &df, jobs[njobs++], sdiv)) return rc;
             if (l.c2 > 0)
-                if (int rc = make_wgrad(dy, l.L_out, l.cout, 0, l.cout, tensor(t.src2_l), l.L_in, l.c2, 0, l.c2, sb, ob, l.ks, B, part, gw, Cin, l.c1, &df, jobs[njobs++])) return rc;
+                if (int rc = make_wgrad(dy, l.L_out, l.cout, 0, l.cout, tensor(t.src2_l), l.L_in, l.c2, 0, l.c2, sb, ob, l.ks, B, part, gw, Cin, l.c1, &df, jobs[njobs++], sdiv)) return rc;
         }
         if (l.epi != EPI_GN_MISH) {   // bias gradient = channel sums of dY: rides on the first weight-gradient job, else its own two launches
-            if (!attach_bias(jobs[0], &df, gflat(l.b), l.mode == CONV_UPT)) launch_rowsum(gy, (size_t)B * l.L_out, l.cout, rpart, gflat(l.b), st, &df);
+            if (!attach_bias(jobs[0], &df, gflat(l.b), l.mode == CONV_UPT)) {
+                if (int rc = chain.flush()) return rc;
+                launch_rowsum(gy, (size_t)B * l.L_out, l.cout, rpart, gflat(l.b), st, &df);
+            }
         }
         static const bool pair_off = getenv("MPDX_TRAIN_PAIR") && atoi(getenv("MPDX_TRAIN_PAIR")) == 0;
         // one launch for all of them needs every job on its own partial buffer (the deferred mode)
         const bool paired = t.need_dgrad && !pair_off && jobs[0].deferred && (njobs == 1 || jobs[1].deferred) && bwd_pair_has_tile(t.dg, B);
+        // round 6 (MPDX_TRAIN_WGRAD_LATE, dev A/B switch): a layer's weight gradients leave the chain when their dU operand outlives the pass - it does
+        // whenever it sits in the layer's own gradient slot (grd(i): written once, never recycled), not in the shared dU scratch of an un-fused
+        // GroupNorm backward - and run with everybody else's in wgrad_multi_kernel behind the chain
+        static const int late_env = getenv("MPDX_TRAIN_WGRAD_LATE") ? atoi(getenv("MPDX_TRAIN_WGRAD_LATE")) : -1;   // -1: by batch (measured: batch 32 no gain, 128 -3 %, 512 -4.6 %)
+        const bool late_on = late_env < 0 ? B >= 64 : late_env != 0;
+        static const bool resamp_fold_off_c = getenv("MPDX_TRAIN_RESAMPLE_FOLD") && atoi(getenv("MPDX_TRAIN_RESAMPLE_FOLD")) == 0;
+        // this layer's input-gradient convolution as a step of the backward chain?
+        const bool chain_d = chain.on && paired && dy == gy && ChainBuilder::conv_ok(t.dg, chain_min_L) && !resamp_fold_off_c &&
+                             (l.mode != CONV_UPT || t.src1_l >= 0);
+        bool late = false;
+        if ((late_on || chain_d) && paired && dy == gy) {
+            late = true;
+            for (int k = 0; k < njobs; ++k) lone.push_back(jobs[k]);
+            njobs = 0;
+        }
         if (!paired)
             for (int k = 0; k < njobs; ++k) {
                 if (!t.need_dgrad && !pair_off && jobs[k].deferred) lone.push_back(jobs[k]);
-                else run_wgrad(jobs[k], st);
+                else {
+                    if (int rc = chain.flush()) return rc;
+                    run_wgrad(jobs[k], st);
+                }
             }
+        (void)late;
         if (t.need_dgrad) {
             const Layer& dgl = t.dg;
             const float* din = dy;
             static const bool resamp_fold_off = getenv("MPDX_TRAIN_RESAMPLE_FOLD") && atoi(getenv("MPDX_TRAIN_RESAMPLE_FOLD")) == 0;   // dev A/B switch
             const bool fold = !resamp_fold_off;
             if (l.mode == CONV_DOWN && !fold) {
+                if (int rc = chain.flush()) return rc;
                 const size_t tot = (size_t)B * 2 * l.L_out * l.cout;
                 hipLaunchKernelGGL(zero_stuff_kernel, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, st, dy, ws + w.zst, B, l.L_out, l.cout);
                 din = ws + w.zst;
@@ -733,24 +878,44 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
                     }
                     df.pcur += (size_t)3 * B * lj.cout;
                     if (lj.tb_off >= 0) { a.bw_dT = ws + w.dT + lj.tb_off; a.bw_dT_stride = u->tt_row; }
-                    if (int rc = dgl.ks == 5 ? launch_bwd_pair<5, true>(dg2, a, B, jobs, njobs, st) : launch_bwd_pair<3, true>(dg2, a, B, jobs, njobs, st)) return rc;
+                    if (chain_d) {
+                        if (int rc = chain.add_conv(dg2, a, true)) return rc;
+                    } else {
+                        if (int rc = chain.flush()) return rc;
+                        if (int rc = dgl.ks == 5 ? launch_bwd_pair<5, true>(dg2, a, B, jobs, njobs, st) : launch_bwd_pair<3, true>(dg2, a, B, jobs, njobs, st)) return rc;
+                    }
                     du_ready[j] = 1;
                     gn_fused = true;
                 }
             }
             if (gn_fused) {
+            } else if (chain_d) {
+                if (int rc = chain.add_conv(dgl, a, false)) return rc;
             } else if (paired) {
+                if (int rc0 = chain.flush()) return rc0;
                 int rc;
                 if (dgl.ks == 5) rc = launch_bwd_pair<5>(dgl, a, B, jobs, njobs, st);
                 else if (dgl.ks == 3) rc = launch_bwd_pair<3>(dgl, a, B, jobs, njobs, st);
                 else rc = launch_bwd_pair<1>(dgl, a, B, jobs, njobs, st);
                 if (rc) return rc;
-            } else if (int rc = launch_layer(dgl, a, B, st)) return rc;
+            } else {
+                if (int rc = chain.flush()) return rc;
+                if (int rc = launch_layer(dgl, a, B, st)) return rc;
+            }
+            if (l.mode == CONV_UPT && t.src1_l >= 0 && !a.decim) if (int rc = chain.flush()) return rc;
             if (l.mode == CONV_UPT && t.src1_l >= 0 && !a.decim) launch_acc(grd(t.src1_l), ws + w.tmpX, B, l.L_in, l.c1, dgl.L_out, Cin, 0, 2, first_write(t.src1_l) ? 1 : 0, st);
         }
     }
-    for (size_t k = 0; k < lone.size(); k += 3)
-        if (int rc = launch_lone_wgrads(lone.data() + k, (int)std::min<size_t>(3, lone.size() - k), st)) return rc;
+    if (int rc = chain.flush()) return rc;
+    if (getenv("MPDX_DEBUG_TRAIN")) fprintf(stderr, "[mpdx] backward: %d chain launch(es) of %d steps, %zu weight-gradient jobs behind them\n", chain.launches, chain.steps, lone.size());
+    {
+        static const bool multi_off = getenv("MPDX_TRAIN_WGRAD_MULTI") && atoi(getenv("MPDX_TRAIN_WGRAD_MULTI")) == 0;   // dev A/B switch
+        if (!multi_off) {
+            if (int rc = launch_wgrads_multi(lone, st)) return rc;
+        } else
+            for (size_t k = 0; k < lone.size(); k += 3)
+                if (int rc = launch_lone_wgrads(lone.data() + k, (int)std::min<size_t>(3, lone.size() - k), st)) return rc;
+    }
     if (df.red.n) {
         int blocks = 0;
         for (int k = 0; k < df.red.n; ++k) {

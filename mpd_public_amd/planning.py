@@ -231,6 +231,86 @@ class PlanningTask:
         return torch.tensor(lo[:qd], device=device), torch.tensor(hi[:qd], device=device)
 
 
+def task_from_torch_robotics(tr_task, tensor_args=None, use_extra_objects=True) -> PlanningTask:
+    """Adapter: a REAL `torch_robotics.tasks.tasks.PlanningTask` (what `inference.py:161,181,191-201` builds) -> this package's `PlanningTask`, i.e. the
+    primitive tables the guide / metrics kernels read.  torch_robotics is an empty submodule in the reference checkout (`deps/torch_robotics`,
+    `.gitmodules:7-9`), so the attribute names below are the published package's AS RECALLED and cannot be exercised here against the real classes
+    (tests/test_adapter_cpu.py drives it with stand-in objects of the same shape); every attribute read is listed, and a missing one raises
+    AttributeError naming it instead of guessing:
+
+      tr_task.env                      EnvBase:  .name (str, optional), .dim (2 | 3), .limits ([2, dim] tensor: workspace min / max)
+      tr_task.env.obj_fixed_list       [ObjectField]  - the environment's own obstacles
+      tr_task.env.obj_extra_list       [ObjectField] or None - `use_extra_objects=True` obstacles (inference.py:109)
+        ObjectField.fields             [primitive fields]; ObjectField.pos (optional [dim] offset added to every centre; rotations are NOT supported: a
+                                       non-identity ObjectField.ori raises)
+          MultiSphereField             .centers [n, dim], .radii [n]
+          MultiBoxField                .centers [n, dim], .sizes [n, dim] (FULL edge lengths; halved here) - or .half_sizes [n, dim]
+      tr_task.robot                    .name ('RobotPointMass' | 'RobotPanda' | ...), .q_dim; RobotPointMass: .link_margins_for_object_collision_checking
+                                       ([margin]) or .link_margin
+      tr_task.obstacle_cutoff_margin   float (inference.py:110)
+
+    Signed-distance GRIDS (`GridMapSDF`) and meshes have no primitive form: they raise NotImplementedError (the kernels scan sphere / box tables).
+    The arithmetic on the tables (hinge on the SDF, FK, interpolation) is this package's restatement (parity unpinned)."""
+    def need(obj, *names):
+        for n in names:
+            if hasattr(obj, n) and getattr(obj, n) is not None:
+                return getattr(obj, n)
+        raise AttributeError(f"{type(obj).__name__} has none of the attributes {names} the adapter reads (see task_from_torch_robotics.__doc__)")
+
+    def arr(v, cols=None):
+        a = np.asarray(v.detach().cpu().numpy() if torch.is_tensor(v) else v, np.float32)
+        return a.reshape(-1, cols) if cols else a.reshape(-1)
+
+    env_t = need(tr_task, "env")
+    dim = int(need(env_t, "dim"))
+    if dim not in (2, 3):
+        raise NotImplementedError(f"workspace dimension {dim}")
+
+    def object_set(obj_list):
+        sc, sr, bc, bh = [], [], [], []
+        for obj in (obj_list or []):
+            ori = getattr(obj, "ori", None)
+            if ori is not None:
+                o = arr(ori)
+                ident = (o.size == 4 and abs(abs(o[0]) - 1.0) < 1e-6 and np.abs(o[1:]).max() < 1e-6) or (o.size == 9 and np.abs(o.reshape(3, 3) - np.eye(3)).max() < 1e-6) \
+                    or np.abs(o).max() < 1e-12
+                if not ident:
+                    raise NotImplementedError("rotated ObjectField: the primitive tables hold axis-aligned boxes")
+            off = arr(obj.pos)[:dim] if getattr(obj, "pos", None) is not None else np.zeros(dim, np.float32)
+            for f in need(obj, "fields"):
+                kind = type(f).__name__
+                if hasattr(f, "radii"):
+                    c = arr(need(f, "centers"), dim) + off
+                    sc.append(_pad3(c, dim)); sr.append(arr(f.radii))
+                elif hasattr(f, "sizes") or hasattr(f, "half_sizes"):
+                    c = arr(need(f, "centers"), dim) + off
+                    h = arr(f.half_sizes, dim) if getattr(f, "half_sizes", None) is not None else 0.5 * arr(f.sizes, dim)
+                    hp = np.concatenate([h, np.full((h.shape[0], 3 - dim), 1.0, np.float32)], 1)   # 2-D boxes are unbounded along the unused axis
+                    bc.append(_pad3(c, dim)); bh.append(hp)
+                else:
+                    raise NotImplementedError(f"{kind}: only sphere (.centers, .radii) and box (.centers, .sizes) primitive fields have a table form")
+        z = ObjectSet.empty()
+        return ObjectSet(np.concatenate(sc) if sc else z.sphere_centers, np.concatenate(sr) if sr else z.sphere_radii,
+                         np.concatenate(bc) if bc else z.box_centers, np.concatenate(bh) if bh else z.box_half)
+
+    env = Env(str(getattr(env_t, "name", type(env_t).__name__)), dim, object_set(need(env_t, "obj_fixed_list")),
+              object_set(getattr(env_t, "obj_extra_list", None)))
+    lim = arr(need(env_t, "limits"), dim)
+    env.limits = (lim[0].copy(), lim[1].copy())
+    rob_t = need(tr_task, "robot")
+    rname = str(getattr(rob_t, "name", type(rob_t).__name__))
+    if "Panda" in rname:
+        robot = RobotPanda()
+    elif "PointMass" in rname:
+        margin = getattr(rob_t, "link_margins_for_object_collision_checking", None)
+        margin = float(arr(margin)[0]) if margin is not None else float(getattr(rob_t, "link_margin", 0.01))
+        robot = RobotPointMass(int(need(rob_t, "q_dim")), margin)
+    else:
+        raise NotImplementedError(f"robot {rname!r}: the kernels know the point mass (2-D / 3-D) and the Panda")
+    return PlanningTask(env, robot, obstacle_cutoff_margin=float(need(tr_task, "obstacle_cutoff_margin")), use_extra_objects=use_extra_objects,
+                        tensor_args=tensor_args)
+
+
 def compute_smoothness(trajs, robot, task=None):
     """sum_h |v_{h+1} - v_h| per trajectory (torch_robotics.trajectory.metrics.compute_smoothness, restated)."""
     v = robot.get_velocity(trajs)

@@ -693,3 +693,8 @@ print("HASH", h.hexdigest())
     ref = run({})
     for sw in ("MPDX_TIME_TAIL_SPLIT", "MPDX_TRAIN_RESTREAM_RIDE", "MPDX_TRAIN_REDUCE_JOIN"):
         assert run({sw: "0"}) == ref, sw
+    # round 6: the weight gradients behind the chain in ONE launch (wgrad_multi_kernel; the default from batch 64 on) instead of riding on the
+    # input-gradient launches, the lone ones three per launch instead of all together, and the experimental backward chain kernel (one workgroup per
+    # trajectory walks the outer levels' steps: bwd_chain_kernel, GroupNorm backwards in place) - same operands, same summation orders: same bytes
+    for sw, v in (("MPDX_TRAIN_WGRAD_LATE", "1"), ("MPDX_TRAIN_WGRAD_MULTI", "0"), ("MPDX_TRAIN_CHAIN", "32"), ("MPDX_TRAIN_CHAIN", "16")):
+        assert run({sw: v}) == ref, (sw, v)
