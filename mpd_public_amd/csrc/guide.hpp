@@ -438,7 +438,7 @@ __device__ __forceinline__ void clip_waypoint_grad(const mpdx_guide_params& gp, 
 template <int QD>
 __device__ __forceinline__ void guide_gp_apply(const GuideArgs& a, int b, int ctx, int lane, int h, int H, bool live, const float (&xn)[2 * QD],
                                                const float (&xu)[2 * QD], const float* sx, float (&total)[2 * QD], size_t base, long long* tr,
-                                               const float* snoise = nullptr) {
+                                               const float* snoise = nullptr, const float* shc = nullptr) {
     constexpr int D = 2 * QD;
     const bool interior = live && h > 0 && h < H - 1;
     if (a.gp.use_gp) {
@@ -487,8 +487,10 @@ __device__ __forceinline__ void guide_gp_apply(const GuideArgs& a, int b, int ct
                     r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.noise_scale, z), a.noise_extra));
                 }
                 else if (a.noise) r = __fadd_rn(r, __fmul_rn(__fmul_rn(a.noise_scale, a.noise[base + d]), a.noise_extra));
-                if (a.hs && h == 0) r = a.hs[(size_t)b * D + d];
-                if (a.hg && h == H - 1) r = a.hg[(size_t)b * D + d];
+                // hard conditions: from LDS when the prologue staged this trajectory's two rows (shc: [start | goal] x D; round 6 - the global loads sat on
+                // the kernel's tail: 7 us of a 200-us Panda launch at B = 6400, tools/guide_inplan_probe.py), else from global memory
+                if (a.hs && h == 0) r = shc ? shc[d] : a.hs[(size_t)b * D + d];
+                if (a.hg && h == H - 1) r = shc ? shc[D + d] : a.hg[(size_t)b * D + d];
                 a.x[base + d] = r;
                 if (a.chain) a.chain[base + d] = r;
                 vmax = fmaxf(vmax, fabsf(r));
@@ -855,6 +857,12 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void guide_step_panda_kernel(co
     float* snz_x = snz + H * D + 4;           //                    trajectory (last guide iteration of a step, rng.on) | [H * D] the normalised state
     float* sprim = snz_x + H * D;
     for (int i = threadIdx.x; i < gp.n_prim_floats; i += 64 * WPT) sprim[i] = gp.prims[i];
+    float* shc = sprim + ((gp.n_prim_floats + 3) & ~3);   // [2][D] this trajectory's hard conditions (apply mode), staged here: their loads fly with the state's
+    if (!a.grad_out && (int)threadIdx.x < 2 * D) {
+        const int which = (int)threadIdx.x >= D ? 1 : 0, d = (int)threadIdx.x - which * D;
+        const float* p = which ? a.hg : a.hs;
+        if (p) shc[which * D + d] = p[(size_t)b * D + d];
+    }
 
     // ---- load + unnormalise (normalization.py:156-167), by the whole workgroup: the trajectory's H * D floats are CONTIGUOUS - one coalesced
     //      16-byte load per thread into LDS (sxn), then element-wise unnormalisation (two elements per thread).  (Rounds 1-4: the support
@@ -1013,7 +1021,7 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void guide_step_panda_kernel(co
         }
     }
     guide_gp_apply<QD>(a, b, ctx, lane, hs_, H, live, xn, xu, sx, total, base, (MPDX_TRACE_PTR(a.trace) && b == 0 && lane == 0) ? a.trace + wv * 16 + 6 : nullptr,
-                       snz + (int)(ne0 & 3ull));
+                       snz + (int)(ne0 & 3ull), shc);
 #undef G_STAMP
 }
 
@@ -1021,7 +1029,7 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void guide_step_panda_kernel(co
 inline size_t guide_lds_bytes(const mpdx_guide_params& gp, int H, int D, bool dense = false) {
     const int N = gp.interpolate ? gp.n_interp : H;
     if (gp.robot == MPDX_ROBOT_PANDA)
-        return (size_t)(H * D + (dense ? 0 : N * kPandaFKS) + MPDX_MAX_FIELDS * kPandaParts * N * 7 + MPDX_MAX_FIELDS * H * 7 + (2 * H * D + 4 + 3) + gp.n_prim_floats) * sizeof(float);
+        return (size_t)(H * D + (dense ? 0 : N * kPandaFKS) + MPDX_MAX_FIELDS * kPandaParts * N * 7 + MPDX_MAX_FIELDS * H * 7 + (2 * H * D + 4 + 3) + gp.n_prim_floats + 3 + 2 * D) * sizeof(float);
     return (size_t)(H * D + 2 * MPDX_MAX_FIELDS * N * (D / 2) + gp.n_prim_floats) * sizeof(float);
 }
 

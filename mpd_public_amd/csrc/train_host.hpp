@@ -780,7 +780,10 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         int njobs = 0;
         static const bool pair_off0 = getenv("MPDX_TRAIN_PAIR") && atoi(getenv("MPDX_TRAIN_PAIR")) == 0;
         static const int late_env0 = getenv("MPDX_TRAIN_WGRAD_LATE") ? atoi(getenv("MPDX_TRAIN_WGRAD_LATE")) : -1;
-        static const int late_div = getenv("MPDX_WGRAD_LATE_DIV") ? std::max(1, atoi(getenv("MPDX_WGRAD_LATE_DIV"))) : 1;
+        // fewer batch splits for the weight gradients that run behind the chain (measured, profiles/r06_train_late_div_ab.txt: batch 128 x D = 14 0.898 / 0.84 / 0.82 /
+        // 0.81 ms with 1 / 4 / 8 / 16; batch 512 2.027 / 1.94 / 1.96 / 2.01): 8 up to batch 128, 4 beyond
+        static const int late_div_env = getenv("MPDX_WGRAD_LATE_DIV") ? std::max(1, atoi(getenv("MPDX_WGRAD_LATE_DIV"))) : 0;
+        const int late_div = late_div_env ? late_div_env : (B <= 128 ? 8 : 4);
         // will this layer's weight gradients run behind the chain (decided below, once the jobs exist: the same conditions)?  Then with fewer batch splits.
         const bool late_cand = (late_env0 < 0 ? B >= 64 : late_env0 != 0) && t.need_dgrad && !pair_off0 && df.on && df.red.n + 2 <= 96 && bwd_pair_has_tile(t.dg, B) && dy == gy;
         const int sdiv = late_cand ? late_div : 1;

@@ -8,3 +8,5 @@ f=$(find $O/trace$mode -name "*kernel_trace.csv" | head -1)
 (cd $GRAFT_REPO_ROOT && python tools/train_trace_probe.py show $f > $O/train_iteration_trace_mode$mode.txt); rm -rf $O/trace$mode
 done
 grep -c copyBuffer $O/train_iteration_trace_mode0.txt $O/train_iteration_trace_mode1.txt; tail -5 $O/rocprof_mode0.log
+cd $GRAFT_REPO_ROOT
+bash tools/ab_train_env.sh MPDX_WGRAD_LATE_DIV "1 2 4" 2 2>&1 | tee $O/train_late_div_ab.txt

@@ -3,7 +3,8 @@ next to the runtime's own copy kernels (__amd_rocclr_copyBuffer: 16-17 per itera
 usage: python tools/train_trace_probe.py run <B> <D>      (the workload: 6 iterations through TrainStep.step, eager)
        python tools/train_trace_probe.py show <trace.csv> (print the last iteration's dispatch sequence)"""
 import sys
-sys.path.insert(0, ".")
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 if sys.argv[1] == "run":
     import os
     os.environ["MPDX_TRAIN_GRAPH"] = sys.argv[4] if len(sys.argv) > 4 else "0"
