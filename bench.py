@@ -98,7 +98,7 @@ def _unit_classes(lib, hdl, B, names, flops, n):
     return out
 
 
-_NOT_PLANNING = ("train", "k_train", "k_fused_train", "planner", "k_planner", "loss")
+_NOT_PLANNING = ("train", "k_train", "k_fused_train", "planner", "k_planner", "loss", "fused_bwd")
 
 
 def csrc_fingerprint():

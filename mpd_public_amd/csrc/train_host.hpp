@@ -340,6 +340,40 @@ static int launch_lone_wgrads(const WgradJob* jobs, int njobs, hipStream_t st) {
     return 0;
 }
 
+// ---- whole-trajectory backward programs (fused_bwd.hpp).  The DOWN program: the backward pass of downs[0..2] of the standard network (three levels of
+// [blocks.0 | residual 1x1 | blocks.1] [blocks.0 | blocks.1 (identity residual)] [Downsample1d], 32 / 64 / 128 channels on 64 / 32 / 16 positions) in
+// ONE launch.  Layer indices: level k occupies [6 k, 6 k + 6) = b0.0, r, b0.1, b1.0, b1.1, down.
+struct BwdProgLayout { int off4[5]; int stat_off; size_t lds_bytes; };
+static BwdProgLayout bwd_down_layout() {
+    // five LDS slots of the largest buffer (20 rows x (128 + 4) floats = 660 float4): IN (the stride-2 layer's zero-stuffed dU), GB, DUa, DUb, GA
+    BwdProgLayout L;
+    const int slot4 = 20 * 33 > 68 * 9 ? (20 * 33 > 36 * 17 ? 20 * 33 : 36 * 17) : (68 * 9 > 36 * 17 ? 68 * 9 : 36 * 17);
+    for (int k = 0; k < 5; ++k) L.off4[k] = k * slot4;
+    L.stat_off = 5 * slot4 * 4;
+    L.lds_bytes = (size_t)(L.stat_off + 384) * sizeof(float);
+    return L;
+}
+// is layers [0, 18) the standard three-level down path the program is written for?
+static bool bwd_down_applicable(const mpdx_unet* u) {
+    if ((int)u->layers.size() < 19 || u->cfg.n_support_points != 64 || u->masked()) return false;
+    for (int k = 0; k < 3; ++k) {
+        const int C = 32 << k, Lk = 64 >> k, b = 6 * k;
+        const int cin = k == 0 ? u->cfg.state_dim : C / 2;
+        auto blk = [&](int i, int c_in) { const Layer& l = u->layers[i]; return l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH && l.c1 == c_in && l.c2 == 0 && l.cout == C && l.L_out == Lk && l.gs * 8 == C; };
+        if (!blk(b + 0, cin) || !blk(b + 2, C) || !blk(b + 3, C) || !blk(b + 4, C)) return false;
+        const Layer& r = u->layers[b + 1];
+        if (!(r.mode == CONV_S1 && r.ks == 1 && r.epi == EPI_BIAS && r.c1 == cin && r.cout == C && r.L_out == Lk)) return false;
+        const Layer& d = u->layers[b + 5];
+        if (!(d.mode == CONV_DOWN && d.ks == 3 && d.epi == EPI_BIAS && d.c1 == C && d.cout == C && d.L_in == Lk && d.L_out == Lk / 2)) return false;
+        if (u->layers[b + 0].tb_off < 0 || u->layers[b + 3].tb_off < 0 || u->layers[b + 2].tb_off >= 0 || u->layers[b + 4].tb_off >= 0) return false;
+        const auto& tl = u->tl;
+        if (tl[b + 2].res_l != b + 1 || tl[b + 4].res_l != b + 2 || tl[b + 2].src1_l != b || tl[b + 3].src1_l != b + 2 || tl[b + 4].src1_l != b + 3 || tl[b + 5].src1_l != b + 4) return false;
+        if (k > 0 && (tl[b].src1_l != b - 1 || tl[b + 1].src1_l != b - 1)) return false;
+        for (int i = b + (k == 0 ? 2 : 0); i < b + 6; ++i) if (!tl[i].need_dgrad) return false;
+    }
+    return true;
+}
+
 // The steps of a backward chain (bwd_chain_kernel) collected in launch order; flush() launches them as ONE kernel (more than it can hold: several)
 struct ChainBuilder {
     bool on = false;
@@ -710,7 +744,112 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     std::vector<char> written(n, 0);    // grd(j) has been written in this pass (launches execute in the order they are enqueued here)
     written[n - 1] = 1;                 // train_loss_kernel above
     auto first_write = [&](int j) { const bool f = !written[j]; written[j] = 1; return f; };
+    // round 6: the backward pass of downs[0..2] as ONE whole-trajectory program (fused_bwd.hpp; MPDX_TRAIN_BWD_PROG=0 switches it off)
+    static const int prog_env = getenv("MPDX_TRAIN_BWD_PROG") ? atoi(getenv("MPDX_TRAIN_BWD_PROG")) : 1;
+    static const int prog_max_b = getenv("MPDX_TRAIN_BWD_PROG_MAX_B") ? atoi(getenv("MPDX_TRAIN_BWD_PROG_MAX_B")) : 512;
+    const bool prog_down_on = prog_env != 0 && df.on && !masked && B <= prog_max_b && w.total < ((size_t)1 << 31) && bwd_down_applicable(u);
+    auto run_down_program = [&]() -> int {   // layers [0, 18): returns 0 ok, < 0 error, 1 not applicable here (the per-layer path takes over)
+        if (!written[17] || df.red.n + 18 > 96 || df.col.n + 12 * 3 + 6 > 120) return 1;
+        static const int late_div_env = getenv("MPDX_WGRAD_LATE_DIV") ? std::max(1, atoi(getenv("MPDX_WGRAD_LATE_DIV"))) : 0;
+        const int sdiv = late_div_env ? late_div_env : (B >= 64 ? (B <= 128 ? 8 : 4) : 1);
+        const BwdProgLayout lay = bwd_down_layout();
+        BwdArgs a;
+        memset(&a, 0, sizeof(a));
+        a.packedT = packedT; a.flat = flat; a.ws = ws; a.B = B; a.dT_stride = u->tt_row; a.stat_off = lay.stat_off;
+        auto goff = [&](const float* p) { return (int)(p - ws); };
+        enum { IN = 0, GB = 1, DUA = 2, DUB = 3, GA = 4 };
+        auto rs4_of = [](int C) { return C / 4 + 1; };
+        a.gin = grd(17); a.in_L = 8; a.in_C = 128; a.in_stuff = 1; a.in_off4 = lay.off4[IN]; a.in_rs4 = rs4_of(128);
+        int nop = 0;
+        auto gn_part = [&](int li, BwdOp& op) {   // the lower Conv1dBlock `li`: its GroupNorm input, parameters and the partial-sum rows of its gamma / beta / bias gradients
+            const Layer& lj = u->layers[li];
+            op.pre_g = goff(pre(li));
+            op.gamma_f = (int)u->params[lj.gamma].foff; op.beta_f = (int)u->params[lj.beta].foff;
+            op.part_g = (int)df.pcur;
+            const int prm[3] = {lj.gamma, lj.beta, lj.b};
+            for (int k = 0; k < 3; ++k) {
+                auto& e = df.col.e[df.col.n++];
+                e.part = df.pcur + (size_t)k * B * lj.cout; e.out = u->params[prm[k]].foff; e.rows = B; e.C = lj.cout;
+            }
+            df.pcur += (size_t)3 * B * lj.cout;
+            op.dT_g = lj.tb_off >= 0 ? (int)(w.dT + lj.tb_off) : -1;
+        };
+        for (int k = 2; k >= 0; --k) {
+            const int C = 32 << k, Lk = 64 >> k, b0 = 6 * k, r4 = rs4_of(C);
+            auto base_op = [&](int shape_ks, int nc16, int ncr, int cout, int gn) -> BwdOp& {
+                BwdOp& op = a.ops[nop++];
+                memset(&op, 0, sizeof(op));
+                op.shape = bwd_shape_id(shape_ks, nc16, ncr, cout, Lk, gn);
+                op.add_off4 = -1; op.gadd = -1; op.gy_off4 = -1; op.gy_g = -1; op.dst_off4 = -1; op.out_g = -1; op.part_g = -1; op.dT_g = -1;
+                return op;
+            };
+            {   // P1: dgrad of the Downsample1d (its dU zero-stuffed in IN) + the skip connection's gradient -> G(b1.1 out) -> GB; GroupNorm backward of b1.1
+                BwdOp& op = base_op(3, C / 16, 0, C, 1);
+                op.src_off4 = lay.off4[IN]; op.src_rs4 = r4;
+                op.wbase = (int)u->tl[b0 + 5].dgrad_woff;
+                if (written[b0 + 4]) op.gadd = goff(grd(b0 + 4));
+                op.gy_off4 = lay.off4[GB]; op.gy_rs4 = r4;
+                op.dst_off4 = lay.off4[DUA]; op.dst_rs4 = r4; op.out_g = goff(grd(b0 + 4));
+                gn_part(b0 + 4, op);
+            }
+            {   // P2: dgrad of b1.1 -> G(b1.0 out) (its time-bias gradient), GroupNorm backward of b1.0
+                BwdOp& op = base_op(5, C / 16, 0, C, 1);
+                op.src_off4 = lay.off4[DUA]; op.src_rs4 = r4;
+                op.wbase = (int)u->tl[b0 + 4].dgrad_woff;
+                op.dst_off4 = lay.off4[DUB]; op.dst_rs4 = r4; op.out_g = goff(grd(b0 + 3));
+                gn_part(b0 + 3, op);
+            }
+            {   // P3: dgrad of b1.0 + the identity residual's G (GB) -> G(b0.1 out) -> GA + the residual 1x1's dY (global); GroupNorm backward of b0.1
+                BwdOp& op = base_op(5, C / 16, 0, C, 1);
+                op.src_off4 = lay.off4[DUB]; op.src_rs4 = r4;
+                op.wbase = (int)u->tl[b0 + 3].dgrad_woff;
+                op.add_off4 = lay.off4[GB]; op.add_rs4 = r4;
+                op.gy_off4 = lay.off4[GA]; op.gy_rs4 = r4; op.gy_g = goff(grd(b0 + 1));
+                op.dst_off4 = lay.off4[DUA]; op.dst_rs4 = r4; op.out_g = goff(grd(b0 + 2));
+                gn_part(b0 + 2, op);
+            }
+            {   // P4: dgrad of b0.1 -> G(b0.0 out) (time bias), GroupNorm backward of b0.0
+                BwdOp& op = base_op(5, C / 16, 0, C, 1);
+                op.src_off4 = lay.off4[DUA]; op.src_rs4 = r4;
+                op.wbase = (int)u->tl[b0 + 2].dgrad_woff;
+                op.dst_off4 = k > 0 ? lay.off4[DUB] : -1; op.dst_rs4 = r4; op.out_g = goff(grd(b0 + 0));
+                gn_part(b0 + 0, op);
+            }
+            if (k > 0) {   // P5: dgrad of b0.0 + the residual 1x1's (from GA) -> dU of the level above's Downsample1d, zero-stuffed into IN
+                const int Cp = C / 2;
+                BwdOp& op = base_op(5, C / 16, C / 16, Cp, 0);
+                op.src_off4 = lay.off4[DUB]; op.src_rs4 = r4;
+                op.rsrc_off4 = lay.off4[GA]; op.rsrc_rs4 = r4;
+                op.wbase = (int)u->tl[b0 + 0].dgrad_woff; op.rwbase = (int)u->tl[b0 + 1].dgrad_woff;
+                op.dst_off4 = lay.off4[IN]; op.dst_rs4 = rs4_of(Cp); op.dst_mode = 1; op.out_g = goff(grd(b0 - 1));
+            }
+        }
+        a.nops = nop;
+        for (int k = 0; k < nop; ++k)
+            if (a.ops[k].shape < 0) return fail(MPDX_E_INVALID, "backward program: op %d has no shape", k);
+        if (int rc = raise_lds_limit((const void*)fused_bwd_kernel)) return rc;
+        hipLaunchKernelGGL(fused_bwd_kernel, dim3(B), dim3(kFusedThreads), lay.lds_bytes, st, a);
+        // the layers' weight gradients (their dY operands now sit in grd(i)) behind the chain; bias gradients of the three convolutions without GroupNorm
+        for (int i = 17; i >= 0; --i) {
+            const Layer& l = u->layers[i];
+            const auto& t = u->tl[i];
+            written[i] = 1; du_ready[i] = 1;
+            const int sb = l.mode == CONV_DOWN ? 2 : 1, ob = l.mode == CONV_DOWN ? -1 : -(l.ks / 2);
+            WgradJob j;
+            if (int rc = make_wgrad(grd(i), l.L_out, l.cout, 0, l.cout, tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, sb, ob, l.ks, B, part, gflat(l.w), l.c1, 0, &df, j, sdiv)) return rc;
+            if (!j.deferred) return fail(MPDX_E_STATE, "backward program: no partial-sum storage left for layer %d", i);
+            if (l.epi != EPI_GN_MISH && !attach_bias(j, &df, gflat(l.b), false)) return fail(MPDX_E_STATE, "backward program: no column-sum slot left for layer %d", i);
+            lone.push_back(j);
+        }
+        return 0;
+    };
     for (int i = n - 1; i >= 0; --i) {
+        if (prog_down_on && i == 17) {
+            if (int rc = chain.flush()) return rc;
+            const int rc = run_down_program();
+            if (rc < 0 || rc > 1) return rc;
+            if (rc == 0) break;   // layers [0, 18) are done
+        }
         const Layer& l = u->layers[i];
         const auto& t = u->tl[i];
         const int Cin = l.c1 + l.c2;

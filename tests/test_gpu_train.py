@@ -696,5 +696,9 @@ print("HASH", h.hexdigest())
     # round 6: the weight gradients behind the chain in ONE launch (wgrad_multi_kernel; the default from batch 64 on) instead of riding on the
     # input-gradient launches, the lone ones three per launch instead of all together, and the experimental backward chain kernel (one workgroup per
     # trajectory walks the outer levels' steps: bwd_chain_kernel, GroupNorm backwards in place) - same operands, same summation orders: same bytes
-    for sw, v in (("MPDX_TRAIN_WGRAD_LATE", "1"), ("MPDX_TRAIN_WGRAD_MULTI", "0"), ("MPDX_TRAIN_CHAIN", "32"), ("MPDX_TRAIN_CHAIN", "16")):
-        assert run({sw: v}) == ref, (sw, v)
+    # (the whole-trajectory backward program of round 6 accumulates a convolution's whole K in one wave - other summation order - so the per-layer path
+    #  is the common ground of these runs: MPDX_TRAIN_BWD_PROG=0; late weight gradients with the splits of the riding ones: MPDX_WGRAD_LATE_DIV=1)
+    base = {"MPDX_TRAIN_BWD_PROG": "0"}
+    ref0 = run(base)
+    for extra in ({"MPDX_TRAIN_WGRAD_LATE": "1", "MPDX_WGRAD_LATE_DIV": "1"}, {"MPDX_TRAIN_WGRAD_MULTI": "0"}, {"MPDX_TRAIN_CHAIN": "32"}, {"MPDX_TRAIN_CHAIN": "16"}):
+        assert run(dict(base, **extra)) == ref0, extra
