@@ -22,15 +22,25 @@
 #pragma once
 #include "fused_level.hpp"
 
+#ifdef MPDX_DEV_HOOKS   // ablation bits of BwdArgs::dbg (MPDX_BWD_DBG): honoured in dev builds only (in the production kernel the tests cost 2.5 us per program)
+#define MPDX_BWD_DBGBIT(a, bit) ((a).dbg & (bit))
+#else
+#define MPDX_BWD_DBGBIT(a, bit) (0)
+#endif
+
 namespace mpdx {
 
-// ---- compile-time op shapes: (id, KS, C_in/16 of the dgrad conv = the layer's C_out/16, folded 1x1 C_in/16 or 0, C_out = the layer's C_in, L, GroupNorm backward?)
-#define MPDX_BWD_SHAPES(X)                                                                                                  \
-    X(0, 3, 8, 0, 128, 16, 1) X(1, 5, 8, 0, 128, 16, 1) X(2, 5, 8, 8, 64, 16, 0)                                            \
-    X(3, 3, 4, 0, 64, 32, 1) X(4, 5, 4, 0, 64, 32, 1) X(5, 5, 4, 4, 32, 32, 0)                                              \
-    X(6, 3, 2, 0, 32, 64, 1) X(7, 5, 2, 0, 32, 64, 1)
-inline int bwd_shape_id(int ks, int nc16, int rnc16, int cout, int L, int gn) {
-#define X(id, K, N, R, CO, LO, G) if (ks == K && nc16 == N && rnc16 == R && cout == CO && L == LO && gn == G) return id;
+// ---- compile-time op shapes: (id, MODE, KS, C_in/16 of the dgrad conv = the layer's C_out/16, folded 1x1 C_in/16 or 0, C_out = the layer's C_in (or the half of a
+// channel concat this op produces), L_out, GroupNorm backward of the Conv1dBlock below?).  MODE CONV_DOWN = the input gradient of a ConvTranspose1d(4, 2, 1):
+// its 5-tap dgrad pack (a zero tap + the four transposed taps, train.hpp) applied at stride 2 - what the per-layer path computes at full resolution and decimates.
+#define MPDX_BWD_SHAPES(X)                                                                                                            \
+    X(0, CONV_S1, 3, 8, 0, 128, 16, 1) X(1, CONV_S1, 5, 8, 0, 128, 16, 1) X(2, CONV_S1, 5, 8, 8, 64, 16, 0)                           \
+    X(3, CONV_S1, 3, 4, 0, 64, 32, 1) X(4, CONV_S1, 5, 4, 0, 64, 32, 1) X(5, CONV_S1, 5, 4, 4, 32, 32, 0)                             \
+    X(6, CONV_S1, 3, 2, 0, 32, 64, 1) X(7, CONV_S1, 5, 2, 0, 32, 64, 1)                                                              \
+    X(8, CONV_S1, 5, 2, 0, 32, 64, 0) X(9, CONV_DOWN, 5, 2, 0, 32, 32, 1) X(10, CONV_S1, 5, 2, 0, 32, 32, 1) X(11, CONV_S1, 5, 2, 2, 64, 32, 0) \
+    X(12, CONV_DOWN, 5, 4, 0, 64, 16, 1) X(13, CONV_S1, 5, 4, 0, 64, 16, 1) X(14, CONV_S1, 5, 4, 4, 128, 16, 0)
+inline int bwd_shape_id(int mode, int ks, int nc16, int rnc16, int cout, int L, int gn) {
+#define X(id, M, K, N, R, CO, LO, G) if (mode == M && ks == K && nc16 == N && rnc16 == R && cout == CO && L == LO && gn == G) return id;
     MPDX_BWD_SHAPES(X)
 #undef X
     return -1;
@@ -62,8 +72,50 @@ struct BwdArgs {
     int in_off4, in_rs4, in_L, in_C, in_stuff;   // in_stuff: staged zero-stuffed (row 2 l), the buffer has 2 in_L + 4 rows
     int B, nops, dT_stride;
     int stat_off;               // LDS exchange area (floats)
+    int dbg;                    // dev ablation mask (MPDX_BWD_DBG; results are wrong with any bit set): 1 no epilogue operand loads, 2 no global stores, 4 no GroupNorm backward
     BwdOp ops[kMaxBwdOps];
 };
+
+// ---- compile-time LDS geometry of the two static programs (train_host.hpp builds the same layout at run time and compares: a mismatch runs the generic kernel).
+// Five slots of kBwdSlot4 float4 (the largest buffer: 20 rows x (128 + 4) floats): IN, GB, DUA, DUB, GA; a buffer of C channels has rows of C / 4 + 1 float4.
+struct BwdGeomOp { int src_off4, src_rs4, rsrc_off4, rsrc_rs4, add_off4, add_rs4, gy_off4, gy_rs4, dst_off4, dst_rs4, dst_mode; };
+constexpr int kBwdSlot4 = 660;
+constexpr int kBwdIN = 0, kBwdGB = 1, kBwdDUA = 2, kBwdDUB = 3, kBwdGA = 4;
+constexpr int bwd_slot(int k) { return k * kBwdSlot4; }
+constexpr BwdGeomOp bwd_down_geom(int i) {
+    const int k = i < 5 ? 2 : (i < 10 ? 1 : 0), p = i - (i < 5 ? 0 : (i < 10 ? 5 : 10));
+    const int C = 32 << k, r4 = C / 4 + 1;
+    BwdGeomOp g{0, 0, 0, 0, -1, 0, -1, 0, -1, 0, 0};
+    if (p == 0) { g.src_off4 = bwd_slot(kBwdIN); g.src_rs4 = r4; g.gy_off4 = bwd_slot(kBwdGB); g.gy_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = r4; }
+    else if (p == 1) { g.src_off4 = bwd_slot(kBwdDUA); g.src_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUB); g.dst_rs4 = r4; }
+    else if (p == 2) { g.src_off4 = bwd_slot(kBwdDUB); g.src_rs4 = r4; g.add_off4 = bwd_slot(kBwdGB); g.add_rs4 = r4; g.gy_off4 = bwd_slot(kBwdGA); g.gy_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = r4; }
+    else if (p == 3) { g.src_off4 = bwd_slot(kBwdDUA); g.src_rs4 = r4; g.dst_off4 = k > 0 ? bwd_slot(kBwdDUB) : -1; g.dst_rs4 = r4; }
+    else { g.src_off4 = bwd_slot(kBwdDUB); g.src_rs4 = r4; g.rsrc_off4 = bwd_slot(kBwdGA); g.rsrc_rs4 = r4; g.dst_off4 = bwd_slot(kBwdIN); g.dst_rs4 = (C / 2) / 4 + 1; g.dst_mode = 1; }
+    return g;
+}
+constexpr BwdGeomOp bwd_up_geom(int i) {
+    BwdGeomOp g{0, 0, 0, 0, -1, 0, -1, 0, -1, 0, 0};
+    if (i == 0) { g.src_off4 = bwd_slot(kBwdIN); g.src_rs4 = 9; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = 9; return g; }
+    const int k = i < 7 ? 0 : 1, p = i - (k == 0 ? 1 : 7);
+    const int C = k == 0 ? 32 : 64, r4 = C / 4 + 1;
+    if (p == 0) { g.src_off4 = bwd_slot(k == 0 ? kBwdDUA : kBwdIN); g.src_rs4 = r4; g.gy_off4 = bwd_slot(kBwdGB); g.gy_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUB); g.dst_rs4 = r4; }
+    else if (p == 1) { g.src_off4 = bwd_slot(kBwdDUB); g.src_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = r4; }
+    else if (p == 2) { g.src_off4 = bwd_slot(kBwdDUA); g.src_rs4 = r4; g.add_off4 = bwd_slot(kBwdGB); g.add_rs4 = r4; g.gy_off4 = bwd_slot(kBwdGA); g.gy_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUB); g.dst_rs4 = r4; }
+    else if (p == 3) { g.src_off4 = bwd_slot(kBwdDUB); g.src_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = r4; }
+    else {   // the two halves of the concat's gradient
+        g.src_off4 = bwd_slot(kBwdDUA); g.src_rs4 = r4; g.rsrc_off4 = bwd_slot(kBwdGA); g.rsrc_rs4 = r4;
+        if (p == 4 && k == 0) { g.dst_off4 = bwd_slot(kBwdIN); g.dst_rs4 = (2 * C) / 4 + 1; }
+    }
+    return g;
+}
+template <int PROG, int I> struct BwdGeomOf { static constexpr bool has = true; static constexpr BwdGeomOp g = PROG == 0 ? bwd_down_geom(I) : bwd_up_geom(I); };
+struct BwdGeomNone { static constexpr bool has = false; static constexpr BwdGeomOp g{0, 0, 0, 0, -1, 0, -1, 0, -1, 0, 0}; };
+// host: does op `o` (as train_host.hpp laid it out) have the table's LDS geometry?
+inline bool bwd_geom_matches(const BwdOp& o, const BwdGeomOp& g, bool has_rsrc) {
+    return o.src_off4 == g.src_off4 && o.src_rs4 == g.src_rs4 && (!has_rsrc || (o.rsrc_off4 == g.rsrc_off4 && o.rsrc_rs4 == g.rsrc_rs4)) && o.add_off4 == g.add_off4 &&
+           (g.add_off4 < 0 || o.add_rs4 == g.add_rs4) && o.gy_off4 == g.gy_off4 && (g.gy_off4 < 0 || o.gy_rs4 == g.gy_rs4) && o.dst_off4 == g.dst_off4 &&
+           (g.dst_off4 < 0 || (o.dst_rs4 == g.dst_rs4 && o.dst_mode == g.dst_mode));
+}
 
 // request the first min(16, slen) blocks of an op's wave-stream.  Block r of the stream: pass p = r / tot (tile row ms + p * msw), block rr = r % tot of that
 // row; rr < nblk: the convolution's pack, else the folded 1x1's.  All wave-uniform.
@@ -84,13 +136,20 @@ __device__ __forceinline__ void bwd_ring_request(f32x4 (&ring)[kFusedRing], __am
 
 struct BwdNext { int wbase, rwbase, msw, nblk, ncr, slen, msn; };   // what the ring needs of the NEXT op (runtime)
 
-template <int KS_, int NC16_, int NCR_, int COUT_, int LOUT_, int GN_>
-using BwdShape = FusedShape<CONV_S1, KS_, NC16_, NCR_, COUT_, LOUT_, GN_>;
+template <int MODE_, int KS_, int NC16_, int NCR_, int COUT_, int LOUT_, int GN_>
+using BwdShape = FusedShape<MODE_, KS_, NC16_, NCR_, COUT_, LOUT_, GN_>;
 
-template <class S>
-__device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& op, const BwdNext& nx, f32x4 (&ring)[kFusedRing], float* smem, int wave, int lane, int b) {
+// G: the op's LDS geometry as compile-time constants (static programs: every LDS address folds into `lane base + immediate`) or BwdGeomNone (the descriptor's fields)
+template <class S, class G = BwdGeomNone>
+__device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& opd, const BwdNext& nx, f32x4 (&ring)[kFusedRing], float* smem, int wave, int lane, int b) {
     constexpr int P = kFusedRing, DB = MPDX_FUSED_DB, NTW = S::NTW, NJ = S::NJ;
-    static_assert(S::MODE == CONV_S1, "backward ops are stride-1 convolutions");
+    BwdOp op = opd;
+    if constexpr (G::has) {
+        constexpr BwdGeomOp g = G::g;
+        op.src_off4 = g.src_off4; op.src_rs4 = g.src_rs4; op.rsrc_off4 = g.rsrc_off4; op.rsrc_rs4 = g.rsrc_rs4; op.add_off4 = g.add_off4; op.add_rs4 = g.add_rs4;
+        op.gy_off4 = g.gy_off4; op.gy_rs4 = g.gy_rs4; op.dst_off4 = g.dst_off4; op.dst_rs4 = g.dst_rs4; op.dst_mode = g.dst_mode;
+    }
+    static_assert(S::MODE == CONV_S1 || S::MODE == CONV_DOWN, "backward ops: stride-1 convolutions, or a dgrad pack applied at stride 2");
     f32x4* const sm4 = (f32x4*)smem;
     const int j = lane & 15, q = lane >> 4;
     const int ms = wave & (S::MSW - 1);
@@ -109,6 +168,7 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& op, 
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
         const size_t o = ((size_t)b * S::LOUT + npos[t]) * S::COUT + c0t[t];
+        if (MPDX_BWD_DBGBIT(a, 1)) { uu[t] = gad[t] = (f32x4){0.1f * (float)lane, 0.2f, 0.3f, 0.4f}; gam[t] = bet[t] = uu[t]; continue; }
         if (S::GN) {
             uu[t] = *(const f32x4*)(a.ws + op.pre_g + o);
             if (S::MP > 1 || t == 0) { gam[t] = *(const f32x4*)(a.flat + op.gamma_f + c0t[t]); bet[t] = *(const f32x4*)(a.flat + op.beta_f + c0t[t]); }
@@ -122,7 +182,7 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& op, 
     for (int t = 0; t < NJ; ++t) {
         constexpr int pad = S::KS / 2;
         const int l = ns[t] * 16 + j;
-        brow[t] = sm4 + op.src_off4 + (l + 2 - pad) * op.src_rs4 + q;
+        brow[t] = sm4 + op.src_off4 + ((S::MODE == CONV_DOWN ? 2 * l : l) + 2 - pad) * op.src_rs4 + q;
         rrow[t] = sm4 + (S::NCR > 0 ? op.rsrc_off4 + (l + 2) * op.rsrc_rs4 + q : 0);
     }
     const int rs4 = op.src_rs4;
@@ -133,6 +193,14 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& op, 
         const int pass = r / S::TOT, rr = r % S::TOT;
         const int row = ms + pass * S::MSW;
         return rr < S::NBLK ? (op.wbase + (row * S::NBLK + rr) * 256) * 4 : (op.rwbase + (row * S::NCR + (rr - S::NBLK)) * 256) * 4;
+    };
+    // byte offset of block k (< 16) of the NEXT op's stream of this wave (runtime shape: wave-uniform scalar arithmetic; clamped to its last block)
+    const int nx_tot = nx.nblk + nx.ncr, nx_ms = wave & (nx.msw - 1);
+    auto nx_off = [&](int k) -> int {
+        const int kk = k < nx.slen ? k : nx.slen - 1;
+        const int pass = kk / nx_tot, rr = kk - pass * nx_tot;
+        const int row = nx_ms + pass * nx.msw;
+        return rr < nx.nblk ? (nx.wbase + (row * nx.nblk + rr) * 256) * 4 : (nx.rwbase + (row * nx.ncr + (rr - nx.nblk)) * 256) * 4;
     };
     auto read_b = [&](int r, int t) -> f32x4 {
         const int rr = r % S::TOT;
@@ -167,11 +235,17 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& op, 
                 f32x4& d = is_res ? racc[tt][e & 1] : acc[tt][e & 1];
                 d = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bq[r % (DB + 1)][t][e], d, 0, 0, 0);
             }
+        // refill slot r % P: the block P further down this op's stream or - in the op's last P steps - the NEXT op's block of that slot: the ring runs on
+        // across the ops (fused_conv_op's scheme), so a weight block has 16 blocks of MFMAs plus an epilogue to arrive
         if (r + P < S::SLEN) ring[r % P] = fused_ld_block(wrs, blk_off(r + P), 0, lane_bytes);
+        else ring[r % P] = fused_ld_block(wrs, nx_off(r % P), 0, lane_bytes);
+        if (S::SLEN < P) {   // slots this op never uses belong to the next op from the start
+#pragma unroll
+            for (int k = S::SLEN; k < P; ++k)
+                if ((k - S::SLEN) % S::SLEN == r) ring[k] = fused_ld_block(wrs, nx_off(k), 0, lane_bytes);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
-    // the NEXT op's first blocks: requested here, they fly under this op's epilogue (the ring is free from now on)
-    if (nx.slen > 0) bwd_ring_request(ring, wrs, nx.wbase, nx.rwbase, wave & (nx.msw - 1), nx.msw, nx.nblk, nx.ncr, nx.slen, lane_bytes);
 
     // ------------------------------------------------------------------ epilogue
     f32x4 gy[NTW];
@@ -182,11 +256,22 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& op, 
         if (op.add_off4 >= 0) gy[t] += sm4[op.add_off4 + (npos[t] + 2) * op.add_rs4 + (c0t[t] >> 2)];
         if (op.gadd >= 0) gy[t] += gad[t];
         if (op.gy_off4 >= 0) sm4[op.gy_off4 + (npos[t] + 2) * op.gy_rs4 + (c0t[t] >> 2)] = gy[t];
-        if (op.gy_g >= 0) *(f32x4*)(a.ws + op.gy_g + ((size_t)b * S::LOUT + npos[t]) * S::COUT + c0t[t]) = gy[t];
+        if (op.gy_g >= 0 && !MPDX_BWD_DBGBIT(a, 2)) *(f32x4*)(a.ws + op.gy_g + ((size_t)b * S::LOUT + npos[t]) * S::COUT + c0t[t]) = gy[t];
     }
     f32x4 y[NTW];
     float* const stat = smem + a.stat_off;
     if constexpr (S::GN) {
+      if (MPDX_BWD_DBGBIT(a, 4)) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) y[t] = gy[t];
+      } else {
+        // Mish + GroupNorm backward of the Conv1dBlock below (gn_mish_bwd_kernel's formulas; reciprocals on v_rcp / v_rsq as the forward programs do):
+        //   vhat = (u - mean) rstd;  gm = gy mish'(gamma vhat + beta);  dvh = gm gamma;  dU = rstd (dvh - mean(dvh) - vhat mean(dvh vhat))
+        // per-trajectory channel sums: sum(gm vhat) [gamma], sum(gm) [beta], sum(dU) [conv bias], sum(gy) [time bias];
+        //   sum_l dU[c] = rstd (gamma_c sum_l gm[c] - L s1 - s2 sum_l vhat[c])  - from the sums of gm and vhat, so that everything a partner wave
+        //   has to contribute travels in ONE exchange.
+        // LOCAL (C_out >= 64: the wave owns every position of its rows): reductions inside the wave (DPP rows, LDS crossbar).  C_out = 32 (two waves share a
+        // tile row): two exchange rounds through LDS - (mean, M2) of the halves combined with Chan's formula; then (sum dvh, sum dvh vhat, channel sums).
         constexpr bool LOCAL = (S::MSW == kFusedWaves);
         constexpr int NG = (S::MP > 1) ? NTW : 1;
         constexpr int TPG = NTW / NG;
@@ -197,21 +282,18 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& op, 
                 x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, x)));
             return x;
         };
-        constexpr int NLOC = 64 * TPG * (LOCAL ? S::RB : 1);
-        constexpr float inv_n = 1.0f / (float)(LOCAL ? NLOC : 2 * NLOC);   // elements of a GroupNorm region
-        // group sum of a per-lane partial: in-wave (LOCAL) or with the partner wave through LDS (two waves share a tile row: C_out = 32)
-        int xr = 0;   // exchange round (alternating halves of the exchange area: a wave may run one round ahead of its partner)
-        auto group_sum = [&](float part) -> float {
-            float s = rows_sum(row_sum16(part));
-            if constexpr (!LOCAL) {
-                float* ex = stat + (xr & 1) * 64;
-                if (j == 0) ex[(nsg * S::MSW + ms) * 4 + q] = s;
-                lds_barrier();
-                s += ex[((nsg ^ 1) * S::MSW + ms) * 4 + q];
-                ++xr;
-            }
-            return s;
+        auto wave_group_sum = [&](float part) -> float { return rows_sum(row_sum16(part)); };
+        constexpr int NLOC = 64 * TPG * (LOCAL ? S::RB : 1);                 // elements one in-wave reduction covers
+        constexpr float inv_loc = 1.0f / (float)NLOC;
+        constexpr float inv_n = 1.0f / (float)(LOCAL ? NLOC : 2 * NLOC);     // elements of a GroupNorm region
+        auto mish_grad_fast = [](float v) -> float {   // d/dv [v tanh(softplus(v))] with v_exp / v_rcp (mish_grad: two IEEE divisions per element)
+            const float e = __builtin_amdgcn_exp2f(fminf(v, 20.0f) * 1.4426950408889634f);
+            const float p1 = 1.0f + e, n = p1 * p1;
+            const float th = (n - 1.0f) * __builtin_amdgcn_rcpf(n + 1.0f);
+            const float sg = e * __builtin_amdgcn_rcpf(p1);
+            return th + v * (1.0f - th * th) * sg;
         };
+        const int pw = (nsg ^ 1) * S::MSW + ms;   // the partner wave (non-LOCAL)
         float mean_g[NG], rstd_g[NG];
         f32x4 d[NTW];
 #pragma unroll
@@ -219,7 +301,7 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& op, 
             float sl = 0.f;
 #pragma unroll
             for (int k = 0; k < TPG; ++k) { const f32x4& x = uu[g * TPG + k]; sl += (x[0] + x[1]) + (x[2] + x[3]); }
-            mean_g[g] = group_sum(sl) * inv_n;
+            mean_g[g] = wave_group_sum(sl) * inv_loc;
             float ql = 0.f;
 #pragma unroll
             for (int k = 0; k < TPG; ++k) {
@@ -227,11 +309,23 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& op, 
                 d[t] = uu[t] - mean_g[g];
                 ql += (d[t][0] * d[t][0] + d[t][1] * d[t][1]) + (d[t][2] * d[t][2] + d[t][3] * d[t][3]);
             }
-            const float var = group_sum(ql) * inv_n;
-            rstd_g[g] = 1.0f / sqrtf(var + 1e-5f);   // (gn_mish_bwd_kernel's form)
+            float m2 = wave_group_sum(ql);
+            if constexpr (!LOCAL) {   // round A: (mean, M2) of this wave's half <-> the partner's; Chan for two parts of NLOC elements
+                if (j == 0) *(f32x2*)(stat + (wave * 4 + q) * 2) = (f32x2){mean_g[g], m2};
+                lds_barrier();
+                const f32x2 o = *(const f32x2*)(stat + (pw * 4 + q) * 2);
+                const float dm = o[0] - mean_g[g];
+                const float mean = 0.5f * (mean_g[g] + o[0]);
+                m2 = (m2 + o[1]) + (0.5f * (float)NLOC) * (dm * dm);
+                const float shift = mean_g[g] - mean;
+#pragma unroll
+                for (int k = 0; k < TPG; ++k) d[g * TPG + k] = d[g * TPG + k] + shift;
+                mean_g[g] = mean;
+            }
+            rstd_g[g] = gn_rstd(m2 * inv_n);
         }
         f32x4 vh[NTW], gm[NTW], dvh[NTW];
-        float s1_g[NG], s2_g[NG];
+        float p1_g[NG], p2_g[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             float p1 = 0.f, p2 = 0.f;
@@ -241,23 +335,16 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& op, 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     vh[t][e] = d[t][e] * rstd_g[g];
-                    gm[t][e] = gy[t][e] * mish_grad(vh[t][e] * gam[t][e] + bet[t][e]);
+                    gm[t][e] = gy[t][e] * mish_grad_fast(vh[t][e] * gam[t][e] + bet[t][e]);
                     dvh[t][e] = gm[t][e] * gam[t][e];
                     p1 += dvh[t][e];
                     p2 += dvh[t][e] * vh[t][e];
                 }
             }
-            s1_g[g] = group_sum(p1) * inv_n;
-            s2_g[g] = group_sum(p2) * inv_n;
+            p1_g[g] = wave_group_sum(p1);
+            p2_g[g] = wave_group_sum(p2);
         }
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const int g = (S::MP > 1) ? t : 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[t][e] = rstd_g[g] * (dvh[t][e] - s1_g[g] - vh[t][e] * s2_g[g]);
-        }
-        // ---- per-trajectory channel sums over the positions: sum(gm vhat), sum(gm), sum(dU), sum(gy)
-        // a lane's four channels x its tiles of the SAME channels (NJ position tiles) -> DPP row sum over the 16 positions
+        // per-channel sums over the positions this wave holds: sum(gm vhat), sum(gm), sum(vhat), sum(gy)
         constexpr int NCH = (S::MP > 1) ? NTW : 1;   // distinct channel quads of this lane
         f32x4 cs[NCH][4];
 #pragma unroll
@@ -271,7 +358,7 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& op, 
                 for (int e = 0; e < 4; ++e) {
                     cs[c][0][e] += gm[t][e] * vh[t][e];
                     cs[c][1][e] += gm[t][e];
-                    cs[c][2][e] += y[t][e];
+                    cs[c][2][e] += vh[t][e];
                     cs[c][3][e] += gy[t][e];
                 }
             }
@@ -280,33 +367,48 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& op, 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) cs[c][k4][e] = row_sum16(cs[c][k4][e]);
         }
-        if constexpr (!LOCAL) {   // the partner wave (other position tiles of the same channels): through the exchange area, [wave][q][4 kinds][4 channels]
-            float* ex = stat + 128;
+        if constexpr (!LOCAL) {   // round B: (sum dvh, sum dvh vhat) + the channel sums of this wave's positions <-> the partner's
+            float* ex = stat + 64;   // [wave][q][2 + 16 floats -> 20]
             if (j == 0) {
+                float* e0 = ex + (wave * 4 + q) * 20;
+                *(f32x2*)e0 = (f32x2){p1_g[0], p2_g[0]};
 #pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) *(f32x4*)(ex + ((wave * 4 + q) * 4 + k4) * 4) = cs[0][k4];
+                for (int k4 = 0; k4 < 4; ++k4) *(f32x4*)(e0 + 4 + 4 * k4) = cs[0][k4];
             }
             lds_barrier();
-            const int pw = (nsg ^ 1) * S::MSW + ms;
+            const float* o0 = ex + (pw * 4 + q) * 20;
+            const f32x2 o = *(const f32x2*)o0;
+            p1_g[0] += o[0]; p2_g[0] += o[1];
 #pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                const f32x4 o = *(const f32x4*)(ex + ((pw * 4 + q) * 4 + k4) * 4);
-                // fixed order (position-tile group 0 first): both partners compute the same bits
-                cs[0][k4] = nsg == 0 ? cs[0][k4] + o : o + cs[0][k4];
-            }
+            for (int k4 = 0; k4 < 4; ++k4) cs[0][k4] = cs[0][k4] + *(const f32x4*)(o0 + 4 + 4 * k4);
         }
-        if (j == 0 && (LOCAL || nsg == 0)) {
+        float s1_g[NG], s2_g[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { s1_g[g] = p1_g[g] * inv_n; s2_g[g] = p2_g[g] * inv_n; }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int g = (S::MP > 1) ? t : 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[t][e] = rstd_g[g] * (dvh[t][e] - s1_g[g] - vh[t][e] * s2_g[g]);
+        }
+        if (j == 0 && (LOCAL || nsg == 0) && !MPDX_BWD_DBGBIT(a, 2)) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                const int c0 = c0t[c * (NTW / NCH)];
+                const int t0 = c * (NTW / NCH);
+                const int g = (S::MP > 1) ? c : 0;
+                const int c0 = c0t[t0];
                 const size_t po = (size_t)b * S::COUT + c0;
                 const size_t BC = (size_t)a.B * S::COUT;
+                f32x4 sdu;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sdu[e] = rstd_g[g] * (gam[t0][e] * cs[c][1][e] - (float)S::LOUT * s1_g[g] - s2_g[g] * cs[c][2][e]);
                 *(f32x4*)(a.ws + op.part_g + po) = cs[c][0];
                 *(f32x4*)(a.ws + op.part_g + BC + po) = cs[c][1];
-                *(f32x4*)(a.ws + op.part_g + 2 * BC + po) = cs[c][2];
+                *(f32x4*)(a.ws + op.part_g + 2 * BC + po) = sdu;
                 if (op.dT_g >= 0) *(f32x4*)(a.ws + op.dT_g + (size_t)b * a.dT_stride + c0) = cs[c][3];
             }
         }
+      }
     } else {
 #pragma unroll
         for (int t = 0; t < NTW; ++t) y[t] = gy[t];
@@ -318,7 +420,7 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& op, 
             sm4[op.dst_off4 + (row + 2) * op.dst_rs4 + (c0t[t] >> 2)] = y[t];
             if (op.dst_mode == 1) sm4[op.dst_off4 + (row + 3) * op.dst_rs4 + (c0t[t] >> 2)] = (f32x4){0.f, 0.f, 0.f, 0.f};   // the stuffed zero row
         }
-        if (op.out_g >= 0) *(f32x4*)(a.ws + op.out_g + ((size_t)b * S::LOUT + npos[t]) * S::COUT + c0t[t]) = y[t];
+        if (op.out_g >= 0 && !MPDX_BWD_DBGBIT(a, 2)) *(f32x4*)(a.ws + op.out_g + ((size_t)b * S::LOUT + npos[t]) * S::COUT + c0t[t]) = y[t];
     }
     {   // halo rows of the buffers this op defines (2 above, 2 below the interior rows)
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -336,53 +438,62 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& op, 
     lds_barrier();
 }
 
-// the generic op-list kernel: walks the program's ops (runtime shapes)
-__global__ __launch_bounds__(kFusedThreads) void fused_bwd_kernel(const BwdArgs a) {
+template <int ID> struct BwdShapeOf;
+#define X(id, M, K, N, R, CO, LO, G) template <> struct BwdShapeOf<id> { using type = BwdShape<M, K, N, R, CO, LO, G>; };
+MPDX_BWD_SHAPES(X)
+#undef X
+
+__device__ __forceinline__ void fused_bwd_prologue(const BwdArgs& a, const BwdNext& n0, f32x4 (&ring)[kFusedRing], float* smem, int tid, int lane, int wave, int b) {
+    f32x4* const sm4 = (f32x4*)smem;
+    // the first op's ring, the input gradient into its source buffer (plain or zero-stuffed), zeros everywhere else in that buffer
+    bwd_ring_request(ring, fused_weights_rsrc(a.packedT), n0.wbase, n0.rwbase, wave & (n0.msw - 1), n0.msw, n0.nblk, n0.ncr, n0.slen, (unsigned)lane * 16u);
+    const int c4n = a.in_C >> 2;
+    const int rows = (a.in_stuff ? 2 * a.in_L : a.in_L) + 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < rows * a.in_rs4; i += kFusedThreads) sm4[a.in_off4 + i] = z;
+    lds_barrier();
+    const int n4 = a.in_L * c4n;
+    for (int i = tid; i < n4; i += kFusedThreads) {
+        const int l = i / c4n, c = i - l * c4n;
+        sm4[a.in_off4 + ((a.in_stuff ? 2 * l : l) + 2) * a.in_rs4 + c] = *(const f32x4*)(a.gin + ((size_t)b * a.in_L + l) * a.in_C + 4 * c);
+    }
+    lds_barrier();
+}
+
+// ---- STATIC programs: the op sequence as a compile-time list of shape ids - no op loop, no shape switch (the generic kernel below keeps every shape's address
+// arithmetic alive across a 8-way switch: 256 VGPRs + 108 AGPRs; fused_level.hpp's round-2 lesson), the next op's ring constants fold
+template <int PROG, int... SH>
+struct BwdSeq {
+    static constexpr int N = sizeof...(SH);
+    static constexpr int ids[sizeof...(SH)] = {SH...};
+    template <int I>
+    __device__ static __forceinline__ BwdNext next_desc(const BwdArgs& a) {
+        constexpr int J = I < N ? I : N - 1;   // behind the last op: its own first blocks again (harmless loads, never used)
+        using S = typename BwdShapeOf<ids[J]>::type;
+        return BwdNext{a.ops[J].wbase, a.ops[J].rwbase, S::MSW, S::NBLK, S::NCR, S::SLEN, S::MSn};
+    }
+    template <int I>
+    __device__ static __forceinline__ void run_from(const BwdArgs& a, f32x4 (&ring)[kFusedRing], float* smem, int wave, int lane, int b) {
+        if constexpr (I < N) {
+            fused_bwd_op<typename BwdShapeOf<ids[I]>::type, BwdGeomOf<PROG, I>>(a, a.ops[I], next_desc<I + 1>(a), ring, smem, wave, lane, b);
+            run_from<I + 1>(a, ring, smem, wave, lane, b);
+        }
+    }
+};
+template <class SEQ>
+__global__ __launch_bounds__(kFusedThreads) void fused_bwd_program_kernel(const BwdArgs a) {
     warm_kernarg<(int)sizeof(BwdArgs)>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x4* const sm4 = (f32x4*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     f32x4 ring[kFusedRing];
-    auto next_of = [&](int oi) -> BwdNext {
-        BwdNext n{0, 0, 1, 1, 0, 0, 1};
-        if (oi < a.nops) {
-            const BwdOp& o = a.ops[oi];
-            switch (o.shape) {
-#define X(id, K, N, R, CO, LO, G) case id: { using S = BwdShape<K, N, R, CO, LO, G>; n = BwdNext{o.wbase, o.rwbase, S::MSW, S::NBLK, S::NCR, S::SLEN, S::MSn}; } break;
-                MPDX_BWD_SHAPES(X)
-#undef X
-                default: break;
-            }
-        }
-        return n;
-    };
-    {   // prologue: the first op's ring, the input gradient into its source buffer (plain or zero-stuffed), zeros everywhere else in that buffer
-        const BwdNext n0 = next_of(0);
-        bwd_ring_request(ring, fused_weights_rsrc(a.packedT), n0.wbase, n0.rwbase, wave & (n0.msw - 1), n0.msw, n0.nblk, n0.ncr, n0.slen, (unsigned)lane * 16u);
-        const int c4n = a.in_C >> 2;
-        const int rows = (a.in_stuff ? 2 * a.in_L : a.in_L) + 4;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < rows * a.in_rs4; i += kFusedThreads) sm4[a.in_off4 + i] = z;
-        lds_barrier();
-        const int n4 = a.in_L * c4n;
-        for (int i = tid; i < n4; i += kFusedThreads) {
-            const int l = i / c4n, c = i - l * c4n;
-            sm4[a.in_off4 + ((a.in_stuff ? 2 * l : l) + 2) * a.in_rs4 + c] = *(const f32x4*)(a.gin + ((size_t)b * a.in_L + l) * a.in_C + 4 * c);
-        }
-        lds_barrier();
-    }
-    for (int oi = 0; oi < a.nops; ++oi) {
-        const BwdOp op = a.ops[oi];
-        const BwdNext nx = next_of(oi + 1);
-        switch (op.shape) {
-#define X(id, K, N, R, CO, LO, G) case id: fused_bwd_op<BwdShape<K, N, R, CO, LO, G>>(a, op, nx, ring, smem, wave, lane, b); break;
-            MPDX_BWD_SHAPES(X)
-#undef X
-            default: break;
-        }
-    }
+    fused_bwd_prologue(a, SEQ::template next_desc<0>(a), ring, smem, tid, lane, wave, b);
+    SEQ::template run_from<0>(a, ring, smem, wave, lane, b);
 }
+// the backward pass of downs[0..2] of the standard network (train_host.hpp run_down_program)
+using BwdSeqDown3 = BwdSeq<0, 0, 1, 1, 1, 2, 3, 4, 4, 4, 5, 6, 7, 7, 7>;
+// the backward pass of final_conv[0] + ups[2] + ups[1] (run_up_program)
+using BwdSeqUp2 = BwdSeq<1, 8, 9, 10, 10, 10, 11, 11, 12, 13, 13, 13, 14, 14>;
 
 }  // namespace mpdx

@@ -143,6 +143,7 @@ static TrainWs train_ws(const mpdx_unet* u, int B) {
             pv += (l.epi == EPI_GN_MISH ? (size_t)3 * B : (size_t)256 + 64) * l.cout;
         }
         tot += wgrad_splits(D, u->cfg.unet_input_dim, B) * D * (size_t)u->cfg.unet_input_dim;
+        if (B < 64) tot *= 4;   // (the backward programs' layers may take up to 4 x the rule's splits at small batches: MPDX_WGRAD_PROG_MUL <= 4)
         pv += (size_t)(256 + 64) * D;
         static const bool off = getenv("MPDX_TRAIN_DEFERRED") && atoi(getenv("MPDX_TRAIN_DEFERRED")) == 0;
         w.deferred = !off && tot <= ((size_t)96 << 20);   // floats
@@ -194,8 +195,8 @@ struct WgradJob { WgradArgs a; dim3 grid; size_t lds; int KS; bool deferred; flo
 static int make_wgrad(const float* A, int LA, int lda, int a_off, int M, const float* Bm, int LB, int ldb, int b_off, int N, int sb, int ob, int KS,
                       int B, float* part, float* g, int n_tot, int n_off, Deferred* df, WgradJob& j, int s_div = 1) {
     size_t S_use = wgrad_splits(M, N, B);
-    if (s_div > 1 && df && df->on) {
-        const size_t want = std::max<size_t>(1, S_use / (size_t)s_div);
+    if ((s_div > 1 || s_div < -1) && df && df->on) {   // (s_div < -1: MORE splits - the small batches, where a block's chain of trajectories is the launch's length)
+        const size_t want = s_div > 1 ? std::max<size_t>(1, S_use / (size_t)s_div) : std::min<size_t>((size_t)B, S_use * (size_t)(-s_div));
         const int per = (int)((B + want - 1) / want);
         S_use = (size_t)((B + per - 1) / per);
     }
@@ -347,7 +348,7 @@ struct BwdProgLayout { int off4[5]; int stat_off; size_t lds_bytes; };
 static BwdProgLayout bwd_down_layout() {
     // five LDS slots of the largest buffer (20 rows x (128 + 4) floats = 660 float4): IN (the stride-2 layer's zero-stuffed dU), GB, DUa, DUb, GA
     BwdProgLayout L;
-    const int slot4 = 20 * 33 > 68 * 9 ? (20 * 33 > 36 * 17 ? 20 * 33 : 36 * 17) : (68 * 9 > 36 * 17 ? 68 * 9 : 36 * 17);
+    const int slot4 = kBwdSlot4;   // >= 20 x 33, 36 x 17, 68 x 9 float4
     for (int k = 0; k < 5; ++k) L.off4[k] = k * slot4;
     L.stat_off = 5 * slot4 * 4;
     L.lds_bytes = (size_t)(L.stat_off + 384) * sizeof(float);
@@ -372,6 +373,30 @@ static bool bwd_down_applicable(const mpdx_unet* u) {
         for (int i = b + (k == 0 ? 2 : 0); i < b + 6; ++i) if (!tl[i].need_dgrad) return false;
     }
     return true;
+}
+
+// is layers [33, 46) the standard network's ups[1] (64 channels on 16 positions) + ups[2] (32 on 32) + final_conv[0] the UP program is written for?
+static bool bwd_up_applicable(const mpdx_unet* u) {
+    if ((int)u->layers.size() != 46 || u->cfg.n_support_points != 64 || u->masked()) return false;
+    const auto& tl = u->tl;
+    const Layer& f = u->layers[45];
+    if (!(f.mode == CONV_S1 && f.ks == 5 && f.epi == EPI_GN_MISH && f.c1 == 32 && f.c2 == 0 && f.cout == 32 && f.L_out == 64 && f.gs == 4 && f.tb_off < 0 && tl[45].src1_l == 44 && tl[45].res_l < 0))
+        return false;
+    const int bases[2] = {39, 33}, Cs[2] = {32, 64}, Ls[2] = {32, 16}, skips[2] = {10, 16};
+    for (int k = 0; k < 2; ++k) {
+        const int b = bases[k], C = Cs[k], Lk = Ls[k];
+        auto blk = [&](int i, int c1, int c2) { const Layer& l = u->layers[i]; return l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH && l.c1 == c1 && l.c2 == c2 && l.cout == C && l.L_out == Lk && l.gs * 8 == C; };
+        if (!blk(b, 2 * C, 2 * C) || !blk(b + 2, C, 0) || !blk(b + 3, C, 0) || !blk(b + 4, C, 0)) return false;
+        const Layer& r = u->layers[b + 1];
+        if (!(r.mode == CONV_S1 && r.ks == 1 && r.epi == EPI_BIAS && r.c1 == 2 * C && r.c2 == 2 * C && r.cout == C && r.L_out == Lk)) return false;
+        const Layer& up = u->layers[b + 5];
+        if (!(up.mode == CONV_UPT && up.ks == 4 && up.epi == EPI_BIAS && up.c1 == C && up.cout == C && up.L_in == Lk && up.L_out == 2 * Lk)) return false;
+        if (u->layers[b].tb_off < 0 || u->layers[b + 3].tb_off < 0 || u->layers[b + 2].tb_off >= 0 || u->layers[b + 4].tb_off >= 0) return false;
+        if (tl[b].src1_l != b - 1 || tl[b + 1].src1_l != b - 1 || tl[b].src2_l != skips[k] || tl[b + 1].src2_l != skips[k]) return false;
+        if (tl[b + 2].res_l != b + 1 || tl[b + 4].res_l != b + 2 || tl[b + 2].src1_l != b || tl[b + 3].src1_l != b + 2 || tl[b + 4].src1_l != b + 3 || tl[b + 5].src1_l != b + 4) return false;
+        for (int i = b; i < b + 6; ++i) if (!tl[i].need_dgrad) return false;
+    }
+    return u->layers[32].mode == CONV_UPT && u->layers[32].cout == 128 && u->layers[16].cout == 128 && u->layers[10].cout == 64 && tl[45].need_dgrad;
 }
 
 // The steps of a backward chain (bwd_chain_kernel) collected in launch order; flush() launches them as ONE kernel (more than it can hold: several)
@@ -751,11 +776,13 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     auto run_down_program = [&]() -> int {   // layers [0, 18): returns 0 ok, < 0 error, 1 not applicable here (the per-layer path takes over)
         if (!written[17] || df.red.n + 18 > 96 || df.col.n + 12 * 3 + 6 > 120) return 1;
         static const int late_div_env = getenv("MPDX_WGRAD_LATE_DIV") ? std::max(1, atoi(getenv("MPDX_WGRAD_LATE_DIV"))) : 0;
-        const int sdiv = late_div_env ? late_div_env : (B >= 64 ? (B <= 128 ? 8 : 4) : 1);
+        static const int small_mul = getenv("MPDX_WGRAD_PROG_MUL") ? atoi(getenv("MPDX_WGRAD_PROG_MUL")) : 1;   // batch < 64: split multiplier of the program layers' weight gradients
+        const int sdiv = late_div_env ? late_div_env : (B >= 64 ? (B <= 128 ? 8 : 4) : (small_mul > 1 ? -std::min(small_mul, 4) : 1));
         const BwdProgLayout lay = bwd_down_layout();
         BwdArgs a;
         memset(&a, 0, sizeof(a));
         a.packedT = packedT; a.flat = flat; a.ws = ws; a.B = B; a.dT_stride = u->tt_row; a.stat_off = lay.stat_off;
+        a.dbg = getenv("MPDX_BWD_DBG") ? atoi(getenv("MPDX_BWD_DBG")) : 0;
         auto goff = [&](const float* p) { return (int)(p - ws); };
         enum { IN = 0, GB = 1, DUA = 2, DUB = 3, GA = 4 };
         auto rs4_of = [](int C) { return C / 4 + 1; };
@@ -779,7 +806,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             auto base_op = [&](int shape_ks, int nc16, int ncr, int cout, int gn) -> BwdOp& {
                 BwdOp& op = a.ops[nop++];
                 memset(&op, 0, sizeof(op));
-                op.shape = bwd_shape_id(shape_ks, nc16, ncr, cout, Lk, gn);
+                op.shape = bwd_shape_id(CONV_S1, shape_ks, nc16, ncr, cout, Lk, gn);
                 op.add_off4 = -1; op.gadd = -1; op.gy_off4 = -1; op.gy_g = -1; op.dst_off4 = -1; op.out_g = -1; op.part_g = -1; op.dT_g = -1;
                 return op;
             };
@@ -827,8 +854,11 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         a.nops = nop;
         for (int k = 0; k < nop; ++k)
             if (a.ops[k].shape < 0) return fail(MPDX_E_INVALID, "backward program: op %d has no shape", k);
-        if (int rc = raise_lds_limit((const void*)fused_bwd_kernel)) return rc;
-        hipLaunchKernelGGL(fused_bwd_kernel, dim3(B), dim3(kFusedThreads), lay.lds_bytes, st, a);
+        bool is_static = nop == BwdSeqDown3::N;
+        for (int k = 0; k < nop && is_static; ++k) is_static = a.ops[k].shape == BwdSeqDown3::ids[k] && bwd_geom_matches(a.ops[k], bwd_down_geom(k), a.ops[k].shape == 2 || a.ops[k].shape == 5);
+        if (!is_static) return fail(MPDX_E_STATE, "backward program (down): the layout differs from the static program's table");
+        if (int rc = raise_lds_limit((const void*)fused_bwd_program_kernel<BwdSeqDown3>)) return rc;
+        hipLaunchKernelGGL(fused_bwd_program_kernel<BwdSeqDown3>, dim3(B), dim3(kFusedThreads), lay.lds_bytes, st, a);
         // the layers' weight gradients (their dY operands now sit in grd(i)) behind the chain; bias gradients of the three convolutions without GroupNorm
         for (int i = 17; i >= 0; --i) {
             const Layer& l = u->layers[i];
@@ -843,7 +873,151 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         }
         return 0;
     };
+    const bool prog_up_on = prog_env != 0 && prog_env != 2 && df.on && !masked && B <= prog_max_b && w.total < ((size_t)1 << 31) && bwd_up_applicable(u);   // (2: the down program only)
+    auto run_up_program = [&]() -> int {   // layers [33, 46): final_conv[0], ups[2], ups[1]; 0 ok, < 0 error, 1 not applicable here
+        if (!written[45] || df.red.n + 17 > 96 || df.col.n + 9 * 3 + 4 > 120) return 1;
+        static const int late_div_env = getenv("MPDX_WGRAD_LATE_DIV") ? std::max(1, atoi(getenv("MPDX_WGRAD_LATE_DIV"))) : 0;
+        static const int small_mul = getenv("MPDX_WGRAD_PROG_MUL") ? atoi(getenv("MPDX_WGRAD_PROG_MUL")) : 1;
+        const int sdiv = late_div_env ? late_div_env : (B >= 64 ? (B <= 128 ? 8 : 4) : (small_mul > 1 ? -std::min(small_mul, 4) : 1));
+        const BwdProgLayout lay = bwd_down_layout();   // (the same five slots: the largest buffer here is 68 rows x 36 floats = 612 float4)
+        BwdArgs a;
+        memset(&a, 0, sizeof(a));
+        a.packedT = packedT; a.flat = flat; a.ws = ws; a.B = B; a.dT_stride = u->tt_row; a.stat_off = lay.stat_off;
+        a.dbg = getenv("MPDX_BWD_DBG") ? atoi(getenv("MPDX_BWD_DBG")) : 0;
+        auto goff = [&](const float* p) { return (int)(p - ws); };
+        enum { IN = 0, GB = 1, DUA = 2, DUB = 3, GA = 4 };
+        auto rs4_of = [](int C) { return C / 4 + 1; };
+        auto part3 = [&](int li, int& part_g) {   // partial-sum rows + column-sum entries of a Conv1dBlock's gamma / beta / bias gradients
+            const Layer& lj = u->layers[li];
+            part_g = (int)df.pcur;
+            const int prm[3] = {lj.gamma, lj.beta, lj.b};
+            for (int k = 0; k < 3; ++k) {
+                auto& e = df.col.e[df.col.n++];
+                e.part = df.pcur + (size_t)k * B * lj.cout; e.out = u->params[prm[k]].foff; e.rows = B; e.C = lj.cout;
+            }
+            df.pcur += (size_t)3 * B * lj.cout;
+        };
+        {   // final_conv[0]'s Mish + GroupNorm backward on the loss kernel's gradient, in place: dU -> grd(45), the program's input
+            const Layer& l = u->layers[45];
+            GnBwdArgs g;
+            memset(&g, 0, sizeof(g));
+            g.gy = grd(45); g.du = grd(45); g.pre = pre(45); g.gamma = flat + u->params[l.gamma].foff; g.beta = flat + u->params[l.beta].foff;
+            int pg = 0;
+            part3(45, pg);
+            g.pg = ws + pg; g.pb = g.pg + (size_t)B * l.cout; g.pbias = g.pb + (size_t)B * l.cout;
+            g.B = B; g.L = l.L_out; g.C = l.cout; g.gs = l.gs; g.n_groups = l.cout / l.gs; g.lg_gs = 2; g.Lv = 0;
+            hipLaunchKernelGGL(gn_mish_bwd_kernel<4>, dim3((B * g.n_groups + 3) / 4), dim3(256), 0, st, g);
+        }
+        a.gin = grd(45); a.in_L = 64; a.in_C = 32; a.in_stuff = 0; a.in_off4 = lay.off4[IN]; a.in_rs4 = rs4_of(32);
+        int nop = 0;
+        auto new_op = [&](int mode, int ks, int nc16, int ncr, int cout, int L, int gn) -> BwdOp& {
+            BwdOp& op = a.ops[nop++];
+            memset(&op, 0, sizeof(op));
+            op.shape = bwd_shape_id(mode, ks, nc16, ncr, cout, L, gn);
+            op.add_off4 = -1; op.gadd = -1; op.gy_off4 = -1; op.gy_g = -1; op.dst_off4 = -1; op.out_g = -1; op.part_g = -1; op.dT_g = -1;
+            return op;
+        };
+        auto gn_part = [&](int li, BwdOp& op) {
+            const Layer& lj = u->layers[li];
+            op.pre_g = goff(pre(li));
+            op.gamma_f = (int)u->params[lj.gamma].foff; op.beta_f = (int)u->params[lj.beta].foff;
+            part3(li, op.part_g);
+            op.dT_g = lj.tb_off >= 0 ? (int)(w.dT + lj.tb_off) : -1;
+        };
+        {   // U1: dgrad of final_conv[0] -> dU of ups[2]'s Upsample1d (64 positions)
+            BwdOp& op = new_op(CONV_S1, 5, 2, 0, 32, 64, 0);
+            op.src_off4 = lay.off4[IN]; op.src_rs4 = rs4_of(32);
+            op.wbase = (int)u->tl[45].dgrad_woff;
+            op.dst_off4 = lay.off4[DUA]; op.dst_rs4 = rs4_of(32); op.out_g = goff(grd(44));
+        }
+        const int bases[2] = {39, 33}, Cs[2] = {32, 64}, Ls[2] = {32, 16}, skips[2] = {10, 16};
+        int src_slot = DUA;   // where the level's Upsample1d dU sits (2 L positions)
+        for (int k = 0; k < 2; ++k) {
+            const int b0 = bases[k], C = Cs[k], Lk = Ls[k], r4 = rs4_of(C);
+            {   // dgrad of the Upsample1d (its 5-tap pack at stride 2) -> G(b1.1 out) -> GB; GroupNorm backward of b1.1
+                BwdOp& op = new_op(CONV_DOWN, 5, C / 16, 0, C, Lk, 1);
+                op.src_off4 = lay.off4[src_slot]; op.src_rs4 = r4;
+                op.wbase = (int)u->tl[b0 + 5].dgrad_woff;
+                op.gy_off4 = lay.off4[GB]; op.gy_rs4 = r4;
+                op.dst_off4 = lay.off4[DUB]; op.dst_rs4 = r4; op.out_g = goff(grd(b0 + 4));
+                gn_part(b0 + 4, op);
+            }
+            {   // dgrad of b1.1 -> G(b1.0 out) (time bias), GroupNorm backward of b1.0
+                BwdOp& op = new_op(CONV_S1, 5, C / 16, 0, C, Lk, 1);
+                op.src_off4 = lay.off4[DUB]; op.src_rs4 = r4;
+                op.wbase = (int)u->tl[b0 + 4].dgrad_woff;
+                op.dst_off4 = lay.off4[DUA]; op.dst_rs4 = r4; op.out_g = goff(grd(b0 + 3));
+                gn_part(b0 + 3, op);
+            }
+            {   // dgrad of b1.0 + the identity residual's G -> G(b0.1 out) -> GA + the residual 1x1's dY; GroupNorm backward of b0.1
+                BwdOp& op = new_op(CONV_S1, 5, C / 16, 0, C, Lk, 1);
+                op.src_off4 = lay.off4[DUA]; op.src_rs4 = r4;
+                op.wbase = (int)u->tl[b0 + 3].dgrad_woff;
+                op.add_off4 = lay.off4[GB]; op.add_rs4 = r4;
+                op.gy_off4 = lay.off4[GA]; op.gy_rs4 = r4; op.gy_g = goff(grd(b0 + 1));
+                op.dst_off4 = lay.off4[DUB]; op.dst_rs4 = r4; op.out_g = goff(grd(b0 + 2));
+                gn_part(b0 + 2, op);
+            }
+            {   // dgrad of b0.1 -> G(b0.0 out) (time bias), GroupNorm backward of b0.0
+                BwdOp& op = new_op(CONV_S1, 5, C / 16, 0, C, Lk, 1);
+                op.src_off4 = lay.off4[DUB]; op.src_rs4 = r4;
+                op.wbase = (int)u->tl[b0 + 2].dgrad_woff;
+                op.dst_off4 = lay.off4[DUA]; op.dst_rs4 = r4; op.out_g = goff(grd(b0));
+                gn_part(b0, op);
+            }
+            // dgrad of b0.0 + the residual 1x1's (from GA): the gradient of the channel concat [x | skip], one op per half (2 C channels each)
+            const int nblk = (C / 16) * 5, ncr = C / 16, rows_half = 2 * C / 16;
+            for (int half = 0; half < 2; ++half) {
+                BwdOp& op = new_op(CONV_S1, 5, C / 16, C / 16, 2 * C, Lk, 0);
+                op.src_off4 = lay.off4[DUA]; op.src_rs4 = r4;
+                op.rsrc_off4 = lay.off4[GA]; op.rsrc_rs4 = r4;
+                op.wbase = (int)u->tl[b0].dgrad_woff + half * rows_half * nblk * 256;
+                op.rwbase = (int)u->tl[b0 + 1].dgrad_woff + half * rows_half * ncr * 256;
+                if (half == 0) {   // x: the level below's Upsample1d output (its dU); the next level of this program reads it from LDS
+                    op.out_g = goff(grd(b0 - 1));
+                    if (k == 0) { op.dst_off4 = lay.off4[IN]; op.dst_rs4 = rs4_of(2 * C); }
+                } else op.out_g = goff(grd(skips[k]));   // the skip connection's gradient (first writer: stored)
+            }
+            src_slot = IN;
+        }
+        a.nops = nop;
+        for (int k = 0; k < nop; ++k)
+            if (a.ops[k].shape < 0) return fail(MPDX_E_INVALID, "backward program (up): op %d has no shape", k);
+        bool is_static = nop == BwdSeqUp2::N;
+        for (int k = 0; k < nop && is_static; ++k) is_static = a.ops[k].shape == BwdSeqUp2::ids[k] && bwd_geom_matches(a.ops[k], bwd_up_geom(k), a.ops[k].shape == 11 || a.ops[k].shape == 14);
+        if (!is_static && getenv("MPDX_DEBUG_TRAIN")) fprintf(stderr, "[mpdx] backward program (up): layout differs from the static program's table -> generic kernel\n");
+        if (!is_static) return fail(MPDX_E_STATE, "backward program (up): the layout differs from the static program's table");
+        if (int rc = raise_lds_limit((const void*)fused_bwd_program_kernel<BwdSeqUp2>)) return rc;
+        hipLaunchKernelGGL(fused_bwd_program_kernel<BwdSeqUp2>, dim3(B), dim3(kFusedThreads), lay.lds_bytes, st, a);
+        written[32] = written[16] = written[10] = 1;
+        for (int i = 45; i >= 33; --i) {
+            const Layer& l = u->layers[i];
+            const auto& t = u->tl[i];
+            written[i] = 1; du_ready[i] = 1;
+            const int Cin = l.c1 + l.c2;
+            WgradJob jb[2];
+            int nj = 0;
+            if (l.mode == CONV_UPT) {
+                if (int rc = make_wgrad(tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, grd(i), l.L_out, l.cout, 0, l.cout, 2, -1, 4, B, part, gflat(l.w), l.cout, 0, &df, jb[nj++], sdiv)) return rc;
+            } else {
+                const int ob = -(l.ks / 2);
+                if (int rc = make_wgrad(grd(i), l.L_out, l.cout, 0, l.cout, tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, 1, ob, l.ks, B, part, gflat(l.w), Cin, 0, &df, jb[nj++], sdiv)) return rc;
+                if (l.c2 > 0)
+                    if (int rc = make_wgrad(grd(i), l.L_out, l.cout, 0, l.cout, tensor(t.src2_l), l.L_in, l.c2, 0, l.c2, 1, ob, l.ks, B, part, gflat(l.w), Cin, l.c1, &df, jb[nj++], sdiv)) return rc;
+            }
+            for (int k = 0; k < nj; ++k) if (!jb[k].deferred) return fail(MPDX_E_STATE, "backward program: no partial-sum storage left for layer %d", i);
+            if (l.epi != EPI_GN_MISH && !attach_bias(jb[0], &df, gflat(l.b), l.mode == CONV_UPT)) return fail(MPDX_E_STATE, "backward program: no column-sum slot left for layer %d", i);
+            for (int k = 0; k < nj; ++k) lone.push_back(jb[k]);
+        }
+        return 0;
+    };
     for (int i = n - 1; i >= 0; --i) {
+        if (prog_up_on && i == 45) {
+            if (int rc = chain.flush()) return rc;
+            const int rc = run_up_program();
+            if (rc < 0 || rc > 1) return rc;
+            if (rc == 0) { i = 33; continue; }   // layers [33, 46) are done: on with layer 32
+        }
         if (prog_down_on && i == 17) {
             if (int rc = chain.flush()) return rc;
             const int rc = run_down_program();

@@ -53,6 +53,32 @@ def test_loss_backward_every_gradient_vs_oracle(D, opt, loss_type, pred_eps):
     print(f"D={D} {loss_type}: worst relative gradient error {worst:.2e}")
 
 
+@pytest.mark.parametrize("B,D", [(64, 4), (96, 14)])
+def test_loss_backward_at_the_batches_of_the_late_weight_gradients_vs_oracle(B, D):
+    """From batch 64 on the layers' weight-gradient GEMMs run behind the backward chain in ONE launch (wgrad_multi_kernel) with fewer batch splits, and at
+    every batch the outer levels' backward pass runs as the two whole-trajectory programs (fused_bwd.hpp: dim_mults (1,2,4,8), horizon 64) - the path
+    bench.py's training numbers at batch 128 / 512 are measured on: loss and every gradient against float64 autograd of the oracle."""
+    from mpd_public_amd.trainer import TrainStep
+    from oracle import train as otrain
+    opt, T = 1, 25
+    dm = _model(D, opt)
+    x0, noise = t(f"late_x0_{B}", (B, 64, D), "uniform", 0.8), t(f"late_noise_{B}", (B, 64, D))
+    hc = {0: t(f"late_hc0_{B}", (B, D), "uniform", 0.7), 63: t(f"late_hc1_{B}", (B, D), "uniform", 0.7)}
+    tt = (torch.arange(B) * 7) % T
+    ts = TrainStep(dm)
+    loss, _ = ts.loss_backward(x0.cuda(), {k: v.cuda() for k, v in hc.items()}, t=tt.cuda(), noise=noise.cuda())
+    ref_loss, ref = otrain.loss_and_grads(synth_sd(D, opt), x0, tt, hc, noise, T, predict_epsilon=True, loss_type="l2", dtype=torch.float64)
+    assert abs(float(loss) - float(ref_loss)) < 5e-6 * max(1.0, abs(float(ref_loss)))
+    worst = 0.0
+    for name, p in dm.model.named_parameters():
+        g, r = p.grad.detach().cpu().double(), ref[name]
+        assert g.shape == r.shape and bool(torch.isfinite(g).all()), name
+        err = float((g - r).abs().max())
+        worst = max(worst, err / max(float(r.abs().max()), 1e-7))
+        assert err <= 2e-4 * max(float(r.abs().max()), 1e-7), (name, err, float(r.abs().max()))
+    print(f"batch {B} x D = {D}: worst relative gradient error {worst:.2e}")
+
+
 @pytest.mark.parametrize("D,opt", [(4, 1), (14, 0)])
 def test_two_training_steps_vs_reference_golden(golden_dir, D, opt):
     """Two iterations of trainer.py:186-283 (loss.backward, clip_grad_norm_(1.0), Adam(1e-4)) + EMA against what the REAL reference
