@@ -38,7 +38,8 @@ namespace mpdx {
     X(3, CONV_S1, 3, 4, 0, 64, 32, 1) X(4, CONV_S1, 5, 4, 0, 64, 32, 1) X(5, CONV_S1, 5, 4, 4, 32, 32, 0)                             \
     X(6, CONV_S1, 3, 2, 0, 32, 64, 1) X(7, CONV_S1, 5, 2, 0, 32, 64, 1)                                                              \
     X(8, CONV_S1, 5, 2, 0, 32, 64, 0) X(9, CONV_DOWN, 5, 2, 0, 32, 32, 1) X(10, CONV_S1, 5, 2, 0, 32, 32, 1) X(11, CONV_S1, 5, 2, 2, 64, 32, 0) \
-    X(12, CONV_DOWN, 5, 4, 0, 64, 16, 1) X(13, CONV_S1, 5, 4, 0, 64, 16, 1) X(14, CONV_S1, 5, 4, 4, 128, 16, 0)
+    X(12, CONV_DOWN, 5, 4, 0, 64, 16, 1) X(13, CONV_S1, 5, 4, 0, 64, 16, 1) X(14, CONV_S1, 5, 4, 4, 128, 16, 0)              \
+    X(15, CONV_S1, 5, 0, 0, 32, 64, 1)   /* no convolution: the result is the global addend (final_conv[0]'s output gradient from the loss kernel) */
 inline int bwd_shape_id(int mode, int ks, int nc16, int rnc16, int cout, int L, int gn) {
 #define X(id, M, K, N, R, CO, LO, G) if (mode == M && ks == K && nc16 == N && rnc16 == R && cout == CO && L == LO && gn == G) return id;
     MPDX_BWD_SHAPES(X)
@@ -76,7 +77,7 @@ struct BwdArgs {
     BwdOp ops[kMaxBwdOps];
 };
 
-// ---- compile-time LDS geometry of the two static programs (train_host.hpp builds the same layout at run time and compares: a mismatch runs the generic kernel).
+// ---- compile-time LDS geometry of the two static programs (train_host.hpp builds the same layout at run time and compares: a mismatch is an error).
 // Five slots of kBwdSlot4 float4 (the largest buffer: 20 rows x (128 + 4) floats): IN, GB, DUA, DUB, GA; a buffer of C channels has rows of C / 4 + 1 float4.
 struct BwdGeomOp { int src_off4, src_rs4, rsrc_off4, rsrc_rs4, add_off4, add_rs4, gy_off4, gy_rs4, dst_off4, dst_rs4, dst_mode; };
 constexpr int kBwdSlot4 = 660;
@@ -95,8 +96,9 @@ constexpr BwdGeomOp bwd_down_geom(int i) {
 }
 constexpr BwdGeomOp bwd_up_geom(int i) {
     BwdGeomOp g{0, 0, 0, 0, -1, 0, -1, 0, -1, 0, 0};
-    if (i == 0) { g.src_off4 = bwd_slot(kBwdIN); g.src_rs4 = 9; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = 9; return g; }
-    const int k = i < 7 ? 0 : 1, p = i - (k == 0 ? 1 : 7);
+    if (i == 0) { g.dst_off4 = bwd_slot(kBwdIN); g.dst_rs4 = 9; return g; }   // the GroupNorm backward of final_conv[0] on the loss kernel's gradient -> IN
+    if (i == 1) { g.src_off4 = bwd_slot(kBwdIN); g.src_rs4 = 9; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = 9; return g; }
+    const int k = i < 8 ? 0 : 1, p = i - (k == 0 ? 2 : 8);
     const int C = k == 0 ? 32 : 64, r4 = C / 4 + 1;
     if (p == 0) { g.src_off4 = bwd_slot(k == 0 ? kBwdDUA : kBwdIN); g.src_rs4 = r4; g.gy_off4 = bwd_slot(kBwdGB); g.gy_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUB); g.dst_rs4 = r4; }
     else if (p == 1) { g.src_off4 = bwd_slot(kBwdDUB); g.src_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = r4; }
@@ -143,6 +145,7 @@ using BwdShape = FusedShape<MODE_, KS_, NC16_, NCR_, COUT_, LOUT_, GN_>;
 template <class S, class G = BwdGeomNone>
 __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& opd, const BwdNext& nx, f32x4 (&ring)[kFusedRing], float* smem, int wave, int lane, int b) {
     constexpr int P = kFusedRing, DB = MPDX_FUSED_DB, NTW = S::NTW, NJ = S::NJ;
+    constexpr int TOTD = S::TOT > 0 ? S::TOT : 1;   // (an op WITHOUT a convolution - S::TOT == 0: the program's first op, a GroupNorm backward on the staged gradient)
     BwdOp op = opd;
     if constexpr (G::has) {
         constexpr BwdGeomOp g = G::g;
@@ -190,7 +193,7 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& opd,
     const unsigned lane_bytes = (unsigned)lane * 16u;
     // byte offset of stream block r of THIS wave (compile-time r; ms wave-uniform)
     auto blk_off = [&](int r) -> int {
-        const int pass = r / S::TOT, rr = r % S::TOT;
+        const int pass = r / TOTD, rr = r % TOTD;
         const int row = ms + pass * S::MSW;
         return rr < S::NBLK ? (op.wbase + (row * S::NBLK + rr) * 256) * 4 : (op.rwbase + (row * S::NCR + (rr - S::NBLK)) * 256) * 4;
     };
@@ -203,7 +206,7 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& opd,
         return rr < nx.nblk ? (nx.wbase + (row * nx.nblk + rr) * 256) * 4 : (nx.rwbase + (row * nx.ncr + (rr - nx.nblk)) * 256) * 4;
     };
     auto read_b = [&](int r, int t) -> f32x4 {
-        const int rr = r % S::TOT;
+        const int rr = r % TOTD;
         if (rr < S::NBLK) {
             const int c16 = rr / S::NTAP, ts = rr % S::NTAP;
             return brow[t][ts * rs4 + c16 * 4];
@@ -226,12 +229,12 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& opd,
             for (int t = 0; t < NJ; ++t) bq[(r + DB) % (DB + 1)][t] = read_b(r + DB, t);
         }
         const f32x4 af = ring[r % P];
-        const bool is_res = (r % S::TOT) >= S::NBLK;
+        const bool is_res = (r % TOTD) >= S::NBLK;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int t = 0; t < NJ; ++t) {
-                const int tt = (S::NSEQ > 1) ? r / S::TOT : t;
+                const int tt = (S::NSEQ > 1) ? r / TOTD : t;
                 f32x4& d = is_res ? racc[tt][e & 1] : acc[tt][e & 1];
                 d = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bq[r % (DB + 1)][t][e], d, 0, 0, 0);
             }
@@ -242,10 +245,13 @@ __device__ __forceinline__ void fused_bwd_op(const BwdArgs& a, const BwdOp& opd,
         if (S::SLEN < P) {   // slots this op never uses belong to the next op from the start
 #pragma unroll
             for (int k = S::SLEN; k < P; ++k)
-                if ((k - S::SLEN) % S::SLEN == r) ring[k] = fused_ld_block(wrs, nx_off(k), 0, lane_bytes);
+                if ((k - S::SLEN) % (S::SLEN > 0 ? S::SLEN : 1) == r) ring[k] = fused_ld_block(wrs, nx_off(k), 0, lane_bytes);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+
+    if constexpr (S::SLEN == 0)   // nothing streamed: the next op's first blocks are requested here (they fly under the epilogue)
+        bwd_ring_request(ring, wrs, nx.wbase, nx.rwbase, wave & (nx.msw - 1), nx.msw, nx.nblk, nx.ncr, nx.slen, lane_bytes);
 
     // ------------------------------------------------------------------ epilogue
     f32x4 gy[NTW];
@@ -452,7 +458,7 @@ __device__ __forceinline__ void fused_bwd_prologue(const BwdArgs& a, const BwdNe
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     for (int i = tid; i < rows * a.in_rs4; i += kFusedThreads) sm4[a.in_off4 + i] = z;
     lds_barrier();
-    const int n4 = a.in_L * c4n;
+    const int n4 = a.gin ? a.in_L * c4n : 0;   // (gin == null: the first op takes its input as a global addend; only the zeros above)
     for (int i = tid; i < n4; i += kFusedThreads) {
         const int l = i / c4n, c = i - l * c4n;
         sm4[a.in_off4 + ((a.in_stuff ? 2 * l : l) + 2) * a.in_rs4 + c] = *(const f32x4*)(a.gin + ((size_t)b * a.in_L + l) * a.in_C + 4 * c);
@@ -494,6 +500,6 @@ __global__ __launch_bounds__(kFusedThreads) void fused_bwd_program_kernel(const 
 // the backward pass of downs[0..2] of the standard network (train_host.hpp run_down_program)
 using BwdSeqDown3 = BwdSeq<0, 0, 1, 1, 1, 2, 3, 4, 4, 4, 5, 6, 7, 7, 7>;
 // the backward pass of final_conv[0] + ups[2] + ups[1] (run_up_program)
-using BwdSeqUp2 = BwdSeq<1, 8, 9, 10, 10, 10, 11, 11, 12, 13, 13, 13, 14, 14>;
+using BwdSeqUp2 = BwdSeq<1, 15, 8, 9, 10, 10, 10, 11, 11, 12, 13, 13, 13, 14, 14>;
 
 }  // namespace mpdx

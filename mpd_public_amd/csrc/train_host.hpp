@@ -897,18 +897,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             }
             df.pcur += (size_t)3 * B * lj.cout;
         };
-        {   // final_conv[0]'s Mish + GroupNorm backward on the loss kernel's gradient, in place: dU -> grd(45), the program's input
-            const Layer& l = u->layers[45];
-            GnBwdArgs g;
-            memset(&g, 0, sizeof(g));
-            g.gy = grd(45); g.du = grd(45); g.pre = pre(45); g.gamma = flat + u->params[l.gamma].foff; g.beta = flat + u->params[l.beta].foff;
-            int pg = 0;
-            part3(45, pg);
-            g.pg = ws + pg; g.pb = g.pg + (size_t)B * l.cout; g.pbias = g.pb + (size_t)B * l.cout;
-            g.B = B; g.L = l.L_out; g.C = l.cout; g.gs = l.gs; g.n_groups = l.cout / l.gs; g.lg_gs = 2; g.Lv = 0;
-            hipLaunchKernelGGL(gn_mish_bwd_kernel<4>, dim3((B * g.n_groups + 3) / 4), dim3(256), 0, st, g);
-        }
-        a.gin = grd(45); a.in_L = 64; a.in_C = 32; a.in_stuff = 0; a.in_off4 = lay.off4[IN]; a.in_rs4 = rs4_of(32);
+        a.gin = nullptr; a.in_L = 64; a.in_C = 32; a.in_stuff = 0; a.in_off4 = lay.off4[IN]; a.in_rs4 = rs4_of(32);   // (no staged input: U0 reads the loss kernel's gradient itself)
         int nop = 0;
         auto new_op = [&](int mode, int ks, int nc16, int ncr, int cout, int L, int gn) -> BwdOp& {
             BwdOp& op = a.ops[nop++];
@@ -924,6 +913,13 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             part3(li, op.part_g);
             op.dT_g = lj.tb_off >= 0 ? (int)(w.dT + lj.tb_off) : -1;
         };
+        {   // U0: final_conv[0]'s Mish + GroupNorm backward on the loss kernel's gradient (an op without a convolution: the gradient is its global addend);
+            // dU -> IN and, in place, grd(45) (the operand of final_conv[0]'s weight gradient)
+            BwdOp& op = new_op(CONV_S1, 5, 0, 0, 32, 64, 1);
+            op.gadd = goff(grd(45));
+            op.dst_off4 = lay.off4[IN]; op.dst_rs4 = rs4_of(32); op.out_g = goff(grd(45));
+            gn_part(45, op);
+        }
         {   // U1: dgrad of final_conv[0] -> dU of ups[2]'s Upsample1d (64 positions)
             BwdOp& op = new_op(CONV_S1, 5, 2, 0, 32, 64, 0);
             op.src_off4 = lay.off4[IN]; op.src_rs4 = rs4_of(32);
