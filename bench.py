@@ -995,7 +995,8 @@ def training_leg(steps=100, B=32, T=25, D=4, opt=1, baseline=True):
     dt_native = (time.perf_counter() - t0) / steps
     rec = {"workload": f"p_losses + backward + clip_grad_norm_ + Adam + EMA/10, batch {B} x H=64 x D={D}, T={T}, dim_mults option {opt}, fp32",
            "launch_mode": {"note": "TrainStep.step measures both forms on this host + GPU (eager launches: calls 2-3; one hipGraph replay per iteration: "
-                                   "calls 5-6) and keeps the faster; MPDX_TRAIN_GRAPH=1 / 0 forces either", "decided": ts.launch_mode()},
+                                   "calls 5-6) and keeps the faster (same launches, same device-side RNG / step count / lr: same numbers); MPDX_TRAIN_GRAPH=1 / 0 forces either",
+                           "decided": ts.launch_mode()},
            "train_steps_per_s": round(1.0 / dt_native, 1), "ms_per_train_step": round(dt_native * 1e3, 3)}
     # roofline of the iteration: algorithmic FLOPs = 3 x the forward pass (forward + input gradients + weight gradients of every
     # convolution; GroupNorm / Mish / Adam are O(activations + parameters)), the forward count from the library's own layer table
@@ -1009,7 +1010,7 @@ def training_leg(steps=100, B=32, T=25, D=4, opt=1, baseline=True):
                                          torch.cuda.current_stream().cuda_stream, cap, ms_, fl_, nm_, C.byref(n_)), "mpdx_unet_profile")
         fwd = float(sum(fl_[k] for k in range(n_.value)))
         tf = 3.0 * fwd / dt_native / 1e12
-        rec["roofline"] = {"bound": "launch latency (a chain of ~90 dependent 3-50 us kernels; fp32 MFMA for the convolutions)",
+        rec["roofline"] = {"bound": "latency of a chain of ~50 dependent launches (4 whole-trajectory programs of 27-59 us, ~30 inner-level launches of 5-10 us; fp32 MFMA for the convolutions)",
                            "algorithmic_flop_per_iteration": 3.0 * fwd, "forward_flop": fwd, "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 4),
                            "launches_per_iteration": _train_launches_from_profile(B)}

@@ -10,7 +10,9 @@
 //     (packedT: transposed + tap-flipped, train.hpp) - M = the layer's INPUT channels, N = L positions - on v_mfma_f32_16x16x4_f32,
 //     tile ownership and accumulation order as fused_conv_op (a wave owns its tiles for the whole K; two accumulator chains);
 //   * the dgrad packs are read AS THEY ARE (their [m16][c16][tap] block order is the k-loop's consumption order): a 16-slot register
-//     ring per wave, refilled inside the op; the NEXT op's first blocks are requested right behind the k-loop, so they fly under the epilogue;
+//     ring per wave that runs on ACROSS the ops (in an op's last 16 steps a consumed slot is refilled with the next op's block of that slot: fused_conv_op's scheme);
+//     static programs (BwdSeq): compile-time op sequence, shapes and LDS geometry (BwdGeomOf) - the first, generic op-list version kept every shape's address arithmetic
+//     alive across a switch (256 VGPRs + 108 AGPRs, 92 us for the down program; 58 us now);
 //   * epilogue = what the per-layer path does between two launches: + the folded residual 1x1's input gradient (second accumulator),
 //     + the identity-residual branch's G (LDS), + the other consumers' gradient (global: the skip connection), then - if the tensor
 //     below is a Conv1dBlock - its Mish + GroupNorm backward (statistics of the kept GroupNorm input re-derived from global memory,

@@ -777,7 +777,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         if (!written[17] || df.red.n + 18 > 96 || df.col.n + 12 * 3 + 6 > 120) return 1;
         static const int late_div_env = getenv("MPDX_WGRAD_LATE_DIV") ? std::max(1, atoi(getenv("MPDX_WGRAD_LATE_DIV"))) : 0;
         static const int small_mul = getenv("MPDX_WGRAD_PROG_MUL") ? atoi(getenv("MPDX_WGRAD_PROG_MUL")) : 1;   // batch < 64: split multiplier of the program layers' weight gradients
-        const int sdiv = late_div_env ? late_div_env : (B >= 64 ? (B <= 128 ? 8 : 4) : (small_mul > 1 ? -std::min(small_mul, 4) : 1));
+        const int sdiv = late_div_env ? late_div_env : (B >= 64 ? (B <= 128 ? 8 : 4) : (small_mul > 1 ? -std::min(small_mul, 4) : (B >= 48 ? 2 : 1)));
         const BwdProgLayout lay = bwd_down_layout();
         BwdArgs a;
         memset(&a, 0, sizeof(a));
@@ -878,7 +878,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         if (!written[45] || df.red.n + 17 > 96 || df.col.n + 9 * 3 + 4 > 120) return 1;
         static const int late_div_env = getenv("MPDX_WGRAD_LATE_DIV") ? std::max(1, atoi(getenv("MPDX_WGRAD_LATE_DIV"))) : 0;
         static const int small_mul = getenv("MPDX_WGRAD_PROG_MUL") ? atoi(getenv("MPDX_WGRAD_PROG_MUL")) : 1;
-        const int sdiv = late_div_env ? late_div_env : (B >= 64 ? (B <= 128 ? 8 : 4) : (small_mul > 1 ? -std::min(small_mul, 4) : 1));
+        const int sdiv = late_div_env ? late_div_env : (B >= 64 ? (B <= 128 ? 8 : 4) : (small_mul > 1 ? -std::min(small_mul, 4) : (B >= 48 ? 2 : 1)));
         const BwdProgLayout lay = bwd_down_layout();   // (the same five slots: the largest buffer here is 68 rows x 36 floats = 612 float4)
         BwdArgs a;
         memset(&a, 0, sizeof(a));
@@ -1092,9 +1092,9 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         // fewer batch splits for the weight gradients that run behind the chain (measured, profiles/r06_train_late_div_ab.txt: batch 128 x D = 14 0.898 / 0.84 / 0.82 /
         // 0.81 ms with 1 / 4 / 8 / 16; batch 512 2.027 / 1.94 / 1.96 / 2.01): 8 up to batch 128, 4 beyond
         static const int late_div_env = getenv("MPDX_WGRAD_LATE_DIV") ? std::max(1, atoi(getenv("MPDX_WGRAD_LATE_DIV"))) : 0;
-        const int late_div = late_div_env ? late_div_env : (B <= 128 ? 8 : 4);
+        const int late_div = late_div_env ? late_div_env : (B < 64 ? 2 : (B <= 128 ? 8 : 4));
         // will this layer's weight gradients run behind the chain (decided below, once the jobs exist: the same conditions)?  Then with fewer batch splits.
-        const bool late_cand = (late_env0 < 0 ? B >= 64 : late_env0 != 0) && t.need_dgrad && !pair_off0 && df.on && df.red.n + 2 <= 96 && bwd_pair_has_tile(t.dg, B) && dy == gy;
+        const bool late_cand = (late_env0 < 0 ? B >= 48 : late_env0 != 0) && t.need_dgrad && !pair_off0 && df.on && df.red.n + 2 <= 96 && bwd_pair_has_tile(t.dg, B) && dy == gy;
         const int sdiv = late_cand ? late_div : 1;
         if (l.mode == CONV_UPT) {
             if (int rc = make_wgrad(tensor(t.src1_l), l.L_in, l.c1, 0, l.c1, dy, l.L_out, l.cout, 0, l.cout, 2, -1, 4, B, part, gw, l.cout, 0, &df, jobs[njobs++], sdiv)) return rc;
@@ -1117,7 +1117,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         // whenever it sits in the layer's own gradient slot (grd(i): written once, never recycled), not in the shared dU scratch of an un-fused
         // GroupNorm backward - and run with everybody else's in wgrad_multi_kernel behind the chain
         static const int late_env = getenv("MPDX_TRAIN_WGRAD_LATE") ? atoi(getenv("MPDX_TRAIN_WGRAD_LATE")) : -1;   // -1: by batch (measured: batch 32 no gain, 128 -3 %, 512 -4.6 %)
-        const bool late_on = late_env < 0 ? B >= 64 : late_env != 0;
+        const bool late_on = late_env < 0 ? B >= 48 : late_env != 0;   // (batch 48: 0.58 -> 0.543 ms, batch 32: within noise: profiles/r06_train_b32_late_ab.txt)
         static const bool resamp_fold_off_c = getenv("MPDX_TRAIN_RESAMPLE_FOLD") && atoi(getenv("MPDX_TRAIN_RESAMPLE_FOLD")) == 0;
         // this layer's input-gradient convolution as a step of the backward chain?
         const bool chain_d = chain.on && paired && dy == gy && ChainBuilder::conv_ok(t.dg, chain_min_L) && !resamp_fold_off_c &&
