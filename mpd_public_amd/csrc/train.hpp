@@ -747,6 +747,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_colsum_kernel(const ReduceCo
 //  divisions per element - 42 us per call for 8 M outputs.)
 // struct PackChunk: train_types.hpp
 
+// (round 6: a chunk is kPackChunk = 4096 outputs - four passes of the 1024-output body below, all sixteen loads of a thread in flight before its first store:
+//  with 1024-output blocks the launch was 11.7 k blocks that each waited ~2 us for their two dependent table reads and then moved 4 KB: 20 us for 47 MB)
+constexpr unsigned kPackChunk = 4096;
 __global__ __launch_bounds__(256) void pack_train_kernel(const PackDesc* __restrict__ descs, const PackChunk* __restrict__ chunks, const float* __restrict__ flat,
                                                          float* __restrict__ packed, float* __restrict__ packedT) {
     const PackChunk c = chunks[blockIdx.x];
@@ -754,52 +757,56 @@ __global__ __launch_bounds__(256) void pack_train_kernel(const PackDesc* __restr
     const float* src = flat + d.src;
     const unsigned n = (unsigned)d.n;
     const unsigned cin = (unsigned)d.cin, cout = (unsigned)d.cout, ks = (unsigned)d.ks;
-    // A thread takes the four CONSECUTIVE outputs i0 .. i0 + 3 of one lane of one 256-float fragment block (round 4; before: outputs i, i + 256, i + 512,
-    // i + 768 - four decompositions of the block index per thread, and the kernel was VALU-bound on their 32-bit divisions: 22 us for 47 MB): one
-    // decomposition, the four sources a constant stride apart.
-    const unsigned i0 = c.first + 4u * threadIdx.x;
-    const unsigned lane = (i0 >> 2) & 63;
-    unsigned r = i0 >> 8;
-    unsigned sa0 = i0, sstep = 1, lim_ci = 0, ci0 = 0;   // source of element e: sa0 + e * sstep, valid while ci0 + e < lim_ci (vectors: i0 + e < n)
-    bool okq = true;
-    float* dst;
-    unsigned total;
-    if (c.which == 0) {
-        total = (unsigned)d.pn;
-        dst = packed + d.dst;
-        if (d.kind == 0) { ci0 = i0; lim_ci = n; }   // PK_VEC: a copy
-        else {   // forward layout [m16][c16][slot][lane][4]
-            const unsigned nc16 = (unsigned)d.cin_pad >> 4, nslot = (unsigned)d.nslot;
-            const unsigned slot = r % nslot; r /= nslot;
-            const unsigned c16 = r % nc16, m16 = r / nc16;
-            const unsigned co = m16 * 16 + (lane & 15);
-            ci0 = c16 * 16 + (lane >> 4) * 4; lim_ci = cin;
-            if (d.kind == 2) { sa0 = (ci0 * cout + co) * ks + (unsigned)upt_slot_to_k((int)slot); sstep = cout * ks; }
-            else { sa0 = (co * cin + ci0) * ks + slot; sstep = ks; }
+    if (c.which != 0 && !packedT) return;
+    float* const dst = c.which == 0 ? packed + d.dst : packedT + d.dstT;
+    const unsigned total = c.which == 0 ? (unsigned)d.pn : (unsigned)d.pnT;
+    constexpr int NP = (int)(kPackChunk / 1024u);
+    bool ok[NP][4];
+    float v[NP][4];
+    unsigned i0s[NP];
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        // A thread takes the four CONSECUTIVE outputs i0 .. i0 + 3 of one lane of one 256-float fragment block (round 4; before: outputs i, i + 256, i + 512,
+        // i + 768 - four decompositions of the block index per thread, and the kernel was VALU-bound on their 32-bit divisions): one
+        // decomposition, the four sources a constant stride apart.
+        const unsigned i0 = c.first + (unsigned)it * 1024u + 4u * threadIdx.x;
+        i0s[it] = i0;
+        const unsigned lane = (i0 >> 2) & 63;
+        unsigned r = i0 >> 8;
+        unsigned sa0 = i0, sstep = 1, lim_ci = 0, ci0 = 0;   // source of element e: sa0 + e * sstep, valid while ci0 + e < lim_ci (vectors: i0 + e < n)
+        bool okq = true;
+        if (c.which == 0) {
+            if (d.kind == 0) { ci0 = i0; lim_ci = n; }   // PK_VEC: a copy
+            else {   // forward layout [m16][c16][slot][lane][4]
+                const unsigned nc16 = (unsigned)d.cin_pad >> 4, nslot = (unsigned)d.nslot;
+                const unsigned slot = r % nslot; r /= nslot;
+                const unsigned c16 = r % nc16, m16 = r / nc16;
+                const unsigned co = m16 * 16 + (lane & 15);
+                ci0 = c16 * 16 + (lane >> 4) * 4; lim_ci = cin;
+                if (d.kind == 2) { sa0 = (ci0 * cout + co) * ks + (unsigned)upt_slot_to_k((int)slot); sstep = cout * ks; }
+                else { sa0 = (co * cin + ci0) * ks + slot; sstep = ks; }
+            }
+        } else {   // dgrad layout: a CONV_S1 weight [t_cout][t_cin][t_ks]
+            const unsigned tnc16 = (unsigned)d.t_cin_pad >> 4, tks = (unsigned)d.t_ks, tcin = (unsigned)d.t_cin, tcout = (unsigned)d.t_cout;
+            const unsigned slot = r % tks; r /= tks;
+            const unsigned c16 = r % tnc16, m16 = r / tnc16;
+            const unsigned o = m16 * 16 + (lane & 15);     // output channel of the dgrad conv = input channel of the layer
+            ci0 = c16 * 16 + (lane >> 4) * 4;               // input channel of the dgrad conv = output channel of the layer
+            lim_ci = tcin;
+            okq = o < tcout && (d.t_mode == 0 || slot > 0);
+            if (d.t_mode == 0) { sa0 = (ci0 * cin + o) * ks + (ks - 1 - slot); sstep = cin * ks; }   // W[co = ii][ci = o][k - 1 - k']
+            else { sa0 = (o * cout + ci0) * ks + (slot - 1); sstep = ks; }                             // W[ci = o][co = ii][k' - 1]
         }
-    } else {   // dgrad layout: a CONV_S1 weight [t_cout][t_cin][t_ks]
-        if (!packedT) return;
-        total = (unsigned)d.pnT;
-        dst = packedT + d.dstT;
-        const unsigned tnc16 = (unsigned)d.t_cin_pad >> 4, tks = (unsigned)d.t_ks, tcin = (unsigned)d.t_cin, tcout = (unsigned)d.t_cout;
-        const unsigned slot = r % tks; r /= tks;
-        const unsigned c16 = r % tnc16, m16 = r / tnc16;
-        const unsigned o = m16 * 16 + (lane & 15);     // output channel of the dgrad conv = input channel of the layer
-        ci0 = c16 * 16 + (lane >> 4) * 4;               // input channel of the dgrad conv = output channel of the layer
-        lim_ci = tcin;
-        okq = o < tcout && (d.t_mode == 0 || slot > 0);
-        if (d.t_mode == 0) { sa0 = (ci0 * cin + o) * ks + (ks - 1 - slot); sstep = cin * ks; }   // W[co = ii][ci = o][k - 1 - k']
-        else { sa0 = (o * cout + ci0) * ks + (slot - 1); sstep = ks; }                             // W[ci = o][co = ii][k' - 1]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ok[it][e] = okq && i0 + e < total && ci0 + e < lim_ci;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[it][e] = src[ok[it][e] ? sa0 + e * sstep : 0u];   // (unconditional loads from clamped addresses; zeros selected afterwards)
     }
-    bool ok[4];
-    float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ok[e] = okq && i0 + e < total && ci0 + e < lim_ci;
+    for (int it = 0; it < NP; ++it)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = src[ok[e] ? sa0 + e * sstep : 0u];   // (unconditional loads from clamped addresses; zeros selected afterwards)
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-        if (i0 + e < total) dst[i0 + e] = ok[e] ? v[e] : 0.f;
+        for (int e = 0; e < 4; ++e)
+            if (i0s[it] + e < total) dst[i0s[it] + e] = ok[it][e] ? v[it][e] : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

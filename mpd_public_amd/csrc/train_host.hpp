@@ -66,14 +66,14 @@ static void build_train_plan(mpdx_unet* u) {
 
 static int ensure_pack_descs(mpdx_unet* u) {
     if (u->pack_descs_dev) return 0;
-    // the chunk table of pack_train_kernel: 1024 outputs of one pack of one parameter per block
+    // the chunk table of pack_train_kernel: kPackChunk outputs of one pack of one parameter per block
     std::vector<PackChunk> chunks;
     for (size_t k = 0; k < u->pack_descs_host.size(); ++k) {
         const PackDesc& d = u->pack_descs_host[k];
         if (d.pn >= (1ull << 32) || d.pnT >= (1ull << 32) || d.n >= (1ull << 32)) return fail(MPDX_E_INVALID, "parameter %zu: more than 2^32 packed floats", k);
-        for (unsigned long long f = 0; f < d.pn; f += 1024) chunks.push_back(PackChunk{(int)k, 0, (unsigned)f, 0u});
+        for (unsigned long long f = 0; f < d.pn; f += kPackChunk) chunks.push_back(PackChunk{(int)k, 0, (unsigned)f, 0u});
         if (d.dstT != ~0ull)
-            for (unsigned long long f = 0; f < d.pnT; f += 1024) chunks.push_back(PackChunk{(int)k, 1, (unsigned)f, 0u});
+            for (unsigned long long f = 0; f < d.pnT; f += kPackChunk) chunks.push_back(PackChunk{(int)k, 1, (unsigned)f, 0u});
     }
     u->n_pack_chunks = chunks.size();
     HIP_TRY(hipMalloc(&u->pack_chunks_dev, chunks.size() * sizeof(PackChunk)));
