@@ -41,7 +41,8 @@ namespace mpdx {
     X(6, CONV_S1, 3, 2, 0, 32, 64, 1) X(7, CONV_S1, 5, 2, 0, 32, 64, 1)                                                              \
     X(8, CONV_S1, 5, 2, 0, 32, 64, 0) X(9, CONV_DOWN, 5, 2, 0, 32, 32, 1) X(10, CONV_S1, 5, 2, 0, 32, 32, 1) X(11, CONV_S1, 5, 2, 2, 64, 32, 0) \
     X(12, CONV_DOWN, 5, 4, 0, 64, 16, 1) X(13, CONV_S1, 5, 4, 0, 64, 16, 1) X(14, CONV_S1, 5, 4, 4, 128, 16, 0)              \
-    X(15, CONV_S1, 5, 0, 0, 32, 64, 1)   /* no convolution: the result is the global addend (final_conv[0]'s output gradient from the loss kernel) */
+    X(15, CONV_S1, 5, 0, 0, 32, 64, 1)   /* no convolution: the result is the global addend (final_conv[0]'s output gradient from the loss kernel) */ \
+    X(16, CONV_S1, 5, 0, 0, 128, 16, 1)  /* no convolution: the innermost level of a THREE-level network has no Downsample1d; its blocks.1's output gradient is the addend */
 inline int bwd_shape_id(int mode, int ks, int nc16, int rnc16, int cout, int L, int gn) {
 #define X(id, M, K, N, R, CO, LO, G) if (mode == M && ks == K && nc16 == N && rnc16 == R && cout == CO && L == LO && gn == G) return id;
     MPDX_BWD_SHAPES(X)
@@ -85,11 +86,14 @@ struct BwdGeomOp { int src_off4, src_rs4, rsrc_off4, rsrc_rs4, add_off4, add_rs4
 constexpr int kBwdSlot4 = 660;
 constexpr int kBwdIN = 0, kBwdGB = 1, kBwdDUA = 2, kBwdDUB = 3, kBwdGA = 4;
 constexpr int bwd_slot(int k) { return k * kBwdSlot4; }
-constexpr BwdGeomOp bwd_down_geom(int i) {
+constexpr BwdGeomOp bwd_down_geom(int i, bool first_noconv = false) {
     const int k = i < 5 ? 2 : (i < 10 ? 1 : 0), p = i - (i < 5 ? 0 : (i < 10 ? 5 : 10));
     const int C = 32 << k, r4 = C / 4 + 1;
     BwdGeomOp g{0, 0, 0, 0, -1, 0, -1, 0, -1, 0, 0};
-    if (p == 0) { g.src_off4 = bwd_slot(kBwdIN); g.src_rs4 = r4; g.gy_off4 = bwd_slot(kBwdGB); g.gy_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = r4; }
+    if (p == 0) {
+        g.src_off4 = bwd_slot(kBwdIN); g.src_rs4 = r4; g.gy_off4 = bwd_slot(kBwdGB); g.gy_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = r4;
+        if (i == 0 && first_noconv) { g.src_off4 = 0; g.src_rs4 = 0; }   // (no source: the op's input is its global addend)
+    }
     else if (p == 1) { g.src_off4 = bwd_slot(kBwdDUA); g.src_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUB); g.dst_rs4 = r4; }
     else if (p == 2) { g.src_off4 = bwd_slot(kBwdDUB); g.src_rs4 = r4; g.add_off4 = bwd_slot(kBwdGB); g.add_rs4 = r4; g.gy_off4 = bwd_slot(kBwdGA); g.gy_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = r4; }
     else if (p == 3) { g.src_off4 = bwd_slot(kBwdDUA); g.src_rs4 = r4; g.dst_off4 = k > 0 ? bwd_slot(kBwdDUB) : -1; g.dst_rs4 = r4; }
@@ -112,7 +116,7 @@ constexpr BwdGeomOp bwd_up_geom(int i) {
     }
     return g;
 }
-template <int PROG, int I> struct BwdGeomOf { static constexpr bool has = true; static constexpr BwdGeomOp g = PROG == 0 ? bwd_down_geom(I) : bwd_up_geom(I); };
+template <int PROG, int I> struct BwdGeomOf { static constexpr bool has = true; static constexpr BwdGeomOp g = PROG == 0 ? bwd_down_geom(I) : (PROG == 2 ? bwd_down_geom(I, true) : bwd_up_geom(I)); };
 struct BwdGeomNone { static constexpr bool has = false; static constexpr BwdGeomOp g{0, 0, 0, 0, -1, 0, -1, 0, -1, 0, 0}; };
 // host: does op `o` (as train_host.hpp laid it out) have the table's LDS geometry?
 inline bool bwd_geom_matches(const BwdOp& o, const BwdGeomOp& g, bool has_rsrc) {
@@ -501,7 +505,9 @@ __global__ __launch_bounds__(kFusedThreads) void fused_bwd_program_kernel(const 
 }
 // the backward pass of downs[0..2] of the standard network (train_host.hpp run_down_program)
 using BwdSeqDown3 = BwdSeq<0, 0, 1, 1, 1, 2, 3, 4, 4, 4, 5, 6, 7, 7, 7>;
-// the backward pass of final_conv[0] + ups[2] + ups[1] (run_up_program)
+// the same for the THREE-level network (dim_mults (1, 2, 4)): its innermost level has no Downsample1d - the first op is the GroupNorm backward alone
+using BwdSeqDown3Last = BwdSeq<2, 16, 1, 1, 1, 2, 3, 4, 4, 4, 5, 6, 7, 7, 7>;
+// the backward pass of final_conv[0] + the two outer up levels (run_up_program; the same shapes in the three- and the four-level network)
 using BwdSeqUp2 = BwdSeq<1, 15, 8, 9, 10, 10, 10, 11, 11, 12, 13, 13, 13, 14, 14>;
 
 }  // namespace mpdx

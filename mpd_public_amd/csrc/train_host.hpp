@@ -354,49 +354,62 @@ static BwdProgLayout bwd_down_layout() {
     L.lds_bytes = (size_t)(L.stat_off + 384) * sizeof(float);
     return L;
 }
-// is layers [0, 18) the standard three-level down path the program is written for?
-static bool bwd_down_applicable(const mpdx_unet* u) {
-    if ((int)u->layers.size() < 19 || u->cfg.n_support_points != 64 || u->masked()) return false;
+// is the head of the network the three-level down path the program is written for?  1: layers [0, 18), every level ends in a Downsample1d (dim_mults (1, 2, 4, 8));
+// 2: layers [0, 17), the third level is the innermost one and has none (dim_mults (1, 2, 4): the reference's UNET_DIM_MULTS option 0); 0: neither
+static int bwd_down_applicable(const mpdx_unet* u) {
+    if ((int)u->layers.size() < 19 || u->cfg.n_support_points != 64 || u->masked()) return 0;
+    int variant = 1;
     for (int k = 0; k < 3; ++k) {
         const int C = 32 << k, Lk = 64 >> k, b = 6 * k;
         const int cin = k == 0 ? u->cfg.state_dim : C / 2;
         auto blk = [&](int i, int c_in) { const Layer& l = u->layers[i]; return l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH && l.c1 == c_in && l.c2 == 0 && l.cout == C && l.L_out == Lk && l.gs * 8 == C; };
-        if (!blk(b + 0, cin) || !blk(b + 2, C) || !blk(b + 3, C) || !blk(b + 4, C)) return false;
+        if (!blk(b + 0, cin) || !blk(b + 2, C) || !blk(b + 3, C) || !blk(b + 4, C)) return 0;
         const Layer& r = u->layers[b + 1];
-        if (!(r.mode == CONV_S1 && r.ks == 1 && r.epi == EPI_BIAS && r.c1 == cin && r.cout == C && r.L_out == Lk)) return false;
+        if (!(r.mode == CONV_S1 && r.ks == 1 && r.epi == EPI_BIAS && r.c1 == cin && r.cout == C && r.L_out == Lk)) return 0;
         const Layer& d = u->layers[b + 5];
-        if (!(d.mode == CONV_DOWN && d.ks == 3 && d.epi == EPI_BIAS && d.c1 == C && d.cout == C && d.L_in == Lk && d.L_out == Lk / 2)) return false;
-        if (u->layers[b + 0].tb_off < 0 || u->layers[b + 3].tb_off < 0 || u->layers[b + 2].tb_off >= 0 || u->layers[b + 4].tb_off >= 0) return false;
         const auto& tl = u->tl;
-        if (tl[b + 2].res_l != b + 1 || tl[b + 4].res_l != b + 2 || tl[b + 2].src1_l != b || tl[b + 3].src1_l != b + 2 || tl[b + 4].src1_l != b + 3 || tl[b + 5].src1_l != b + 4) return false;
-        if (k > 0 && (tl[b].src1_l != b - 1 || tl[b + 1].src1_l != b - 1)) return false;
-        for (int i = b + (k == 0 ? 2 : 0); i < b + 6; ++i) if (!tl[i].need_dgrad) return false;
+        const bool has_down = d.mode == CONV_DOWN && d.ks == 3 && d.epi == EPI_BIAS && d.c1 == C && d.cout == C && d.L_in == Lk && d.L_out == Lk / 2 && tl[b + 5].src1_l == b + 4;
+        if (!has_down) {
+            if (k < 2) return 0;
+            variant = 2;   // (layer 17 is mid_block1's first convolution: the per-layer path has put its gradient into grd(16) by the time the program runs)
+        }
+        if (u->layers[b + 0].tb_off < 0 || u->layers[b + 3].tb_off < 0 || u->layers[b + 2].tb_off >= 0 || u->layers[b + 4].tb_off >= 0) return 0;
+        if (tl[b + 2].res_l != b + 1 || tl[b + 4].res_l != b + 2 || tl[b + 2].src1_l != b || tl[b + 3].src1_l != b + 2 || tl[b + 4].src1_l != b + 3) return 0;
+        if (k > 0 && (tl[b].src1_l != b - 1 || tl[b + 1].src1_l != b - 1)) return 0;
+        for (int i = b + (k == 0 ? 2 : 0); i < b + (has_down ? 6 : 5); ++i) if (!tl[i].need_dgrad) return 0;
     }
-    return true;
+    return variant;
 }
 
-// is layers [33, 46) the standard network's ups[1] (64 channels on 16 positions) + ups[2] (32 on 32) + final_conv[0] the UP program is written for?
-static bool bwd_up_applicable(const mpdx_unet* u) {
-    if ((int)u->layers.size() != 46 || u->cfg.n_support_points != 64 || u->masked()) return false;
+// is the tail of the network [Upsample1d(128) | up level of 64 channels on 16 positions | up level of 32 on 32 | final_conv[0]] the UP program is written for?
+// The four-level network: layers [33, 46) (ups[1], ups[2]); the three-level one: [21, 34) (ups[0], ups[1]).  Returns the first layer of the program, or -1.
+static int bwd_up_applicable(const mpdx_unet* u) {
+    const int n = (int)u->layers.size();
+    if (n < 34 || u->cfg.n_support_points != 64 || u->masked()) return -1;
     const auto& tl = u->tl;
-    const Layer& f = u->layers[45];
-    if (!(f.mode == CONV_S1 && f.ks == 5 && f.epi == EPI_GN_MISH && f.c1 == 32 && f.c2 == 0 && f.cout == 32 && f.L_out == 64 && f.gs == 4 && f.tb_off < 0 && tl[45].src1_l == 44 && tl[45].res_l < 0))
-        return false;
-    const int bases[2] = {39, 33}, Cs[2] = {32, 64}, Ls[2] = {32, 16}, skips[2] = {10, 16};
+    const int fi = n - 2;   // final_conv[0] (the last layer is final_conv[1], the 1x1)
+    const Layer& f = u->layers[fi];
+    if (!(f.mode == CONV_S1 && f.ks == 5 && f.epi == EPI_GN_MISH && f.c1 == 32 && f.c2 == 0 && f.cout == 32 && f.L_out == 64 && f.gs == 4 && f.tb_off < 0 && tl[fi].src1_l == fi - 1 && tl[fi].res_l < 0))
+        return -1;
+    const int bases[2] = {fi - 6, fi - 12}, Cs[2] = {32, 64}, Ls[2] = {32, 16}, skips[2] = {10, 16};
     for (int k = 0; k < 2; ++k) {
         const int b = bases[k], C = Cs[k], Lk = Ls[k];
         auto blk = [&](int i, int c1, int c2) { const Layer& l = u->layers[i]; return l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH && l.c1 == c1 && l.c2 == c2 && l.cout == C && l.L_out == Lk && l.gs * 8 == C; };
-        if (!blk(b, 2 * C, 2 * C) || !blk(b + 2, C, 0) || !blk(b + 3, C, 0) || !blk(b + 4, C, 0)) return false;
+        if (!blk(b, 2 * C, 2 * C) || !blk(b + 2, C, 0) || !blk(b + 3, C, 0) || !blk(b + 4, C, 0)) return -1;
         const Layer& r = u->layers[b + 1];
-        if (!(r.mode == CONV_S1 && r.ks == 1 && r.epi == EPI_BIAS && r.c1 == 2 * C && r.c2 == 2 * C && r.cout == C && r.L_out == Lk)) return false;
+        if (!(r.mode == CONV_S1 && r.ks == 1 && r.epi == EPI_BIAS && r.c1 == 2 * C && r.c2 == 2 * C && r.cout == C && r.L_out == Lk)) return -1;
         const Layer& up = u->layers[b + 5];
-        if (!(up.mode == CONV_UPT && up.ks == 4 && up.epi == EPI_BIAS && up.c1 == C && up.cout == C && up.L_in == Lk && up.L_out == 2 * Lk)) return false;
-        if (u->layers[b].tb_off < 0 || u->layers[b + 3].tb_off < 0 || u->layers[b + 2].tb_off >= 0 || u->layers[b + 4].tb_off >= 0) return false;
-        if (tl[b].src1_l != b - 1 || tl[b + 1].src1_l != b - 1 || tl[b].src2_l != skips[k] || tl[b + 1].src2_l != skips[k]) return false;
-        if (tl[b + 2].res_l != b + 1 || tl[b + 4].res_l != b + 2 || tl[b + 2].src1_l != b || tl[b + 3].src1_l != b + 2 || tl[b + 4].src1_l != b + 3 || tl[b + 5].src1_l != b + 4) return false;
-        for (int i = b; i < b + 6; ++i) if (!tl[i].need_dgrad) return false;
+        if (!(up.mode == CONV_UPT && up.ks == 4 && up.epi == EPI_BIAS && up.c1 == C && up.cout == C && up.L_in == Lk && up.L_out == 2 * Lk)) return -1;
+        if (u->layers[b].tb_off < 0 || u->layers[b + 3].tb_off < 0 || u->layers[b + 2].tb_off >= 0 || u->layers[b + 4].tb_off >= 0) return -1;
+        if (tl[b].src1_l != b - 1 || tl[b + 1].src1_l != b - 1 || tl[b].src2_l != skips[k] || tl[b + 1].src2_l != skips[k]) return -1;
+        if (tl[b + 2].res_l != b + 1 || tl[b + 4].res_l != b + 2 || tl[b + 2].src1_l != b || tl[b + 3].src1_l != b + 2 || tl[b + 4].src1_l != b + 3 || tl[b + 5].src1_l != b + 4) return -1;
+        for (int i = b; i < b + 6; ++i) if (!tl[i].need_dgrad) return -1;
     }
-    return u->layers[32].mode == CONV_UPT && u->layers[32].cout == 128 && u->layers[16].cout == 128 && u->layers[10].cout == 64 && tl[45].need_dgrad;
+    const int first = fi - 12;
+    // the producer of the inner level's x half: 128 channels on 16 positions (the Upsample1d of the level below, or - three levels - mid_block2's blocks.1)
+    const Layer& x = u->layers[first - 1];
+    if (!(x.cout == 128 && x.L_out == 16 && u->layers[16].cout == 128 && u->layers[10].cout == 64 && tl[fi].need_dgrad)) return -1;
+    return first;
 }
 
 // The steps of a backward chain (bwd_chain_kernel) collected in launch order; flush() launches them as ONE kernel (more than it can hold: several)
@@ -772,9 +785,11 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     // round 6: the backward pass of downs[0..2] as ONE whole-trajectory program (fused_bwd.hpp; MPDX_TRAIN_BWD_PROG=0 switches it off)
     static const int prog_env = getenv("MPDX_TRAIN_BWD_PROG") ? atoi(getenv("MPDX_TRAIN_BWD_PROG")) : 1;
     static const int prog_max_b = getenv("MPDX_TRAIN_BWD_PROG_MAX_B") ? atoi(getenv("MPDX_TRAIN_BWD_PROG_MAX_B")) : 512;
-    const bool prog_down_on = prog_env != 0 && df.on && !masked && B <= prog_max_b && w.total < ((size_t)1 << 31) && bwd_down_applicable(u);
-    auto run_down_program = [&]() -> int {   // layers [0, 18): returns 0 ok, < 0 error, 1 not applicable here (the per-layer path takes over)
-        if (!written[17] || df.red.n + 18 > 96 || df.col.n + 12 * 3 + 6 > 120) return 1;
+    const int down_variant = (prog_env != 0 && df.on && !masked && B <= prog_max_b && w.total < ((size_t)1 << 31)) ? bwd_down_applicable(u) : 0;
+    const bool prog_down_on = down_variant != 0;
+    const int dn_last = down_variant == 2 ? 16 : 17;   // the program covers layers [0, dn_last]
+    auto run_down_program = [&]() -> int {   // layers [0, 18) (three-level network: [0, 17)): returns 0 ok, < 0 error, 1 not applicable here (the per-layer path takes over)
+        if (!written[dn_last] || df.red.n + 18 > 96 || df.col.n + 12 * 3 + 6 > 120) return 1;
         static const int late_div_env = getenv("MPDX_WGRAD_LATE_DIV") ? std::max(1, atoi(getenv("MPDX_WGRAD_LATE_DIV"))) : 0;
         static const int small_mul = getenv("MPDX_WGRAD_PROG_MUL") ? atoi(getenv("MPDX_WGRAD_PROG_MUL")) : 1;   // batch < 64: split multiplier of the program layers' weight gradients
         const int sdiv = late_div_env ? late_div_env : (B >= 64 ? (B <= 128 ? 8 : 4) : (small_mul > 1 ? -std::min(small_mul, 4) : (B >= 48 ? 2 : 1)));
@@ -787,6 +802,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         enum { IN = 0, GB = 1, DUA = 2, DUB = 3, GA = 4 };
         auto rs4_of = [](int C) { return C / 4 + 1; };
         a.gin = grd(17); a.in_L = 8; a.in_C = 128; a.in_stuff = 1; a.in_off4 = lay.off4[IN]; a.in_rs4 = rs4_of(128);
+        if (down_variant == 2) { a.gin = nullptr; a.in_L = 0; a.in_stuff = 0; }   // (no staged input: the first op takes grd(16) as its global addend)
         int nop = 0;
         auto gn_part = [&](int li, BwdOp& op) {   // the lower Conv1dBlock `li`: its GroupNorm input, parameters and the partial-sum rows of its gamma / beta / bias gradients
             const Layer& lj = u->layers[li];
@@ -810,7 +826,13 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
                 op.add_off4 = -1; op.gadd = -1; op.gy_off4 = -1; op.gy_g = -1; op.dst_off4 = -1; op.out_g = -1; op.part_g = -1; op.dT_g = -1;
                 return op;
             };
-            {   // P1: dgrad of the Downsample1d (its dU zero-stuffed in IN) + the skip connection's gradient -> G(b1.1 out) -> GB; GroupNorm backward of b1.1
+            if (k == 2 && down_variant == 2) {   // P1 of an innermost level (no Downsample1d): G(b1.1 out) is what the per-layer path accumulated in grd(16)
+                BwdOp& op = base_op(5, 0, 0, C, 1);
+                op.gadd = goff(grd(b0 + 4));
+                op.gy_off4 = lay.off4[GB]; op.gy_rs4 = r4;
+                op.dst_off4 = lay.off4[DUA]; op.dst_rs4 = r4; op.out_g = goff(grd(b0 + 4));
+                gn_part(b0 + 4, op);
+            } else {   // P1: dgrad of the Downsample1d (its dU zero-stuffed in IN) + the skip connection's gradient -> G(b1.1 out) -> GB; GroupNorm backward of b1.1
                 BwdOp& op = base_op(3, C / 16, 0, C, 1);
                 op.src_off4 = lay.off4[IN]; op.src_rs4 = r4;
                 op.wbase = (int)u->tl[b0 + 5].dgrad_woff;
@@ -854,13 +876,17 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         a.nops = nop;
         for (int k = 0; k < nop; ++k)
             if (a.ops[k].shape < 0) return fail(MPDX_E_INVALID, "backward program: op %d has no shape", k);
+        const bool last = down_variant == 2;
         bool is_static = nop == BwdSeqDown3::N;
-        for (int k = 0; k < nop && is_static; ++k) is_static = a.ops[k].shape == BwdSeqDown3::ids[k] && bwd_geom_matches(a.ops[k], bwd_down_geom(k), a.ops[k].shape == 2 || a.ops[k].shape == 5);
+        for (int k = 0; k < nop && is_static; ++k)
+            is_static = a.ops[k].shape == (last ? BwdSeqDown3Last::ids[k] : BwdSeqDown3::ids[k]) && bwd_geom_matches(a.ops[k], bwd_down_geom(k, last), a.ops[k].shape == 2 || a.ops[k].shape == 5);
         if (!is_static) return fail(MPDX_E_STATE, "backward program (down): the layout differs from the static program's table");
-        if (int rc = raise_lds_limit((const void*)fused_bwd_program_kernel<BwdSeqDown3>)) return rc;
-        hipLaunchKernelGGL(fused_bwd_program_kernel<BwdSeqDown3>, dim3(B), dim3(kFusedThreads), lay.lds_bytes, st, a);
+        const void* kern = last ? (const void*)fused_bwd_program_kernel<BwdSeqDown3Last> : (const void*)fused_bwd_program_kernel<BwdSeqDown3>;
+        if (int rc = raise_lds_limit(kern)) return rc;
+        if (last) hipLaunchKernelGGL(fused_bwd_program_kernel<BwdSeqDown3Last>, dim3(B), dim3(kFusedThreads), lay.lds_bytes, st, a);
+        else hipLaunchKernelGGL(fused_bwd_program_kernel<BwdSeqDown3>, dim3(B), dim3(kFusedThreads), lay.lds_bytes, st, a);
         // the layers' weight gradients (their dY operands now sit in grd(i)) behind the chain; bias gradients of the three convolutions without GroupNorm
-        for (int i = 17; i >= 0; --i) {
+        for (int i = dn_last; i >= 0; --i) {
             const Layer& l = u->layers[i];
             const auto& t = u->tl[i];
             written[i] = 1; du_ready[i] = 1;
@@ -873,9 +899,11 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         }
         return 0;
     };
-    const bool prog_up_on = prog_env != 0 && prog_env != 2 && df.on && !masked && B <= prog_max_b && w.total < ((size_t)1 << 31) && bwd_up_applicable(u);   // (2: the down program only)
-    auto run_up_program = [&]() -> int {   // layers [33, 46): final_conv[0], ups[2], ups[1]; 0 ok, < 0 error, 1 not applicable here
-        if (!written[45] || df.red.n + 17 > 96 || df.col.n + 9 * 3 + 4 > 120) return 1;
+    const int up_first = (prog_env != 0 && prog_env != 2 && df.on && !masked && B <= prog_max_b && w.total < ((size_t)1 << 31)) ? bwd_up_applicable(u) : -1;   // (2: the down program only)
+    const bool prog_up_on = up_first >= 0;
+    const int up_fi = n - 2;   // final_conv[0]
+    auto run_up_program = [&]() -> int {   // layers [up_first, n - 1) = [33, 46) ([21, 34) with three levels): final_conv[0] and the two outer up levels; 0 ok, < 0 error, 1 not applicable here
+        if (!written[up_fi] || df.red.n + 17 > 96 || df.col.n + 9 * 3 + 4 > 120) return 1;
         static const int late_div_env = getenv("MPDX_WGRAD_LATE_DIV") ? std::max(1, atoi(getenv("MPDX_WGRAD_LATE_DIV"))) : 0;
         static const int small_mul = getenv("MPDX_WGRAD_PROG_MUL") ? atoi(getenv("MPDX_WGRAD_PROG_MUL")) : 1;
         const int sdiv = late_div_env ? late_div_env : (B >= 64 ? (B <= 128 ? 8 : 4) : (small_mul > 1 ? -std::min(small_mul, 4) : (B >= 48 ? 2 : 1)));
@@ -916,17 +944,17 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         {   // U0: final_conv[0]'s Mish + GroupNorm backward on the loss kernel's gradient (an op without a convolution: the gradient is its global addend);
             // dU -> IN and, in place, grd(45) (the operand of final_conv[0]'s weight gradient)
             BwdOp& op = new_op(CONV_S1, 5, 0, 0, 32, 64, 1);
-            op.gadd = goff(grd(45));
-            op.dst_off4 = lay.off4[IN]; op.dst_rs4 = rs4_of(32); op.out_g = goff(grd(45));
-            gn_part(45, op);
+            op.gadd = goff(grd(up_fi));
+            op.dst_off4 = lay.off4[IN]; op.dst_rs4 = rs4_of(32); op.out_g = goff(grd(up_fi));
+            gn_part(up_fi, op);
         }
         {   // U1: dgrad of final_conv[0] -> dU of ups[2]'s Upsample1d (64 positions)
             BwdOp& op = new_op(CONV_S1, 5, 2, 0, 32, 64, 0);
             op.src_off4 = lay.off4[IN]; op.src_rs4 = rs4_of(32);
-            op.wbase = (int)u->tl[45].dgrad_woff;
-            op.dst_off4 = lay.off4[DUA]; op.dst_rs4 = rs4_of(32); op.out_g = goff(grd(44));
+            op.wbase = (int)u->tl[up_fi].dgrad_woff;
+            op.dst_off4 = lay.off4[DUA]; op.dst_rs4 = rs4_of(32); op.out_g = goff(grd(up_fi - 1));
         }
-        const int bases[2] = {39, 33}, Cs[2] = {32, 64}, Ls[2] = {32, 16}, skips[2] = {10, 16};
+        const int bases[2] = {up_fi - 6, up_fi - 12}, Cs[2] = {32, 64}, Ls[2] = {32, 16}, skips[2] = {10, 16};
         int src_slot = DUA;   // where the level's Upsample1d dU sits (2 L positions)
         for (int k = 0; k < 2; ++k) {
             const int b0 = bases[k], C = Cs[k], Lk = Ls[k], r4 = rs4_of(C);
@@ -981,12 +1009,11 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             if (a.ops[k].shape < 0) return fail(MPDX_E_INVALID, "backward program (up): op %d has no shape", k);
         bool is_static = nop == BwdSeqUp2::N;
         for (int k = 0; k < nop && is_static; ++k) is_static = a.ops[k].shape == BwdSeqUp2::ids[k] && bwd_geom_matches(a.ops[k], bwd_up_geom(k), a.ops[k].shape == 11 || a.ops[k].shape == 14);
-        if (!is_static && getenv("MPDX_DEBUG_TRAIN")) fprintf(stderr, "[mpdx] backward program (up): layout differs from the static program's table -> generic kernel\n");
         if (!is_static) return fail(MPDX_E_STATE, "backward program (up): the layout differs from the static program's table");
         if (int rc = raise_lds_limit((const void*)fused_bwd_program_kernel<BwdSeqUp2>)) return rc;
         hipLaunchKernelGGL(fused_bwd_program_kernel<BwdSeqUp2>, dim3(B), dim3(kFusedThreads), lay.lds_bytes, st, a);
-        written[32] = written[16] = written[10] = 1;
-        for (int i = 45; i >= 33; --i) {
+        written[up_first - 1] = written[16] = written[10] = 1;
+        for (int i = up_fi; i >= up_first; --i) {
             const Layer& l = u->layers[i];
             const auto& t = u->tl[i];
             written[i] = 1; du_ready[i] = 1;
@@ -1008,17 +1035,17 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         return 0;
     };
     for (int i = n - 1; i >= 0; --i) {
-        if (prog_up_on && i == 45) {
+        if (prog_up_on && i == up_fi) {
             if (int rc = chain.flush()) return rc;
             const int rc = run_up_program();
             if (rc < 0 || rc > 1) return rc;
-            if (rc == 0) { i = 33; continue; }   // layers [33, 46) are done: on with layer 32
+            if (rc == 0) { i = up_first; continue; }   // layers [up_first, n - 1) are done: on with the layer below
         }
-        if (prog_down_on && i == 17) {
+        if (prog_down_on && i == dn_last) {
             if (int rc = chain.flush()) return rc;
             const int rc = run_down_program();
             if (rc < 0 || rc > 1) return rc;
-            if (rc == 0) break;   // layers [0, 18) are done
+            if (rc == 0) break;   // layers [0, dn_last] are done
         }
         const Layer& l = u->layers[i];
         const auto& t = u->tl[i];
@@ -1170,6 +1197,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             const int j = t.src1_l;
             bool gn_fused = false;
             if (paired && !masked && !gnfuse_off && ((l.mode == CONV_S1 && l.ks == 5) || (l.mode == CONV_DOWN && dgl.ks == 3)) && l.c2 == 0 && j >= 0 && j != n - 1 && first_consumer[j] == i && t.res_l != j &&
+                !(prog_down_on && j == dn_last) &&   // (the down program's first op is that layer's GroupNorm backward: it wants G, not dU)
                 u->layers[j].epi == EPI_GN_MISH && u->layers[j].cout == l.c1 && df.on && df.col.n + 3 <= 120) {
                 const Layer& lj = u->layers[j];
                 const int re = lj.gs * lj.L_out;
