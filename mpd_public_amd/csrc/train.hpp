@@ -747,9 +747,42 @@ __global__ __launch_bounds__(256) void wgrad_reduce_colsum_kernel(const ReduceCo
 //  divisions per element - 42 us per call for 8 M outputs.)
 // struct PackChunk: train_types.hpp
 
-// (round 6: a chunk is kPackChunk = 4096 outputs - four passes of the 1024-output body below, all sixteen loads of a thread in flight before its first store:
-//  with 1024-output blocks the launch was 11.7 k blocks that each waited ~2 us for their two dependent table reads and then moved 4 KB: 20 us for 47 MB)
-constexpr unsigned kPackChunk = 4096;
+// Round 6: a thread owns one lane of one GROUP = the nslot consecutive 256-float fragment blocks that share (m16, c16); a chunk (block) = kPackGroups groups,
+// one per wave.  In the forward layout of a Conv1d weight the 4 x nslot floats a lane needs are CONTIGUOUS in the reference tensor
+// (w[co][ci0 .. ci0 + 3][0 .. ks - 1]): nslot 16-byte loads instead of 4 nslot dword loads.  Measured (tools/pack_probe.py): the forward pack of the
+// four-level network alone took 18.3 us of the launch's 22.0 - 4.65 M outputs whose dword loads each touch ~40 different cache lines per wave
+// instruction (16 rows x 4 segments 80 B apart) at ~4 clocks a line in the texture cache; the dgrad pack (12 lines per instruction) 3.6 us.
+constexpr unsigned kPackGroups = 4;
+template <int KS>
+__device__ __forceinline__ void pack_group_wide(const float* __restrict__ src16, float* __restrict__ dst16) {
+    // src16: the lane's 4 KS contiguous floats w[e][k] = src16[e * KS + k] (16-byte aligned); dst16: its float4 in the group's first block, blocks 256 floats apart
+    f32x4 v[KS];
+#pragma unroll
+    for (int x = 0; x < KS; ++x) v[x] = *(const f32x4*)(src16 + 4 * x);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int x = e * KS + k; o[e] = v[x >> 2][x & 3]; }
+        *(f32x4*)(dst16 + k * 256) = o;
+    }
+}
+template <int KS>
+__device__ __forceinline__ void pack_group_flip(const float* __restrict__ src, unsigned sa, unsigned estride, bool oko, int nvalid, float* __restrict__ dst16) {
+    // rows e < nvalid (of 4) exist; out[slot][e] = row e's tap KS - 1 - slot
+    float w[4][KS];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) w[e][k] = src[(oko && e < nvalid) ? sa + (unsigned)e * estride + (unsigned)k : 0u];
+#pragma unroll
+    for (int sl = 0; sl < KS; ++sl) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (oko && e < nvalid) ? w[e][KS - 1 - sl] : 0.f;
+        *(f32x4*)(dst16 + sl * 256) = o;
+    }
+}
 __global__ __launch_bounds__(256) void pack_train_kernel(const PackDesc* __restrict__ descs, const PackChunk* __restrict__ chunks, const float* __restrict__ flat,
                                                          float* __restrict__ packed, float* __restrict__ packedT) {
     const PackChunk c = chunks[blockIdx.x];
@@ -760,53 +793,75 @@ __global__ __launch_bounds__(256) void pack_train_kernel(const PackDesc* __restr
     if (c.which != 0 && !packedT) return;
     float* const dst = c.which == 0 ? packed + d.dst : packedT + d.dstT;
     const unsigned total = c.which == 0 ? (unsigned)d.pn : (unsigned)d.pnT;
-    constexpr int NP = (int)(kPackChunk / 1024u);
-    bool ok[NP][4];
-    float v[NP][4];
-    unsigned i0s[NP];
+    const unsigned ns = c.which == 0 ? (d.kind == 0 ? 1u : (unsigned)d.nslot) : (unsigned)d.t_ks;   // blocks per group
+    const unsigned lane = threadIdx.x & 63, g = c.first + (threadIdx.x >> 6);
+    const unsigned gfirst = g * ns * 256u + 4u * lane;   // the lane's first output (slot 0)
+    if (g * ns * 256u >= total) return;
+    if (c.which == 0 && d.kind == 1) {   // Conv1d weight, forward layout: the wide path when the lane's 4 ks floats are all there and 16-byte aligned
+        const unsigned nc16 = (unsigned)d.cin_pad >> 4;
+        const unsigned c16 = g % nc16, m16 = g / nc16;
+        const unsigned co = m16 * 16 + (lane & 15), ci0 = c16 * 16 + (lane >> 4) * 4;
+        const unsigned long long sa = ((unsigned long long)co * cin + ci0) * ks;
+        if (ci0 + 3 < cin && (g + 1) * ns * 256u <= total && ((d.src + sa) & 3ull) == 0 && (d.dst & 3ull) == 0 && ns == ks) {
+            if (ks == 5) { pack_group_wide<5>(src + sa, dst + gfirst); return; }
+            if (ks == 3) { pack_group_wide<3>(src + sa, dst + gfirst); return; }
+            if (ks == 1) { pack_group_wide<1>(src + sa, dst + gfirst); return; }
+        }
+    }
+    if (c.which != 0 && d.t_mode == 0 && ns == ks && (g + 1) * ns * 256u <= total && (d.dstT & 3ull) == 0) {
+        // dgrad layout of a Conv1d weight: the lane's rows W[ci0 + e][o][0 .. ks - 1] (ks contiguous floats each, taps flipped on the way out), float4 stores
+        const unsigned tnc16 = (unsigned)d.t_cin_pad >> 4;
+        const unsigned c16 = g % tnc16, m16 = g / tnc16;
+        const unsigned o = m16 * 16 + (lane & 15), ci0 = c16 * 16 + (lane >> 4) * 4;
+        const unsigned sa = (ci0 * cin + o) * ks, estride = cin * ks;
+        const bool oko = o < (unsigned)d.t_cout;
+        if (ks == 5) { pack_group_flip<5>(src, sa, estride, oko, (unsigned)d.t_cin - ci0, dst + gfirst); return; }
+        if (ks == 3) { pack_group_flip<3>(src, sa, estride, oko, (unsigned)d.t_cin - ci0, dst + gfirst); return; }
+        if (ks == 1) { pack_group_flip<1>(src, sa, estride, oko, (unsigned)d.t_cin - ci0, dst + gfirst); return; }
+    }
+    // the general path: per slot the lane's four outputs i0 .. i0 + 3, sources a constant stride apart (the loads of every slot issued before the first store)
+    constexpr int NSMAX = 5;
+    bool ok[NSMAX][4];
+    float v[NSMAX][4];
 #pragma unroll
-    for (int it = 0; it < NP; ++it) {
-        // A thread takes the four CONSECUTIVE outputs i0 .. i0 + 3 of one lane of one 256-float fragment block (round 4; before: outputs i, i + 256, i + 512,
-        // i + 768 - four decompositions of the block index per thread, and the kernel was VALU-bound on their 32-bit divisions): one
-        // decomposition, the four sources a constant stride apart.
-        const unsigned i0 = c.first + (unsigned)it * 1024u + 4u * threadIdx.x;
-        i0s[it] = i0;
-        const unsigned lane = (i0 >> 2) & 63;
-        unsigned r = i0 >> 8;
+    for (int sl = 0; sl < NSMAX; ++sl) {
+        const unsigned slot = (unsigned)sl < ns ? (unsigned)sl : 0u;
+        const unsigned i0 = gfirst + slot * 256u;
         unsigned sa0 = i0, sstep = 1, lim_ci = 0, ci0 = 0;   // source of element e: sa0 + e * sstep, valid while ci0 + e < lim_ci (vectors: i0 + e < n)
-        bool okq = true;
+        bool okq = (unsigned)sl < ns;
         if (c.which == 0) {
             if (d.kind == 0) { ci0 = i0; lim_ci = n; }   // PK_VEC: a copy
             else {   // forward layout [m16][c16][slot][lane][4]
-                const unsigned nc16 = (unsigned)d.cin_pad >> 4, nslot = (unsigned)d.nslot;
-                const unsigned slot = r % nslot; r /= nslot;
-                const unsigned c16 = r % nc16, m16 = r / nc16;
+                const unsigned nc16 = (unsigned)d.cin_pad >> 4;
+                const unsigned c16 = g % nc16, m16 = g / nc16;
                 const unsigned co = m16 * 16 + (lane & 15);
                 ci0 = c16 * 16 + (lane >> 4) * 4; lim_ci = cin;
                 if (d.kind == 2) { sa0 = (ci0 * cout + co) * ks + (unsigned)upt_slot_to_k((int)slot); sstep = cout * ks; }
                 else { sa0 = (co * cin + ci0) * ks + slot; sstep = ks; }
             }
         } else {   // dgrad layout: a CONV_S1 weight [t_cout][t_cin][t_ks]
-            const unsigned tnc16 = (unsigned)d.t_cin_pad >> 4, tks = (unsigned)d.t_ks, tcin = (unsigned)d.t_cin, tcout = (unsigned)d.t_cout;
-            const unsigned slot = r % tks; r /= tks;
-            const unsigned c16 = r % tnc16, m16 = r / tnc16;
+            const unsigned tnc16 = (unsigned)d.t_cin_pad >> 4, tcin = (unsigned)d.t_cin, tcout = (unsigned)d.t_cout;
+            const unsigned c16 = g % tnc16, m16 = g / tnc16;
             const unsigned o = m16 * 16 + (lane & 15);     // output channel of the dgrad conv = input channel of the layer
             ci0 = c16 * 16 + (lane >> 4) * 4;               // input channel of the dgrad conv = output channel of the layer
             lim_ci = tcin;
-            okq = o < tcout && (d.t_mode == 0 || slot > 0);
+            okq = okq && o < tcout && (d.t_mode == 0 || slot > 0);
             if (d.t_mode == 0) { sa0 = (ci0 * cin + o) * ks + (ks - 1 - slot); sstep = cin * ks; }   // W[co = ii][ci = o][k - 1 - k']
             else { sa0 = (o * cout + ci0) * ks + (slot - 1); sstep = ks; }                             // W[ci = o][co = ii][k' - 1]
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ok[it][e] = okq && i0 + e < total && ci0 + e < lim_ci;
+        for (int e = 0; e < 4; ++e) ok[sl][e] = okq && i0 + e < total && ci0 + e < lim_ci;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[it][e] = src[ok[it][e] ? sa0 + e * sstep : 0u];   // (unconditional loads from clamped addresses; zeros selected afterwards)
+        for (int e = 0; e < 4; ++e) v[sl][e] = src[ok[sl][e] ? sa0 + e * sstep : 0u];   // (unconditional loads from clamped addresses; zeros selected afterwards)
     }
 #pragma unroll
-    for (int it = 0; it < NP; ++it)
+    for (int sl = 0; sl < NSMAX; ++sl) {
+        if ((unsigned)sl >= ns) break;
+        const unsigned i0 = gfirst + (unsigned)sl * 256u;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (i0s[it] + e < total) dst[i0s[it] + e] = ok[it][e] ? v[it][e] : 0.f;
+            if (i0 + e < total) dst[i0 + e] = ok[sl][e] ? v[sl][e] : 0.f;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1502,7 +1557,25 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         if (blockIdx.x == 0 && threadIdx.x == 0) { norm[0] = nrm; norm[1] = coef; }
     }
     const float step = lr / bc1;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    size_t first = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (((((size_t)p) | ((size_t)g) | ((size_t)m) | ((size_t)v)) & 15) == 0) {   // four elements a thread, 16-byte accesses (the same arithmetic per element)
+        const size_t n4 = n >> 2;
+        for (size_t i = first; i < n4; i += (size_t)gridDim.x * 256) {
+            const f32x4 g4 = ((const f32x4*)g)[i];
+            f32x4 m4 = ((const f32x4*)m)[i], v4 = ((const f32x4*)v)[i], p4 = ((const f32x4*)p)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gi = g4[e] * coef;
+                const float mi = b1 * m4[e] + (1.0f - b1) * gi;
+                const float vi = b2 * v4[e] + (1.0f - b2) * gi * gi;
+                m4[e] = mi; v4[e] = vi;
+                p4[e] -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+            }
+            ((f32x4*)m)[i] = m4; ((f32x4*)v)[i] = v4; ((f32x4*)p)[i] = p4;
+        }
+        first += n4 << 2;   // the tail (n % 4 elements)
+    }
+    for (size_t i = first; i < n; i += (size_t)gridDim.x * 256) {
         const float gi = g[i] * coef;
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
         const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;

@@ -66,14 +66,18 @@ static void build_train_plan(mpdx_unet* u) {
 
 static int ensure_pack_descs(mpdx_unet* u) {
     if (u->pack_descs_dev) return 0;
-    // the chunk table of pack_train_kernel: kPackChunk outputs of one pack of one parameter per block
+    // the chunk table of pack_train_kernel: kPackGroups groups of one pack of one parameter per block
     std::vector<PackChunk> chunks;
     for (size_t k = 0; k < u->pack_descs_host.size(); ++k) {
         const PackDesc& d = u->pack_descs_host[k];
         if (d.pn >= (1ull << 32) || d.pnT >= (1ull << 32) || d.n >= (1ull << 32)) return fail(MPDX_E_INVALID, "parameter %zu: more than 2^32 packed floats", k);
-        for (unsigned long long f = 0; f < d.pn; f += kPackChunk) chunks.push_back(PackChunk{(int)k, 0, (unsigned)f, 0u});
+        // (PackChunk::first: the chunk's first GROUP - nslot consecutive 256-float blocks; kPackGroups groups per chunk)
+        const unsigned long long gf = 256ull * (unsigned long long)(d.kind == 0 ? 1 : d.nslot), gt = 256ull * (unsigned long long)std::max(d.t_ks, 1);
+        if (d.kind != 0 && d.nslot > 5) return fail(MPDX_E_INVALID, "parameter %zu: %d tap slots (the repack kernel holds 5)", k, d.nslot);
+        if (d.dstT != ~0ull && d.t_ks > 5) return fail(MPDX_E_INVALID, "parameter %zu: %d dgrad taps (the repack kernel holds 5)", k, d.t_ks);
+        for (unsigned long long g = 0; g * gf < d.pn; g += kPackGroups) chunks.push_back(PackChunk{(int)k, 0, (unsigned)g, 0u});
         if (d.dstT != ~0ull)
-            for (unsigned long long f = 0; f < d.pnT; f += kPackChunk) chunks.push_back(PackChunk{(int)k, 1, (unsigned)f, 0u});
+            for (unsigned long long g = 0; g * gt < d.pnT; g += kPackGroups) chunks.push_back(PackChunk{(int)k, 1, (unsigned)g, 0u});
     }
     u->n_pack_chunks = chunks.size();
     HIP_TRY(hipMalloc(&u->pack_chunks_dev, chunks.size() * sizeof(PackChunk)));
@@ -387,7 +391,7 @@ static int bwd_up_applicable(const mpdx_unet* u) {
     const int n = (int)u->layers.size();
     if (n < 34 || u->cfg.n_support_points != 64 || u->masked()) return -1;
     const auto& tl = u->tl;
-    const int fi = n - 2;   // final_conv[0] (the last layer is final_conv[1], the 1x1)
+    const int fi = n - 1;   // final_conv[0] (final_conv[1], the 1x1, lives in the loss kernel and in final_conv[0]'s epilogue: it is no layer of the list)
     const Layer& f = u->layers[fi];
     if (!(f.mode == CONV_S1 && f.ks == 5 && f.epi == EPI_GN_MISH && f.c1 == 32 && f.c2 == 0 && f.cout == 32 && f.L_out == 64 && f.gs == 4 && f.tb_off < 0 && tl[fi].src1_l == fi - 1 && tl[fi].res_l < 0))
         return -1;
@@ -901,8 +905,8 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     };
     const int up_first = (prog_env != 0 && prog_env != 2 && df.on && !masked && B <= prog_max_b && w.total < ((size_t)1 << 31)) ? bwd_up_applicable(u) : -1;   // (2: the down program only)
     const bool prog_up_on = up_first >= 0;
-    const int up_fi = n - 2;   // final_conv[0]
-    auto run_up_program = [&]() -> int {   // layers [up_first, n - 1) = [33, 46) ([21, 34) with three levels): final_conv[0] and the two outer up levels; 0 ok, < 0 error, 1 not applicable here
+    const int up_fi = n - 1;   // final_conv[0]
+    auto run_up_program = [&]() -> int {   // layers [up_first, n) = [33, 46) ([21, 34) with three levels): final_conv[0] and the two outer up levels; 0 ok, < 0 error, 1 not applicable here
         if (!written[up_fi] || df.red.n + 17 > 96 || df.col.n + 9 * 3 + 4 > 120) return 1;
         static const int late_div_env = getenv("MPDX_WGRAD_LATE_DIV") ? std::max(1, atoi(getenv("MPDX_WGRAD_LATE_DIV"))) : 0;
         static const int small_mul = getenv("MPDX_WGRAD_PROG_MUL") ? atoi(getenv("MPDX_WGRAD_PROG_MUL")) : 1;
@@ -1034,18 +1038,19 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         }
         return 0;
     };
+    bool ran_up = false, ran_down = false;
     for (int i = n - 1; i >= 0; --i) {
         if (prog_up_on && i == up_fi) {
             if (int rc = chain.flush()) return rc;
             const int rc = run_up_program();
             if (rc < 0 || rc > 1) return rc;
-            if (rc == 0) { i = up_first; continue; }   // layers [up_first, n - 1) are done: on with the layer below
+            if (rc == 0) { ran_up = true; i = up_first; continue; }   // layers [up_first, n) are done: on with the layer below
         }
         if (prog_down_on && i == dn_last) {
             if (int rc = chain.flush()) return rc;
             const int rc = run_down_program();
             if (rc < 0 || rc > 1) return rc;
-            if (rc == 0) break;   // layers [0, dn_last] are done
+            if (rc == 0) { ran_down = true; break; }   // layers [0, dn_last] are done
         }
         const Layer& l = u->layers[i];
         const auto& t = u->tl[i];
@@ -1247,6 +1252,8 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         }
     }
     if (int rc = chain.flush()) return rc;
+    if (getenv("MPDX_DEBUG_TRAIN"))   // (tests/test_gpu_train.py reads this line: the programs must RUN on both networks the reference trains)
+        fprintf(stderr, "[mpdx] backward programs: up %d (layers [%d, %d)), down %d (variant %d, layers [0, %d])\n", ran_up ? 1 : 0, up_first, n, ran_down ? 1 : 0, down_variant, dn_last);
     if (getenv("MPDX_DEBUG_TRAIN")) fprintf(stderr, "[mpdx] backward: %d chain launch(es) of %d steps, %zu weight-gradient jobs behind them\n", chain.launches, chain.steps, lone.size());
     {
         static const bool multi_off = getenv("MPDX_TRAIN_WGRAD_MULTI") && atoi(getenv("MPDX_TRAIN_WGRAD_MULTI")) == 0;   // dev A/B switch

@@ -729,3 +729,23 @@ print("HASH", h.hexdigest())
     ref0 = run(base)
     for extra in ({"MPDX_TRAIN_WGRAD_LATE": "1", "MPDX_WGRAD_LATE_DIV": "1"}, {"MPDX_TRAIN_WGRAD_MULTI": "0"}, {"MPDX_TRAIN_CHAIN": "32"}, {"MPDX_TRAIN_CHAIN": "16"}):
         assert run(dict(base, **extra)) == ref0, extra
+
+
+@pytest.mark.parametrize("opt,variant,up_first", [(1, 1, 33), (0, 2, 21)])
+def test_backward_programs_run_on_both_networks_the_reference_trains(opt, variant, up_first):
+    """The whole-trajectory backward programs (fused_bwd.hpp) are what the training numbers are measured on: on both UNET_DIM_MULTS options
+    (launch_train_01.py:81-84) at horizon 64 both must actually RUN - the per-layer path behind them computes the same gradients, so a program that
+    silently stopped applying would pass every gradient test (it happened in round 6: an off-by-one layer index switched the up program off)."""
+    import os, subprocess, sys
+    code = (
+        "import sys; sys.path.insert(0, 'tests')\n"
+        "import torch, test_gpu_train as T\n"
+        "from mpd_public_amd.trainer import TrainStep\n"
+        f"dm = T._model(4, {opt}); x0, noise, hc = T._batch(4)\n"
+        "TrainStep(dm).loss_backward(x0.cuda(), {k: v.cuda() for k, v in hc.items()}, t=T.TTS[0].cuda(), noise=noise.cuda()); torch.cuda.synchronize()\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env={**os.environ, "MPDX_DEBUG_TRAIN": "1"}, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stderr.splitlines() if "backward programs:" in l]
+    assert lines, r.stderr[-2000:]
+    assert f"up 1 (layers [{up_first}," in lines[-1] and f"down 1 (variant {variant}," in lines[-1], lines[-1]
