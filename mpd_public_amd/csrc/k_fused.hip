@@ -30,6 +30,10 @@ int launch_fused_args(const mpdx_unet::Fused& f, const FusedArgs& a, int B, hipS
             if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqDown3>)) return rc;
             hipLaunchKernelGGL(fused_program_kernel<FusedSeqDown3>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
             break;
+        case 6:
+            if (int rc = raise_lds_limit((const void*)fused_program_kernel<FusedSeqMid3>)) return rc;
+            hipLaunchKernelGGL(fused_program_kernel<FusedSeqMid3>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);
+            break;
         default:
             if (int rc = raise_lds_limit((const void*)fused_level_kernel<false>)) return rc;
             hipLaunchKernelGGL(fused_level_kernel<false>, dim3(B), dim3(kFusedThreads), f.lds_bytes, st, a);

@@ -499,21 +499,30 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
         if (write) bufs[id].def = std::min(bufs[id].def, opi);
         bufs[id].last = std::max(bufs[id].last, opi);
     };
+    int in_buf = -1;
+    bool in_slot_rewritten = false;   // a layer of the segment has written the workspace slot the segment's input came in
+    // the LDS buffer a layer writes its output (workspace slot `slot`, L positions) to.  A slot written again with the same shape re-uses its buffer (the
+    // blocks' HB / RB temporaries, an up level's second block writing the slot the level's input came in) - except a buffer too narrow for it (three-level
+    // network, round 6: mid_block1's 128 channels go to the slot downs.1's Downsample1d output - the segment input, 64 channels - came in): a buffer of its own
     auto buf_for = [&](int slot, int L, int cpad) {
         const long key = (long)(slot + 8) * 4096 + L;
         auto it = bufmap.find(key);
-        if (it != bufmap.end()) return it->second;
+        if (it != bufmap.end()) {
+            const int rs = pick_row_stride(cpad, CONV_S1, L, L, L + 4);
+            if (it->second == in_buf) in_slot_rewritten = true;   // (src_buf: from here on that slot is a tensor of the segment, no longer its input)
+            if (bufs[it->second].rs4 >= rs / 4) return it->second;
+        }
         const int id = new_buf(cpad, L);
         bufmap[key] = id;
         return id;
     };
-    const int in_buf = new_buf(l0.cin_pad, l0.L_in);
+    in_buf = new_buf(l0.cin_pad, l0.L_in);
     a.in_clear = (l0.cin_pad != l0.c1 + l0.c2) ? 1 : 0;  // channel padding of the staged input
     touch(in_buf, -1, true);
     bufmap[(long)(l0.src1 + 8) * 4096 + l0.L_in] = in_buf;
     int cat_buf = -1;    // buffer whose tail columns hold a skip tensor staged by the prologue (concat inside the program)
     auto src_buf = [&](const Layer& l, int i) -> int {   // LDS buffer a layer reads (-1: not available inside the segment)
-        if (i == i0 || (l.src1 == l0.src1 && l.src2 == l0.src2 && l.L_in == l0.L_in)) return in_buf;
+        if (i == i0 || (!in_slot_rewritten && l.src1 == l0.src1 && l.src2 == l0.src2 && l.L_in == l0.L_in)) return in_buf;
         const long key = (long)(l.src1 + 8) * 4096 + l.L_in;
         if (!bufmap.count(key)) return -1;
         if (l.src2 != SRC_NONE) {   // cat(x produced in LDS, skip from global): the producer's buffer was made wide enough (below)
@@ -748,6 +757,7 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
             else if (matches(FusedSeqUpAB::ids, FusedSeqUpAB::N)) f.program = 3;
             else if (matches(FusedSeqMid2::ids, FusedSeqMid2::N)) f.program = 4;
             else if (matches(FusedSeqDown3::ids, FusedSeqDown3::N)) f.program = 5;
+            else if (matches(FusedSeqMid3::ids, FusedSeqMid3::N)) f.program = 6;
             // the static programs with a geometry table read their LDS layout as compile-time constants (fused_geom.hpp): the layout computed
             // above must BE that table, otherwise the segment runs on the generic op-list kernel (runtime descriptors)
             const int sdim = u->cfg.state_dim;
@@ -825,6 +835,15 @@ static void build_units(mpdx_unet* u) {
     }
     // the third down level (C = 128, L = 16: two tile rows per wave) as its own program
     if (nl >= 4 && !getenv("MPDX_NO_MID2")) try_seg("downs.2.", false);
+    // three levels: the innermost level (no Downsample1d) and the two middle blocks - eight Conv1dBlocks of 128 channels on L / 4 positions - as ONE
+    // program (round 6; they were nine launches of ~4.8 us: a training iteration at batch 32 spent 43 us there).  MPDX_NO_MID3=1: per layer as before
+    if (nl == 3 && !getenv("MPDX_NO_MID3")) {
+        int a0, a1, b0, b1, c0, c1;
+        bool free_ = range_of("downs.2.", a0, a1) && range_of("mid_block1.", b0, b1) && range_of("mid_block2.", c0, c1) && a1 == b0 && b1 == c0;
+        for (int i = a0; free_ && i < c1; ++i) free_ = owner[i] < 0;
+        if (free_ && build_fused_segment(u, a0, c1, false))
+            for (int i = a0; i < c1; ++i) owner[i] = (int)u->fused.size() - 1;
+    }
     // the two outer up levels + final_conv + DDPM step as ONE program (the second level's skip tensor is staged by the prologue)
     bool merged_up = false;
     if (nl >= 3 && !getenv("MPDX_NO_MERGE_UP") && !getenv("MPDX_NO_MERGE")) {
@@ -1113,7 +1132,7 @@ int claim_fused_stream_jobs(mpdx_unet* u, const float* packed, const void** jobs
 }
 
 // programs that exist in the training-forward variant (the two of the standard 4-level network, and the generic op-list kernel)
-bool fused_save_variant(const mpdx_unet::Fused& f) { return f.program == 3 || f.program == 5 || f.program < 0; }
+bool fused_save_variant(const mpdx_unet::Fused& f) { return f.program == 0 || f.program == 3 || f.program == 5 || f.program == 6 || f.program < 0; }
 static int run_fused(mpdx_unet* u, const mpdx_unet::Fused& f, const float* packed, const float* tt_row, const float* x, float* ws,
                      int B, const FinalArgs* fa, hipStream_t st) {
     const size_t slot = u->slot_floats * (size_t)B;
