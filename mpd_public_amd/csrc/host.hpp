@@ -163,6 +163,7 @@ int claim_fused_stream_jobs(mpdx_unet* u, const float* packed, const void** jobs
 int launch_final_step(const FinalArgs& fa, hipStream_t st);   // final_step_kernel (fa.B/H/D/C set)
 // ---- k_conv.hip: every conv_block_kernel / conv_pair_kernel instantiation
 int launch_conv_layer(const Layer& l, ConvArgs& a, int B, hipStream_t st);
+bool pair_tile(const Layer& l1, const Layer& l2, int B, int& MT, int& NT);   // (mpdx.hip) do blocks[0] + the block's residual 1x1 conv run as one launch, on which tile?
 int launch_conv_pair(int MT, int NT, const ConvArgs& a1, const ConvArgs& a2, const Layer& l1, const Layer& l2, hipStream_t st);   // 1 launched, 0 does not fit, -1 error
 // ---- k_ws.hip: the weight-stationary persistent kernels
 int launch_weight_stationary(int variant, const Layer& l, ConvArgs& a, const ConvArgs& a2, int B, hipStream_t st);

@@ -988,7 +988,7 @@ static int run_layer(const mpdx_unet* u, const Layer& l, const float* packed, co
 }
 
 // blocks[0] + residual 1x1 conv of one ResidualTemporalBlock qualify for ONE launch (conv_pair_kernel)?  On success the tile.
-static bool pair_tile(const Layer& l1, const Layer& l2, int B, int& MT, int& NT) {
+bool pair_tile(const Layer& l1, const Layer& l2, int B, int& MT, int& NT) {
     static const bool off = getenv("MPDX_PAIR") && atoi(getenv("MPDX_PAIR")) == 0;
     if (off) return false;
     if (!(l1.mode == CONV_S1 && l1.ks == 5 && l1.epi == EPI_GN_MISH && l2.mode == CONV_S1 && l2.ks == 1 && l2.epi == EPI_BIAS)) return false;

@@ -701,20 +701,38 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             if (int rc = launch_fused_args(f, a, B, st, true)) return rc;
             continue;
         }
+        auto layer_args = [&](int li, ConvArgs& a) -> int {
+            const Layer& l = u->layers[li];
+            const auto& t = u->tl[li];
+            memset(&a, 0, sizeof(a));
+            if (int rc = fill_geom(l, B, a)) return rc;
+            a.src1 = tensor(t.src1_l); a.src2 = tensor(t.src2_l);
+            a.wp = packed + u->params[l.w].off;
+            a.bias = packed + u->params[l.b].off;
+            a.gamma = l.gamma >= 0 ? packed + u->params[l.gamma].off : nullptr;
+            a.beta = l.beta >= 0 ? packed + u->params[l.beta].off : nullptr;
+            if (l.tb_off >= 0) { a.tbias = ws + w.tb + l.tb_off; a.tb_stride = u->tt_row; }
+            a.res = tensor(t.res_l);
+            a.dst = out(li);
+            a.pre = l.epi == EPI_GN_MISH ? pre(li) : nullptr;
+            return 0;
+        };
         const Layer& l = u->layers[i];
-        const auto& t = u->tl[i];
         ConvArgs a;
-        memset(&a, 0, sizeof(a));
-        if (int rc = fill_geom(l, B, a)) return rc;
-        a.src1 = tensor(t.src1_l); a.src2 = tensor(t.src2_l);
-        a.wp = packed + u->params[l.w].off;
-        a.bias = packed + u->params[l.b].off;
-        a.gamma = l.gamma >= 0 ? packed + u->params[l.gamma].off : nullptr;
-        a.beta = l.beta >= 0 ? packed + u->params[l.beta].off : nullptr;
-        if (l.tb_off >= 0) { a.tbias = ws + w.tb + l.tb_off; a.tb_stride = u->tt_row; }
-        a.res = tensor(t.res_l);
-        a.dst = out(i);
-        a.pre = l.epi == EPI_GN_MISH ? pre(i) : nullptr;
+        if (int rc = layer_args(i, a)) return rc;
+        // blocks[0] and the same block's residual 1x1 convolution (the next layer; both read the block input) as ONE launch - the planning path's conv_pair_kernel
+        // (round 6: two launches of ~4.8 us less per pass on the four-level network; MPDX_TRAIN_PAIR_FWD=0: one launch per layer)
+        static const bool pair_fwd_off = getenv("MPDX_TRAIN_PAIR_FWD") && atoi(getenv("MPDX_TRAIN_PAIR_FWD")) == 0;
+        int MT = 0, NT = 0;
+        if (!pair_fwd_off && !masked && i + 1 < n && !(fused_fwd && u->owner[i + 1] >= 0 && ((fused_mask(B) >> u->owner[i + 1]) & 1u)) && u->tl[i + 1].src1_l == u->tl[i].src1_l &&
+            u->tl[i + 1].src2_l == u->tl[i].src2_l && pair_tile(l, u->layers[i + 1], B, MT, NT)) {
+            ConvArgs a2;
+            if (int rc = layer_args(i + 1, a2)) return rc;
+            a.n_tiles_n = a2.n_tiles_n = (int)(((long)B * l.L_out + NT - 1) / NT);
+            const int rc = launch_conv_pair(MT, NT, a, a2, l, u->layers[i + 1], st);
+            if (rc < 0) return rc;
+            if (rc == 1) { ++i; continue; }
+        }
         if (int rc = launch_layer(l, a, B, st)) return rc;
     }
     {   // final_conv[1] -> eps (the network output), hard conditions, loss value and its gradient
