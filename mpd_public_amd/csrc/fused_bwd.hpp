@@ -67,7 +67,7 @@ struct BwdOp {
     int part_g;                 // global: per-trajectory channel sums [3][B][C]: sum(gm vhat) | sum(gm) | sum(dU)   (gamma / beta / conv-bias gradients)
     int dT_g;                   // global: + b * dT_stride + c <- sum over positions of the incoming gradient (the block's time-bias gradient; -1: none)
 };
-constexpr int kMaxBwdOps = 16;
+constexpr int kMaxBwdOps = 20;
 struct BwdArgs {
     const float* packedT;
     const float* flat;
@@ -100,6 +100,21 @@ constexpr BwdGeomOp bwd_down_geom(int i, bool first_noconv = false) {
     else { g.src_off4 = bwd_slot(kBwdDUB); g.src_rs4 = r4; g.rsrc_off4 = bwd_slot(kBwdGA); g.rsrc_rs4 = r4; g.dst_off4 = bwd_slot(kBwdIN); g.dst_rs4 = (C / 2) / 4 + 1; g.dst_mode = 1; }
     return g;
 }
+// the three-level network's down program WITH the two middle blocks in front (18 ops): M1 .. M5 = [GroupNorm backward of mid_block2.blocks.1 on the up
+// program's gradient | dgrad + GroupNorm backward of mid_block2.blocks.0 | of mid_block1.blocks.1 (+ the identity residual's gradient) | of mid_block1.blocks.0 |
+// of downs.2.1.blocks.1 (+ identity residual + the skip connection's gradient from global memory)], then ops 1 .. 13 of the program above
+constexpr BwdGeomOp bwd_down_mid_geom(int i) {
+    if (i >= 5) return bwd_down_geom(i - 4, true);
+    constexpr int r4 = 33;
+    BwdGeomOp g{0, 0, 0, 0, -1, 0, -1, 0, -1, 0, 0};
+    if (i == 0) { g.gy_off4 = bwd_slot(kBwdGB); g.gy_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = r4; }
+    else if (i == 1 || i == 3) { g.src_off4 = bwd_slot(kBwdDUA); g.src_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUB); g.dst_rs4 = r4; }
+    else {   // i == 2: + GB -> GA;  i == 4: + GA -> GB
+        g.src_off4 = bwd_slot(kBwdDUB); g.src_rs4 = r4; g.add_off4 = bwd_slot(i == 2 ? kBwdGB : kBwdGA); g.add_rs4 = r4;
+        g.gy_off4 = bwd_slot(i == 2 ? kBwdGA : kBwdGB); g.gy_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = r4;
+    }
+    return g;
+}
 constexpr BwdGeomOp bwd_up_geom(int i) {
     BwdGeomOp g{0, 0, 0, 0, -1, 0, -1, 0, -1, 0, 0};
     if (i == 0) { g.dst_off4 = bwd_slot(kBwdIN); g.dst_rs4 = 9; return g; }   // the GroupNorm backward of final_conv[0] on the loss kernel's gradient -> IN
@@ -116,7 +131,7 @@ constexpr BwdGeomOp bwd_up_geom(int i) {
     }
     return g;
 }
-template <int PROG, int I> struct BwdGeomOf { static constexpr bool has = true; static constexpr BwdGeomOp g = PROG == 0 ? bwd_down_geom(I) : (PROG == 2 ? bwd_down_geom(I, true) : bwd_up_geom(I)); };
+template <int PROG, int I> struct BwdGeomOf { static constexpr bool has = true; static constexpr BwdGeomOp g = PROG == 0 ? bwd_down_geom(I) : (PROG == 2 ? bwd_down_geom(I, true) : (PROG == 3 ? bwd_down_mid_geom(I) : bwd_up_geom(I))); };
 struct BwdGeomNone { static constexpr bool has = false; static constexpr BwdGeomOp g{0, 0, 0, 0, -1, 0, -1, 0, -1, 0, 0}; };
 // host: does op `o` (as train_host.hpp laid it out) have the table's LDS geometry?
 inline bool bwd_geom_matches(const BwdOp& o, const BwdGeomOp& g, bool has_rsrc) {
@@ -507,6 +522,8 @@ __global__ __launch_bounds__(kFusedThreads) void fused_bwd_program_kernel(const 
 using BwdSeqDown3 = BwdSeq<0, 0, 1, 1, 1, 2, 3, 4, 4, 4, 5, 6, 7, 7, 7>;
 // the same for the THREE-level network (dim_mults (1, 2, 4)): its innermost level has no Downsample1d - the first op is the GroupNorm backward alone
 using BwdSeqDown3Last = BwdSeq<2, 16, 1, 1, 1, 2, 3, 4, 4, 4, 5, 6, 7, 7, 7>;
+// ... with mid_block2 and mid_block1 (128 channels on 16 positions, as the innermost level) in front: everything below the up program in ONE launch
+using BwdSeqDown3Mid = BwdSeq<3, 16, 1, 1, 1, 1, 1, 1, 1, 2, 3, 4, 4, 4, 5, 6, 7, 7, 7>;
 // the backward pass of final_conv[0] + the two outer up levels (run_up_program; the same shapes in the three- and the four-level network)
 using BwdSeqUp2 = BwdSeq<1, 15, 8, 9, 10, 10, 10, 11, 11, 12, 13, 13, 13, 14, 14>;
 

@@ -382,6 +382,17 @@ static int bwd_down_applicable(const mpdx_unet* u) {
         if (k > 0 && (tl[b].src1_l != b - 1 || tl[b + 1].src1_l != b - 1)) return 0;
         for (int i = b + (k == 0 ? 2 : 0); i < b + (has_down ? 6 : 5); ++i) if (!tl[i].need_dgrad) return 0;
     }
+    if (variant == 2 && (int)u->layers.size() == 34) {   // 3: ... and the two middle blocks (layers 17 .. 20: identity residuals, 128 channels on 16 positions) in front
+        static const bool mid_off = getenv("MPDX_TRAIN_BWD_MID") && atoi(getenv("MPDX_TRAIN_BWD_MID")) == 0;
+        const auto& tl = u->tl;
+        bool ok = !mid_off;
+        for (int i = 17; i <= 20 && ok; ++i) {
+            const Layer& l = u->layers[i];
+            ok = l.mode == CONV_S1 && l.ks == 5 && l.epi == EPI_GN_MISH && l.c1 == 128 && l.c2 == 0 && l.cout == 128 && l.L_out == 16 && l.gs == 16 && tl[i].src1_l == i - 1 && tl[i].need_dgrad &&
+                 ((i & 1) ? l.tb_off >= 0 : l.tb_off < 0);
+        }
+        if (ok && tl[18].res_l == 16 && tl[20].res_l == 18 && tl[17].res_l < 0 && tl[19].res_l < 0) variant = 3;
+    }
     return variant;
 }
 
@@ -809,9 +820,11 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
     static const int prog_max_b = getenv("MPDX_TRAIN_BWD_PROG_MAX_B") ? atoi(getenv("MPDX_TRAIN_BWD_PROG_MAX_B")) : 512;
     const int down_variant = (prog_env != 0 && df.on && !masked && B <= prog_max_b && w.total < ((size_t)1 << 31)) ? bwd_down_applicable(u) : 0;
     const bool prog_down_on = down_variant != 0;
-    const int dn_last = down_variant == 2 ? 16 : 17;   // the program covers layers [0, dn_last]
+    const int dn_last = down_variant == 3 ? 20 : (down_variant == 2 ? 16 : 17);   // the program covers layers [0, dn_last]
     auto run_down_program = [&]() -> int {   // layers [0, 18) (three-level network: [0, 17)): returns 0 ok, < 0 error, 1 not applicable here (the per-layer path takes over)
-        if (!written[dn_last] || df.red.n + 18 > 96 || df.col.n + 12 * 3 + 6 > 120) return 1;
+        const int n_gn = down_variant == 3 ? 16 : 12;   // GroupNorm ops (three column-sum entries each); dn_last + 1 weight-gradient jobs
+        if (!written[dn_last] || df.red.n + dn_last + 1 > 96 || df.col.n + n_gn * 3 + 6 > 120) return 1;
+        if (down_variant == 3 && !written[16]) return 1;   // (the skip connection's gradient, an addend of op M5)
         static const int late_div_env = getenv("MPDX_WGRAD_LATE_DIV") ? std::max(1, atoi(getenv("MPDX_WGRAD_LATE_DIV"))) : 0;
         static const int small_mul = getenv("MPDX_WGRAD_PROG_MUL") ? atoi(getenv("MPDX_WGRAD_PROG_MUL")) : 1;   // batch < 64: split multiplier of the program layers' weight gradients
         const int sdiv = late_div_env ? late_div_env : (B >= 64 ? (B <= 128 ? 8 : 4) : (small_mul > 1 ? -std::min(small_mul, 4) : (B >= 48 ? 2 : 1)));
@@ -824,7 +837,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         enum { IN = 0, GB = 1, DUA = 2, DUB = 3, GA = 4 };
         auto rs4_of = [](int C) { return C / 4 + 1; };
         a.gin = grd(17); a.in_L = 8; a.in_C = 128; a.in_stuff = 1; a.in_off4 = lay.off4[IN]; a.in_rs4 = rs4_of(128);
-        if (down_variant == 2) { a.gin = nullptr; a.in_L = 0; a.in_stuff = 0; }   // (no staged input: the first op takes grd(16) as its global addend)
+        if (down_variant >= 2) { a.gin = nullptr; a.in_L = 0; a.in_stuff = 0; }   // (no staged input: the first op takes grd(16) / grd(20) as its global addend)
         int nop = 0;
         auto gn_part = [&](int li, BwdOp& op) {   // the lower Conv1dBlock `li`: its GroupNorm input, parameters and the partial-sum rows of its gamma / beta / bias gradients
             const Layer& lj = u->layers[li];
@@ -839,6 +852,43 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             df.pcur += (size_t)3 * B * lj.cout;
             op.dT_g = lj.tb_off >= 0 ? (int)(w.dT + lj.tb_off) : -1;
         };
+        if (down_variant == 3) {   // M1 .. M4: the two middle blocks (fused_bwd.hpp bwd_down_mid_geom); M5 = the level loop's first op below
+            const int r4 = rs4_of(128);
+            auto mid_op = [&](int nc16) -> BwdOp& {
+                BwdOp& op = a.ops[nop++];
+                memset(&op, 0, sizeof(op));
+                op.shape = bwd_shape_id(CONV_S1, 5, nc16, 0, 128, 16, 1);
+                op.add_off4 = -1; op.gadd = -1; op.gy_off4 = -1; op.gy_g = -1; op.dst_off4 = -1; op.out_g = -1; op.part_g = -1; op.dT_g = -1;
+                return op;
+            };
+            {   // M1: G(layer 20 out) from the up program -> GB (the identity residual of mid_block2 passes it on to layer 18's output); GroupNorm backward of layer 20
+                BwdOp& op = mid_op(0);
+                op.gadd = goff(grd(20));
+                op.gy_off4 = lay.off4[GB]; op.gy_rs4 = r4;
+                op.dst_off4 = lay.off4[DUA]; op.dst_rs4 = r4; op.out_g = goff(grd(20));
+                gn_part(20, op);
+            }
+            {   // M2: dgrad of layer 20 -> G(19 out) (time bias), GroupNorm backward of 19
+                BwdOp& op = mid_op(8);
+                op.src_off4 = lay.off4[DUA]; op.src_rs4 = r4; op.wbase = (int)u->tl[20].dgrad_woff;
+                op.dst_off4 = lay.off4[DUB]; op.dst_rs4 = r4; op.out_g = goff(grd(19));
+                gn_part(19, op);
+            }
+            {   // M3: dgrad of 19 + GB -> G(18 out) -> GA; GroupNorm backward of 18
+                BwdOp& op = mid_op(8);
+                op.src_off4 = lay.off4[DUB]; op.src_rs4 = r4; op.wbase = (int)u->tl[19].dgrad_woff;
+                op.add_off4 = lay.off4[GB]; op.add_rs4 = r4;
+                op.gy_off4 = lay.off4[GA]; op.gy_rs4 = r4;
+                op.dst_off4 = lay.off4[DUA]; op.dst_rs4 = r4; op.out_g = goff(grd(18));
+                gn_part(18, op);
+            }
+            {   // M4: dgrad of 18 -> G(17 out) (time bias), GroupNorm backward of 17
+                BwdOp& op = mid_op(8);
+                op.src_off4 = lay.off4[DUA]; op.src_rs4 = r4; op.wbase = (int)u->tl[18].dgrad_woff;
+                op.dst_off4 = lay.off4[DUB]; op.dst_rs4 = r4; op.out_g = goff(grd(17));
+                gn_part(17, op);
+            }
+        }
         for (int k = 2; k >= 0; --k) {
             const int C = 32 << k, Lk = 64 >> k, b0 = 6 * k, r4 = rs4_of(C);
             auto base_op = [&](int shape_ks, int nc16, int ncr, int cout, int gn) -> BwdOp& {
@@ -848,7 +898,15 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
                 op.add_off4 = -1; op.gadd = -1; op.gy_off4 = -1; op.gy_g = -1; op.dst_off4 = -1; op.out_g = -1; op.part_g = -1; op.dT_g = -1;
                 return op;
             };
-            if (k == 2 && down_variant == 2) {   // P1 of an innermost level (no Downsample1d): G(b1.1 out) is what the per-layer path accumulated in grd(16)
+            if (k == 2 && down_variant == 3) {   // M5: dgrad of layer 17 + GA (mid_block1's identity residual) + the skip connection's gradient -> G(16 out) -> GB; GroupNorm backward of 16
+                BwdOp& op = base_op(5, C / 16, 0, C, 1);
+                op.src_off4 = lay.off4[DUB]; op.src_rs4 = r4; op.wbase = (int)u->tl[17].dgrad_woff;
+                op.add_off4 = lay.off4[GA]; op.add_rs4 = r4;
+                op.gadd = goff(grd(b0 + 4));
+                op.gy_off4 = lay.off4[GB]; op.gy_rs4 = r4;
+                op.dst_off4 = lay.off4[DUA]; op.dst_rs4 = r4; op.out_g = goff(grd(b0 + 4));
+                gn_part(b0 + 4, op);
+            } else if (k == 2 && down_variant == 2) {   // P1 of an innermost level (no Downsample1d): G(b1.1 out) is what the per-layer path accumulated in grd(16)
                 BwdOp& op = base_op(5, 0, 0, C, 1);
                 op.gadd = goff(grd(b0 + 4));
                 op.gy_off4 = lay.off4[GB]; op.gy_rs4 = r4;
@@ -898,14 +956,16 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         a.nops = nop;
         for (int k = 0; k < nop; ++k)
             if (a.ops[k].shape < 0) return fail(MPDX_E_INVALID, "backward program: op %d has no shape", k);
-        const bool last = down_variant == 2;
-        bool is_static = nop == BwdSeqDown3::N;
+        const bool last = down_variant == 2, mid = down_variant == 3;
+        bool is_static = nop == (mid ? BwdSeqDown3Mid::N : BwdSeqDown3::N);
         for (int k = 0; k < nop && is_static; ++k)
-            is_static = a.ops[k].shape == (last ? BwdSeqDown3Last::ids[k] : BwdSeqDown3::ids[k]) && bwd_geom_matches(a.ops[k], bwd_down_geom(k, last), a.ops[k].shape == 2 || a.ops[k].shape == 5);
+            is_static = a.ops[k].shape == (mid ? BwdSeqDown3Mid::ids[k] : (last ? BwdSeqDown3Last::ids[k] : BwdSeqDown3::ids[k])) &&
+                        bwd_geom_matches(a.ops[k], mid ? bwd_down_mid_geom(k) : bwd_down_geom(k, last), a.ops[k].shape == 2 || a.ops[k].shape == 5);
         if (!is_static) return fail(MPDX_E_STATE, "backward program (down): the layout differs from the static program's table");
-        const void* kern = last ? (const void*)fused_bwd_program_kernel<BwdSeqDown3Last> : (const void*)fused_bwd_program_kernel<BwdSeqDown3>;
+        const void* kern = mid ? (const void*)fused_bwd_program_kernel<BwdSeqDown3Mid> : (last ? (const void*)fused_bwd_program_kernel<BwdSeqDown3Last> : (const void*)fused_bwd_program_kernel<BwdSeqDown3>);
         if (int rc = raise_lds_limit(kern)) return rc;
-        if (last) hipLaunchKernelGGL(fused_bwd_program_kernel<BwdSeqDown3Last>, dim3(B), dim3(kFusedThreads), lay.lds_bytes, st, a);
+        if (mid) hipLaunchKernelGGL(fused_bwd_program_kernel<BwdSeqDown3Mid>, dim3(B), dim3(kFusedThreads), lay.lds_bytes, st, a);
+        else if (last) hipLaunchKernelGGL(fused_bwd_program_kernel<BwdSeqDown3Last>, dim3(B), dim3(kFusedThreads), lay.lds_bytes, st, a);
         else hipLaunchKernelGGL(fused_bwd_program_kernel<BwdSeqDown3>, dim3(B), dim3(kFusedThreads), lay.lds_bytes, st, a);
         // the layers' weight gradients (their dY operands now sit in grd(i)) behind the chain; bias gradients of the three convolutions without GroupNorm
         for (int i = dn_last; i >= 0; --i) {

@@ -731,7 +731,7 @@ print("HASH", h.hexdigest())
         assert run(dict(base, **extra)) == ref0, extra
 
 
-@pytest.mark.parametrize("opt,variant,up_first", [(1, 1, 33), (0, 2, 21)])
+@pytest.mark.parametrize("opt,variant,up_first", [(1, 1, 33), (0, 3, 21)])
 def test_backward_programs_run_on_both_networks_the_reference_trains(opt, variant, up_first):
     """The whole-trajectory backward programs (fused_bwd.hpp) are what the training numbers are measured on: on both UNET_DIM_MULTS options
     (launch_train_01.py:81-84) at horizon 64 both must actually RUN - the per-layer path behind them computes the same gradients, so a program that
