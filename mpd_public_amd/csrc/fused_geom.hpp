@@ -70,6 +70,21 @@ struct GeomDown {
     }};
 };
 
+// downs.2 (no Downsample1d) + mid_block1 + mid_block2 of dim_mults (1, 2, 4) - eight Conv1dBlocks of 128 channels on 16 positions: program 6 (FusedSeqMid3)
+struct GeomMid3 {
+    static constexpr bool has = true;
+    static constexpr FusedGeom g = { 8, 0, 18, 20, 16, 64, 0, 0, 0, 0, 0, 0, 9600, 10176, 4096, 9664, 512, 0, 0, 0, {
+        {16, 0, 18, 0, 0, -1, 0, 360, 34, -1, 0, 0},
+        {17, 360, 34, 0, 18, -1, 0, 1040, 34, -1, 512, -1},
+        {18, 1040, 34, 0, 0, -1, 0, 360, 34, -1, 1024, 128},
+        {18, 360, 34, 0, 0, 1040, 34, 1720, 34, 0, 1536, -1},
+        {18, 1720, 34, 0, 0, -1, 0, 360, 34, -1, 2048, 256},
+        {18, 360, 34, 0, 0, 1720, 34, 1040, 34, -1, 2560, -1},
+        {18, 1040, 34, 0, 0, -1, 0, 360, 34, -1, 3072, 384},
+        {18, 360, 34, 0, 0, 1040, 34, -1, 0, 1, 3584, -1},
+    }};
+};
+
 // the last two up levels + final_conv + DDPM step (both standard networks): program 3 (FusedSeqUpAB)
 struct GeomUpAB {
     static constexpr bool has = true;

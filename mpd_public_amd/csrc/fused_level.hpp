@@ -831,6 +831,6 @@ using FusedSeqUpB = FusedSeq<GeomNone, 12, 13, 14, 14, 15, 2, kFusedShapeFinal>;
 using FusedSeqUpAB = FusedSeq<GeomUpAB, 8, 9, 10, 10, 11, 12, 13, 14, 14, 15, 2, kFusedShapeFinal>;   // both up levels in one launch
 using FusedSeqDown3 = FusedSeq<GeomDown3, 0, 1, 2, 2, 3, 4, 5, 6, 6, 7, 16, 17, 18, 18, 19>;   // downs.0 + downs.1 + downs.2 in one launch
 using FusedSeqMid2 = FusedSeq<GeomNone, 16, 17, 18, 18, 19>;                                 // downs.2 (C = 128, L = 16): two tile rows per wave
-using FusedSeqMid3 = FusedSeq<GeomNone, 16, 17, 18, 18, 18, 18, 18, 18>;                     // three-level network: downs.2 (no Downsample1d) + mid_block1 + mid_block2
+using FusedSeqMid3 = FusedSeq<GeomMid3, 16, 17, 18, 18, 18, 18, 18, 18>;                     // three-level network: downs.2 (no Downsample1d) + mid_block1 + mid_block2
 
 }  // namespace mpdx

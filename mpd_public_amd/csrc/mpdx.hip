@@ -762,7 +762,7 @@ static bool build_fused_segment(mpdx_unet* u, int i0, int i1, bool with_final) {
             // above must BE that table, otherwise the segment runs on the generic op-list kernel (runtime descriptors)
             const int sdim = u->cfg.state_dim;
             if ((f.program == 0 && !fused_geom_matches(a, GeomDown::g, sdim)) || (f.program == 3 && !fused_geom_matches(a, GeomUpAB::g, sdim)) ||
-                (f.program == 5 && !fused_geom_matches(a, GeomDown3::g, sdim))) {
+                (f.program == 5 && !fused_geom_matches(a, GeomDown3::g, sdim)) || (f.program == 6 && !fused_geom_matches(a, GeomMid3::g, sdim))) {
                 if (getenv("MPDX_DEBUG_FUSE")) fprintf(stderr, "[mpdx] fused segment: geometry differs from the table of program %d -> generic kernel\n", f.program);
                 f.program = -1;
             }

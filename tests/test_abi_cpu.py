@@ -183,14 +183,15 @@ def test_resample_path_uniform_arclength_and_zero_end_velocities():
 def test_standard_networks_run_the_static_programs_with_compile_time_geometry(lib):
     """The whole-trajectory programs of the standard networks read their LDS geometry from compile-time tables (csrc/fused_geom.hpp); the
     host computes the placement and must arrive at exactly those tables - otherwise the segment silently falls back to the generic
-    op-list kernel (correct, slower).  Both dim_mults options x both state dims: programs 5 + 3 (four levels) / 0 + 3 (three levels)."""
-    for kw, want in ((dict(state_dim=4), [5, 3]), (dict(state_dim=14), [5, 3]), (dict(state_dim=4, n_levels=3, dim_mults=(1, 2, 4)), [0, 3]),
-                     (dict(state_dim=14, n_levels=3, dim_mults=(1, 2, 4)), [0, 3])):
+    op-list kernel (correct, slower).  Both dim_mults options x both state dims: programs 5 + 3 (four levels) / 0 + 6 + 3 (three levels: downs.0-1,
+    downs.2 + the two middle blocks - round 6 -, the up levels)."""
+    for kw, want in ((dict(state_dim=4), [5, 3]), (dict(state_dim=14), [5, 3]), (dict(state_dim=4, n_levels=3, dim_mults=(1, 2, 4)), [0, 6, 3]),
+                     (dict(state_dim=14, n_levels=3, dim_mults=(1, 2, 4)), [0, 6, 3])):
         rc, h = _create(lib, **kw)
         assert rc == 0, (kw, lib.mpdx_last_error())
-        got = [lib.mpdx_unet_fused_program(h, k) for k in range(2)]
+        got = [lib.mpdx_unet_fused_program(h, k) for k in range(len(want))]
         assert got == want, (kw, got)
-        assert lib.mpdx_unet_fused_program(h, 2) == -2
+        assert lib.mpdx_unet_fused_program(h, len(want)) == -2
         lib.mpdx_unet_destroy(h)
     # a horizon in a padded container runs no fused segment at all (one masking launch per layer)
     rc, h = _create(lib, n_support_points=48)
