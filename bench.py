@@ -1134,7 +1134,7 @@ def compact_line(out):
     c["serving_plan_ms"] = sv.get("plan_ms")
     tr = out.get("training") or {}
     c["train_ms"] = {"b32_D4": tr.get("ms_per_train_step"), "b128_D14": _get(tr, "batch128_D14", "ms_per_train_step"),
-                     "b512_D14": _get(tr, "batch512_D14", "ms_per_train_step")}
+                     "b512_D14": _get(tr, "batch512_D14", "ms_per_train_step"), "three_level_b128_D14": _get(tr, "three_level_batch128_D14", "ms_per_train_step")}
     c["train_fp32_peak_frac"] = {"b32_D4": _get(tr, "roofline", "frac"), "b128_D14": _get(tr, "batch128_D14", "fp32_peak_frac"),
                                  "b512_D14": _get(tr, "batch512_D14", "fp32_peak_frac")}
     c["train_launch_mode"] = [m_.get("mode") for m_ in (_get(tr, "launch_mode", "decided") or [])]
@@ -1351,6 +1351,11 @@ def main():
                     out["training"][nm] = {"ms_per_train_step": r["ms_per_train_step"], "train_steps_per_s": r["train_steps_per_s"],
                                            "fp32_TFLOPs": r.get("roofline", {}).get("achieved"), "fp32_peak_frac": r.get("roofline", {}).get("frac"),
                                            "launch_mode": r.get("launch_mode")}
+                # the OTHER network the reference's launch script trains (launch_train_01.py:81-84: unet_dim_mults_option 0 = (1, 2, 4), batch 128)
+                r = timed("training_3level_b128", training_leg, steps=100, B=128, D=14, opt=0, baseline=False)
+                out["training"]["three_level_batch128_D14"] = {"ms_per_train_step": r["ms_per_train_step"], "train_steps_per_s": r["train_steps_per_s"],
+                                                               "fp32_TFLOPs": r.get("roofline", {}).get("achieved"),
+                                                               "fp32_peak_frac": r.get("roofline", {}).get("frac"), "launch_mode": r.get("launch_mode")}
             except Exception as e:
                 out["training"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -59,7 +59,8 @@ def test_compact_line_carries_the_quoted_numbers_in_under_6_kb(capsys, tmp_path,
     assert c["guide_us_per_launch"]["panda"] == full["guided"]["cfg4"]["guide_kernel"]["us_per_launch"]
     assert c["serving_ms_per_context"] == full["serving"]["ms_per_context"]
     assert c["train_ms"] == {"b32_D4": full["training"]["ms_per_train_step"], "b128_D14": full["training"]["batch128_D14"]["ms_per_train_step"],
-                             "b512_D14": full["training"]["batch512_D14"]["ms_per_train_step"]}
+                             "b512_D14": full["training"]["batch512_D14"]["ms_per_train_step"],
+                             "three_level_b128_D14": full["training"].get("three_level_batch128_D14", {}).get("ms_per_train_step")}
     assert len(c["trained"]["free_rate_guided"]) == 3
     assert json.loads((tmp_path / "bench_full.json").read_text()) == full
     err = [ln for ln in cap.err.splitlines() if ln.startswith("# bench_full ")]
