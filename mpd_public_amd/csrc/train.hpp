@@ -802,13 +802,13 @@ __global__ __launch_bounds__(256) void pack_train_kernel(const PackDesc* __restr
         const unsigned c16 = g % nc16, m16 = g / nc16;
         const unsigned co = m16 * 16 + (lane & 15), ci0 = c16 * 16 + (lane >> 4) * 4;
         const unsigned long long sa = ((unsigned long long)co * cin + ci0) * ks;
-        if (ci0 + 3 < cin && (g + 1) * ns * 256u <= total && ((d.src + sa) & 3ull) == 0 && (d.dst & 3ull) == 0 && ns == ks) {
+        if (ci0 + 3 < cin && (g + 1) * ns * 256u <= total && (((size_t)(src + sa)) & 15) == 0 && (((size_t)dst) & 15) == 0 && ns == ks) {
             if (ks == 5) { pack_group_wide<5>(src + sa, dst + gfirst); return; }
             if (ks == 3) { pack_group_wide<3>(src + sa, dst + gfirst); return; }
             if (ks == 1) { pack_group_wide<1>(src + sa, dst + gfirst); return; }
         }
     }
-    if (c.which != 0 && d.t_mode == 0 && ns == ks && (g + 1) * ns * 256u <= total && (d.dstT & 3ull) == 0) {
+    if (c.which != 0 && d.t_mode == 0 && ns == ks && (g + 1) * ns * 256u <= total && (((size_t)dst) & 15) == 0) {
         // dgrad layout of a Conv1d weight: the lane's rows W[ci0 + e][o][0 .. ks - 1] (ks contiguous floats each, taps flipped on the way out), float4 stores
         const unsigned tnc16 = (unsigned)d.t_cin_pad >> 4;
         const unsigned c16 = g % tnc16, m16 = g / tnc16;

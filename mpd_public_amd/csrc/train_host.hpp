@@ -827,7 +827,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         if (down_variant == 3 && !written[16]) return 1;   // (the skip connection's gradient, an addend of op M5)
         static const int late_div_env = getenv("MPDX_WGRAD_LATE_DIV") ? std::max(1, atoi(getenv("MPDX_WGRAD_LATE_DIV"))) : 0;
         static const int small_mul = getenv("MPDX_WGRAD_PROG_MUL") ? atoi(getenv("MPDX_WGRAD_PROG_MUL")) : 1;   // batch < 64: split multiplier of the program layers' weight gradients
-        const int sdiv = late_div_env ? late_div_env : (B >= 64 ? (B <= 128 ? 8 : 4) : (small_mul > 1 ? -std::min(small_mul, 4) : (B >= 48 ? 2 : 1)));
+        const int sdiv = late_div_env ? late_div_env : (B >= 64 ? (B <= 128 ? 8 : 4) : (small_mul > 1 ? -std::min(small_mul, 4) : 4));   // (batch < 64: 4 - measured with the host out of the way, profiles/r06_train_b32_split_ab.txt)
         const BwdProgLayout lay = bwd_down_layout();
         BwdArgs a;
         memset(&a, 0, sizeof(a));
@@ -988,7 +988,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         if (!written[up_fi] || df.red.n + 17 > 96 || df.col.n + 9 * 3 + 4 > 120) return 1;
         static const int late_div_env = getenv("MPDX_WGRAD_LATE_DIV") ? std::max(1, atoi(getenv("MPDX_WGRAD_LATE_DIV"))) : 0;
         static const int small_mul = getenv("MPDX_WGRAD_PROG_MUL") ? atoi(getenv("MPDX_WGRAD_PROG_MUL")) : 1;
-        const int sdiv = late_div_env ? late_div_env : (B >= 64 ? (B <= 128 ? 8 : 4) : (small_mul > 1 ? -std::min(small_mul, 4) : (B >= 48 ? 2 : 1)));
+        const int sdiv = late_div_env ? late_div_env : (B >= 64 ? (B <= 128 ? 8 : 4) : (small_mul > 1 ? -std::min(small_mul, 4) : 4));   // (batch < 64: 4 - measured with the host out of the way, profiles/r06_train_b32_split_ab.txt)
         const BwdProgLayout lay = bwd_down_layout();   // (the same five slots: the largest buffer here is 68 rows x 36 floats = 612 float4)
         BwdArgs a;
         memset(&a, 0, sizeof(a));
@@ -1202,7 +1202,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         // fewer batch splits for the weight gradients that run behind the chain (measured, profiles/r06_train_late_div_ab.txt: batch 128 x D = 14 0.898 / 0.84 / 0.82 /
         // 0.81 ms with 1 / 4 / 8 / 16; batch 512 2.027 / 1.94 / 1.96 / 2.01): 8 up to batch 128, 4 beyond
         static const int late_div_env = getenv("MPDX_WGRAD_LATE_DIV") ? std::max(1, atoi(getenv("MPDX_WGRAD_LATE_DIV"))) : 0;
-        const int late_div = late_div_env ? late_div_env : (B < 64 ? 2 : (B <= 128 ? 8 : 4));
+        const int late_div = late_div_env ? late_div_env : (B < 64 ? 4 : (B <= 128 ? 8 : 4));
         // will this layer's weight gradients run behind the chain (decided below, once the jobs exist: the same conditions)?  Then with fewer batch splits.
         const bool late_cand = (late_env0 < 0 ? B >= 48 : late_env0 != 0) && t.need_dgrad && !pair_off0 && df.on && df.red.n + 2 <= 96 && bwd_pair_has_tile(t.dg, B) && dy == gy;
         const int sdiv = late_cand ? late_div : 1;

@@ -87,6 +87,13 @@ class FlatParams:
             self.slices[name] = (off.value, cnt.value)
             self.order.append(name)
         self.packedT = torch.zeros(int(lib.mpdx_train_dgrad_pack_floats(h)), dtype=torch.float32, device=dev)
+        # where the three parameters of the per-step checks live (module, attribute): named_parameters() walks the whole module tree - 0.15 ms per call,
+        # twice per step it was most of the HOST time of an iteration (0.455 ms against 0.48 ms of GPU time at batch 32: round 6, tools/train_enqueue_probe2.py)
+        self._spot = []
+        for k in (self.order[0], self.order[len(self.order) // 2], self.order[-1]):
+            parent, _, attr = k.rpartition(".")
+            self._spot.append((k, unet.get_submodule(parent) if parent else unet, attr))
+        self._n_checks = 0
         self._pending = None   # weakref to the _GradHolder of the autograd loss whose gradient currently sits in self.grad (snapshot_pending)
 
     def snapshot_pending(self):
@@ -104,6 +111,14 @@ class FlatParams:
         """Do the module's parameters still live in the flat vector?  (`.to()` / `.cuda()` / re-creating parameters breaks the
         aliasing.)  The per-step check looks at three parameters; `full` at all of them."""
         base = self.flat.data_ptr()
+        self._n_checks += 1
+        if not full and self._n_checks % 256:   # the spot check: three parameters looked up where they were registered (every 256th call walks the tree: a
+            # replaced SUBMODULE keeps the old module object alive here)
+            for k, mod, attr in self._spot:
+                p = mod._parameters.get(attr)
+                if p is None or p.data_ptr() != base + 4 * self.slices[k][0]:
+                    return False
+            return True
         named = dict(self.unet.named_parameters())
         keys = self.order if full else (self.order[0], self.order[len(self.order) // 2], self.order[-1])
         return all(k in named and named[k].data_ptr() == base + 4 * self.slices[k][0] for k in keys)
@@ -112,9 +127,14 @@ class FlatParams:
         """Is every parameter's .grad still its view of the flat gradient?  (optimizer.zero_grad(set_to_none=True), the autograd
         bridge of model.loss() and `p.grad = None` all detach it.)"""
         base = self.grad.data_ptr()
+        if not full:   # (the spot check, as in aliased())
+            for k, mod, attr in self._spot:
+                p = mod._parameters.get(attr)
+                if p is None or p.grad is None or p.grad.data_ptr() != base + 4 * self.slices[k][0]:
+                    return False
+            return True
         named = dict(self.unet.named_parameters())
-        keys = self.order if full else (self.order[0], self.order[len(self.order) // 2], self.order[-1])
-        return all(named[k].grad is not None and named[k].grad.data_ptr() == base + 4 * self.slices[k][0] for k in keys)
+        return all(named[k].grad is not None and named[k].grad.data_ptr() == base + 4 * self.slices[k][0] for k in self.order)
 
     def bind_grads(self):
         """Re-point every p.grad at its slice of the flat gradient (what the native backward pass writes): torch optimisers and
