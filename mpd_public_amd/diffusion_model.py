@@ -19,7 +19,9 @@ from .schedules import diffusion_buffers
 
 
 def make_timesteps(batch_size, i, device):
-    return torch.full((batch_size,), i, device=device, dtype=torch.long)
+    t = torch.full((batch_size,), i, device=device, dtype=torch.long)
+    t._mpdx_value = int(i)   # the loop index rides on the tensor: this package's sample functions read it instead of synchronising (`int(t[0])`, sample_functions.py:28)
+    return t
 
 
 class GaussianDiffusionModel(nn.Module):
@@ -55,7 +57,13 @@ class GaussianDiffusionModel(nn.Module):
     # ---------------------------------------------------------------------------------------------- helpers
     def host_buffers(self):
         """CPU copies of the schedule buffers (scalars are passed to the kernels by value)."""
-        stamp = tuple((b.data_ptr(), b._version) for b in self.buffers())
+        d = self.__dict__   # (the buffer list is cached like TemporalUnet._param_stamp's parameter list: the walk cost 0.1 ms per denoising step of the protocol loop)
+        n = d.get("_hb_calls", 0) + 1
+        d["_hb_calls"] = n
+        bl = d.get("_blist")
+        if bl is None or n % 16 == 0:
+            bl = d["_blist"] = [b for k, b in self.named_buffers() if "." not in k]
+        stamp = tuple((b.data_ptr(), b._version) for b in bl)
         if self._host is None or self._host_stamp != stamp:
             host = {k: v.detach().to("cpu", torch.float32) for k, v in self.named_buffers() if "." not in k}
             # model_std = exp(0.5 * posterior_log_variance_clipped[t])  (sample_functions.py:35-36), fp32 like the reference
@@ -65,6 +73,15 @@ class GaussianDiffusionModel(nn.Module):
             self._host_stamp = stamp
             self._coef_cache = {}
         return self._host
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__["_blist"] = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.__dict__["_blist"] = None
+        return r
 
     def manual_seed(self, seed: int):
         """Seed of the device noise generator (Philox counter stream of mpdx_randn)."""
@@ -185,7 +202,9 @@ class GaussianDiffusionModel(nn.Module):
             raise NotImplementedError("context is always None on this path")
         if not self.clip_denoised:
             raise RuntimeError("clip_denoised=False is an error in the reference too (:152)")
-        tt = int(t.reshape(-1)[0])
+        tt = getattr(t, "_mpdx_value", None)
+        if tt is None:
+            tt = int(t.reshape(-1)[0])
         B = x.shape[0]
         hdl, packed, tab, ws = self.model.engine(self.n_diffusion_steps, B)
         mean = x.to(torch.float32).contiguous().clone()
@@ -222,15 +241,25 @@ class GaussianDiffusionModel(nn.Module):
         x = apply_hard_conditioning(x, hard_conds)
         chain = [x] if return_chain else None
         k = 1
-        for i in reversed(range(-n_diffusion_steps_without_noise, self.n_diffusion_steps)):
-            t = make_timesteps(batch_size, i, device)
-            if noise is not None:
-                sample_kwargs["noise"] = noise[k]
-            x, values = sample_fn(self, x, hard_conds, context, t, **sample_kwargs)
-            x = apply_hard_conditioning(x, hard_conds)
-            if return_chain:
-                chain.append(x)
-            k += 1
+        # the weights cannot change inside one loop: they are compared with the engine's pack ONCE here, not in every step's eps-model call
+        unet = self.model
+        freeze = hasattr(unet, "engine") and next(unet.parameters()).device.type == "cuda"
+        if freeze:
+            unet.engine(self.n_diffusion_steps, batch_size)
+            unet.__dict__["_weights_frozen"] = True
+        try:
+            for i in reversed(range(-n_diffusion_steps_without_noise, self.n_diffusion_steps)):
+                t = make_timesteps(batch_size, i, device)
+                if noise is not None:
+                    sample_kwargs["noise"] = noise[k]
+                x, values = sample_fn(self, x, hard_conds, context, t, **sample_kwargs)
+                x = apply_hard_conditioning(x, hard_conds)
+                if return_chain:
+                    chain.append(x)
+                k += 1
+        finally:
+            if freeze:
+                unet.__dict__["_weights_frozen"] = False
         if return_chain:
             return x, torch.stack(chain, dim=1)
         return x

@@ -73,7 +73,9 @@ def ddpm_sample_fn(model, x, hard_conds, context, t, guide=None, n_guide_steps=1
     randn_like draw for parity runs."""
     if context is not None:
         raise NotImplementedError("context is always None on this path (inference.py:182)")
-    t_single = int(t.reshape(-1)[0])  # host sync, as the reference's `if t_single < 0`
+    t_single = getattr(t, "_mpdx_value", None)   # make_timesteps' tensors carry their value (no host sync); any other tensor: read it, as the reference's `if t_single < 0`
+    if t_single is None:
+        t_single = int(t.reshape(-1)[0])
     tt = max(t_single, 0)
     B, H, D = x.shape
     x = x.to(torch.float32).contiguous()

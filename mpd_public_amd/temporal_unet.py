@@ -153,7 +153,26 @@ class TemporalUnet(nn.Module):
         return self._h
 
     def _param_stamp(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        """(address, version counter) of every parameter: load_state_dict, an optimiser step, .to() and in-place edits all change it.  The parameter LIST is
+        cached - walking the module tree costs 0.15 ms, which the step-by-step protocol loop paid per denoising step (round 6: 65.7 -> 21 ms per plan together
+        with the other host-side items, tools/stepwise_probe.py) - and rebuilt by _apply (.to / .cuda / .float), after load_state_dict (assign=True replaces the
+        Parameter objects) and on every 16th call (a Parameter object swapped in by hand)."""
+        d = self.__dict__
+        n = d.get("_stamp_calls", 0) + 1
+        d["_stamp_calls"] = n
+        pl = d.get("_plist")
+        if pl is None or n % 16 == 0:
+            pl = d["_plist"] = list(self.parameters())
+        return tuple((p.data_ptr(), p._version) for p in pl)
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__["_plist"] = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.__dict__["_plist"] = None
+        return r
 
     def engine(self, T: int, B: int):
         """(handle, packed, timetab, workspace) ready for a batch of B trajectories and timesteps < T.
@@ -163,7 +182,9 @@ class TemporalUnet(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("mpd_public_amd.TemporalUnet runs on an AMD GPU only (move the model to 'cuda'); there is no CPU fallback")
         st = _lib.current_stream()
-        stamp = self._param_stamp()
+        # (inside GaussianDiffusionModel.p_sample_loop the weights are checked ONCE, before the first step: `_weights_frozen`)
+        frozen = self.__dict__.get("_weights_frozen", False) and self._packed is not None and self._stamp is not None
+        stamp = self._stamp if frozen else self._param_stamp()
         if self._packed is None or self._stamp != stamp or self._packed.device != dev:
             packed = torch.zeros(lib.mpdx_unet_packed_floats(h), dtype=torch.float32, device=dev)
             sd = self.state_dict()
@@ -197,7 +218,8 @@ class TemporalUnet(nn.Module):
         if h != self.n_support_points or d != self.state_dim:
             raise ValueError(f"expected [B,{self.n_support_points},{self.state_dim}], got {tuple(x.shape)}")
         x = x.to(torch.float32).contiguous()
-        tl = time.reshape(-1).tolist()  # one host sync, as sample_functions.py:28-29 has
+        hint = getattr(time, "_mpdx_value", None)   # (make_timesteps' tensors carry their batch-constant value: no host sync)
+        tl = [hint] * int(time.numel()) if hint is not None and time.numel() in (1, b) else time.reshape(-1).tolist()  # one host sync, as sample_functions.py:28-29 has
         if len(tl) not in (1, b):
             raise ValueError(f"time must have 1 or {b} entries, got {len(tl)}")
         out = torch.empty_like(x)
