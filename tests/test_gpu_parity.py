@@ -513,3 +513,31 @@ def test_in_kernel_noise_equals_pregenerated_stream(B, guided, fused, panda):
         xb, cb = dm.plan(hc, B, 64, noise=noise, **kw)
     assert torch.equal(ca, cb) and torch.equal(xa, xb)
     assert float(ca[1].std()) > 0.1 and not torch.equal(ca[1], ca[2])
+
+
+def test_protocol_loop_host_side_keeps_the_protocol():
+    """The step-by-step protocol loop reads the loop index from make_timesteps' tensor and compares the weights with the engine's pack once per loop (round 6: it
+    was host-bound).  What must still hold: a `t` tensor made by anyone else gives the same step (read with a sync, as sample_functions.py:28 does); the weight
+    check is back after the loop - a load_state_dict between two plans is seen, also when the second plan runs the protocol loop; both loops agree bit for bit."""
+    import mpd_public_amd as m
+    from mpd_public_amd.diffusion_model import make_timesteps
+    from mpd_public_amd.sample_functions import ddpm_sample_fn
+    D, opt, T, B = 4, 1, 25, 6
+    dm = _gpu_model(D, opt, T=T)
+    dm.manual_seed(5)
+    x = t("proto_x", (B, 64, D)).cuda()
+    hc = {0: t("proto_h0", (D,), "uniform", 0.6).cuda(), 63: t("proto_h1", (D,), "uniform", 0.6).cuda()}
+    nz = t("proto_nz", (B, 64, D)).cuda()
+    a, _ = ddpm_sample_fn(dm, x, hc, None, make_timesteps(B, 7, "cuda"), noise=nz)
+    b, _ = ddpm_sample_fn(dm, x, hc, None, torch.full((B,), 7, device="cuda", dtype=torch.long), noise=nz)
+    assert torch.equal(a, b)
+    noise = t("proto_chain", (T + 1, B, 64, D)).cuda()
+    p1 = dm.run_inference(None, hc, n_samples=B, horizon=64, return_chain=True, noise=noise, fused=False)
+    assert dm.model.__dict__.get("_weights_frozen") is False
+    p0 = dm.run_inference(None, hc, n_samples=B, horizon=64, return_chain=True, noise=noise, fused=True)
+    assert torch.equal(p0, p1)
+    sd2 = {k: (v * 1.01 if v.dtype.is_floating_point and "final_conv.1.weight" in k else v) for k, v in dm.model.state_dict().items()}
+    dm.model.load_state_dict(sd2)
+    q1 = dm.run_inference(None, hc, n_samples=B, horizon=64, return_chain=True, noise=noise, fused=False)
+    q0 = dm.run_inference(None, hc, n_samples=B, horizon=64, return_chain=True, noise=noise, fused=True)
+    assert torch.equal(q0, q1) and not torch.equal(q1, p1)
