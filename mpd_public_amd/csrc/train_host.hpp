@@ -1173,6 +1173,11 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
                 if (int rc = chain.add_gn(g, re == 256 ? 4 : 2)) return rc;
             } else {
             if (int rc = chain.flush()) return rc;
+            // du IN PLACE for the two kernels whose body allows it (a lane reads its elements before it writes them): grd(i) outlives the pass, the shared
+            // dU scratch does not - so this layer's weight gradients can run behind the chain too (dy == gy below).  Round 6: the one 256 -> 256 layer whose
+            // GroupNorm backward is its own launch kept its weight-gradient blocks riding on its dgrad launch - 22.6 us against its six siblings' 12.5 at batch 128
+            static const bool gn_inplace_off = getenv("MPDX_TRAIN_GN_INPLACE") && atoi(getenv("MPDX_TRAIN_GN_INPLACE")) == 0;
+            if (!gn_inplace_off && !mrows && (re == 256 || re == 128)) g.du = gy;
             if (re == 256 && !mrows) hipLaunchKernelGGL(gn_mish_bwd_kernel<4>, ggrid, dim3(256), 0, st, g);
             else if (re == 128 && !mrows) hipLaunchKernelGGL(gn_mish_bwd_kernel<2>, ggrid, dim3(256), 0, st, g);
             else if (re == 256 && l.gs >= 4) hipLaunchKernelGGL((gn_mish_bwd_gen_kernel<4, 1>), ggrid, dim3(256), 0, st, g);
