@@ -70,6 +70,7 @@ class FlatParams:
         self.grad = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.slices = {}
         self.order = []
+        self.plist = []   # the Parameter objects in `order` (valid while aliased(): the autograd bridge walks this list instead of the module tree)
         named = dict(unet.named_parameters())
         name_p, shape, ndim = C.c_char_p(), (C.c_int32 * 3)(), C.c_int32()
         off, cnt = C.c_size_t(), C.c_size_t()
@@ -86,6 +87,7 @@ class FlatParams:
             p.grad = self.grad[off.value:off.value + cnt.value].view(p.shape)
             self.slices[name] = (off.value, cnt.value)
             self.order.append(name)
+            self.plist.append(p)
         self.packedT = torch.zeros(int(lib.mpdx_train_dgrad_pack_floats(h)), dtype=torch.float32, device=dev)
         # where the three parameters of the per-step checks live (module, attribute): named_parameters() walks the whole module tree - 0.15 ms per call,
         # twice per step it was most of the HOST time of an iteration (0.455 ms against 0.48 ms of GPU time at batch 32: round 6, tools/train_enqueue_probe2.py)
@@ -441,11 +443,10 @@ class _PLossesFn(torch.autograd.Function):
         fp = ctx.step.fp
         flat = ctx.holder.flat if ctx.holder.flat is not None else fp.grad
         scaled = flat * grad_out   # ONE parameter-sized product; the per-parameter gradients are views of it
-        named = dict(fp.unet.named_parameters())
         grads = []
-        for name in fp.order:
+        for name, p in zip(fp.order, fp.plist):
             off, cnt = fp.slices[name]
-            grads.append(scaled[off:off + cnt].view(named[name].shape))
+            grads.append(scaled[off:off + cnt].view(p.shape))
         return (None, None, None, None, None) + tuple(grads)
 
 
@@ -464,11 +465,13 @@ def loss_with_grad(model, x_start, hard_conds=None, t=None, noise=None):
     if step is None or not step.fp.aliased():
         step = TrainStep(model)
         model._train_step = step
-    named = dict(step.unet.named_parameters())
-    params = [named[k] for k in step.fp.order]
+    params = step.fp.plist   # (the Parameter objects FlatParams re-pointed at the flat vector: aliased() above vouches for them)
     # p.grad aliases the flat gradient that the native pass overwrites: autograd must accumulate into its own tensors
+    g0 = step.fp.grad.data_ptr()
+    g1 = g0 + 4 * step.fp.n
     for p in params:
-        if p.grad is not None and p.grad.data_ptr() >= step.fp.grad.data_ptr() and p.grad.data_ptr() < step.fp.grad.data_ptr() + 4 * step.fp.n:
+        g = p.grad
+        if g is not None and g0 <= g.data_ptr() < g1:
             p.grad = None
     return _PLossesFn.apply(step, x_start, hard_conds, t, noise, *params)
 
