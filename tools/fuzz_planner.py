@@ -1,6 +1,8 @@
 """Randomised fuzz of the baseline planners on one GPU (dev tool): random environment / robot / start-goal context / batch - RRT-Connect trajectories start and end
 exactly at the context with zero end velocities and are finite; GPMP2 (Levenberg-Marquardt) never raises its objective across optimize() calls, keeps the end states,
-stays finite, and does not lose more than a few collision-free trajectories; the final objective equals the oracle's for the same trajectory.
+stays finite; the final objective equals the oracle's for the same trajectory.  PARITY mismatches are counted apart from QUALITY flags (GPMP2 lost more than a
+quarter of the collision-free trajectories on a context: a property of its objective there - `tools/gpmp_case_probe.py <seed> <case>` replays the float64 oracle
+on the same initial trajectories to show it).
 python tools/fuzz_planner.py [n_cases] [seed]"""
 import random
 import sys
@@ -16,7 +18,7 @@ from oracle import gpmp as ogpmp   # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-bad = 0
+bad = flagged = 0
 for case in range(n_cases):
     env_id, robot_id = rng.choice([("EnvSimple2D", "RobotPointMass"), ("EnvDense2D", "RobotPointMass"), ("EnvNarrowPassageDense2D", "RobotPointMass"), ("EnvSpheres3D", "RobotPanda")])
     n = rng.choice([1, 3, 8, 16, 40])
@@ -46,7 +48,7 @@ for case in range(n_cases):
         ok = ok and bool((Fs[1:] <= Fs[:-1] * (1 + 1e-5)).all()) and bool(torch.isfinite(x).all())
         ok = ok and bool(torch.equal(x[:, 0], x0[:, 0])) and bool(torch.equal(x[:, -1], x0[:, -1]))
         f0, f1 = float(ds.task.compute_fraction_free_trajs(x0)), float(ds.task.compute_fraction_free_trajs(x))
-        ok = ok and f1 >= f0 - 0.25
+        quality = f1 >= f0 - 0.25
         _, comp = oracle_guide(ds, 1.0, 1.0, clip_grad=False, dtype=torch.float64)
         coll = comp.cost_l[:-1]
         for c in coll:
@@ -54,8 +56,9 @@ for case in range(n_cases):
         F0 = float(ogpmp.objective(x[0].cpu().double(), coll[0].robot, coll, dt, 1.0, opt.opts.sigma_obs, 128))
         ok = ok and abs(float(Fs[-1, 0]) - F0) <= 1e-3 * F0 + 1e-6
         bad += 0 if ok else 1
-        print(f"{'ok' if ok else 'MISMATCH'} case {case}: {desc}: rrt solved {int(rrt.done.sum())}/{n}, F {float(Fs[0].mean()):.4g} -> {float(Fs[-1].mean()):.4g}, "
+        flagged += 0 if (quality or not ok) else 1
+        print(f"{'MISMATCH' if not ok else ('ok' if quality else 'quality')} case {case}: {desc}: rrt solved {int(rrt.done.sum())}/{n}, F {float(Fs[0].mean()):.4g} -> {float(Fs[-1].mean()):.4g}, "
               f"free {f0:.2f} -> {f1:.2f}, F[0] kernel {float(Fs[-1, 0]):.6g} oracle {F0:.6g}")
     except Exception as e:
         print(f"refused case {case}: {desc}: {type(e).__name__}: {str(e)[:150]}")
-print(f"{n_cases} cases, {bad} mismatches")
+print(f"{n_cases} cases, {bad} mismatches" + (f" ({flagged} quality flags: free rate dropped by more than 0.25 under GPMP2, objective equal to the oracle's)" if flagged else ""))
