@@ -21,7 +21,14 @@ from .schedules import diffusion_buffers
 def make_timesteps(batch_size, i, device):
     t = torch.full((batch_size,), i, device=device, dtype=torch.long)
     t._mpdx_value = int(i)   # the loop index rides on the tensor: this package's sample functions read it instead of synchronising (`int(t[0])`, sample_functions.py:28)
+    t._mpdx_version = t._version   # ... while nobody has written to the tensor since (an in-place `t -= 1` bumps the version counter: the hint is dropped)
     return t
+
+
+def timestep_hint(t):
+    """The batch-constant value of a timestep tensor made by make_timesteps and not modified since, else None (the caller reads the tensor: one host sync)."""
+    v = getattr(t, "_mpdx_value", None)
+    return v if v is not None and getattr(t, "_mpdx_version", -1) == t._version else None
 
 
 class GaussianDiffusionModel(nn.Module):
@@ -202,7 +209,7 @@ class GaussianDiffusionModel(nn.Module):
             raise NotImplementedError("context is always None on this path")
         if not self.clip_denoised:
             raise RuntimeError("clip_denoised=False is an error in the reference too (:152)")
-        tt = getattr(t, "_mpdx_value", None)
+        tt = timestep_hint(t)
         if tt is None:
             tt = int(t.reshape(-1)[0])
         B = x.shape[0]

@@ -73,7 +73,8 @@ def ddpm_sample_fn(model, x, hard_conds, context, t, guide=None, n_guide_steps=1
     randn_like draw for parity runs."""
     if context is not None:
         raise NotImplementedError("context is always None on this path (inference.py:182)")
-    t_single = getattr(t, "_mpdx_value", None)   # make_timesteps' tensors carry their value (no host sync); any other tensor: read it, as the reference's `if t_single < 0`
+    from .diffusion_model import timestep_hint
+    t_single = timestep_hint(t)   # make_timesteps' tensors carry their value (no host sync); any other (or modified) tensor: read it, as the reference's `if t_single < 0`
     if t_single is None:
         t_single = int(t.reshape(-1)[0])
     tt = max(t_single, 0)

@@ -218,7 +218,8 @@ class TemporalUnet(nn.Module):
         if h != self.n_support_points or d != self.state_dim:
             raise ValueError(f"expected [B,{self.n_support_points},{self.state_dim}], got {tuple(x.shape)}")
         x = x.to(torch.float32).contiguous()
-        hint = getattr(time, "_mpdx_value", None)   # (make_timesteps' tensors carry their batch-constant value: no host sync)
+        from .diffusion_model import timestep_hint
+        hint = timestep_hint(time)   # (make_timesteps' tensors carry their batch-constant value: no host sync)
         tl = [hint] * int(time.numel()) if hint is not None and time.numel() in (1, b) else time.reshape(-1).tolist()  # one host sync, as sample_functions.py:28-29 has
         if len(tl) not in (1, b):
             raise ValueError(f"time must have 1 or {b} entries, got {len(tl)}")

@@ -65,4 +65,7 @@ def test_make_timesteps_carries_the_loop_index():
     t = make_timesteps(5, 17, "cpu")
     assert t.dtype == torch.long and t.shape == (5,) and bool((t == 17).all()) and t._mpdx_value == 17
     assert make_timesteps(2, -3, "cpu")._mpdx_value == -3   # the n_diffusion_steps_without_noise tail
-    assert getattr(torch.full((5,), 17), "_mpdx_value", None) is None   # any other tensor: read with a sync, as the reference does
+    from mpd_public_amd.diffusion_model import timestep_hint
+    assert timestep_hint(t) == 17 and timestep_hint(torch.full((5,), 17)) is None   # any other tensor: read with a sync, as the reference does
+    t -= 1   # written to since: the hint is stale and dropped (the tensor says 16 now)
+    assert timestep_hint(t) is None and int(t[0]) == 16
