@@ -70,3 +70,13 @@ def test_compact_line_carries_the_quoted_numbers_in_under_6_kb(capsys, tmp_path,
     multi["sharded"] = dict(full["sharded"], process_group_world_size=8, backend="nccl", rccl_version="2.22.3")
     c8 = bench.compact_line(multi)
     assert c8["rccl_world_size"] == 8 and c8["checksums_ok"] is True and "collective" in c8["gather_ms"] and len(json.dumps(c8)) < 6144
+
+
+def test_profile_tools_share_the_bench_fingerprint_function():
+    """The tools that stamp a profile with the kernel-source fingerprint must use bench.csrc_fingerprint itself: a private copy in tools/pmc_traffic.py once
+    missed a file family bench.py had started to leave out, and every PMC traffic figure of round 6 was labelled `measured_on_these_sources: False`."""
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    for tool in ("pmc_traffic.py", "kernel_stats_json.py"):
+        src = (root / "tools" / tool).read_text()
+        assert "bench.csrc_fingerprint()" in src and "hashlib" not in src, tool
