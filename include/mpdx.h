@@ -341,8 +341,8 @@ int mpdx_unet_time_without(mpdx_unet* u, const float* packed_dev, const float* t
                            float* ws, void* stream, unsigned long long skip_mask, int reps, float* ms_avg);
 /* layer index behind launch unit i of mpdx_unet_profile at batch B (-1: fused whole-trajectory segment or the final kernel) */
 int mpdx_unet_unit_layer(const mpdx_unet* u, int B, int i);
-/* introspection: the kernel that runs fused segment `seg` of this network - 0..5: a static whole-trajectory program (0, 3, 5 with
- * compile-time LDS geometry, csrc/fused_geom.hpp), -1: the generic op-list kernel, -2: no such segment.  Replaces nothing in the reference. */
+/* introspection: the kernel that runs fused segment `seg` of this network - 0..6: a static whole-trajectory program (0, 3, 5, 6 with
+ * compile-time LDS geometry, csrc/fused_geom.hpp; four levels: 5 + 3, three levels: 0 + 6 + 3), -1: the generic op-list kernel, -2: no such segment.  Replaces nothing in the reference. */
 int mpdx_unet_fused_program(const mpdx_unet* u, int seg);
 /* measurement helper: ALGORITHMIC bytes of launch unit i of a U-Net pass at batch B - its weights / parameters once plus the activations
  * that cross its boundary once (bench.py: roofline.traffic_over_algorithmic).  Replaces nothing in the reference. */
