@@ -75,7 +75,10 @@ class RRTConnectBatch:
 
     def grow(self, max_iters: int = 4000, max_connect_steps: int = 64) -> int:
         """Runs the search; returns the largest number of iterations any problem used.  One iteration = extend the active tree
-        towards a random sample, then connect the other tree greedily towards the new node (alternating trees)."""
+        towards a random sample, then connect the other tree greedily towards the new node (alternating trees).
+        The search's random stream is keyed by (the generator's initial seed, the number of searches launched in this process so far): a fixed sequence of
+        calls in a fresh process reproduces its trajectories - what the reference's global torch RNG behind fix_random_seed gives - while two searches of one
+        process never share a stream, also with equal generator seeds."""
         o = _lib.RrtOpts()
         for j in range(self.q):
             o.q_lo[j], o.q_hi[j] = float(self.lo[j]), float(self.hi[j])
