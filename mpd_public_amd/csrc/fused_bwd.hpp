@@ -82,13 +82,17 @@ struct BwdArgs {
 
 // ---- compile-time LDS geometry of the two static programs (train_host.hpp builds the same layout at run time and compares: a mismatch is an error).
 // Five slots of kBwdSlot4 float4 (the largest buffer: 20 rows x (128 + 4) floats): IN, GB, DUA, DUB, GA; a buffer of C channels has rows of C / 4 + 1 float4.
+#ifndef MPDX_BWD_PAD4
+#define MPDX_BWD_PAD4 1
+#endif
 struct BwdGeomOp { int src_off4, src_rs4, rsrc_off4, rsrc_rs4, add_off4, add_rs4, gy_off4, gy_rs4, dst_off4, dst_rs4, dst_mode; };
-constexpr int kBwdSlot4 = 660;
+constexpr int kBwdPad4 = MPDX_BWD_PAD4;   // float4 of row padding (dev: -DMPDX_BWD_PAD4=1 / 2)
+constexpr int kBwdSlot4 = 68 * (8 + kBwdPad4) > 20 * (32 + kBwdPad4) ? 68 * (8 + kBwdPad4) : 20 * (32 + kBwdPad4);
 constexpr int kBwdIN = 0, kBwdGB = 1, kBwdDUA = 2, kBwdDUB = 3, kBwdGA = 4;
 constexpr int bwd_slot(int k) { return k * kBwdSlot4; }
 constexpr BwdGeomOp bwd_down_geom(int i, bool first_noconv = false) {
     const int k = i < 5 ? 2 : (i < 10 ? 1 : 0), p = i - (i < 5 ? 0 : (i < 10 ? 5 : 10));
-    const int C = 32 << k, r4 = C / 4 + 1;
+    const int C = 32 << k, r4 = C / 4 + kBwdPad4;
     BwdGeomOp g{0, 0, 0, 0, -1, 0, -1, 0, -1, 0, 0};
     if (p == 0) {
         g.src_off4 = bwd_slot(kBwdIN); g.src_rs4 = r4; g.gy_off4 = bwd_slot(kBwdGB); g.gy_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = r4;
@@ -97,7 +101,7 @@ constexpr BwdGeomOp bwd_down_geom(int i, bool first_noconv = false) {
     else if (p == 1) { g.src_off4 = bwd_slot(kBwdDUA); g.src_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUB); g.dst_rs4 = r4; }
     else if (p == 2) { g.src_off4 = bwd_slot(kBwdDUB); g.src_rs4 = r4; g.add_off4 = bwd_slot(kBwdGB); g.add_rs4 = r4; g.gy_off4 = bwd_slot(kBwdGA); g.gy_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = r4; }
     else if (p == 3) { g.src_off4 = bwd_slot(kBwdDUA); g.src_rs4 = r4; g.dst_off4 = k > 0 ? bwd_slot(kBwdDUB) : -1; g.dst_rs4 = r4; }
-    else { g.src_off4 = bwd_slot(kBwdDUB); g.src_rs4 = r4; g.rsrc_off4 = bwd_slot(kBwdGA); g.rsrc_rs4 = r4; g.dst_off4 = bwd_slot(kBwdIN); g.dst_rs4 = (C / 2) / 4 + 1; g.dst_mode = 1; }
+    else { g.src_off4 = bwd_slot(kBwdDUB); g.src_rs4 = r4; g.rsrc_off4 = bwd_slot(kBwdGA); g.rsrc_rs4 = r4; g.dst_off4 = bwd_slot(kBwdIN); g.dst_rs4 = (C / 2) / 4 + kBwdPad4; g.dst_mode = 1; }
     return g;
 }
 // the three-level network's down program WITH the two middle blocks in front (18 ops): M1 .. M5 = [GroupNorm backward of mid_block2.blocks.1 on the up
@@ -105,7 +109,7 @@ constexpr BwdGeomOp bwd_down_geom(int i, bool first_noconv = false) {
 // of downs.2.1.blocks.1 (+ identity residual + the skip connection's gradient from global memory)], then ops 1 .. 13 of the program above
 constexpr BwdGeomOp bwd_down_mid_geom(int i) {
     if (i >= 5) return bwd_down_geom(i - 4, true);
-    constexpr int r4 = 33;
+    constexpr int r4 = 32 + kBwdPad4;
     BwdGeomOp g{0, 0, 0, 0, -1, 0, -1, 0, -1, 0, 0};
     if (i == 0) { g.gy_off4 = bwd_slot(kBwdGB); g.gy_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = r4; }
     else if (i == 1 || i == 3) { g.src_off4 = bwd_slot(kBwdDUA); g.src_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUB); g.dst_rs4 = r4; }
@@ -117,17 +121,17 @@ constexpr BwdGeomOp bwd_down_mid_geom(int i) {
 }
 constexpr BwdGeomOp bwd_up_geom(int i) {
     BwdGeomOp g{0, 0, 0, 0, -1, 0, -1, 0, -1, 0, 0};
-    if (i == 0) { g.dst_off4 = bwd_slot(kBwdIN); g.dst_rs4 = 9; return g; }   // the GroupNorm backward of final_conv[0] on the loss kernel's gradient -> IN
-    if (i == 1) { g.src_off4 = bwd_slot(kBwdIN); g.src_rs4 = 9; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = 9; return g; }
+    if (i == 0) { g.dst_off4 = bwd_slot(kBwdIN); g.dst_rs4 = 8 + kBwdPad4; return g; }   // the GroupNorm backward of final_conv[0] on the loss kernel's gradient -> IN
+    if (i == 1) { g.src_off4 = bwd_slot(kBwdIN); g.src_rs4 = 8 + kBwdPad4; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = 8 + kBwdPad4; return g; }
     const int k = i < 8 ? 0 : 1, p = i - (k == 0 ? 2 : 8);
-    const int C = k == 0 ? 32 : 64, r4 = C / 4 + 1;
+    const int C = k == 0 ? 32 : 64, r4 = C / 4 + kBwdPad4;
     if (p == 0) { g.src_off4 = bwd_slot(k == 0 ? kBwdDUA : kBwdIN); g.src_rs4 = r4; g.gy_off4 = bwd_slot(kBwdGB); g.gy_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUB); g.dst_rs4 = r4; }
     else if (p == 1) { g.src_off4 = bwd_slot(kBwdDUB); g.src_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = r4; }
     else if (p == 2) { g.src_off4 = bwd_slot(kBwdDUA); g.src_rs4 = r4; g.add_off4 = bwd_slot(kBwdGB); g.add_rs4 = r4; g.gy_off4 = bwd_slot(kBwdGA); g.gy_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUB); g.dst_rs4 = r4; }
     else if (p == 3) { g.src_off4 = bwd_slot(kBwdDUB); g.src_rs4 = r4; g.dst_off4 = bwd_slot(kBwdDUA); g.dst_rs4 = r4; }
     else {   // the two halves of the concat's gradient
         g.src_off4 = bwd_slot(kBwdDUA); g.src_rs4 = r4; g.rsrc_off4 = bwd_slot(kBwdGA); g.rsrc_rs4 = r4;
-        if (p == 4 && k == 0) { g.dst_off4 = bwd_slot(kBwdIN); g.dst_rs4 = (2 * C) / 4 + 1; }
+        if (p == 4 && k == 0) { g.dst_off4 = bwd_slot(kBwdIN); g.dst_rs4 = (2 * C) / 4 + kBwdPad4; }
     }
     return g;
 }

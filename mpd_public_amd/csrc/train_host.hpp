@@ -835,7 +835,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         a.dbg = getenv("MPDX_BWD_DBG") ? atoi(getenv("MPDX_BWD_DBG")) : 0;
         auto goff = [&](const float* p) { return (int)(p - ws); };
         enum { IN = 0, GB = 1, DUA = 2, DUB = 3, GA = 4 };
-        auto rs4_of = [](int C) { return C / 4 + 1; };
+        auto rs4_of = [](int C) { return C / 4 + kBwdPad4; };
         a.gin = grd(17); a.in_L = 8; a.in_C = 128; a.in_stuff = 1; a.in_off4 = lay.off4[IN]; a.in_rs4 = rs4_of(128);
         if (down_variant >= 2) { a.gin = nullptr; a.in_L = 0; a.in_stuff = 0; }   // (no staged input: the first op takes grd(16) / grd(20) as its global addend)
         int nop = 0;
@@ -996,7 +996,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         a.dbg = getenv("MPDX_BWD_DBG") ? atoi(getenv("MPDX_BWD_DBG")) : 0;
         auto goff = [&](const float* p) { return (int)(p - ws); };
         enum { IN = 0, GB = 1, DUA = 2, DUB = 3, GA = 4 };
-        auto rs4_of = [](int C) { return C / 4 + 1; };
+        auto rs4_of = [](int C) { return C / 4 + kBwdPad4; };
         auto part3 = [&](int li, int& part_g) {   // partial-sum rows + column-sum entries of a Conv1dBlock's gamma / beta / bias gradients
             const Layer& lj = u->layers[li];
             part_g = (int)df.pcur;
