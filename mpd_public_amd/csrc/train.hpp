@@ -495,6 +495,10 @@ struct BwdPairArgs {
     int gx[3], gy[3];    // their grids: x = N tiles, y = M tiles, z = batch splits
     int ks_w[3];         // taps of each weight gradient (1, 3, 4 or 5)
     int two[3];          // the job's blocks run two wave groups (wgrad_body ngrp = 2: all 512 threads work)
+    // a SECOND input-gradient convolution behind the first one's blocks (round 6): the 1x1 dgrad of a ResidualTemporalBlock's residual_conv riding on the
+    // launch of the block's blocks[1] dgrad - they read different gradients (G of the block output / dU of blocks[1]) and write different tensors
+    ConvArgs cd2;
+    int n_dgrad2;        // 0: none
 };
 // EPI_D = EPI_GN_BWD: the dgrad blocks also take their result through the Mish + GroupNorm backward of the Conv1dBlock below (conv_block.hpp)
 template <int KS_D, int MT, int NT, int EPI_D = EPI_BIAS>
@@ -503,7 +507,11 @@ __global__ __launch_bounds__(512) void bwd_pair_kernel(const BwdPairArgs a) {
         conv_block_body<CONV_S1, KS_D, EPI_D, MT, NT, 1, 8>(a.cd, blockIdx.x);
         return;
     }
-    int idx = (int)blockIdx.x - a.n_dgrad;
+    if ((int)blockIdx.x < a.n_dgrad + a.n_dgrad2) {
+        conv_block_body<CONV_S1, 1, EPI_BIAS, MT, NT, 1, 8>(a.cd2, (int)blockIdx.x - a.n_dgrad);
+        return;
+    }
+    int idx = (int)blockIdx.x - a.n_dgrad - a.n_dgrad2;
     int which = 0;
     while (which < 2 && idx >= a.nw[which]) { idx -= a.nw[which]; ++which; }
     const int ngrp = a.two[which] ? 2 : 1;

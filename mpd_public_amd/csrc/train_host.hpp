@@ -283,19 +283,28 @@ static bool bwd_pair_has_tile(const Layer& dgl, int B) {
 // dgrad convolution + the layer's weight-gradient GEMM(s) in ONE launch (bwd_pair_kernel); the jobs must use distinct partial buffers
 // GN_BWD: the dgrad blocks run the EPI_GN_BWD epilogue (cd carries its operands; `dgl` then has epi = EPI_GN_MISH and the group size
 // of the Conv1dBlock below, so that the tile holds whole GroupNorm regions)
+// dgl2 / cd2 (optional): a second, 1x1 input-gradient convolution on the same tile behind the first one's blocks (BwdPairArgs::cd2); returns kNoPair2 (nothing
+// launched) when that convolution does not fit the first one's tile
+constexpr int kNoPair2 = 99;
 template <int KS_D, bool GN_BWD = false>
-static int launch_bwd_pair(const Layer& dgl, ConvArgs& cd, int B, const WgradJob* jobs, int njobs, hipStream_t st) {
+static int launch_bwd_pair(const Layer& dgl, ConvArgs& cd, int B, const WgradJob* jobs, int njobs, hipStream_t st, const Layer* dgl2 = nullptr, ConvArgs* cd2 = nullptr) {
     int MT, NT;
     choose_tile(dgl, B, MT, NT);
     if (dgl.cout % MT) MT = 16;
     if (dgl.cout % MT || NT % dgl.L_out) return fail(MPDX_E_INVALID, "layer %s: no tile for C_out=%d L=%d", dgl.name.c_str(), dgl.cout, dgl.L_out);
+    if (dgl2 && (dgl2->cout % MT || dgl2->L_out != dgl.L_out || dgl2->ks != 1 || dgl2->mode != CONV_S1 || njobs > 3)) return kNoPair2;
     cd.n_tiles_n = (int)(((long)B * dgl.L_out + NT - 1) / NT);
     BwdPairArgs a;
     memset(&a, 0, sizeof(a));
     a.cd = cd;
     a.n_dgrad = (dgl.cout / MT) * cd.n_tiles_n;
     size_t lds = 0;
-    int total = a.n_dgrad;
+    if (dgl2) {
+        cd2->n_tiles_n = cd.n_tiles_n;
+        a.cd2 = *cd2;
+        a.n_dgrad2 = (dgl2->cout / MT) * cd2->n_tiles_n;
+    }
+    int total = a.n_dgrad + a.n_dgrad2;
     for (int k = 0; k < njobs; ++k) {
         a.w[k] = jobs[k].a; a.ks_w[k] = jobs[k].KS;
         a.gx[k] = jobs[k].grid.x; a.gy[k] = jobs[k].grid.y;
@@ -307,6 +316,7 @@ static int launch_bwd_pair(const Layer& dgl, ConvArgs& cd, int B, const WgradJob
 #define MPDX_BP_TILE(mt, nt)                                                                              \
     if (MT == mt && NT == nt) {                                                                           \
         lds = std::max(lds, conv_block_lds_bytes<CONV_S1, KS_D, mt, nt, 8>(cd.L_in, cd.L_out, cd.rs));      \
+        if (dgl2) lds = std::max(lds, conv_block_lds_bytes<CONV_S1, 1, mt, nt, 8>(cd2->L_in, cd2->L_out, cd2->rs)); \
         if (lds > 160 * 1024) return fail(MPDX_E_INVALID, "backward pair needs %zu B of LDS", lds);        \
         auto kern = bwd_pair_kernel<KS_D, mt, nt, GN_BWD ? EPI_GN_BWD : EPI_BIAS>;                         \
         if (lds > 64 * 1024)                                                                              \
@@ -1117,7 +1127,19 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
         return 0;
     };
     bool ran_up = false, ran_down = false;
+    // round 6: the dgrad launch of a ResidualTemporalBlock's blocks[1] (with the GroupNorm backward of blocks[0] in its epilogue) WAITS one layer for the block's
+    // residual 1x1 convolution (the next layer in backward order): its 1x1 dgrad - and at batch < 48 both layers' weight-gradient blocks - ride on the same
+    // launch (BwdPairArgs::cd2): one launch less per such block.  MPDX_TRAIN_PAIR_RES=0: one launch per layer as before
+    static const bool pair_res_off = getenv("MPDX_TRAIN_PAIR_RES") && atoi(getenv("MPDX_TRAIN_PAIR_RES")) == 0;
+    struct Pending { bool on = false; int i_next = -1; Layer dg; ConvArgs a; WgradJob jobs[3]; int njobs = 0; } pend;
+    auto flush_pending = [&]() -> int {
+        if (!pend.on) return 0;
+        pend.on = false;
+        return launch_bwd_pair<5, true>(pend.dg, pend.a, B, pend.jobs, pend.njobs, st);
+    };
     for (int i = n - 1; i >= 0; --i) {
+        if (pend.on && i != pend.i_next)
+            if (int rc = flush_pending()) return rc;
         if (prog_up_on && i == up_fi) {
             if (int rc = chain.flush()) return rc;
             const int rc = run_up_program();
@@ -1310,7 +1332,16 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
                         if (int rc = chain.add_conv(dg2, a, true)) return rc;
                     } else {
                         if (int rc = chain.flush()) return rc;
-                        if (int rc = dgl.ks == 5 ? launch_bwd_pair<5, true>(dg2, a, B, jobs, njobs, st) : launch_bwd_pair<3, true>(dg2, a, B, jobs, njobs, st)) return rc;
+                        // is the next layer in backward order this block's residual 1x1 convolution?  Then this launch waits for it (see `pend`)
+                        bool defer = false;
+                        if (!pair_res_off && dgl.ks == 5 && i >= 1 && t.res_l == i - 1 && njobs <= 1) {
+                            const Layer& r = u->layers[i - 1];
+                            defer = r.mode == CONV_S1 && r.ks == 1 && r.epi == EPI_BIAS && u->tl[i - 1].need_dgrad && r.L_out == l.L_out && !(prog_down_on && i - 1 <= dn_last);
+                        }
+                        if (defer) {
+                            pend.on = true; pend.i_next = i - 1; pend.dg = dg2; pend.a = a; pend.njobs = njobs;
+                            for (int k = 0; k < njobs; ++k) pend.jobs[k] = jobs[k];
+                        } else if (int rc = dgl.ks == 5 ? launch_bwd_pair<5, true>(dg2, a, B, jobs, njobs, st) : launch_bwd_pair<3, true>(dg2, a, B, jobs, njobs, st)) return rc;
                     }
                     du_ready[j] = 1;
                     gn_fused = true;
@@ -1321,7 +1352,20 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
                 if (int rc = chain.add_conv(dgl, a, false)) return rc;
             } else if (paired) {
                 if (int rc0 = chain.flush()) return rc0;
-                int rc;
+                int rc = kNoPair2;
+                if (pend.on && dgl.ks == 1 && pend.njobs + njobs <= 3) {   // the residual 1x1's dgrad (and weight-gradient blocks) ride on the waiting blocks[1] launch
+                    WgradJob all[3];
+                    int na = 0;
+                    for (int k = 0; k < pend.njobs; ++k) all[na++] = pend.jobs[k];
+                    for (int k = 0; k < njobs; ++k) all[na++] = jobs[k];
+                    rc = launch_bwd_pair<5, true>(pend.dg, pend.a, B, all, na, st, &dgl, &a);
+                    if (rc != kNoPair2) pend.on = false;
+                }
+                if (rc == kNoPair2) {
+                    if (int rc1 = flush_pending()) return rc1;
+                } else if (rc) return rc;
+                if (rc != kNoPair2) {
+                } else
                 if (dgl.ks == 5) rc = launch_bwd_pair<5>(dgl, a, B, jobs, njobs, st);
                 else if (dgl.ks == 3) rc = launch_bwd_pair<3>(dgl, a, B, jobs, njobs, st);
                 else rc = launch_bwd_pair<1>(dgl, a, B, jobs, njobs, st);
@@ -1334,6 +1378,7 @@ int mpdx_train_loss_backward(mpdx_unet* u, const float* flat, const float* packe
             if (l.mode == CONV_UPT && t.src1_l >= 0 && !a.decim) launch_acc(grd(t.src1_l), ws + w.tmpX, B, l.L_in, l.c1, dgl.L_out, Cin, 0, 2, first_write(t.src1_l) ? 1 : 0, st);
         }
     }
+    if (int rc = flush_pending()) return rc;
     if (int rc = chain.flush()) return rc;
     if (getenv("MPDX_DEBUG_TRAIN"))   // (tests/test_gpu_train.py reads this line: the programs must RUN on both networks the reference trains)
         fprintf(stderr, "[mpdx] backward programs: up %d (layers [%d, %d)), down %d (variant %d, layers [0, %d])\n", ran_up ? 1 : 0, up_first, n, ran_down ? 1 : 0, down_variant, dn_last);
