@@ -343,10 +343,14 @@ class TrainStep:
         # the batch (and a supplied noise tensor) by plain copies - contiguous device-to-device: the runtime's copy kernel, 2-3 us; the hard conditions
         # (a few KB each) in ONE launch.  (All of them in one _foreach_copy_ was 4.7 us at batch 32 but 17.5 us at batch 128 x D = 14: multi_tensor_apply
         # hands a 458-KB tensor to two blocks - profiles/r05_train128_kernel_stats.csv.)
+        # (round 6: a LARGE contiguous tensor goes into the same launch as 16 K-element slices - multi_tensor_apply spreads list entries over blocks,
+        #  so the batch of 128 x 64 x 14 floats is seven entries instead of a copy launch of its own: one launch for all inputs at every batch size)
         small_d, small_s = [], []
         for a, b in zip(dsts, srcs):
             if a.dtype == b.dtype and a.device == b.device and a.shape == b.shape and a.numel() <= 16384:
                 small_d.append(a); small_s.append(b)
+            elif a.dtype == b.dtype and a.device == b.device and a.shape == b.shape and b.is_contiguous() and a.is_contiguous() and a.numel() <= (1 << 20):
+                small_d.extend(a.view(-1).split(16384)); small_s.extend(b.view(-1).split(16384))
             else:
                 a.copy_(b, non_blocking=True)
         if small_d:
